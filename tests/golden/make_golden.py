@@ -1,0 +1,512 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference, read-only):
+
+    python tests/golden/make_golden.py
+
+The reference has no CPU implementation of its six CUDA extensions, so the
+extension modules are replaced by stubs that call the reference's OWN test-file
+oracles (mvpnet/ops/tests/test_*.py: farthest_point_sample_np, ball_query_np,
+ball_query_distance_np, knn_distance_torch, group_points_torch,
+feature_interpolate_torch) -- SURVEY.md Appendix C.  With those in place the
+reference's op wrappers (mvpnet/ops/*.py) and modules (mvpnet/models/pn2/*,
+mvpnet/models/mvpnet_3d.py, mvpnet/models/loss.py, common/nn/*) are imported
+and run unmodified on the CPU; their outputs are stored as .npz vectors.
+
+Nothing from /root/reference is copied: fixtures hold inputs (or the seeds that
+regenerate them) and expected outputs only.  `mvpnet/data/scannet_2d3d.py`
+cannot be imported (open3d / torchvision); its ten lifting lines
+(depth2xyz :33-39, pose :262, masks :260,274-281, ball-tree k-NN :305-313) are
+re-typed below as the vector generator for the lifting fixtures.
+"""
+import collections
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+from tests.golden.weights import load_into  # noqa: E402
+from mvpnet_amd.synthetic import make_chunk  # noqa: E402
+
+torch.set_num_threads(8)
+EXT = ['fps_cuda', 'ball_query_cuda', 'ball_query_distance_cuda', 'group_points_cuda', 'knn_distance_cuda',
+       'interpolate_cuda']
+
+
+# --------------------------------------------------------------------------- #
+# stub the six CUDA extensions with the reference's own test-file oracles
+# --------------------------------------------------------------------------- #
+def install_reference():
+    import mvpnet.ops as ops_pkg
+    stubs = {}
+    for name in EXT:
+        m = types.ModuleType('mvpnet.ops.' + name)
+        sys.modules['mvpnet.ops.' + name] = m
+        setattr(ops_pkg, name, m)
+        stubs[name] = m
+
+    def load_test(fname):
+        spec = importlib.util.spec_from_file_location('ref_' + fname, os.path.join(REF, 'mvpnet/ops/tests', fname + '.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    t_fps, t_bq, t_gp = load_test('test_fps'), load_test('test_ball_query'), load_test('test_group_points')
+    t_knn, t_int = load_test('test_knn_distance'), load_test('test_interpolate')
+
+    def fps(points, m):
+        return torch.from_numpy(np.asarray(t_fps.farthest_point_sample_np(points.numpy(), int(m), transpose=False), np.int64))
+
+    def bq(q, k, r, mx):
+        return torch.from_numpy(t_bq.ball_query_np(q.numpy(), k.numpy(), r, int(mx), transpose=False))
+
+    def bqd(q, k, r, mx):
+        i, d = t_bq.ball_query_distance_np(q.numpy(), k.numpy(), r, int(mx), transpose=False)
+        return torch.from_numpy(i), torch.from_numpy(d)
+
+    def knn(q, k, kk):
+        assert kk == 3
+        return t_knn.knn_distance_torch(q, k, kk, transpose=False)
+
+    def gp_bwd(grad, idx, n):
+        b, c, n2, k = grad.shape
+        out = grad.new_zeros(b, c, n)
+        out.scatter_add_(2, idx.reshape(b, 1, n2 * k).expand(b, c, n2 * k), grad.reshape(b, c, n2 * k))
+        return out
+
+    def int_bwd(grad, idx, w, n):
+        b, c, n2 = grad.shape
+        out = grad.new_zeros(b, c, n)
+        src = grad.unsqueeze(-1) * w.unsqueeze(1)
+        out.scatter_add_(2, idx.reshape(b, 1, n2 * 3).expand(b, c, n2 * 3), src.reshape(b, c, n2 * 3))
+        return out
+
+    stubs['fps_cuda'].farthest_point_sample = fps
+    stubs['ball_query_cuda'].ball_query = bq
+    stubs['ball_query_distance_cuda'].ball_query_distance = bqd
+    stubs['knn_distance_cuda'].knn_distance = knn
+    stubs['group_points_cuda'].group_points_forward = t_gp.group_points_torch
+    stubs['group_points_cuda'].group_points_backward = gp_bwd
+    stubs['interpolate_cuda'].interpolate_forward = t_int.feature_interpolate_torch
+    stubs['interpolate_cuda'].interpolate_backward = int_bwd
+    return dict(fps=t_fps, bq=t_bq, gp=t_gp, knn=t_knn, interp=t_int)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('{:28s} {:8.1f} KB  {} arrays'.format(name + '.npz', os.path.getsize(path) / 1024.0, len(arrays)))
+
+
+def i32(a):
+    a = np.asarray(a)
+    assert np.abs(a).max() < 2 ** 31
+    return a.astype(np.int32)
+
+
+# --------------------------------------------------------------------------- #
+# op-level vectors: the reference's own test grids (non-profile rows)
+# --------------------------------------------------------------------------- #
+def gen_fps(T):
+    out = {}
+    grid = [(2, 3, 1024, 128, True), (2, 2, 1024, 128, True), (3, 3, 1025, 129, True), (3, 3, 1025, 129, False)]
+    out['grid'] = np.asarray([[b, c, n, m, int(t)] for b, c, n, m, t in grid])
+    for ci, (b, c, n, m, t) in enumerate(grid):  # mvpnet/ops/tests/test_fps.py:40-62
+        np.random.seed(0)
+        pts = np.random.rand(b, c, n) if t else np.random.rand(b, n, c)
+        out['c{}_points'.format(ci)] = pts
+        out['c{}_index_f64'.format(ci)] = i32(T['fps'].farthest_point_sample_np(pts, m, transpose=t))
+        out['c{}_index_f32'.format(ci)] = i32(T['fps'].farthest_point_sample_np(pts.astype(np.float32), m, transpose=t))
+    # edge cases the reference does not test, fp32, (B,N,3) layout
+    rs = np.random.RandomState(11)
+    base = rs.rand(1, 600, 3).astype(np.float32)
+    dup = np.concatenate([base, base[:, rs.randint(600, size=424)]], 1)          # padded by duplication
+    lattice = (np.round(rs.rand(2, 1024, 3) * 50) / 50).astype(np.float32)        # 2 cm lattice: exact ties
+    same = np.full((1, 128, 3), 0.25, np.float32)                                 # all coincident
+    for name, pts, m in [('dup', dup, 256), ('lattice', lattice, 200), ('same', same, 16), ('full', base[:, :97], 97)]:
+        out['e_{}_points'.format(name)] = pts
+        out['e_{}_index'.format(name)] = i32(T['fps'].farthest_point_sample_np(pts, m, transpose=False))
+    save('ops_fps', **out)
+
+
+def gen_ball_query(T):
+    out = {}
+    grid = [(2, 64, 128, 0.1, 32, True), (3, 65, 129, 0.1, 32, True), (3, 65, 129, 10.0, 32, True), (3, 65, 129, 0.1, 32, False)]
+    out['grid'] = np.asarray([[b, n1, n2, r, k, int(t)] for b, n1, n2, r, k, t in grid], np.float64)
+    for ci, (b, n1, n2, r, k, t) in enumerate(grid):  # mvpnet/ops/tests/test_ball_query.py:71-98
+        np.random.seed(0)
+        if t:
+            key = np.random.randn(b, 3, n2)
+            query = np.array([p[:, np.random.choice(n2, n1, replace=False)] for p in key])
+        else:
+            key = np.random.randn(b, n2, 3)
+            query = np.array([p[np.random.choice(n2, n1, replace=False)] for p in key])
+        out['c{}_key'.format(ci)], out['c{}_query'.format(ci)] = key, query
+        idx, dist = T['bq'].ball_query_distance_np(query, key, r, k, transpose=t)
+        assert np.array_equal(idx, T['bq'].ball_query_np(query, key, r, k, transpose=t))
+        out['c{}_index_f64'.format(ci)], out['c{}_dist_f64'.format(ci)] = i32(idx), dist
+        idx, dist = T['bq'].ball_query_distance_np(query.astype(np.float32), key.astype(np.float32), r, k, transpose=t)
+        out['c{}_index_f32'.format(ci)], out['c{}_dist_f32'.format(ci)] = i32(idx), dist
+    # denser fp32 case where many rows overflow K (order-sensitive) -- (B,N,3) layout
+    rs = np.random.RandomState(5)
+    key = rs.rand(2, 2048, 3).astype(np.float32)
+    query = np.stack([key[b, rs.choice(2048, 256, replace=False)] for b in range(2)])
+    for r in (0.1, 0.2):
+        idx, dist = T['bq'].ball_query_distance_np(query, key, r, 32, transpose=False)
+        out['dense_r{}_index'.format(int(r * 10))], out['dense_r{}_dist'.format(int(r * 10))] = i32(idx), dist
+    out['dense_key'], out['dense_query'] = key, query
+    save('ops_ball_query', **out)
+
+
+def gen_knn(T):
+    out = {}
+    grid = [(2, 512, 1024, True), (3, 513, 1025, True), (3, 513, 1025, False), (3, 31, 63, True)]
+    out['grid'] = np.asarray([[b, n1, n2, int(t)] for b, n1, n2, t in grid])
+    for ci, (b, n1, n2, t) in enumerate(grid):  # mvpnet/ops/tests/test_knn_distance.py:35-54
+        np.random.seed(0)
+        if t:
+            q, k = np.random.randn(b, 3, n1).astype(np.float32), np.random.randn(b, 3, n2).astype(np.float32)
+        else:
+            q, k = np.random.randn(b, n1, 3).astype(np.float32), np.random.randn(b, n2, 3).astype(np.float32)
+        idx, dist = T['knn'].knn_distance_torch(torch.tensor(q), torch.tensor(k), 3, transpose=t)
+        out['c{}_query'.format(ci)], out['c{}_key'.format(ci)] = q, k
+        out['c{}_index'.format(ci)], out['c{}_dist'.format(ci)] = i32(idx.numpy()), dist.numpy()
+    save('ops_knn_distance', **out)
+
+
+def gen_group_points(T):
+    from mvpnet.ops.group_points import group_points
+    out = {}
+    grid = [(2, 3, 512, 128, 32), (5, 64, 513, 129, 33)]
+    out['grid'] = np.asarray(grid)
+    for ci, (b, c, n1, n2, k) in enumerate(grid):  # mvpnet/ops/tests/test_group_points.py:22-44
+        torch.manual_seed(0)
+        feature = torch.randn(b, c, n1)
+        index = torch.randint(0, n1, [b, n2, k]).long()
+        f = feature.clone().requires_grad_(True)
+        o = T['gp'].group_points_torch(f, index)
+        o.backward(torch.ones_like(o))
+        f2 = feature.clone().requires_grad_(True)
+        o2 = group_points(f2, index)              # reference wrapper over the stub: must agree
+        o2.backward(torch.ones_like(o2))
+        assert torch.equal(o, o2) and torch.allclose(f.grad, f2.grad)
+        out['c{}_feature'.format(ci)], out['c{}_index'.format(ci)] = feature.numpy(), i32(index.numpy())
+        out['c{}_grad_ones'.format(ci)] = f.grad.numpy()   # forward output is a pure gather: recomputed in the test
+        if ci == 0:  # random cotangent only for the small case (keeps the fixture small)
+            g = torch.randn(b, c, n2, k)
+            f3 = feature.clone().requires_grad_(True)
+            T['gp'].group_points_torch(f3, index).backward(g)
+            out['c{}_cotangent'.format(ci)], out['c{}_grad_rand'.format(ci)] = g.numpy(), f3.grad.numpy()
+    save('ops_group_points', **out)
+
+
+def gen_interpolate(T):
+    out = {}
+    grid = [(2, 64, 128, 512), (3, 65, 129, 513)]
+    out['grid'] = np.asarray(grid)
+    for ci, (b, c, n1, n2) in enumerate(grid):  # mvpnet/ops/tests/test_interpolate.py:31-64
+        torch.manual_seed(0)
+        feature = torch.randn(b, c, n1).double()
+        index = torch.randint(0, n1, [b, n2, 3]).long()
+        weight = torch.rand(b, n2, 3).double()
+        weight = weight / weight.sum(dim=2, keepdim=True)
+        f = feature.clone().requires_grad_(True)
+        o = T['interp'].feature_interpolate_torch(f, index, weight)
+        o.backward(torch.ones_like(o))
+        out['c{}_feature'.format(ci)], out['c{}_index'.format(ci)] = feature.numpy(), i32(index.numpy())
+        out['c{}_weight'.format(ci)], out['c{}_out'.format(ci)] = weight.numpy(), o.detach().numpy()
+        out['c{}_grad_ones'.format(ci)] = f.grad.numpy()
+    save('ops_interpolate', **out)
+
+
+# --------------------------------------------------------------------------- #
+# lifting vectors: re-typed from mvpnet/data/scannet_2d3d.py (see module doc)
+# --------------------------------------------------------------------------- #
+def reference_lifting(chunk, k):
+    """depth2xyz (:33-39) + :255-313 on one synthetic chunk.  Returns image_xyz (nv,h,w,3) f32,
+    image_mask (nv,h,w) bool, knn_indices (N,k) int64 -- exactly the dict entries of :315-320."""
+    from sklearn.neighbors import NearestNeighbors
+    cam_matrix = chunk['cam_matrix']
+    nv, h, w = chunk['depth_mm'].shape
+    chunk_box = chunk['chunk_box']
+    image_xyz_list, image_mask_list, image_ind_list = [], [], []
+    for i in range(nv):
+        depth = np.asarray(chunk['depth_mm'][i], dtype=np.float32) / 1000.
+        v, u = np.indices(depth.shape)
+        u, v = u.ravel(), v.ravel()
+        uv1_points = np.stack([u, v, np.ones_like(u)], axis=1)
+        image_xyz = (np.linalg.inv(cam_matrix[:3, :3]).dot(uv1_points.T) * depth.ravel()).T
+        image_mask = image_xyz[:, 2] > 0
+        pose = chunk['pose'][i]
+        image_xyz = np.matmul(image_xyz, pose[:3, :3].T) + pose[:3, 3]
+        margin = 0.1
+        in_chunk_mask = np.logical_and.reduce(
+            (image_xyz[:, 0] > chunk_box[0] - margin, image_xyz[:, 0] < chunk_box[2] + margin,
+             image_xyz[:, 1] > chunk_box[1] - margin, image_xyz[:, 1] < chunk_box[3] + margin))
+        image_mask = np.logical_and(image_mask, in_chunk_mask)
+        image_xyz_list.append(image_xyz.reshape(h, w, 3))
+        image_mask_list.append(image_mask.reshape(h, w))
+        image_ind_list.append(np.nonzero(image_mask)[0] + i * h * w)
+    image_xyz_valid = np.concatenate([x[m] for x, m in zip(image_xyz_list, image_mask_list)], axis=0)
+    image_ind_all = np.hstack(image_ind_list)
+    nbrs = NearestNeighbors(n_neighbors=k, algorithm='ball_tree').fit(image_xyz_valid)
+    _, knn_indices = nbrs.kneighbors(chunk['points'])
+    knn_indices = image_ind_all[knn_indices]
+    return (np.stack(image_xyz_list, 0).astype(np.float32), np.stack(image_mask_list, 0).astype(np.bool_),
+            knn_indices.astype(np.int64))
+
+
+def digest(chunk):
+    hsh = hashlib.sha256()
+    for key in sorted(chunk):
+        if isinstance(chunk[key], np.ndarray):
+            hsh.update(np.ascontiguousarray(chunk[key]).tobytes())
+    return np.frombuffer(hsh.digest(), np.uint8).copy()
+
+
+def gen_lifting():
+    out = {}
+    cases = [('small', dict(chunk_id=3, nb_pts=1024, nv=2, h=30, w=40, channels=8), 3),
+             ('k5', dict(chunk_id=4, nb_pts=2048, nv=3, h=60, w=80, channels=8), 5),
+             ('full', dict(chunk_id=0, nb_pts=8192, nv=3, h=120, w=160, channels=64), 3)]
+    for name, kw, k in cases:
+        chunk = make_chunk(with_feature=False, **kw)
+        xyz, mask, knn = reference_lifting(chunk, k)
+        out[name + '_kwargs'] = np.asarray(json.dumps(kw))
+        out[name + '_k'] = np.asarray(k)
+        out[name + '_input_sha256'] = digest(chunk)
+        out[name + '_image_xyz'] = xyz
+        out[name + '_image_mask'] = np.packbits(mask)
+        out[name + '_knn_indices'] = i32(knn)
+    save('lifting', **out)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# module-level vectors (reference nn.Modules, seeded weights from weights.py)
+# --------------------------------------------------------------------------- #
+class StubNet2D(torch.nn.Module):
+    """Stand-in for UNetResNet34 (out of scope): hands back a supplied (b*nv, c, h, w) feature map."""
+
+    def __init__(self):
+        super().__init__()
+        self.feature = None
+
+    def forward(self, data):
+        return {'feature': self.feature}
+
+
+def hook_outputs(model):
+    rec = collections.OrderedDict()
+
+    def mk(name):
+        def fn(mod, inp, outp):
+            rec[name] = outp
+        return fn
+    for i, m in enumerate(model.sa_modules):
+        m.register_forward_hook(mk('sa{}'.format(i)))
+    for i, m in enumerate(model.fp_modules):
+        m.register_forward_hook(mk('fp{}'.format(i)))
+    return rec
+
+
+def pn2_geometry(xyz, num_centroids, radius, max_neighbors):
+    """FPS / ball-query / 3-NN index chains exactly as SetAbstraction / FeatureInterpolator call them
+    (mvpnet/models/pn2/modules.py:100-102, 22, 137)."""
+    from mvpnet.ops.fps import farthest_point_sample
+    from mvpnet.ops.ball_query import ball_query
+    from mvpnet.ops.knn_distance import knn_distance
+    from common.nn.functional import batch_index_select
+    out, xyzs = {}, [xyz]
+    for i, (m, r, k) in enumerate(zip(num_centroids, radius, max_neighbors)):
+        idx = farthest_point_sample(xyzs[-1], m)
+        new_xyz = batch_index_select(xyzs[-1], idx, dim=2)
+        out['fps{}'.format(i)] = i32(idx.numpy())
+        out['ball{}'.format(i)] = i32(ball_query(new_xyz, xyzs[-1], r, k).numpy())
+        xyzs.append(new_xyz)
+    for i in range(len(num_centroids)):
+        idx, dist = knn_distance(xyzs[-2 - i], xyzs[-1 - i], 3)
+        out['knn{}'.format(i)], out['knn_dist{}'.format(i)] = i32(idx.numpy()), dist.numpy()
+    return out
+
+
+def gen_modules(lifting):
+    from mvpnet.models.pn2.pn2ssg import PN2SSG
+    from mvpnet.models.mvpnet_3d import MVPNet3D, FeatureAggregation
+    from mvpnet.models.loss import SegLoss
+
+    log_w = np.loadtxt(os.path.join(REF, 'mvpnet/data/meta_files/scannetv2_train_3d_log_weights_20_classes.txt'), dtype=np.float32)
+
+    # ---- (1) PN2SSG baseline (in_channels=0), small ------------------------
+    out = {}
+    cfg = dict(num_centroids=(256, 64, 16, 4), radius=(0.1, 0.2, 0.4, 0.8), max_neighbors=(32, 32, 32, 32))
+    chunks = [make_chunk(10 + b, nb_pts=1024, nv=2, h=30, w=40, channels=8, with_feature=False) for b in range(2)]
+    points = torch.from_numpy(np.stack([c['points'].T for c in chunks]))  # (2,3,1024)
+    label = torch.from_numpy(np.stack([c['seg_label'] for c in chunks]))
+    net = PN2SSG(0, 20, dropout_prob=0.0, **cfg)
+    shapes = load_into(net, seed=101)
+    out['state_keys'] = np.asarray(json.dumps([[k, list(v)] for k, v in shapes.items()]))
+    out.update({'geo_' + k: v for k, v in pn2_geometry(points, **cfg).items()})
+    rec = hook_outputs(net)
+    for mode in ('eval', 'train'):
+        net.train(mode == 'train')
+        net.zero_grad()
+        preds = net({'points': points})
+        for name, val in rec.items():
+            if name.startswith('sa'):
+                out['{}_{}_xyz'.format(mode, name)], out['{}_{}_feature'.format(mode, name)] = val[0].detach().numpy(), val[1].detach().numpy()
+            else:
+                out['{}_{}_feature'.format(mode, name)] = val.detach().numpy()
+        out[mode + '_seg_logit'] = preds['seg_logit'].detach().numpy()
+        loss = SegLoss(weight=torch.from_numpy(log_w))(preds, {'seg_label': label})['seg_loss']
+        out[mode + '_loss'] = loss.detach().numpy()
+        loss.backward()
+        for pname in ('sa_modules.0.mlp.0.conv.weight', 'sa_modules.3.mlp.2.bn.weight', 'fp_modules.3.mlp.0.conv.weight',
+                      'seg_logit.weight', 'seg_logit.bias'):
+            out['{}_grad_{}'.format(mode, pname)] = dict(net.named_parameters())[pname].grad.numpy().copy()
+        out[mode + '_grad_norms'] = np.asarray([p.grad.norm().item() for p in net.parameters()], np.float64)
+    out['train_running_mean_sa0_0'] = net.sa_modules[0].mlp[0].bn.running_mean.numpy().copy()
+    out['train_running_var_sa0_0'] = net.sa_modules[0].mlp[0].bn.running_var.numpy().copy()
+    out['log_weights'] = log_w
+    save('pn2ssg_small', **out)
+
+    # ---- (2) MVPNet3D (stub 2D net) small + FeatureAggregation -------------
+    out = {}
+    kw = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
+    chunks = [make_chunk(20 + b, **kw) for b in range(2)]
+    lifts = [reference_lifting(c, 3) for c in chunks]
+    points = torch.from_numpy(np.stack([c['points'].T for c in chunks]))
+    image_xyz = torch.from_numpy(np.stack([l[0] for l in lifts]))              # (b,nv,h,w,3)
+    knn = torch.from_numpy(np.stack([l[2] for l in lifts]))                     # (b,N,3)
+    feat_cl = np.stack([c['feature_2d'] for c in chunks])                       # (b,nv,h,w,c) channels-last
+    feat_nchw = torch.from_numpy(np.ascontiguousarray(np.moveaxis(feat_cl, -1, 2))).reshape(-1, 16, 30, 40)
+    label = torch.from_numpy(np.stack([c['seg_label'] for c in chunks]))
+    net2d = StubNet2D()
+    net3d = PN2SSG(64, 20, dropout_prob=0.0, **cfg)
+    model = MVPNet3D(net2d, '', net3d, in_channels=16, mlp_channels=(64, 64, 64), reduction='sum', use_relation=True)
+    shapes = load_into(model, seed=202)
+    out['state_keys'] = np.asarray(json.dumps([[k, list(v)] for k, v in shapes.items()]))
+    fa = {}
+    model.feat_aggreg.register_forward_hook(lambda m, i, o: fa.__setitem__('o', o))
+    for mode in ('eval', 'train'):
+        model.train(mode == 'train')
+        model.zero_grad()
+        net2d.feature = feat_nchw.clone().requires_grad_(True)
+        preds = model({'images': torch.zeros(2, 2, 3, 30, 40), 'image_xyz': image_xyz, 'knn_indices': knn, 'points': points})
+        out[mode + '_feature_2d3d'] = fa['o'].detach().numpy()
+        out[mode + '_seg_logit'] = preds['seg_logit'].detach().numpy()
+        loss = SegLoss(weight=torch.from_numpy(log_w))(preds, {'seg_label': label})['seg_loss']
+        out[mode + '_loss'] = loss.detach().numpy()
+        loss.backward()
+        out[mode + '_grad_feature_2d'] = net2d.feature.grad.numpy().copy()   # bwd of the lifting gather
+        out[mode + '_grad_aggr_w0'] = model.feat_aggreg.mlp[0].conv.weight.grad.numpy().copy()
+        out[mode + '_grad_norms'] = np.asarray([p.grad.norm().item() for p in model.parameters()], np.float64)
+    out['knn_indices'] = i32(knn.numpy())
+    out['image_xyz'] = image_xyz.numpy()
+    save('mvpnet3d_small', **out)
+
+    # ---- (3) full-size chunk: N=8192, 3x120x160, C=64, default PN2SSG ------
+    out = {}
+    chunk = make_chunk(0)
+    assert np.array_equal(digest({k: v for k, v in chunk.items() if k != 'feature_2d'}), lifting['full_input_sha256'])
+    xyz, mask, knn = lifting['full_image_xyz'], None, lifting['full_knn_indices'].astype(np.int64)
+    points = torch.from_numpy(chunk['points'].T[None].copy())
+    feat_nchw = torch.from_numpy(np.ascontiguousarray(np.moveaxis(chunk['feature_2d'], -1, 1)))  # (nv,c,h,w)
+    net2d = StubNet2D()
+    net3d = PN2SSG(64, 20, dropout_prob=0.0)
+    model = MVPNet3D(net2d, '', net3d, in_channels=64, mlp_channels=(64, 64, 64), reduction='sum', use_relation=True)
+    shapes = load_into(model, seed=303)
+    out['state_keys'] = np.asarray(json.dumps([[k, list(v)] for k, v in shapes.items()]))
+    geo = pn2_geometry(points, (2048, 512, 128, 32), (0.1, 0.2, 0.4, 0.8), (32, 32, 32, 32))
+    out.update({'geo_' + k: v for k, v in geo.items() if not k.startswith('knn_dist')})
+    model.feat_aggreg.register_forward_hook(lambda m, i, o: fa.__setitem__('o', o))
+    for mode in ('eval', 'train'):
+        model.train(mode == 'train')
+        net2d.feature = feat_nchw
+        with torch.no_grad():
+            preds = model({'images': torch.zeros(1, 3, 3, 120, 160), 'image_xyz': torch.from_numpy(xyz[None]),
+                           'knn_indices': torch.from_numpy(knn[None]), 'points': points})
+        out[mode + '_seg_logit'] = preds['seg_logit'].numpy()
+        out[mode + '_feature_2d3d_checksum'] = np.asarray([fa['o'].double().sum().item(), fa['o'].double().abs().sum().item()])
+    save('mvpnet3d_full', **out)
+
+
+# --------------------------------------------------------------------------- #
+# vote + train-step known answers (inline script code, re-typed: SURVEY.md sec.8c)
+# --------------------------------------------------------------------------- #
+def gen_vote_trainstep():
+    out = {}
+    rs = np.random.RandomState(9)
+    n_pts, C = 5000, 20
+    pred = np.zeros([n_pts, C], dtype=np.float32)      # mvpnet/test_mvpnet_3d.py:137-138,160-174
+    cnt = np.zeros(n_pts, dtype=np.uint8)
+    for c in range(6):
+        ind = np.sort(rs.choice(n_pts - 300, 1500, replace=False))   # last 300 points never predicted
+        logit = rs.standard_normal((1500, C)).astype(np.float32)
+        pred[ind] += logit
+        cnt[ind] += 1
+        out['chunk{}_ind'.format(c)], out['chunk{}_logit'.format(c)] = i32(ind), logit
+    mean = pred / np.maximum(cnt[:, np.newaxis], 1)
+    label = np.argmax(mean, axis=1)
+    label[np.nonzero(cnt == 0)[0]] = C
+    out['mean'], out['label'], out['count'] = mean, i32(label), cnt
+    save('vote', **out)
+
+    # train step: zero_grad -> SegLoss -> backward -> Adam(lr 2e-3) -> MultiStepLR
+    # (mvpnet/train_mvpnet_3d.py:158-180,287-288; yaml OPTIMIZER/SCHEDULER)
+    from mvpnet.models.loss import SegLoss
+    torch.manual_seed(0)
+    lin = torch.nn.Conv1d(8, 20, 1)
+    x = torch.randn(2, 8, 50)
+    y = torch.randint(0, 20, (2, 50))
+    y[0, :5] = -100
+    w = torch.rand(20) + 0.5
+    opt = torch.optim.Adam(lin.parameters(), lr=2e-3, betas=(0.9, 0.999), weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=(2, 3), gamma=0.1)
+    out = dict(w0=lin.weight.detach().numpy().copy(), b0=lin.bias.detach().numpy().copy(), x=x.numpy(), y=y.numpy(), cw=w.numpy())
+    losses = []
+    for it in range(4):
+        opt.zero_grad()
+        loss = SegLoss(weight=w)({'seg_logit': lin(x)}, {'seg_label': y})['seg_loss']
+        loss.backward()
+        opt.step()
+        sched.step()
+        losses.append(loss.item())
+    out['losses'] = np.asarray(losses)
+    out['w4'], out['b4'] = lin.weight.detach().numpy(), lin.bias.detach().numpy()
+    save('train_step', **out)
+
+
+def main():
+    T = install_reference()
+    gen_fps(T)
+    gen_ball_query(T)
+    gen_knn(T)
+    gen_group_points(T)
+    gen_interpolate(T)
+    lifting = gen_lifting()
+    gen_modules(lifting)
+    gen_vote_trainstep()
+    import sklearn
+    manifest = dict(numpy=np.__version__, torch=torch.__version__, sklearn=sklearn.__version__,
+                    reference='/root/reference (maxjaritz/mvpnet @ v0)', generator='tests/golden/make_golden.py')
+    with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
