@@ -1,0 +1,162 @@
+/*
+ * mvp_hip.h -- C ABI of libmvp_hip.so: the MI355X (gfx950) replacement for the six
+ * CUDA extensions of maxjaritz/mvpnet plus the 2D->3D lifting that the reference runs
+ * on the CPU inside its dataloader.
+ *
+ * This is the drop-in boundary.  The reference binds each op as a
+ * pybind11 module taking at::Tensor; here every entry point takes plain DEVICE pointers
+ * and sizes, an explicit HIP stream, and returns an int:
+ *     0            success (kernel(s) enqueued on `stream`; nothing is synchronised)
+ *     < 0          MVP_E* argument error, nothing was launched
+ *     > 0          hipError_t reported by the launch
+ * No entry point allocates, frees, synchronises or keeps state; all are re-entrant.
+ * All tensors are dense row-major ("contiguous") in the stated shape.
+ * Index tensors are int64 as in the reference (all reference index outputs are int64).
+ *
+ * Arithmetic contract: squared distances are
+ * (dx*dx + dy*dy) + dz*dz with every operation individually rounded in T (no FMA
+ * contraction); every tie is won by the lowest index.
+ *
+ * Reference interface each declaration replaces is cited as file:line relative to the
+ * reference checkout.
+ */
+#ifndef MVP_HIP_H_
+#define MVP_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mvp_stream_t; /* hipStream_t; NULL = the null stream */
+
+#define MVP_OK 0
+#define MVP_EINVAL (-1)       /* shape / size precondition violated (reference: CHECK_* -> RuntimeError) */
+#define MVP_EUNSUPPORTED (-2) /* valid request this build does not cover (e.g. k != 3 for knn_distance) */
+#define MVP_ENULL (-3)        /* required pointer is NULL */
+
+/* library version / build info; never fails */
+const char* mvp_version(void);
+/* human readable text for a return code of this library (static storage) */
+const char* mvp_strerror(int code);
+
+/* ---- farthest point sampling -------------------------------------------------------
+ * replaces fps_cuda.farthest_point_sample  (mvpnet/ops/cuda/fps.cpp:7-13,
+ * mvpnet/ops/cuda/fps_kernel.cu:144-180).  points (B,N,D) D in {2,3}; index (B,M).
+ * index[b,0] = 0; index[b,i] = first argmax_j min_{l<i} d2(p_j, p_index[b,l]).
+ * Preconditions (fps_kernel.cu:154-156): M > 0, N >= M. */
+int mvp_fps_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, mvp_stream_t stream);
+int mvp_fps_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, mvp_stream_t stream);
+
+/* ---- ball query ---------------------------------------------------------------------
+ * replaces ball_query_cuda.ball_query (mvpnet/ops/cuda/ball_query.cpp:7-15,
+ * ball_query_kernel.cu:147-187) and ball_query_distance_cuda.ball_query_distance
+ * (ball_query_distance.cpp:7-15, ball_query_distance_kernel.cu:150-195).
+ * query (B,N1,3), key (B,N2,3) -> index (B,N1,K) [, distance (B,N1,K)].
+ * radius is a C float at the boundary and is squared in T (ball_query_kernel.cu:45,73).
+ * First K keys in index order with d2 < r2 (strict); fewer than K hits: remaining index
+ * slots repeat the first hit, remaining distance slots are -1; no hit: whole row -1. */
+int mvp_ball_query_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float radius,
+                       int64_t K, int64_t* index, mvp_stream_t stream);
+int mvp_ball_query_f64(const double* query, const double* key, int64_t B, int64_t N1, int64_t N2, float radius,
+                       int64_t K, int64_t* index, mvp_stream_t stream);
+int mvp_ball_query_distance_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float radius,
+                                int64_t K, int64_t* index, float* distance, mvp_stream_t stream);
+int mvp_ball_query_distance_f64(const double* query, const double* key, int64_t B, int64_t N1, int64_t N2,
+                                float radius, int64_t K, int64_t* index, double* distance, mvp_stream_t stream);
+
+/* ---- group_points -------------------------------------------------------------------
+ * replaces group_points_cuda.group_points_forward / _backward
+ * (mvpnet/ops/cuda/group_points.cpp:7-19, group_points_kernel.cu:25-47, 99-145).
+ * forward : input (B,C,N1), index (B,N2,K) -> out (B,C,N2,K), out[b,c,m,k] = input[b,c,index[b,m,k]]
+ * backward: grad_out (B,C,N2,K), index -> grad_in (B,C,N1) (zero-filled here, then scatter-added).
+ * Index values must lie in [0,N1); out-of-range values are skipped (forward writes 0). */
+int mvp_group_points_forward_f32(const float* input, const int64_t* index, int64_t B, int64_t C, int64_t N1,
+                                 int64_t N2, int64_t K, float* out, mvp_stream_t stream);
+int mvp_group_points_forward_f64(const double* input, const int64_t* index, int64_t B, int64_t C, int64_t N1,
+                                 int64_t N2, int64_t K, double* out, mvp_stream_t stream);
+int mvp_group_points_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t C, int64_t N1,
+                                  int64_t N2, int64_t K, float* grad_in, mvp_stream_t stream);
+int mvp_group_points_backward_f64(const double* grad_out, const int64_t* index, int64_t B, int64_t C, int64_t N1,
+                                  int64_t N2, int64_t K, double* grad_in, mvp_stream_t stream);
+
+/* ---- 3-NN with squared distances ------------------------------------------------------
+ * replaces knn_distance_cuda.knn_distance (mvpnet/ops/cuda/knn_distance.cpp:8-15,
+ * knn_distance_kernel.cu:154-196).  query (B,N1,3), key (B,N2,3) -> index (B,N1,3),
+ * distance (B,N1,3) ascending, SQUARED; k must be 3 (knn_distance_kernel.cu:171) and
+ * N2 >= k (:167-170). */
+int mvp_knn_distance_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, int64_t k,
+                         int64_t* index, float* distance, mvp_stream_t stream);
+int mvp_knn_distance_f64(const double* query, const double* key, int64_t B, int64_t N1, int64_t N2, int64_t k,
+                         int64_t* index, double* distance, mvp_stream_t stream);
+
+/* ---- feature interpolation (K = 3) ----------------------------------------------------
+ * replaces interpolate_cuda.interpolate_forward / _backward
+ * (mvpnet/ops/cuda/interpolate.cpp:8-22, interpolate_kernel.cu:78-124, 184-230).
+ * forward : input (B,C,N1), index (B,N2,3), weight (B,N2,3) -> out (B,C,N2)
+ * backward: grad_out (B,C,N2) -> grad_in (B,C,N1) (zero-filled here; gradient to input only). */
+int mvp_interpolate_forward_f32(const float* input, const int64_t* index, const float* weight, int64_t B, int64_t C,
+                                int64_t N1, int64_t N2, float* out, mvp_stream_t stream);
+int mvp_interpolate_forward_f64(const double* input, const int64_t* index, const double* weight, int64_t B,
+                                int64_t C, int64_t N1, int64_t N2, double* out, mvp_stream_t stream);
+int mvp_interpolate_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B,
+                                 int64_t C, int64_t N1, int64_t N2, float* grad_in, mvp_stream_t stream);
+int mvp_interpolate_backward_f64(const double* grad_out, const int64_t* index, const double* weight, int64_t B,
+                                 int64_t C, int64_t N1, int64_t N2, double* grad_in, mvp_stream_t stream);
+
+/* ---- 2D -> 3D lifting (NEW on the device; the reference does this in dataloader workers) ----
+ * un-projection: replaces depth2xyz + pose + masks of ScanNet2D3DChunks.get_rgbd_data
+ * (mvpnet/data/scannet_2d3d.py:33-39, 255-281).
+ *   depth   (B,nv,h,w)  metres float32, or millimetres uint16 (= PNG/1000, :255)
+ *   kinv    (B,nv,3,3)  float32 inverse intrinsics (np.linalg.inv(cam_matrix[:3,:3]), :38)
+ *   pose    (B,nv,4,4)  float32 camera-to-world
+ *   box     (B,4)       float32 (x_min,y_min,x_max,y_max) ALREADY expanded by the 0.1 m margin, or NULL
+ *   -> image_xyz (B,nv,h,w,3) float32 (float64 math rounded once, like :317), mask (B,nv,h,w) uint8
+ *   pixel (row v, col u): X_w = R.(Kinv.[u,v,1]^T * depth) + t;  mask = z_cam > 0 && inside box (x,y). */
+int mvp_unproject_f32(const float* depth_m, const float* kinv, const float* pose, const float* box, int64_t B,
+                      int64_t nv, int64_t h, int64_t w, float* image_xyz, uint8_t* mask, mvp_stream_t stream);
+int mvp_unproject_u16(const uint16_t* depth_mm, const float* kinv, const float* pose, const float* box, int64_t B,
+                      int64_t nv, int64_t h, int64_t w, float* image_xyz, uint8_t* mask, mvp_stream_t stream);
+
+/* pixel k-NN: replaces NearestNeighbors(k,'ball_tree').fit(valid).kneighbors(points) + remap
+ * (mvpnet/data/scannet_2d3d.py:297-313).  Exact k nearest VALID pixels per chunk point,
+ * ascending, ties -> lowest flat pixel id  view*h*w + row*w + col.
+ *   image_xyz (B,P,3) float32, mask (B,P) uint8, points (B,N,3) float32, 1 <= k <= 8
+ *   -> index (B,N,k) int64 [, distance (B,N,k) float32 squared, may be NULL]; missing -> -1.
+ * _bruteforce: O(N*P) scan, needs no camera model.
+ * _projective: same result; uses the pin-hole structure (cam (B,nv,3,3) forward intrinsics,
+ *   pose (B,nv,4,4)) to search an image window around each point's projection and widens it
+ *   until a conservative bound proves exactness; P = nv*h*w. */
+int mvp_pixel_knn_bruteforce_f32(const float* image_xyz, const uint8_t* mask, const float* points, int64_t B,
+                                 int64_t P, int64_t N, int64_t k, int64_t* index, float* distance,
+                                 mvp_stream_t stream);
+int mvp_pixel_knn_projective_f32(const float* image_xyz, const uint8_t* mask, const float* points, const float* cam,
+                                 const float* pose, int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N,
+                                 int64_t k, int64_t* index, float* distance, mvp_stream_t stream);
+
+/* lifting gather, channels-last: replaces the two group_points calls of MVPNet3D.forward
+ * (mvpnet/models/mvpnet_3d.py:99-109) without the transpose().contiguous() copy of :101.
+ *   feature (B,P,C) float32 (= (B,nv,h,w,C)), image_xyz (B,P,3), index (B,N,k) int64
+ *   -> gfeature (B,N,k,C), gxyz (B,N,k,3) (either output may be NULL).
+ * backward (only needed when the 2D network is trained): grad_gfeature (B,N,k,C) -> grad_feature (B,P,C),
+ * zero-filled here. */
+int mvp_lift_gather_f32(const float* feature, const float* image_xyz, const int64_t* index, int64_t B, int64_t P,
+                        int64_t C, int64_t N, int64_t k, float* gfeature, float* gxyz, mvp_stream_t stream);
+int mvp_lift_gather_backward_f32(const float* grad_gfeature, const int64_t* index, int64_t B, int64_t P, int64_t C,
+                                 int64_t N, int64_t k, float* grad_feature, mvp_stream_t stream);
+
+/* ---- chunk -> scene vote ----------------------------------------------------------------
+ * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.
+ * accumulate: logit (n,C) rows of one chunk (row stride ld, so a (C,n) tensor can be passed
+ *   transposed: element (r,c) at logit[r*ld_r + c*ld_c]); sum (n_pts,C) += , count (n_pts) int32 += 1.
+ * finish    : mean = sum / max(count,1); label = argmax (first max), count == 0 -> C. */
+int mvp_vote_accumulate_f32(const float* logit, int64_t ld_r, int64_t ld_c, const int64_t* chunk_ind, int64_t n,
+                            int64_t C, float* sum, int32_t* count, mvp_stream_t stream);
+int mvp_vote_finish_f32(const float* sum, const int32_t* count, int64_t n_pts, int64_t C, float* mean, int64_t* label,
+                        mvp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVP_HIP_H_ */

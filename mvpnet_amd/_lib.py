@@ -1,0 +1,104 @@
+"""ctypes loader of libmvp_hip.so -- the C-ABI drop-in boundary (include/mvp_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a tensor is not on the GPU
+the call raises.  PyTorch is only used for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmvp_hip.so')
+_lib = None
+
+_i64 = ctypes.c_int64
+_ptr = ctypes.c_void_p
+_f32 = ctypes.c_float
+
+# name -> argtypes (restype is always int); mirrors include/mvp_hip.h one to one
+_SIGNATURES = {
+    'mvp_fps_f32': [_ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_fps_f64': [_ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_ball_query_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr],
+    'mvp_ball_query_f64': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr],
+    'mvp_ball_query_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],
+    'mvp_ball_query_distance_f64': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],
+    'mvp_group_points_forward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_forward_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_backward_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_knn_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_knn_distance_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_interpolate_forward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_forward_f64': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_backward_f64': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_unproject_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_unproject_u16': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_pixel_knn_bruteforce_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_pixel_knn_projective_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_lift_gather_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_lift_gather_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
+}
+EXPORTS = ['mvp_version', 'mvp_strerror'] + sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libmvp_hip.so once.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libmvp_hip.so is not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                               'or `make -C mvpnet_amd/csrc` ({})'.format(LIB_PATH))
+        handle = ctypes.CDLL(LIB_PATH)
+        handle.mvp_version.restype = ctypes.c_char_p
+        handle.mvp_strerror.restype = ctypes.c_char_p
+        handle.mvp_strerror.argtypes = [ctypes.c_int]
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError('{} failed: {} (code {})'.format(what, lib().mvp_strerror(code).decode(), code))
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    """CHECK_INPUT of the reference (fps_kernel.cu:12-14): CUDA/HIP tensor + contiguous."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('mvpnet_amd ops run on the GPU only (got a {} tensor); there is no CPU fallback'.format(t.device))
+        if not t.is_contiguous():
+            raise RuntimeError('tensor must be contiguous')
+
+
+def suffix(t):
+    if t.dtype == torch.float32:
+        return 'f32'
+    if t.dtype == torch.float64:
+        return 'f64'
+    raise RuntimeError('expected a float32 or float64 tensor, got {}'.format(t.dtype))
+
+
+def call(name, tensor_for_device, *args):
+    """Invoke `name(*args, stream)` on the current stream of tensor_for_device's device."""
+    with torch.cuda.device(tensor_for_device.device):
+        code = getattr(lib(), name)(*args, stream_of(tensor_for_device))
+    check(code, name)

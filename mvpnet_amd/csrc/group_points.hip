@@ -1,0 +1,89 @@
+// group_points.hip -- channel-major gather / scatter-add for gfx950.
+//
+// Replaces GroupPointsForward (ATen expand+gather, reference:
+// mvpnet/ops/cuda/group_points_kernel.cu:25-47) and GroupPointsBackwardKernel (:50-89).
+// This is the reference-LAYOUT op ((B,C,N) in, (B,C,M,K) out) kept for drop-in parity; the
+// fused channels-last path (lifting.hip, sa_fused.hip) is what the model pipeline uses.
+// Mapping: one lane per (m,k) element, looping over a slice of channels -- the int64 index
+// is read once and reused for every channel, stores are coalesced along (m,k), and the
+// scattered 4-byte reads stay inside one 4*N1-byte channel row (L1/L2 resident).
+#include "common.h"
+
+namespace {
+
+constexpr int kGPThreads = 256;
+constexpr int kGPChanPerBlock = 8;
+
+template <typename T>
+__global__ __launch_bounds__(kGPThreads) void group_fwd_kernel(const T* __restrict__ in,
+                                                               const int64_t* __restrict__ idx, int C, int N1,
+                                                               int64_t E /* N2*K */, T* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int64_t e = (int64_t)blockIdx.x * kGPThreads + threadIdx.x;
+  if (e >= E) return;
+  const int64_t j = idx[(size_t)b * E + e];
+  const bool ok = j >= 0 && j < N1;
+  const int c0 = blockIdx.y * kGPChanPerBlock;
+  const int c1 = min(C, c0 + kGPChanPerBlock);
+  const T* ip = in + ((size_t)b * C + c0) * N1;
+  T* op = out + ((size_t)b * C + c0) * E + e;
+  for (int c = c0; c < c1; ++c, ip += N1, op += E) *op = ok ? ip[j] : T(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGPThreads) void group_bwd_kernel(const T* __restrict__ gout,
+                                                               const int64_t* __restrict__ idx, int C, int N1,
+                                                               int64_t E, T* __restrict__ gin) {
+  const int b = blockIdx.z;
+  const int64_t e = (int64_t)blockIdx.x * kGPThreads + threadIdx.x;
+  if (e >= E) return;
+  const int64_t j = idx[(size_t)b * E + e];
+  if (j < 0 || j >= N1) return;
+  const int c0 = blockIdx.y * kGPChanPerBlock;
+  const int c1 = min(C, c0 + kGPChanPerBlock);
+  const T* gp = gout + ((size_t)b * C + c0) * E + e;
+  T* ip = gin + ((size_t)b * C + c0) * N1 + j;
+  for (int c = c0; c < c1; ++c, gp += E, ip += N1) atomicAdd(ip, *gp);  // HW fp atomics (-munsafe-fp-atomics)
+}
+
+template <typename T, bool BWD>
+int group_entry(const T* a, const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, T* o,
+                mvp_stream_t stream) {
+  MVP_NONNULL(a);
+  MVP_NONNULL(index);
+  MVP_NONNULL(o);
+  MVP_REQUIRE(B >= 0 && C >= 0 && N1 > 0 && N2 >= 0 && K >= 0);
+  MVP_REQUIRE(B < 65536 && C < (1ll << 31) && N1 < (1ll << 31));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (BWD) {
+    hipError_t e = hipMemsetAsync(o, 0, sizeof(T) * (size_t)(B * C * N1), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t E = N2 * K;
+  if (B == 0 || C == 0 || E == 0) return MVP_OK;
+  dim3 grid((unsigned)cdiv(E, kGPThreads), (unsigned)cdiv(C, kGPChanPerBlock), (unsigned)B);
+  if (BWD)
+    hipLaunchKernelGGL(group_bwd_kernel<T>, grid, dim3(kGPThreads), 0, s, a, index, (int)C, (int)N1, E, o);
+  else
+    hipLaunchKernelGGL(group_fwd_kernel<T>, grid, dim3(kGPThreads), 0, s, a, index, (int)C, (int)N1, E, o);
+  return mvp_launch_status();
+}
+
+}  // namespace
+
+MVP_API int mvp_group_points_forward_f32(const float* input, const int64_t* index, int64_t B, int64_t C, int64_t N1,
+                                         int64_t N2, int64_t K, float* out, mvp_stream_t stream) {
+  return group_entry<float, false>(input, index, B, C, N1, N2, K, out, stream);
+}
+MVP_API int mvp_group_points_forward_f64(const double* input, const int64_t* index, int64_t B, int64_t C, int64_t N1,
+                                         int64_t N2, int64_t K, double* out, mvp_stream_t stream) {
+  return group_entry<double, false>(input, index, B, C, N1, N2, K, out, stream);
+}
+MVP_API int mvp_group_points_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t C,
+                                          int64_t N1, int64_t N2, int64_t K, float* grad_in, mvp_stream_t stream) {
+  return group_entry<float, true>(grad_out, index, B, C, N1, N2, K, grad_in, stream);
+}
+MVP_API int mvp_group_points_backward_f64(const double* grad_out, const int64_t* index, int64_t B, int64_t C,
+                                          int64_t N1, int64_t N2, int64_t K, double* grad_in, mvp_stream_t stream) {
+  return group_entry<double, true>(grad_out, index, B, C, N1, N2, K, grad_in, stream);
+}

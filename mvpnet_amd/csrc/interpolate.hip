@@ -1,0 +1,100 @@
+// interpolate.hip -- 3-neighbour weighted feature interpolation for gfx950.
+//
+// Replaces InterpolateForwardKernel / InterpolateBackwardKernel (reference:
+// mvpnet/ops/cuda/interpolate_kernel.cu:25-68, 131-174).  Reference layout ((B,C,N1) in,
+// (B,C,N2) out).  One lane per query point n, looping over a slice of channels: the three
+// (index, weight) pairs are loaded once and reused for every channel; stores are coalesced
+// along n.  out = (f[i0]*w0 + f[i1]*w1) + f[i2]*w2, each op rounded once.
+#include "common.h"
+
+namespace {
+
+constexpr int kIPThreads = 256;
+constexpr int kIPChanPerBlock = 16;
+
+template <typename T>
+__global__ __launch_bounds__(kIPThreads) void interp_fwd_kernel(const T* __restrict__ in,
+                                                                const int64_t* __restrict__ idx,
+                                                                const T* __restrict__ w, int C, int N1, int N2,
+                                                                T* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int n = blockIdx.x * kIPThreads + threadIdx.x;
+  if (n >= N2) return;
+  const int64_t* ip = idx + ((size_t)b * N2 + n) * 3;
+  const T* wp = w + ((size_t)b * N2 + n) * 3;
+  const int64_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+  const T w0 = wp[0], w1 = wp[1], w2 = wp[2];
+  const bool ok = i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1;
+  const int c0 = blockIdx.y * kIPChanPerBlock;
+  const int c1 = min(C, c0 + kIPChanPerBlock);
+  const T* fp = in + ((size_t)b * C + c0) * N1;
+  T* op = out + ((size_t)b * C + c0) * N2 + n;
+  for (int c = c0; c < c1; ++c, fp += N1, op += N2) *op = ok ? (fp[i0] * w0 + fp[i1] * w1) + fp[i2] * w2 : T(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kIPThreads) void interp_bwd_kernel(const T* __restrict__ gout,
+                                                                const int64_t* __restrict__ idx,
+                                                                const T* __restrict__ w, int C, int N1, int N2,
+                                                                T* __restrict__ gin) {
+  const int b = blockIdx.z;
+  const int n = blockIdx.x * kIPThreads + threadIdx.x;
+  if (n >= N2) return;
+  const int64_t* ip = idx + ((size_t)b * N2 + n) * 3;
+  const T* wp = w + ((size_t)b * N2 + n) * 3;
+  const int64_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+  const T w0 = wp[0], w1 = wp[1], w2 = wp[2];
+  if (!(i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1)) return;
+  const int c0 = blockIdx.y * kIPChanPerBlock;
+  const int c1 = min(C, c0 + kIPChanPerBlock);
+  const T* gp = gout + ((size_t)b * C + c0) * N2 + n;
+  T* fp = gin + ((size_t)b * C + c0) * N1;
+  for (int c = c0; c < c1; ++c, gp += N2, fp += N1) {
+    const T g = *gp;
+    atomicAdd(fp + i0, g * w0);
+    atomicAdd(fp + i1, g * w1);
+    atomicAdd(fp + i2, g * w2);
+  }
+}
+
+template <typename T, bool BWD>
+int interp_entry(const T* a, const int64_t* index, const T* weight, int64_t B, int64_t C, int64_t N1, int64_t N2,
+                 T* o, mvp_stream_t stream) {
+  MVP_NONNULL(a);
+  MVP_NONNULL(index);
+  MVP_NONNULL(weight);
+  MVP_NONNULL(o);
+  MVP_REQUIRE(B >= 0 && C >= 0 && N1 > 0 && N2 >= 0);
+  MVP_REQUIRE(B < 65536 && C < (1ll << 31) && N1 < (1ll << 31) && N2 < (1ll << 31));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (BWD) {
+    hipError_t e = hipMemsetAsync(o, 0, sizeof(T) * (size_t)(B * C * N1), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (B == 0 || C == 0 || N2 == 0) return MVP_OK;
+  dim3 grid((unsigned)cdiv(N2, kIPThreads), (unsigned)cdiv(C, kIPChanPerBlock), (unsigned)B);
+  if (BWD)
+    hipLaunchKernelGGL(interp_bwd_kernel<T>, grid, dim3(kIPThreads), 0, s, a, index, weight, (int)C, (int)N1, (int)N2, o);
+  else
+    hipLaunchKernelGGL(interp_fwd_kernel<T>, grid, dim3(kIPThreads), 0, s, a, index, weight, (int)C, (int)N1, (int)N2, o);
+  return mvp_launch_status();
+}
+
+}  // namespace
+
+MVP_API int mvp_interpolate_forward_f32(const float* input, const int64_t* index, const float* weight, int64_t B,
+                                        int64_t C, int64_t N1, int64_t N2, float* out, mvp_stream_t stream) {
+  return interp_entry<float, false>(input, index, weight, B, C, N1, N2, out, stream);
+}
+MVP_API int mvp_interpolate_forward_f64(const double* input, const int64_t* index, const double* weight, int64_t B,
+                                        int64_t C, int64_t N1, int64_t N2, double* out, mvp_stream_t stream) {
+  return interp_entry<double, false>(input, index, weight, B, C, N1, N2, out, stream);
+}
+MVP_API int mvp_interpolate_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B,
+                                         int64_t C, int64_t N1, int64_t N2, float* grad_in, mvp_stream_t stream) {
+  return interp_entry<float, true>(grad_out, index, weight, B, C, N1, N2, grad_in, stream);
+}
+MVP_API int mvp_interpolate_backward_f64(const double* grad_out, const int64_t* index, const double* weight, int64_t B,
+                                         int64_t C, int64_t N1, int64_t N2, double* grad_in, mvp_stream_t stream) {
+  return interp_entry<double, true>(grad_out, index, weight, B, C, N1, N2, grad_in, stream);
+}

@@ -1,0 +1,35 @@
+"""interpolate_cuda: reference mvpnet/ops/cuda/interpolate.cpp:8-22."""
+import torch
+
+from .. import _lib as L
+
+
+def _check(x, index, weight):
+    if not (x.is_cuda and index.is_cuda and weight.is_cuda):
+        raise RuntimeError('mvpnet_amd ops run on the GPU only; there is no CPU fallback')
+    if x.dim() != 3 or index.dim() != 3 or weight.shape != index.shape or index.size(2) != 3:
+        raise RuntimeError('interpolate: bad shapes')
+    if x.size(0) != index.size(0) or index.dtype != torch.int64 or weight.dtype != x.dtype:
+        raise RuntimeError('interpolate: bad batch size or dtypes')
+
+
+def interpolate_forward(input, index, weight):
+    """input (B,C,M), index (B,N,3), weight (B,N,3) -> (B,C,N)  (interpolate_kernel.cu:78-124)."""
+    _check(input, index, weight)
+    input, index, weight = input.contiguous(), index.contiguous(), weight.contiguous()
+    B, C, M = input.shape
+    N = index.size(1)
+    out = torch.empty((B, C, N), dtype=input.dtype, device=input.device)
+    L.call('mvp_interpolate_forward_' + L.suffix(input), input, L.ptr(input), L.ptr(index), L.ptr(weight), B, C, M, N, L.ptr(out))
+    return out
+
+
+def interpolate_backward(grad_output, index, weight, num_inst):
+    """grad_output (B,C,N) -> grad_input (B,C,num_inst)  (interpolate_kernel.cu:184-230)."""
+    _check(grad_output, index, weight)
+    grad_output, index, weight = grad_output.contiguous(), index.contiguous(), weight.contiguous()
+    B, C, N = grad_output.shape
+    grad_input = torch.empty((B, C, int(num_inst)), dtype=grad_output.dtype, device=grad_output.device)
+    L.call('mvp_interpolate_backward_' + L.suffix(grad_output), grad_output, L.ptr(grad_output), L.ptr(index),
+           L.ptr(weight), B, C, int(num_inst), N, L.ptr(grad_input))
+    return grad_input

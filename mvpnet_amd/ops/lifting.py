@@ -1,0 +1,98 @@
+"""2D->3D lifting ops on the device (new: the reference does these in CPU dataloader workers,
+mvpnet/data/scannet_2d3d.py:33-39,254-313, and gathers channel-major in
+mvpnet/models/mvpnet_3d.py:99-109)."""
+import torch
+from torch.autograd.function import once_differentiable
+
+from .. import _lib as L
+
+
+def unproject(depth, kinv, pose, box=None):
+    """depth (B,nv,h,w) float32 metres or int16/uint16 millimetres (raw PNG values),
+    kinv (B,nv,3,3) = inv(cam_matrix[:3,:3]), pose (B,nv,4,4) camera-to-world,
+    box (B,4) = (x0,y0,x1,y1) already expanded by the 0.1 m pixel margin, or None
+    -> image_xyz (B,nv,h,w,3) float32, image_mask (B,nv,h,w) bool."""
+    L.require_gpu(depth, kinv, pose, box)
+    B, nv, h, w = depth.shape
+    if kinv.shape != (B, nv, 3, 3) or pose.shape != (B, nv, 4, 4) or kinv.dtype != torch.float32 or pose.dtype != torch.float32:
+        raise RuntimeError('unproject: kinv must be (B,nv,3,3) float32 and pose (B,nv,4,4) float32')
+    if box is not None and (box.shape != (B, 4) or box.dtype != torch.float32):
+        raise RuntimeError('unproject: box must be (B,4) float32')
+    xyz = torch.empty((B, nv, h, w, 3), dtype=torch.float32, device=depth.device)
+    mask = torch.empty((B, nv, h, w), dtype=torch.uint8, device=depth.device)
+    if depth.dtype == torch.float32:
+        name = 'mvp_unproject_f32'
+    elif depth.dtype in (torch.int16, torch.uint16):
+        name = 'mvp_unproject_u16'  # int16 storage is reinterpreted as uint16 millimetres
+    else:
+        raise RuntimeError('unproject: depth must be float32 (m) or (u)int16 (mm)')
+    L.call(name, depth, L.ptr(depth), L.ptr(kinv), L.ptr(pose), L.ptr(box), B, nv, h, w, L.ptr(xyz), L.ptr(mask))
+    return xyz, mask.bool()
+
+
+def pixel_knn(image_xyz, image_mask, points, k, cam=None, pose=None, return_distance=False):
+    """image_xyz (B,nv,h,w,3) f32, image_mask (B,nv,h,w) bool/uint8, points (B,N,3) f32
+    -> knn_indices (B,N,k) int64 flat pixel ids view*h*w + row*w + col, nearest first.
+    With cam (B,nv,3,3 forward intrinsics) and pose the projective window search is used,
+    otherwise the O(N*P) scan; both are exact with lowest-id tie-breaking."""
+    mask = image_mask.to(torch.uint8) if image_mask.dtype != torch.uint8 else image_mask
+    L.require_gpu(image_xyz, mask, points, cam, pose)
+    if image_xyz.dtype != torch.float32 or points.dtype != torch.float32 or points.dim() != 3 or points.size(2) != 3:
+        raise RuntimeError('pixel_knn: image_xyz and points (B,N,3) must be float32')
+    B, N, _ = points.shape
+    k = int(k)
+    if not 1 <= k <= 8:
+        raise RuntimeError('pixel_knn: 1 <= k <= 8')
+    P = image_xyz.numel() // (B * 3)
+    index = torch.empty((B, N, k), dtype=torch.int64, device=points.device)
+    dist = torch.empty((B, N, k), dtype=torch.float32, device=points.device) if return_distance else None
+    if cam is not None and pose is not None:
+        _, nv, h, w, _ = image_xyz.shape
+        L.call('mvp_pixel_knn_projective_f32', points, L.ptr(image_xyz), L.ptr(mask), L.ptr(points), L.ptr(cam),
+               L.ptr(pose), B, nv, h, w, N, k, L.ptr(index), L.ptr(dist))
+    else:
+        L.call('mvp_pixel_knn_bruteforce_f32', points, L.ptr(image_xyz), L.ptr(mask), L.ptr(points), B, P, N, k,
+               L.ptr(index), L.ptr(dist))
+    return (index, dist) if return_distance else index
+
+
+class LiftGatherFunction(torch.autograd.Function):
+    """Channels-last replacement of the two group_points calls in MVPNet3D.forward
+    (mvpnet/models/mvpnet_3d.py:103,109); gradient flows to the feature map only."""
+
+    @staticmethod
+    def forward(ctx, feature, image_xyz, index):
+        L.require_gpu(feature, image_xyz, index)
+        B, N, k = index.shape
+        C = feature.size(-1)
+        P = feature.numel() // (B * C)
+        ctx.save_for_backward(index)
+        ctx.shape = tuple(feature.shape)
+        gfeat = torch.empty((B, N, k, C), dtype=torch.float32, device=feature.device)
+        gxyz = torch.empty((B, N, k, 3), dtype=torch.float32, device=feature.device)
+        L.call('mvp_lift_gather_f32', feature, L.ptr(feature), L.ptr(image_xyz), L.ptr(index), B, P, C, N, k,
+               L.ptr(gfeat), L.ptr(gxyz))
+        ctx.mark_non_differentiable(gxyz)
+        return gfeat, gxyz
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_gfeat, _grad_gxyz):
+        (index,) = ctx.saved_tensors
+        B, N, k = index.shape
+        C = ctx.shape[-1]
+        P = 1
+        for s in ctx.shape[1:-1]:
+            P *= s
+        grad = torch.empty(ctx.shape, dtype=torch.float32, device=grad_gfeat.device)
+        g = grad_gfeat.contiguous()
+        L.call('mvp_lift_gather_backward_f32', g, L.ptr(g), L.ptr(index), B, P, C, N, k, L.ptr(grad))
+        return grad, None, None
+
+
+def lift_gather(feature, image_xyz, knn_indices):
+    """feature (B,nv,h,w,C) or (B,P,C) float32 channels-last, image_xyz (B,nv,h,w,3) or (B,P,3),
+    knn_indices (B,N,k) -> gathered feature (B,N,k,C), gathered xyz (B,N,k,3)."""
+    if feature.dtype != torch.float32 or image_xyz.dtype != torch.float32 or knn_indices.dtype != torch.int64:
+        raise RuntimeError('lift_gather: float32 feature/xyz and int64 indices expected')
+    return LiftGatherFunction.apply(feature.contiguous(), image_xyz.contiguous(), knn_indices.contiguous())

@@ -1,0 +1,70 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly what
+include/mvp_hip.h declares; the host mirror refuses CPU tensors (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from tests.conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'mvp_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mvp_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_are_exported():
+    from mvpnet_amd import _lib
+    lib = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 26
+    for name in names:
+        assert hasattr(lib, name), 'libmvp_hip.so does not export ' + name
+    assert sorted(_lib.EXPORTS) == names, 'python signature table and header disagree'
+    assert b'gfx950' in lib.mvp_version()
+    assert lib.mvp_strerror(-1).startswith(b'invalid argument')
+
+
+def test_argument_errors_do_not_launch():
+    """Precondition failures return MVP_E* before any HIP call (safe without a GPU)."""
+    import ctypes
+    from mvpnet_amd import _lib
+    lib = _lib.lib()
+    dummy = ctypes.c_void_p(16)
+    assert lib.mvp_fps_f32(None, 1, 8, 3, 4, dummy, None) == -3                    # MVP_ENULL
+    assert lib.mvp_fps_f32(dummy, 1, 8, 3, 9, dummy, None) == -1                   # N >= M   (fps_kernel.cu:156)
+    assert lib.mvp_fps_f32(dummy, 1, 8, 4, 4, dummy, None) == -1                   # D in {2,3}
+    assert lib.mvp_fps_f32(dummy, 1, 40000, 3, 4, dummy, None) == -2               # > 32768 points: unsupported
+    assert lib.mvp_knn_distance_f32(dummy, dummy, 1, 4, 8, 5, dummy, dummy, None) == -2   # k must be 3 (:171)
+    assert lib.mvp_knn_distance_f32(dummy, dummy, 1, 4, 2, 3, dummy, dummy, None) == -1   # N2 >= k
+    assert lib.mvp_pixel_knn_bruteforce_f32(dummy, dummy, dummy, 1, 8, 8, 9, dummy, None, None) == -1
+
+
+@pytest.mark.parametrize('fn', ['fps', 'ball', 'knn', 'group', 'interp'])
+def test_no_cpu_fallback(fn):
+    import mvpnet_amd.ops as ops
+    x = torch.rand(1, 3, 16)
+    with pytest.raises(RuntimeError):
+        if fn == 'fps':
+            ops.farthest_point_sample(x, 4)
+        elif fn == 'ball':
+            ops.ball_query(x, x, 0.1, 4)
+        elif fn == 'knn':
+            ops.knn_distance(x, x, 3)
+        elif fn == 'group':
+            ops.group_points(x, torch.zeros(1, 2, 2, dtype=torch.long))
+        else:
+            ops.feature_interpolate(x, torch.zeros(1, 2, 3, dtype=torch.long), torch.rand(1, 2, 3))
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never route through oracle/ (tier rule 3)."""
+    pkg = os.path.join(ROOT, 'mvpnet_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+                assert 'mvp_oracle' not in text and 'c_oracle' not in text, f

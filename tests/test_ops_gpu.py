@@ -1,0 +1,400 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP kernels through the C ABI vs
+(1) the golden vectors generated from the reference and (2) the CPU oracle on seeded inputs,
+plus size-independent properties at full BASELINE sizes.  Index results are bit-exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from mvpnet_amd import _lib
+    _lib.lib()  # fail loudly if libmvp_hip.so is missing
+    return torch.device('cuda:0')
+
+
+def O():
+    from oracle import c_oracle
+    return c_oracle
+
+
+def g(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize('ci', range(4))
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_fps_reference_grid(dev, ci, dt):
+    """The reference's own grid (mvpnet/ops/tests/test_fps.py:40-62) replayed on the HIP op."""
+    from mvpnet_amd.ops import farthest_point_sample
+    gd = load_golden('ops_fps')
+    b, c, n, m, t = gd['grid'][ci]
+    pts = g(gd['c{}_points'.format(ci)], dev, torch.float64 if dt == 'f64' else torch.float32)
+    idx = farthest_point_sample(pts, int(m), transpose=bool(t))
+    assert idx.dtype == torch.int64
+    np.testing.assert_array_equal(idx.cpu().numpy(), gd['c{}_index_{}'.format(ci, dt)])
+
+
+@pytest.mark.parametrize('name', ['dup', 'lattice', 'same', 'full'])
+def test_fps_edge_cases(dev, name):
+    from mvpnet_amd.ops import farthest_point_sample
+    gd = load_golden('ops_fps')
+    exp = gd['e_{}_index'.format(name)]
+    idx = farthest_point_sample(g(gd['e_{}_points'.format(name)], dev), exp.shape[1], transpose=False)
+    np.testing.assert_array_equal(idx.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize('B,N,M,D', [(3, 8192, 2048, 3), (2, 2048, 512, 3), (5, 512, 128, 3), (7, 128, 32, 3),
+                                     (2, 1000, 333, 2), (1, 20000, 500, 3), (1, 32768, 256, 3), (4, 64, 64, 3),
+                                     (2, 37, 9, 3), (1, 4096, 1024, 3), (2, 300, 7, 2)])
+def test_fps_vs_oracle(dev, B, N, M, D):
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(N + M)
+    pts = rs.rand(B, N, D).astype(np.float32)
+    idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
+    np.testing.assert_array_equal(idx, O().fps(pts, M))
+
+
+def test_fps_f64_vs_oracle(dev):
+    from mvpnet_amd.ops import farthest_point_sample
+    pts = np.random.RandomState(3).rand(2, 3000, 3)
+    idx = farthest_point_sample(g(pts, dev), 700, transpose=False).cpu().numpy()
+    np.testing.assert_array_equal(idx, O().fps(pts, 700))
+
+
+def test_fps_properties_full_size(dev):
+    """B=32 x 8192 -> 2048 (BASELINE size): distinct indices, idx[0]=0, and the greedy
+    min-distance sequence is non-increasing -- holds for any exact FPS."""
+    from mvpnet_amd.ops import farthest_point_sample
+    torch.manual_seed(0)
+    pts = torch.rand(32, 8192, 3, device=dev)
+    idx = farthest_point_sample(pts, 2048, transpose=False)
+    assert (idx[:, 0] == 0).all()
+    assert all(len(set(r.tolist())) == 2048 for r in idx[:4].cpu())
+    sel = torch.gather(pts, 1, idx.unsqueeze(-1).expand(-1, -1, 3))[:2].double()  # (2,2048,3)
+    d = torch.cdist(sel, sel) ** 2
+    # distance of centroid i to the set of earlier centroids
+    dmin = torch.stack([d[:, i, :i].min(dim=1).values for i in range(1, 2048)], 1)
+    assert (dmin[:, 1:] <= dmin[:, :-1] + 1e-9).all()
+    # batch elements are independent: same cloud twice gives the same row
+    idx2 = farthest_point_sample(pts[:1].repeat(2, 1, 1), 2048, transpose=False)
+    assert torch.equal(idx2[0], idx2[1]) and torch.equal(idx2[0], idx[0])
+
+
+def test_fps_errors(dev):
+    from mvpnet_amd.ops import farthest_point_sample
+    with pytest.raises(RuntimeError):
+        farthest_point_sample(torch.rand(1, 3, 8, device=dev), 9)  # N >= M (fps_kernel.cu:156)
+    with pytest.raises(RuntimeError):
+        farthest_point_sample(torch.rand(1, 4, 8, device=dev), 2)  # dim 2 or 3
+
+
+# ------------------------------------------------------------------ ball query
+@pytest.mark.parametrize('ci', range(4))
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_ball_query_reference_grid(dev, ci, dt):
+    """mvpnet/ops/tests/test_ball_query.py:71-131 replayed (index equal, distance allclose)."""
+    from mvpnet_amd.ops import ball_query, ball_query_distance
+    gd = load_golden('ops_ball_query')
+    b, n1, n2, r, k, t = gd['grid'][ci]
+    td = torch.float64 if dt == 'f64' else torch.float32
+    q, key = g(gd['c{}_query'.format(ci)], dev, td), g(gd['c{}_key'.format(ci)], dev, td)
+    exp = gd['c{}_index_{}'.format(ci, dt)]
+    np.testing.assert_array_equal(ball_query(q, key, float(r), int(k), transpose=bool(t)).cpu().numpy(), exp)
+    idx, dist = ball_query_distance(q, key, float(r), int(k), transpose=bool(t))
+    np.testing.assert_array_equal(idx.cpu().numpy(), exp)
+    np.testing.assert_allclose(dist.cpu().numpy(), gd['c{}_dist_{}'.format(ci, dt)], rtol=1e-6)
+
+
+@pytest.mark.parametrize('r', [0.1, 0.2])
+def test_ball_query_dense_golden(dev, r):
+    from mvpnet_amd.ops import ball_query_distance
+    gd = load_golden('ops_ball_query')
+    idx, dist = ball_query_distance(g(gd['dense_query'], dev), g(gd['dense_key'], dev), r, 32, transpose=False)
+    np.testing.assert_array_equal(idx.cpu().numpy(), gd['dense_r{}_index'.format(int(r * 10))])
+    np.testing.assert_array_equal(dist.cpu().numpy(), gd['dense_r{}_dist'.format(int(r * 10))])
+
+
+@pytest.mark.parametrize('B,N1,N2,r,K', [(2, 2048, 8192, 0.1, 32), (3, 512, 2048, 0.2, 32), (4, 128, 512, 0.4, 32),
+                                          (5, 32, 128, 0.8, 32), (2, 100, 3000, 0.05, 7), (1, 5, 70, 0.3, 64),
+                                          (33, 300, 2500, 0.15, 16)])
+def test_ball_query_vs_oracle(dev, B, N1, N2, r, K):
+    from mvpnet_amd.ops import ball_query_distance
+    rs = np.random.RandomState(N1 + N2)
+    key = rs.rand(B, N2, 3).astype(np.float32)
+    q = np.stack([key[b, rs.choice(N2, N1, replace=False)] for b in range(B)])
+    q[:, 0] = 50.0  # a query with no neighbour at all: row must be -1
+    idx, dist = ball_query_distance(g(q, dev), g(key, dev), r, K, transpose=False)
+    eidx, edist = O().ball_query(q, key, r, K, with_distance=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), eidx)
+    np.testing.assert_array_equal(dist.cpu().numpy(), edist)
+    assert (eidx[:, 0] == -1).all()
+
+
+def test_ball_query_radius_on_a_distance(dev):
+    """strict <: a key exactly at distance r is excluded; r is float32 at the boundary."""
+    from mvpnet_amd.ops import ball_query
+    key = torch.tensor([[[0., 0., 0.], [0.5, 0., 0.], [0.25, 0., 0.]]], device=dev)
+    q = torch.tensor([[[0., 0., 0.]]], device=dev)
+    idx = ball_query(q, key, 0.5, 4, transpose=False)
+    assert idx.tolist() == [[[0, 2, 0, 0]]]
+
+
+# ------------------------------------------------------------------ 3-NN
+@pytest.mark.parametrize('ci', range(4))
+def test_knn_reference_grid(dev, ci):
+    """mvpnet/ops/tests/test_knn_distance.py:35-54 replayed."""
+    from mvpnet_amd.ops import knn_distance
+    gd = load_golden('ops_knn_distance')
+    b, n1, n2, t = gd['grid'][ci]
+    idx, dist = knn_distance(g(gd['c{}_query'.format(ci)], dev), g(gd['c{}_key'.format(ci)], dev), 3, transpose=bool(t))
+    np.testing.assert_array_equal(idx.cpu().numpy(), gd['c{}_index'.format(ci)])
+    np.testing.assert_allclose(dist.cpu().numpy(), gd['c{}_dist'.format(ci)], atol=1e-6)
+
+
+@pytest.mark.parametrize('B,N1,N2', [(2, 8192, 2048), (3, 2048, 512), (4, 512, 128), (5, 128, 32), (2, 1000, 3),
+                                      (1, 77, 1500)])
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_knn_vs_oracle(dev, B, N1, N2, dt):
+    from mvpnet_amd.ops import knn_distance
+    rs = np.random.RandomState(N1 * 7 + N2)
+    q, key = rs.rand(B, N1, 3).astype(dt), rs.rand(B, N2, 3).astype(dt)
+    idx, dist = knn_distance(g(q, dev), g(key, dev), 3, transpose=False)
+    eidx, edist = O().knn3(q, key)
+    np.testing.assert_array_equal(idx.cpu().numpy(), eidx)
+    np.testing.assert_array_equal(dist.cpu().numpy(), edist)
+
+
+def test_knn_ties_lowest_index_and_k_check(dev):
+    from mvpnet_amd.ops import knn_distance
+    key = torch.tensor([[[1., 0, 0], [0, 1., 0], [0, 0, 1.], [-1., 0, 0], [0, 0, 0.5]]], device=dev)
+    q = torch.zeros(1, 1, 3, device=dev)
+    idx, dist = knn_distance(q, key, 3, transpose=False)
+    assert idx.tolist() == [[[4, 0, 1]]] and dist.tolist() == [[[0.25, 1.0, 1.0]]]
+    with pytest.raises(RuntimeError):
+        knn_distance(q, key, 4, transpose=False)  # knn_distance_kernel.cu:171
+
+
+# ------------------------------------------------------------------ group_points / interpolate
+@pytest.mark.parametrize('ci', range(2))
+def test_group_points_golden(dev, ci):
+    """mvpnet/ops/tests/test_group_points.py:22-44: forward == gather, backward of ones."""
+    from mvpnet_amd.ops import group_points
+    gd = load_golden('ops_group_points')
+    x = g(gd['c{}_feature'.format(ci)], dev).requires_grad_(True)
+    idx = g(gd['c{}_index'.format(ci)].astype(np.int64), dev)
+    out = group_points(x, idx)
+    b, c, n1 = x.shape
+    exp = torch.gather(x.detach().unsqueeze(2).expand(b, c, idx.size(1), n1), 3, idx.unsqueeze(1).expand(b, c, -1, -1))
+    assert torch.equal(out.detach(), exp)
+    out.backward(torch.ones_like(out))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gd['c{}_grad_ones'.format(ci)], rtol=1e-6)
+    if ci == 0:
+        x.grad = None
+        group_points(x, idx).backward(g(gd['c0_cotangent'], dev))
+        np.testing.assert_allclose(x.grad.cpu().numpy(), gd['c0_grad_rand'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64])
+def test_group_points_vs_oracle_and_inplace(dev, dt):
+    from mvpnet_amd.ops import group_points
+    torch.manual_seed(1)
+    x = torch.randn(3, 67, 700, dtype=dt)
+    idx = torch.randint(0, 700, (3, 129, 32))
+    out = group_points(x.to(dev), idx.to(dev))
+    np.testing.assert_array_equal(out.cpu().numpy(), O().group_points_fwd(x.numpy(), idx.numpy()))
+    gout = torch.randn(3, 67, 129, 32, dtype=dt)
+    xg = x.to(dev).requires_grad_(True)
+    y = group_points(xg, idx.to(dev))
+    y -= 1.0  # in-place op on a custom Function's output must keep working (pn2/modules.py:27)
+    y.backward(gout.to(dev))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), O().group_points_bwd(gout.numpy(), idx.numpy(), 700),
+                               rtol=1e-4 if dt == torch.float32 else 1e-10, atol=1e-4 if dt == torch.float32 else 1e-10)
+    # non-contiguous input (the reference honours strides, group_points_kernel.cu:131-133)
+    xt = torch.randn(2, 50, 9, dtype=dt).to(dev).transpose(1, 2)
+    i2 = torch.randint(0, 50, (2, 4, 3)).to(dev)
+    assert torch.equal(group_points(xt, i2), group_points(xt.contiguous(), i2))
+
+
+@pytest.mark.parametrize('ci', range(2))
+def test_interpolate_golden(dev, ci):
+    """mvpnet/ops/tests/test_interpolate.py:31-64 (float64, forward + backward of ones)."""
+    from mvpnet_amd.ops import feature_interpolate
+    gd = load_golden('ops_interpolate')
+    x = g(gd['c{}_feature'.format(ci)], dev).requires_grad_(True)
+    idx, w = g(gd['c{}_index'.format(ci)].astype(np.int64), dev), g(gd['c{}_weight'.format(ci)], dev)
+    out = feature_interpolate(x, idx, w)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), gd['c{}_out'.format(ci)], rtol=1e-12, atol=1e-14)
+    out.backward(torch.ones_like(out))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gd['c{}_grad_ones'.format(ci)], rtol=1e-10, atol=1e-12)
+
+
+def test_interpolate_f32_vs_oracle(dev):
+    from mvpnet_amd.ops import feature_interpolate
+    torch.manual_seed(2)
+    x = torch.randn(2, 128, 2048)
+    idx = torch.randint(0, 2048, (2, 8192, 3))
+    w = torch.rand(2, 8192, 3)
+    w = w / w.sum(2, keepdim=True)
+    xg = x.to(dev).requires_grad_(True)
+    out = feature_interpolate(xg, idx.to(dev), w.to(dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O().interpolate_fwd(x.numpy(), idx.numpy(), w.numpy()))
+    gout = torch.randn(2, 128, 8192)
+    out.backward(gout.to(dev))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), O().interpolate_bwd(gout.numpy(), idx.numpy(), w.numpy(), 2048),
+                               rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ lifting
+@pytest.mark.parametrize('name', ['small', 'k5', 'full'])
+@pytest.mark.parametrize('depth_kind', ['u16', 'f32'])
+@pytest.mark.parametrize('method', ['bruteforce', 'projective'])
+def test_lifting_golden(dev, name, depth_kind, method):
+    """Golden vectors from the reference's loader code (depth2xyz + sklearn ball tree,
+    mvpnet/data/scannet_2d3d.py:33-39,255-313): image_xyz bit-equal, mask equal, k-NN ids equal."""
+    from mvpnet_amd.ops import unproject, pixel_knn
+    from mvpnet_amd.synthetic import make_chunk
+    gd = load_golden('lifting')
+    kw = json.loads(str(gd[name + '_kwargs']))
+    k = int(gd[name + '_k'])
+    c = make_chunk(with_feature=False, **kw)
+    if depth_kind == 'u16':
+        depth = g(c['depth_mm'].astype(np.int16)[None], dev)
+    else:
+        depth = g((c['depth_mm'].astype(np.float32) / np.float32(1000.))[None], dev)
+    xyz, mask = unproject(depth, g(c['kinv'][None], dev), g(c['pose'][None], dev), g(c['pixel_box'][None], dev))
+    exp_mask = np.unpackbits(gd[name + '_image_mask'])[:mask.numel()].astype(bool).reshape(mask.shape[1:])
+    np.testing.assert_array_equal(mask[0].cpu().numpy(), exp_mask)
+    np.testing.assert_array_equal(xyz[0].cpu().numpy(), gd[name + '_image_xyz'])
+    cam = g(np.repeat(c['cam_matrix'][None, :3, :3], kw['nv'], 0)[None], dev) if method == 'projective' else None
+    pose = g(c['pose'][None], dev) if method == 'projective' else None
+    idx, dist = pixel_knn(xyz, mask, g(c['points'][None], dev), k, cam=cam, pose=pose, return_distance=True)
+    np.testing.assert_array_equal(idx[0].cpu().numpy(), gd[name + '_knn_indices'])
+    assert (dist[:, :, 1:] >= dist[:, :, :-1]).all()
+
+
+def test_unproject_no_box_and_batch(dev):
+    from mvpnet_amd.ops import unproject
+    from mvpnet_amd.synthetic import make_batch
+    bt = make_batch(40, 3, nb_pts=64, nv=2, h=24, w=32, with_feature=False)
+    depth = (bt['depth_mm'].astype(np.float32) / np.float32(1000.))
+    xyz, mask = unproject(g(depth, dev), g(bt['kinv'], dev), g(bt['pose'], dev), None)
+    exyz, emask = O().unproject(depth, bt['kinv'], bt['pose'], None)
+    np.testing.assert_array_equal(xyz.cpu().numpy(), exyz)
+    np.testing.assert_array_equal(mask.cpu().numpy(), emask)
+    xyz2, mask2 = unproject(g(depth, dev), g(bt['kinv'], dev), g(bt['pose'], dev), g(bt['pixel_box'], dev))
+    exyz2, emask2 = O().unproject(depth, bt['kinv'], bt['pose'], bt['pixel_box'])
+    np.testing.assert_array_equal(mask2.cpu().numpy(), emask2)
+
+
+def test_pixel_knn_few_valid_pixels(dev):
+    """fewer valid pixels than k -> -1 in the missing slots; masked pixels are never returned."""
+    from mvpnet_amd.ops import pixel_knn
+    xyz = torch.rand(1, 1, 4, 5, 3, device=dev)
+    mask = torch.zeros(1, 1, 4, 5, dtype=torch.bool, device=dev)
+    mask[0, 0, 1, 2] = True
+    mask[0, 0, 3, 4] = True
+    pts = torch.rand(1, 9, 3, device=dev)
+    idx = pixel_knn(xyz, mask, pts, 3)
+    assert set(idx[..., :2].flatten().tolist()) == {7, 19} and (idx[..., 2] == -1).all()
+    e = O().pixel_knn(xyz.cpu().numpy(), mask.cpu().numpy(), pts.cpu().numpy(), 3)
+    np.testing.assert_array_equal(idx.cpu().numpy(), e)
+
+
+def test_lift_gather_vs_oracle(dev):
+    from mvpnet_amd.ops import lift_gather
+    rs = np.random.RandomState(4)
+    for C in (64, 16, 5):
+        feat = rs.standard_normal((2, 3, 20, 30, C)).astype(np.float32)
+        xyz = rs.standard_normal((2, 3, 20, 30, 3)).astype(np.float32)
+        idx = rs.randint(0, 1800, (2, 500, 3)).astype(np.int64)
+        f = g(feat, dev).requires_grad_(True)
+        gf, gx = lift_gather(f, g(xyz, dev), g(idx, dev))
+        egf, egx = O().lift_gather(feat.reshape(2, -1, C), xyz.reshape(2, -1, 3), idx)
+        np.testing.assert_array_equal(gf.detach().cpu().numpy(), egf)
+        np.testing.assert_array_equal(gx.cpu().numpy(), egx)
+        # same values as the reference's channel-major group_points (mvpnet_3d.py:101-103)
+        from mvpnet_amd.ops import group_points
+        cm = g(np.ascontiguousarray(np.moveaxis(feat.reshape(2, -1, C), -1, 1)), dev)
+        assert torch.equal(group_points(cm, g(idx, dev)).permute(0, 2, 3, 1), gf.detach())
+        cot = torch.randn_like(gf)
+        gf.backward(cot)
+        ref = torch.zeros(2, 1800, C, device=dev).index_put_(
+            (torch.arange(2, device=dev)[:, None].expand(2, 1500).reshape(-1), g(idx, dev).reshape(-1)),
+            cot.reshape(-1, C), accumulate=True)
+        np.testing.assert_allclose(f.grad.reshape(2, 1800, C).cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_lifting_properties_full_batch(dev):
+    """BASELINE-size batch (B=8 x 8192 pts x 3x120x160): projective == brute force, every returned
+    pixel is valid, distances ascending, gathered xyz reproduce the returned distances."""
+    from mvpnet_amd.ops import unproject, pixel_knn, lift_gather
+    from mvpnet_amd.synthetic import make_batch
+    bt = make_batch(100, 8, with_feature=False)
+    depth = g(bt['depth_mm'].astype(np.int16), dev)
+    xyz, mask = unproject(depth, g(bt['kinv'], dev), g(bt['pose'], dev), g(bt['pixel_box'], dev))
+    pts = g(bt['points'], dev)
+    cam = g(np.repeat(bt['cam_matrix'][None, None, :3, :3], 3, 1).repeat(8, 0), dev)
+    i1, d1 = pixel_knn(xyz, mask, pts, 3, return_distance=True)
+    i2, d2 = pixel_knn(xyz, mask, pts, 3, cam=cam, pose=g(bt['pose'], dev), return_distance=True)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+    assert mask.reshape(8, -1).gather(1, i1.reshape(8, -1)).all()
+    assert (d1[..., 1:] >= d1[..., :-1]).all()
+    _, gx = lift_gather(torch.zeros(8, 57600, 4, device=dev), xyz, i1)
+    diff = gx - pts.unsqueeze(2)
+    dd = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert torch.equal(dd, d1)
+
+
+# ------------------------------------------------------------------ vote
+def test_vote_golden(dev):
+    """mvpnet/test_mvpnet_3d.py:136-174 known answer; logits passed as (C,n) views like the model output."""
+    import ctypes
+    from mvpnet_amd import _lib as L
+    gd = load_golden('vote')
+    n_pts, C = gd['mean'].shape
+    s = torch.zeros(n_pts, C, device=dev)
+    cnt = torch.zeros(n_pts, dtype=torch.int32, device=dev)
+    for c in range(6):
+        ind = g(gd['chunk{}_ind'.format(c)].astype(np.int64), dev)
+        logit_cn = g(gd['chunk{}_logit'.format(c)].T.copy(), dev)  # (C, n) as seg_logit[b]
+        L.call('mvp_vote_accumulate_f32', s, L.ptr(logit_cn), 1, logit_cn.size(1), L.ptr(ind), ind.numel(), C, L.ptr(s), L.ptr(cnt))
+    mean = torch.empty_like(s)
+    label = torch.empty(n_pts, dtype=torch.int64, device=dev)
+    L.call('mvp_vote_finish_f32', s, L.ptr(s), L.ptr(cnt), n_pts, C, L.ptr(mean), L.ptr(label))
+    np.testing.assert_array_equal(cnt.cpu().numpy(), gd['count'])
+    np.testing.assert_allclose(mean.cpu().numpy(), gd['mean'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(label.cpu().numpy(), gd['label'])
+
+
+# ------------------------------------------------------------------ the reference's wrappers, unmodified
+def test_extension_modules_have_reference_names(dev):
+    """`mvpnet_amd.ext.install()` makes `mvpnet.ops.<x>_cuda` importable with the pybind names
+    (mvpnet/ops/cuda/*.cpp) -- what the reference's own mvpnet/ops/*.py bind."""
+    import importlib
+    import sys
+    import types
+    from mvpnet_amd import ext
+    pkg = types.ModuleType('mvpnet_dropin_test')
+    sys.modules['mvpnet_dropin_test'] = pkg
+    ext.install('mvpnet_dropin_test')
+    m = importlib.import_module('mvpnet_dropin_test.fps_cuda')
+    assert m.farthest_point_sample(torch.rand(1, 10, 3, device=dev), 3).shape == (1, 3)
+    for name, fns in [('ball_query_cuda', ['ball_query']), ('ball_query_distance_cuda', ['ball_query_distance']),
+                      ('group_points_cuda', ['group_points_forward', 'group_points_backward']),
+                      ('knn_distance_cuda', ['knn_distance']),
+                      ('interpolate_cuda', ['interpolate_forward', 'interpolate_backward'])]:
+        mod = importlib.import_module('mvpnet_dropin_test.' + name)
+        for fn in fns:
+            assert callable(getattr(mod, fn))
