@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""Headline benchmark: chunks/sec of the MVPNet lifting + PointNet++ hot path, fwd+bwd.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic chunks that are already
+resident in HBM (BASELINE.json configs[2]): device lifting (depth
+un-projection -> exact pixel k-NN -> channels-last feature gather), FeatureAggregation, PN2SSG
+(FPS / ball query / grouping / shared MLPs / 3-NN interpolation), SegLoss, backward, Adam step.
+Per GPU: B=32 chunks of 8192 points with 3 views of 160x120 (yaml TRAIN.BATCH_SIZE), fp32.
+The frozen 2D CNN (UNetResNet34, out of scope; torchvision is absent) is replaced by a supplied
+64-channel feature map, exactly as the reference's training consumes it (net_2d is frozen).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the lifting kernels (un-project + pixel k-NN + gather): algorithmic bytes
+                  (13 403 136 B/chunk) / their device time measured with HIP
+                  events on the launch stream, against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the same fwd+bwd step on the host cores with the CPU oracle (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LIFT_BYTES_PER_CHUNK = 13403136  # 4P + 12N + 2*(4*C*N*k) + 8Nk + 12Nk, P=57600 N=8192 C=64 k=3
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class SuppliedFeature2D(torch.nn.Module):
+    """Stand-in for the frozen UNetResNet34: returns the resident synthetic feature map."""
+
+    def __init__(self):
+        super().__init__()
+        self.feature = None
+
+    def forward(self, data):
+        return {'feature': self.feature}
+
+
+def build_batch(rank, batch_size, dev):
+    """Synthetic chunks -> device tensors (everything the step reads is in HBM before timing)."""
+    from mvpnet_amd.synthetic import make_batch
+    uniq = min(batch_size, 8)  # 8 distinct chunks, tiled: keeps host generation short
+    bt = make_batch(1000 * rank, uniq, config=3)
+    rep = (batch_size + uniq - 1) // uniq
+
+    def t(a, dtype=None):
+        a = np.concatenate([a] * rep)[:batch_size]
+        x = torch.from_numpy(np.ascontiguousarray(a))
+        return (x if dtype is None else x.to(dtype)).to(dev)
+
+    nv = bt['depth_mm'].shape[1]
+    cam = np.repeat(bt['cam_matrix'][None, None, :3, :3], nv, 1).repeat(uniq, 0)
+    batch = {
+        'images': torch.zeros(batch_size, nv, 3, 120, 160, device=dev),
+        'points': t(np.ascontiguousarray(bt['points'].transpose(0, 2, 1))),  # (B,3,N) as the dataset hands it
+        'seg_label': t(bt['seg_label']),
+        'depth': t(bt['depth_mm'].astype(np.int16)),
+        'cam_matrix': t(cam), 'kinv': t(bt['kinv']), 'pose': t(bt['pose']), 'pixel_box': t(bt['pixel_box']), 'k': 3,
+    }
+    # (B*nv, C, h, w) logical NCHW in channels_last memory format == (B,nv,h,w,C) physically
+    feat = t(bt['feature_2d'])  # (B,nv,h,w,C)
+    feature = feat.view(batch_size * nv, 120, 160, 64).permute(0, 3, 1, 2)
+    return batch, feature, bt
+
+
+class TimedLifting:
+    """Wraps MVPNet3D.lift_inputs + ops.lift_gather with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def install(self, model):
+        from mvpnet_amd import ops
+        import mvpnet_amd.mvpnet3d as M
+        orig_lift, orig_gather = model.lift_inputs, ops.lift_gather
+        timer = self
+
+        def lift_inputs(data_batch):
+            if timer.enabled:
+                s = torch.cuda.Event(enable_timing=True)
+                s.record()
+                timer._start = s
+            return orig_lift(data_batch)
+
+        def lift_gather(*a, **k):
+            out = orig_gather(*a, **k)
+            if timer.enabled:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                timer.pairs.append((timer._start, e))
+            return out
+
+        model.lift_inputs = lift_inputs
+        M.ops.lift_gather = lift_gather
+
+    def mean_ms(self):
+        return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else float('nan')
+
+
+def cpu_baseline(bt, batch_chunks=2):
+    """fwd+bwd of the same step on the host with the CPU oracle ("port"): oracle lifting
+    (reference loader arithmetic; scikit-learn ball tree like the reference when it is installed,
+    otherwise the oracle's exact scan) + oracle module graph + SegLoss + backward."""
+    from oracle import torch_model as OM
+    from oracle import c_oracle as O
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D
+    torch.manual_seed(0)
+    ref = MVPNet3D(SuppliedFeature2D(), '', PN2SSG(64, 20, dropout_prob=0.0), in_channels=64)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in ref.state_dict().items()}
+    sub = {k: bt[k][:batch_chunks] for k in ('depth_mm', 'kinv', 'pose', 'pixel_box', 'points', 'seg_label', 'feature_2d')}
+    try:
+        from sklearn.neighbors import NearestNeighbors
+        knn_kind = 'sklearn ball_tree'
+    except Exception:  # noqa: BLE001
+        NearestNeighbors, knn_kind = None, 'oracle exact scan'
+
+    def step():
+        depth = O.depth_mm_to_m(sub['depth_mm'])
+        xyz, mask = O.unproject(depth, sub['kinv'], sub['pose'], sub['pixel_box'])
+        if NearestNeighbors is None:
+            knn = O.pixel_knn(xyz, mask, sub['points'], 3)
+        else:
+            knn = np.empty((batch_chunks, sub['points'].shape[1], 3), np.int64)
+            for b in range(batch_chunks):
+                valid = np.nonzero(mask[b].ravel())[0]
+                nn = NearestNeighbors(n_neighbors=3, algorithm='ball_tree').fit(xyz[b].reshape(-1, 3)[valid].astype(np.float64))
+                knn[b] = valid[nn.kneighbors(sub['points'][b], return_distance=False)]
+        points = torch.from_numpy(np.ascontiguousarray(sub['points'].transpose(0, 2, 1)))
+        nv, h, w, c = sub['feature_2d'].shape[1:]
+        feat = torch.from_numpy(np.ascontiguousarray(np.moveaxis(sub['feature_2d'], -1, 2))).reshape(-1, c, h, w)
+        logit = OM.mvpnet3d_forward(sd, points, feat, torch.from_numpy(xyz), torch.from_numpy(knn), training=True)
+        loss = OM.seg_loss(logit, torch.from_numpy(sub['seg_label']))
+        loss.backward()
+
+    step()  # warm-up (library initialisation)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+        step()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(batch_chunks * reps / dt, 4), 'unit': 'chunks/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '{} fwd+bwd steps of {} chunks (8192 pts, 3x160x120, C=64); lifting k-NN: {}; ops: oracle/mvp_oracle.c '
+                      '(1 thread), MLPs: torch CPU ({} threads of {} cores)'.format(reps, batch_chunks, knn_kind,
+                                                                                    torch.get_num_threads(), os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='chunks per GPU per step (yaml TRAIN.BATCH_SIZE = 32)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from mvpnet_amd import dist as D
+    from mvpnet_amd import _lib
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss, train_step
+
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (there is no CPU fallback of the product path)'
+    _lib.lib()
+    rank, world, local = D.init_from_env()
+    assert world == args.gpus, 'WORLD_SIZE ({}) != --gpus ({})'.format(world, args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+    batch, feature, bt = build_batch(rank, args.batch, dev)
+    torch.manual_seed(0)
+    net2d = SuppliedFeature2D()
+    net2d.feature = feature
+    model = MVPNet3D(net2d, '', PN2SSG(64, 20), in_channels=64, mlp_channels=(64, 64, 64), reduction='sum',
+                     use_relation=True).to(dev).train()  # reference defaults incl. dropout 0.5
+    D.broadcast_parameters(model)
+    weights = torch.linspace(0.5, 1.5, 20, device=dev)  # stands in for the class log-weights file
+    loss_fn = SegLoss(weight=weights)
+    optimizer = torch.optim.Adam(model.parameters(), lr=2e-3, betas=(0.9, 0.999), weight_decay=0.0)
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=(24000, 32000), gamma=0.1)
+    grad_sync = D.GradSync(model.parameters()) if world > 1 else None
+    timer = TimedLifting()
+    timer.install(model)
+
+    def step():
+        return train_step(model, loss_fn, optimizer, batch, scheduler=scheduler, grad_sync=grad_sync)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    assert torch.isfinite(loss).item()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        lift_ms = timer.mean_ms()
+        achieved = LIFT_BYTES_PER_CHUNK * args.batch / (lift_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'chunks/sec (8192 pts, 3x160x120 views) fwd+bwd', 'value': round(args.batch * world * args.steps / elapsed, 3),
+            'unit': 'chunks/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[2]: MVPNet lifting (unproject + pixel k-NN + gather) + FeatureAggregation + '
+                                   'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
+                       'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
+                       'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
+            'roofline': {'bound': 'hbm', 'kernel': 'lifting = unproject_kernel + pixel_knn_proj_kernel + lift_gather_kernel',
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': None, 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(bt)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

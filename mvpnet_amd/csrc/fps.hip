@@ -5,7 +5,8 @@
 //   * one workgroup per batch element, every point AND its running min-distance live in
 //     VGPRs for the whole M-step loop (the reference re-reads N points + temp[] from
 //     global memory every iteration);
-//   * arg-max = per-thread scan -> 64-lane xor-shuffle reduction -> ONE barrier per
+//   * arg-max = per-thread scan -> DPP butterfly on a packed (value:~index) key (cross-lane at
+//     VALU latency; __shfl would be a ds_bpermute LDS round trip per step) -> ONE barrier per
 //     iteration (double-buffered per-wave partials in LDS), no barrier at all when the
 //     workgroup is a single wave (the deep SA levels);
 //   * the winner's coordinates are broadcast from an SoA copy of the points in LDS
@@ -16,27 +17,95 @@
 
 namespace {
 
+// ---- packed arg-max key -----------------------------------------------------------------------
+// np.argmax's "first maximum" = max over (value, then LOWER index).  Running distances are >= +0,
+// so their IEEE bit patterns order like unsigned integers and one unsigned max over
+//   key = value_bits : ~index
+// does both at once.  key 0 = "no candidate" (padding lanes).
 template <typename T>
-struct Part {
-  T v;
-  int i;
+struct Key;
+template <>
+struct Key<float> {
+  uint32_t hi;  // value bits
+  uint32_t lo;  // ~index
+  __device__ __forceinline__ static Key make(float v, int i) { return {__float_as_uint(v), ~(uint32_t)i}; }
+  __device__ __forceinline__ static Key none() { return {0u, 0u}; }
+  __device__ __forceinline__ bool gt(const Key& o) const { return hi > o.hi || (hi == o.hi && lo > o.lo); }
+  __device__ __forceinline__ int index() const { return (int)~lo; }
+  template <int CTRL, int ROW_MASK>
+  __device__ __forceinline__ Key dpp() const {
+    return {(uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xF, false),
+            (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xF, false)};
+  }
+  __device__ __forceinline__ Key lane(int l) const {
+    return {(uint32_t)__builtin_amdgcn_readlane((int)hi, l), (uint32_t)__builtin_amdgcn_readlane((int)lo, l)};
+  }
+};
+template <>
+struct Key<double> {
+  uint32_t h1, h0;  // value bits (high, low word)
+  uint32_t lo;      // ~index
+  __device__ __forceinline__ static Key make(double v, int i) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return {(uint32_t)(b >> 32), (uint32_t)b, ~(uint32_t)i};
+  }
+  __device__ __forceinline__ static Key none() { return {0u, 0u, 0u}; }
+  __device__ __forceinline__ bool gt(const Key& o) const {
+    return h1 > o.h1 || (h1 == o.h1 && (h0 > o.h0 || (h0 == o.h0 && lo > o.lo)));
+  }
+  __device__ __forceinline__ int index() const { return (int)~lo; }
+  template <int CTRL, int ROW_MASK>
+  __device__ __forceinline__ Key dpp() const {
+    return {(uint32_t)__builtin_amdgcn_update_dpp((int)h1, (int)h1, CTRL, ROW_MASK, 0xF, false),
+            (uint32_t)__builtin_amdgcn_update_dpp((int)h0, (int)h0, CTRL, ROW_MASK, 0xF, false),
+            (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xF, false)};
+  }
+  __device__ __forceinline__ Key lane(int l) const {
+    return {(uint32_t)__builtin_amdgcn_readlane((int)h1, l), (uint32_t)__builtin_amdgcn_readlane((int)h0, l),
+            (uint32_t)__builtin_amdgcn_readlane((int)lo, l)};
+  }
 };
 
-// (v, i) "better" = larger v, or equal v and lower index  -> np.argmax's first maximum
-template <typename T>
-__device__ __forceinline__ void take_better(T& v, int& i, T ov, int oi) {
-  bool b = (ov > v) || (ov == v && oi < i);
-  v = b ? ov : v;
-  i = b ? oi : i;
+// DPP controls (gfx9 / CDNA): cross-lane moves at VALU latency, no LDS round trip.
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // reverse within 8 lanes
+constexpr int kDppMirror = 0x140;     // reverse within 16 lanes
+constexpr int kDppBcast15 = 0x142;    // lane 15 of each row -> next row
+constexpr int kDppBcast31 = 0x143;    // lane 31 -> rows 2,3
+
+template <typename K, int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ void key_max_step(K& k) {
+  const K o = k.template dpp<CTRL, ROW_MASK>();
+  if (o.gt(k)) k = o;
+}
+// after this every lane of each 16-lane row holds that row's maximum
+template <typename K, int LANES /* 2,4,8,16 */>
+__device__ __forceinline__ void key_max_row(K& k) {
+  key_max_step<K, kDppXor1>(k);
+  if (LANES > 2) key_max_step<K, kDppXor2>(k);
+  if (LANES > 4) key_max_step<K, kDppHalfMirror>(k);
+  if (LANES > 8) key_max_step<K, kDppMirror>(k);
+}
+// lane 63 ends up holding the wave maximum
+template <typename K>
+__device__ __forceinline__ void key_max_wave_to_lane63(K& k) {
+  key_max_row<K, 16>(k);
+  key_max_step<K, kDppBcast15, 0xA>(k);
+  key_max_step<K, kDppBcast31, 0xC>(k);
 }
 
 template <typename T, int D, int PPT, int NT, bool LDS_PTS>
 __global__ __launch_bounds__(NT) void fps_kernel(const T* __restrict__ pts, int N, int M,
                                                  int64_t* __restrict__ out) {
   constexpr int NW = NT / kWave;
+  using K = Key<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  Part<T>* part = reinterpret_cast<Part<T>*>(smem);  // [2][NW]
-  T* sx = reinterpret_cast<T*>(smem + 2 * 16 * sizeof(Part<T>));
+  K* part = reinterpret_cast<K*>(smem);  // [2][16] per-wave winners, double buffered
+  // Winners are collected in LDS and written out once at the end: a global store inside the loop
+  // would make every __syncthreads() wait for its write acknowledgement (vmcnt counts stores).
+  int* sout = reinterpret_cast<int*>(smem + 2 * 16 * 16);
+  T* sx = reinterpret_cast<T*>(smem + 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15));
   T* sy = sx + (LDS_PTS ? N : 0);
   T* sz = sy + (LDS_PTS ? N : 0);
 
@@ -67,54 +136,54 @@ __global__ __launch_bounds__(NT) void fps_kernel(const T* __restrict__ pts, int 
     }
   }
   T cx = p[0], cy = p[1], cz = D == 3 ? p[2] : T(0);
-  if (tid == 0) o[0] = 0;
+  if (tid == 0) sout[0] = 0;
   if (LDS_PTS) __syncthreads();
 
   for (int it = 1; it < M; ++it) {
     T bv = T(-1);
-    int bi = 0x7fffffff;
+    int bi = 0;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       T d = D == 3 ? dist2_3(px[i], py[i], pz[i], cx, cy, cz) : dist2_2(px[i], py[i], cx, cy);
       T m = d < md[i] ? d : md[i];
       md[i] = m;
-      if (m > bv) {  // strict: indices ascend with i, so the first maximum is kept
+      if (m > bv) {  // strict: indices ascend with i, so the thread's first maximum is kept
         bv = m;
         bi = tid + i * NT;
       }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) take_better(bv, bi, shfl_xor_t(bv, off), __shfl_xor(bi, off, kWave));
-    if (NW > 1) {
-      Part<T>* cur = part + (it & 1) * 16;
-      if (lane == 0) {
-        cur[wave].v = bv;
-        cur[wave].i = bi;
-      }
-      __syncthreads();
-      Part<T> q = cur[lane & (NW - 1)];
-      bv = q.v;
-      bi = q.i;
-#pragma unroll
-      for (int off = NW / 2; off >= 1; off >>= 1) take_better(bv, bi, shfl_xor_t(bv, off), __shfl_xor(bi, off, kWave));
-    }
-    if (bi == 0x7fffffff) bi = 0;  // unreachable for N >= 1; keeps the index in range
-    if (tid == 0) o[it] = bi;
-    if (LDS_PTS) {
-      cx = sx[bi];
-      cy = sy[bi];
-      if (D == 3) cz = sz[bi];
+    K k = bv >= T(0) ? K::make(bv, bi) : K::none();
+    int win;
+    if (NW == 1) {
+      key_max_wave_to_lane63(k);
+      win = k.lane(63).index();
     } else {
-      cx = p[(size_t)bi * D + 0];
-      cy = p[(size_t)bi * D + 1];
-      if (D == 3) cz = p[(size_t)bi * D + 2];
+      key_max_wave_to_lane63(k);
+      K* cur = part + (it & 1) * 16;
+      if (lane == 63) cur[wave] = k;
+      __syncthreads();  // the only barrier of the iteration (partials are double buffered)
+      k = cur[lane & (NW - 1)];
+      key_max_row<K, NW>(k);
+      win = k.index();
+    }
+    if (tid == 0) sout[it] = win;
+    if (LDS_PTS) {
+      cx = sx[win];
+      cy = sy[win];
+      if (D == 3) cz = sz[win];
+    } else {
+      cx = p[(size_t)win * D + 0];
+      cy = p[(size_t)win * D + 1];
+      if (D == 3) cz = p[(size_t)win * D + 2];
     }
   }
+  __syncthreads();
+  for (int i = tid; i < M; i += NT) o[i] = sout[i];
 }
 
 template <typename T, int D, int PPT, int NT>
 int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
-  const size_t part_bytes = 2 * 16 * sizeof(Part<T>);
+  const size_t part_bytes = 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15);  // keys + output buffer
   const size_t pts_bytes = (size_t)N * 3 * sizeof(T);
   const bool lds = pts_bytes + part_bytes <= 150 * 1024;
   if (lds) {
@@ -127,6 +196,10 @@ int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipS
     hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out);
   } else {
     auto k = fps_kernel<T, D, PPT, NT, false>;
+    if (part_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_bytes);
+      if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), part_bytes, s, pts, (int)N, (int)M, out);
   }
   return mvp_launch_status();

@@ -1,0 +1,117 @@
+"""MVPNet 2D->3D lifting + aggregation in front of PN2SSG: mirror of
+`mvpnet.models.mvpnet_3d` (reference: mvpnet/models/mvpnet_3d.py:9-118) and of
+`mvpnet.models.loss.SegLoss` (loss.py:5-21).
+
+Differences from the reference that do not change results:
+  * the 2D feature map is consumed channels-last ((B*nv, C, h, w) in torch.channels_last memory
+    format IS (B,nv,h,w,C) physically), so each gathered neighbour is one contiguous row and the
+    `transpose(1,2).contiguous()` full copy of mvpnet_3d.py:101 disappears;
+  * `knn_indices` / `image_xyz` may be omitted from the data dict when `depth`, `cam_matrix`,
+    `pose` (and optionally `pixel_box`) are given: they are then computed on the device with the
+    lifting kernels instead of by dataloader workers (scannet_2d3d.py:254-313).
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .nn import SharedMLP, xavier_uniform
+from . import ops
+
+
+class FeatureAggregation(nn.Module):
+    """cat[feature, src - tgt, |src - tgt|^2] -> SharedMLP -> reduce over k (mvpnet_3d.py:9-67)."""
+
+    def __init__(self, in_channels, mlp_channels=(64, 64, 64), reduction='sum', use_relation=True):
+        super().__init__()
+        self.in_channels, self.use_relation = in_channels, use_relation
+        if mlp_channels:
+            self.out_channels = mlp_channels[-1]
+            self.mlp = SharedMLP(in_channels + (4 if use_relation else 0), mlp_channels, ndim=2, bn=True)
+        else:
+            self.out_channels, self.mlp = in_channels, None
+        if reduction not in ('sum', 'max'):
+            raise ValueError('reduction must be sum or max')
+        self.reduction_name = reduction
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Linear)):
+                xavier_uniform(m)
+
+    def reduction(self, x, dim):
+        return torch.sum(x, dim) if self.reduction_name == 'sum' else torch.max(x, dim)[0]
+
+    def forward(self, src_xyz, tgt_xyz, feature):
+        """src_xyz (B,3,N,k), tgt_xyz (B,3,N), feature (B,C,N,k) -> (B,C_out,N)."""
+        if self.mlp is None:
+            return self.reduction(feature, 3)
+        x = feature
+        if self.use_relation:
+            diff = src_xyz - tgt_xyz.unsqueeze(-1)
+            x = torch.cat([feature, diff, torch.sum(diff ** 2, dim=1, keepdim=True)], dim=1)
+        return self.reduction(self.mlp(x), 3)
+
+
+class MVPNet3D(nn.Module):
+    def __init__(self, net_2d, net_2d_ckpt_path, net_3d, **feat_aggr_kwargs):
+        super().__init__()
+        self.net_2d = net_2d
+        if net_2d_ckpt_path:
+            checkpoint = torch.load(net_2d_ckpt_path, map_location=torch.device('cpu'))
+            self.net_2d.load_state_dict(checkpoint['model'])
+        self.feat_aggreg = FeatureAggregation(**feat_aggr_kwargs)
+        self.net_3d = net_3d
+
+    @staticmethod
+    def lift_inputs(data_batch):
+        """image_xyz (B,nv,h,w,3) and knn_indices (B,N,k): taken from the dict, or computed on the device."""
+        if 'knn_indices' in data_batch and 'image_xyz' in data_batch:
+            return data_batch['image_xyz'], data_batch['knn_indices']
+        cam = data_batch['cam_matrix']  # (B,nv,3,3) forward intrinsics, already scaled to (h,w)
+        pose = data_batch['pose']
+        kinv = data_batch['kinv'] if 'kinv' in data_batch else torch.linalg.inv(cam)
+        points = data_batch['points'].transpose(1, 2).contiguous()
+        with torch.no_grad():
+            image_xyz, mask = ops.unproject(data_batch['depth'], kinv.contiguous(), pose, data_batch.get('pixel_box'))
+            knn = ops.pixel_knn(image_xyz, mask, points, int(data_batch.get('k', 3)), cam=cam.contiguous(), pose=pose)
+        return image_xyz, knn
+
+    def forward(self, data_batch):
+        images = data_batch['images']  # (B,nv,3,h,w)
+        b, nv, _, h, w = images.shape
+        feature_2d = self.net_2d({'image': images.reshape(b * nv, *images.shape[2:])})['feature']  # (B*nv,C,h,w)
+        c = feature_2d.size(1)
+        # channels-last view (B,nv,h,w,C); free when the 2D net already runs in torch.channels_last
+        feature_cl = feature_2d.permute(0, 2, 3, 1).contiguous().view(b, nv, h, w, c)
+        image_xyz, knn_indices = self.lift_inputs(data_batch)
+        gfeat, gxyz = ops.lift_gather(feature_cl, image_xyz, knn_indices)  # (B,N,k,C), (B,N,k,3)
+        points = data_batch['points']
+        feature_2d3d = self.feat_aggreg(gxyz.permute(0, 3, 1, 2), points, gfeat.permute(0, 3, 1, 2))
+        return self.net_3d({'points': points, 'feature': feature_2d3d})
+
+
+class SegLoss(nn.Module):
+    """Weighted cross entropy with ignore_index (loss.py:5-21)."""
+
+    def __init__(self, weight=None, ignore_index=-100):
+        super().__init__()
+        self.weight, self.ignore_index = weight, ignore_index
+
+    def forward(self, preds, labels):
+        loss = F.cross_entropy(preds['seg_logit'], labels['seg_label'], weight=self.weight, ignore_index=self.ignore_index)
+        return {'seg_loss': loss}
+
+
+def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None):
+    """One iteration of the reference loop (mvpnet/train_mvpnet_3d.py:158-180,287-288):
+    zero_grad -> forward -> SegLoss -> backward -> [grad all-reduce] -> [clip] -> step -> scheduler."""
+    optimizer.zero_grad()
+    preds = model(data_batch)
+    loss = loss_fn(preds, data_batch)['seg_loss']
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    if max_grad_norm > 0:
+        nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_grad_norm)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss.detach(), preds

@@ -1,0 +1,150 @@
+"""CPU restatement of the reference's module graph on top of the C oracle ops.
+
+TEST INFRASTRUCTURE ONLY (checker + bench.py's cpu_baseline leg).  Functional, weight-dict
+driven (reference `state_dict` keys), independent of the product package `mvpnet_amd`.
+
+Restates: SetAbstraction / QueryGrouper / FeatureInterpolator / FeaturePropagation
+(mvpnet/models/pn2/modules.py:13-186), PN2SSG.forward (mvpnet/models/pn2/pn2ssg.py:87-118),
+FeatureAggregation.forward + MVPNet3D.forward lifting (mvpnet/models/mvpnet_3d.py:37-61, 88-118),
+SharedMLP layers (common/nn/modules/conv.py:29-51), SegLoss (mvpnet/models/loss.py:13-21).
+Pinned to the reference by tests/test_oracle_model_golden.py (golden vectors from the imported
+reference modules).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import c_oracle as O
+
+
+# ---- oracle ops as autograd functions (gradients as the reference defines them) -------------
+class _Group(torch.autograd.Function):  # mvpnet/ops/group_points.py:5-18
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.save_for_backward(index)
+        ctx.n = x.size(2)
+        return torch.from_numpy(O.group_points_fwd(x.detach().numpy(), index.numpy()))
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        return torch.from_numpy(O.group_points_bwd(g.contiguous().numpy(), index.numpy(), ctx.n)), None
+
+
+class _Interp(torch.autograd.Function):  # mvpnet/ops/interpolate.py:5-19
+    @staticmethod
+    def forward(ctx, x, index, weight):
+        ctx.save_for_backward(index, weight)
+        ctx.n = x.size(2)
+        return torch.from_numpy(O.interpolate_fwd(x.detach().numpy(), index.numpy(), weight.numpy()))
+
+    @staticmethod
+    def backward(ctx, g):
+        index, weight = ctx.saved_tensors
+        return torch.from_numpy(O.interpolate_bwd(g.contiguous().numpy(), index.numpy(), weight.numpy(), ctx.n)), None, None
+
+
+def _bnc(x):  # (B,3,N) -> (B,N,3) contiguous numpy, as the reference wrappers do (e.g. fps.py:28-30)
+    return np.ascontiguousarray(x.detach().numpy().transpose(0, 2, 1))
+
+
+def shared_mlp(x, sd, prefix, training, dropout_p=0.0):
+    """Conv(k=1, no bias) -> BN -> ReLU per layer (conv.py:29-51); layers found by key."""
+    i = 0
+    while '{}.{}.conv.weight'.format(prefix, i) in sd:
+        p = '{}.{}.'.format(prefix, i)
+        w = sd[p + 'conv.weight']
+        conv = F.conv2d if w.dim() == 4 else F.conv1d
+        x = conv(x, w, sd.get(p + 'conv.bias'))
+        if p + 'bn.weight' in sd:
+            x = F.batch_norm(x, sd[p + 'bn.running_mean'].clone(), sd[p + 'bn.running_var'].clone(),
+                             sd[p + 'bn.weight'], sd[p + 'bn.bias'], training, 0.1, 1e-5)
+        x = F.relu(x)
+        if dropout_p > 0 and training:
+            x = F.dropout(x, dropout_p, True)
+        i += 1
+    return x
+
+
+def set_abstraction(xyz, feature, sd, prefix, num_centroids, radius, max_neighbors, training, use_xyz=True):
+    """modules.py:74-109 (sampling branch)."""
+    index = torch.from_numpy(O.fps(_bnc(xyz), num_centroids))
+    new_xyz = torch.gather(xyz, 2, index.unsqueeze(1).expand(-1, 3, -1))  # batch_index_select
+    ball = torch.from_numpy(O.ball_query(_bnc(new_xyz), _bnc(xyz), radius, max_neighbors))
+    group_xyz = _Group.apply(xyz, ball) - new_xyz.unsqueeze(-1)
+    if feature is not None:
+        group_feature = _Group.apply(feature, ball)
+        if use_xyz:
+            group_feature = torch.cat([group_feature, group_xyz], dim=1)
+    else:
+        group_feature = group_xyz
+    new_feature = shared_mlp(group_feature, sd, prefix + '.mlp', training)
+    return new_xyz, new_feature.max(dim=3)[0], index, ball
+
+
+def feature_propagation(dense_xyz, sparse_xyz, dense_feature, sparse_feature, sd, prefix, training):
+    """modules.py:122-149, 178-186."""
+    idx, dist = O.knn3(_bnc(dense_xyz), _bnc(sparse_xyz))
+    idx, dist = torch.from_numpy(idx), torch.from_numpy(dist)
+    inv = 1.0 / torch.clamp(dist, min=1e-10)
+    weight = inv / inv.sum(dim=2, keepdim=True)
+    x = _Interp.apply(sparse_feature, idx, weight)
+    if dense_feature is not None:
+        x = torch.cat([x, dense_feature], dim=1)
+    return shared_mlp(x, sd, prefix + '.mlp', training)
+
+
+def pn2ssg_forward(sd, points, feature=None, num_centroids=(2048, 512, 128, 32), radius=(0.1, 0.2, 0.4, 0.8),
+                   max_neighbors=(32, 32, 32, 32), training=False, prefix='', return_stages=False):
+    """pn2ssg.py:87-118.  `sd`: tensors keyed like the reference state_dict (under `prefix`)."""
+    xyzs, feats, stages = [points], [None], {}
+    xyz = points
+    for i, (m, r, k) in enumerate(zip(num_centroids, radius, max_neighbors)):
+        xyz, feature, fidx, ball = set_abstraction(xyz, feature, sd, '{}sa_modules.{}'.format(prefix, i), m, r, k, training)
+        xyzs.append(xyz)
+        feats.append(feature)
+        stages['sa{}'.format(i)] = (xyz, feature, fidx, ball)
+    up = feats[-1]
+    for i in range(len(num_centroids)):
+        up = feature_propagation(xyzs[-2 - i], xyzs[-1 - i], feats[-2 - i], up, sd, '{}fp_modules.{}'.format(prefix, i), training)
+        stages['fp{}'.format(i)] = up
+    x = shared_mlp(up, sd, prefix + 'mlp_seg', training)  # dropout_prob = 0 in parity runs
+    logit = F.conv1d(x, sd[prefix + 'seg_logit.weight'], sd[prefix + 'seg_logit.bias'])
+    return (logit, stages) if return_stages else logit
+
+
+def feature_aggregation(src_xyz, tgt_xyz, feature, sd, prefix, training):
+    """mvpnet_3d.py:37-61 with reduction='sum', use_relation=True."""
+    diff = src_xyz - tgt_xyz.unsqueeze(-1)
+    dist = torch.sum(diff ** 2, dim=1, keepdim=True)
+    x = torch.cat([feature, diff, dist], dim=1)
+    return shared_mlp(x, sd, prefix + '.mlp', training).sum(dim=3)
+
+
+def mvpnet3d_forward(sd, points, feature_nchw, image_xyz, knn_indices, training=False, return_stages=False, **pn2_kw):
+    """mvpnet_3d.py:88-118 with the 2D network replaced by a supplied (B*nv,C,h,w) feature map."""
+    b = points.size(0)
+    bn, c, h, w = feature_nchw.shape
+    nv = bn // b
+    f = feature_nchw.reshape(b, nv, c, h, w).transpose(1, 2).contiguous().reshape(b, c, nv * h * w)
+    f = _Group.apply(f, knn_indices)
+    xyz = image_xyz.permute(0, 4, 1, 2, 3).reshape(b, 3, nv * h * w)
+    gx = _Group.apply(xyz.contiguous(), knn_indices)
+    f23 = feature_aggregation(gx, points, f, sd, 'feat_aggreg', training)
+    out = pn2ssg_forward(sd, points, f23, training=training, prefix='net_3d.', return_stages=return_stages, **pn2_kw)
+    if return_stages:
+        return out[0], dict(out[1], feature_2d3d=f23)
+    return out
+
+
+def seg_loss(logit, label, weight=None):
+    """loss.py:13-21"""
+    return F.cross_entropy(logit, label, weight=weight, ignore_index=-100)
+
+
+def lifting(chunk_batch, k=3):
+    """depth/pose/intrinsics -> image_xyz, mask, knn (scannet_2d3d.py:254-313) via the C oracle."""
+    depth = O.depth_mm_to_m(chunk_batch['depth_mm'])
+    xyz, mask = O.unproject(depth, chunk_batch['kinv'], chunk_batch['pose'], chunk_batch['pixel_box'])
+    knn = O.pixel_knn(xyz, mask, chunk_batch['points'], k)
+    return xyz, mask, knn

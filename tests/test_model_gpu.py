@@ -1,0 +1,187 @@
+"""GPU parity of the host-side module mirror (mvpnet_amd.pn2 / mvpnet_amd.mvpnet3d on the HIP ops)
+against golden vectors from the REAL reference modules.  Geometry indices bit-exact, fp32 logits
+within 1e-4 (BASELINE.json north_star)."""
+import collections
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from mvpnet_amd.synthetic import make_chunk
+from tests.conftest import load_golden
+from tests.golden.weights import fill_state_dict
+
+pytestmark = pytest.mark.gpu
+CFG = dict(num_centroids=(256, 64, 16, 4), radius=(0.1, 0.2, 0.4, 0.8), max_neighbors=(32, 32, 32, 32))
+# fp32 logits within 1e-4 of the reference CPU path (BASELINE.json) -- measured 4.5e-7 in eval mode.
+# Train mode uses batch-statistics BatchNorm at B<=2, which amplifies fp32 rounding for ANY fp32
+# implementation: the CPU reference itself is 2.8e-4 away from the float64 value of its own graph
+# (profiles/r01_numerics_diag.txt), so the bar there is 1e-3.
+ATOL = {'eval': 1e-4, 'train': 1e-3}
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    return torch.device('cuda:0')
+
+
+def load_weights(module, g, seed):
+    """Same keys AND order as the reference state_dict, then the seeded fill."""
+    ref_keys = [(k, tuple(s)) for k, s in json.loads(str(g['state_keys']))]
+    mine = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    assert mine == ref_keys, 'state_dict keys/shapes differ from the reference'
+    sd = fill_state_dict(collections.OrderedDict(ref_keys), seed)
+    module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+
+
+class StubNet2D(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.feature = None
+
+    def forward(self, data):
+        return {'feature': self.feature}
+
+
+def hooks(model):
+    rec = {}
+    for i, m in enumerate(model.sa_modules):
+        m.register_forward_hook(lambda mod, inp, out, i=i: rec.__setitem__('sa{}'.format(i), out))
+    for i, m in enumerate(model.fp_modules):
+        m.register_forward_hook(lambda mod, inp, out, i=i: rec.__setitem__('fp{}'.format(i), out))
+    return rec
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_pn2ssg_small(dev, mode):
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import SegLoss
+    g = load_golden('pn2ssg_small')
+    net = PN2SSG(0, 20, dropout_prob=0.0, **CFG)
+    load_weights(net, g, 101)
+    net = net.to(dev).train(mode == 'train')
+    rec = hooks(net)
+    chunks = [make_chunk(10 + b, nb_pts=1024, nv=2, h=30, w=40, channels=8, with_feature=False) for b in range(2)]
+    points = torch.from_numpy(np.stack([c['points'].T for c in chunks])).to(dev)
+    label = torch.from_numpy(np.stack([c['seg_label'] for c in chunks])).to(dev)
+    preds = net({'points': points})
+    for i in range(4):
+        xyz, feat = rec['sa{}'.format(i)]
+        np.testing.assert_array_equal(xyz.cpu().numpy(), g['{}_sa{}_xyz'.format(mode, i)])  # FPS picks identical points
+        np.testing.assert_allclose(feat.detach().cpu().numpy(), g['{}_sa{}_feature'.format(mode, i)], rtol=1e-4, atol=ATOL[mode])
+        np.testing.assert_allclose(rec['fp{}'.format(i)].detach().cpu().numpy(), g['{}_fp{}_feature'.format(mode, i)], rtol=1e-4, atol=ATOL[mode])
+    np.testing.assert_allclose(preds['seg_logit'].detach().cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])
+    loss = SegLoss(weight=torch.from_numpy(g['log_weights']).to(dev))(preds, {'seg_label': label})['seg_loss']
+    np.testing.assert_allclose(loss.item(), g[mode + '_loss'], rtol=1e-5 if mode == 'eval' else 1e-4)
+    loss.backward()
+    params = dict(net.named_parameters())
+    for pname in ('sa_modules.0.mlp.0.conv.weight', 'sa_modules.3.mlp.2.bn.weight', 'fp_modules.3.mlp.0.conv.weight',
+                  'seg_logit.weight', 'seg_logit.bias'):
+        exp = g['{}_grad_{}'.format(mode, pname)]
+        np.testing.assert_allclose(params[pname].grad.cpu().numpy(), exp, rtol=5e-3, atol=(1e-5 if mode == 'eval' else 1e-3) * max(1.0, np.abs(exp).max()))
+    norms = np.asarray([p.grad.norm().item() for p in net.parameters()])
+    np.testing.assert_allclose(norms, g[mode + '_grad_norms'], rtol=2e-3 if mode == 'eval' else 2e-2, atol=1e-6)
+    if mode == 'train':
+        np.testing.assert_allclose(net.sa_modules[0].mlp[0].bn.running_mean.cpu().numpy(), g['train_running_mean_sa0_0'], rtol=1e-4, atol=1e-6)
+
+
+def geometry_chain(points, num_centroids, radius, max_neighbors):
+    from mvpnet_amd import ops
+    from mvpnet_amd.nn import batch_index_select
+    out, xyzs = {}, [points]
+    for i, (m, r, k) in enumerate(zip(num_centroids, radius, max_neighbors)):
+        idx = ops.farthest_point_sample(xyzs[-1], m)
+        new = batch_index_select(xyzs[-1], idx, dim=2)
+        out['fps{}'.format(i)] = idx
+        out['ball{}'.format(i)] = ops.ball_query(new, xyzs[-1], r, k)
+        xyzs.append(new)
+    for i in range(len(num_centroids)):
+        out['knn{}'.format(i)], out['knn_dist{}'.format(i)] = ops.knn_distance(xyzs[-2 - i], xyzs[-1 - i], 3)
+    return out
+
+
+def test_geometry_chain_small_bit_exact(dev):
+    g = load_golden('pn2ssg_small')
+    chunks = [make_chunk(10 + b, nb_pts=1024, nv=2, h=30, w=40, channels=8, with_feature=False) for b in range(2)]
+    points = torch.from_numpy(np.stack([c['points'].T for c in chunks])).to(dev)
+    geo = geometry_chain(points, **CFG)
+    for key, val in geo.items():
+        if key.startswith('knn_dist'):
+            np.testing.assert_allclose(val.cpu().numpy(), g['geo_' + key], atol=1e-6)
+        else:
+            np.testing.assert_array_equal(val.cpu().numpy(), g['geo_' + key])
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_mvpnet3d_small(dev, mode):
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss
+    g = load_golden('mvpnet3d_small')
+    net2d = StubNet2D()
+    model = MVPNet3D(net2d, '', PN2SSG(64, 20, dropout_prob=0.0, **CFG), in_channels=16, mlp_channels=(64, 64, 64),
+                     reduction='sum', use_relation=True)
+    load_weights(model, g, 202)
+    model = model.to(dev).train(mode == 'train')
+    kw = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
+    chunks = [make_chunk(20 + b, **kw) for b in range(2)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    points = t(np.stack([c['points'].T for c in chunks]))
+    feat_cl = np.stack([c['feature_2d'] for c in chunks])
+    net2d.feature = t(np.moveaxis(feat_cl, -1, 2)).reshape(-1, 16, 30, 40).requires_grad_(True)
+    label = t(np.stack([c['seg_label'] for c in chunks]))
+    fa = {}
+    model.feat_aggreg.register_forward_hook(lambda m, i, o: fa.__setitem__('o', o))
+    # (a) loader-supplied image_xyz / knn_indices, exactly the reference's data dict
+    batch = {'images': torch.zeros(2, 2, 3, 30, 40, device=dev), 'image_xyz': t(g['image_xyz']),
+             'knn_indices': t(g['knn_indices'].astype(np.int64)), 'points': points}
+    preds = model(batch)
+    np.testing.assert_allclose(fa['o'].detach().cpu().numpy(), g[mode + '_feature_2d3d'], rtol=1e-4, atol=ATOL[mode])
+    np.testing.assert_allclose(preds['seg_logit'].detach().cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])
+    loss = SegLoss(weight=t(load_golden('pn2ssg_small')['log_weights']))(preds, {'seg_label': label})['seg_loss']
+    np.testing.assert_allclose(loss.item(), g[mode + '_loss'], rtol=1e-5 if mode == 'eval' else 1e-4)
+    loss.backward()
+    exp = g[mode + '_grad_feature_2d']  # backward of the lifting gather, (B*nv,C,h,w)
+    np.testing.assert_allclose(net2d.feature.grad.cpu().numpy(), exp, rtol=5e-3, atol=(1e-5 if mode == 'eval' else 1e-3) * np.abs(exp).max())
+    exp = g[mode + '_grad_aggr_w0']
+    np.testing.assert_allclose(model.feat_aggreg.mlp[0].conv.weight.grad.cpu().numpy(), exp, rtol=5e-3, atol=(1e-5 if mode == 'eval' else 1e-3) * np.abs(exp).max())
+    # (b) lifting on the device from depth / intrinsics / pose: same logits
+    if mode == 'eval':
+        cam = np.stack([np.repeat(c['cam_matrix'][None, :3, :3], 2, 0) for c in chunks])
+        dev_batch = {'images': batch['images'], 'points': points, 'depth': t(np.stack([c['depth_mm'] for c in chunks]).astype(np.int16)),
+                     'cam_matrix': t(cam), 'kinv': t(np.stack([c['kinv'] for c in chunks])), 'pose': t(np.stack([c['pose'] for c in chunks])),
+                     'pixel_box': t(np.stack([c['pixel_box'] for c in chunks])), 'k': 3}
+        with torch.no_grad():
+            preds2 = model(dev_batch)
+        assert torch.equal(preds2['seg_logit'], preds['seg_logit'].detach())
+
+
+def test_mvpnet3d_full_chunk(dev):
+    """BASELINE-size chunk: 8192 points, 3x120x160 views, C=64, default PN2SSG."""
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D
+    g = load_golden('mvpnet3d_full')
+    net2d = StubNet2D()
+    model = MVPNet3D(net2d, '', PN2SSG(64, 20, dropout_prob=0.0), in_channels=64, mlp_channels=(64, 64, 64),
+                     reduction='sum', use_relation=True)
+    load_weights(model, g, 303)
+    model = model.to(dev)
+    c = make_chunk(0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    points = t(c['points'].T[None])
+    geo = geometry_chain(points, (2048, 512, 128, 32), (0.1, 0.2, 0.4, 0.8), (32, 32, 32, 32))
+    for key in g.files:
+        if key.startswith('geo_'):
+            np.testing.assert_array_equal(geo[key[4:]].cpu().numpy(), g[key])
+    net2d.feature = t(np.moveaxis(c['feature_2d'], -1, 1))
+    batch = {'images': torch.zeros(1, 3, 3, 120, 160, device=dev), 'points': points, 'depth': t(c['depth_mm'].astype(np.int16)[None]),
+             'cam_matrix': t(np.repeat(c['cam_matrix'][None, :3, :3], 3, 0)[None]), 'kinv': t(c['kinv'][None]),
+             'pose': t(c['pose'][None]), 'pixel_box': t(c['pixel_box'][None]), 'k': 3}
+    for mode in ('eval', 'train'):
+        model.train(mode == 'train')
+        with torch.no_grad():
+            logit = model(batch)['seg_logit']
+        np.testing.assert_allclose(logit.cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])

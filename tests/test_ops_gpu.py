@@ -312,6 +312,30 @@ def test_pixel_knn_few_valid_pixels(dev):
     np.testing.assert_array_equal(idx.cpu().numpy(), e)
 
 
+@pytest.mark.parametrize('k', [1, 3, 5, 8])
+def test_pixel_knn_projective_adversarial(dev, k):
+    """Queries the window search is NOT tuned for: uniform in a box much larger than the scene
+    (off-surface, outside every frustum, behind cameras, on top of a camera centre), sparse validity
+    masks, a skewed intrinsic matrix in one view.  Must still equal the exhaustive scan bit for bit."""
+    from mvpnet_amd.ops import unproject, pixel_knn
+    from mvpnet_amd.synthetic import make_batch
+    bt = make_batch(300 + k, 3, nb_pts=16, nv=3, h=48, w=64, with_feature=False)
+    rs = np.random.RandomState(k)
+    xyz, mask = unproject(g(bt['depth_mm'].astype(np.int16), dev), g(bt['kinv'], dev), g(bt['pose'], dev), g(bt['pixel_box'], dev))
+    mask = mask & (torch.rand(mask.shape, device=dev) < 0.5)
+    pts = rs.uniform(-2.0, 4.0, (3, 3000, 3)).astype(np.float32)
+    pts[:, :300] = bt['points'][:, rs.randint(0, 16, 300)] + rs.normal(0, 0.02, (3, 300, 3)).astype(np.float32)
+    pts[:, 300:303] = bt['pose'][:, :, :3, 3]  # exactly at the camera centres
+    pts[:, 303:393] = xyz.reshape(3, -1, 3)[:, ::97][:, :90].cpu().numpy()  # exactly on pixels: zero distances, ties
+    cam = np.repeat(bt['cam_matrix'][None, None, :3, :3], 3, 1).repeat(3, 0).copy()
+    cam[1, 2, 0, 1] = 0.3  # skewed K in one view: that view must fall back to the full scan
+    pts = g(pts, dev)
+    i1, d1 = pixel_knn(xyz, mask, pts, k, return_distance=True)
+    i2, d2 = pixel_knn(xyz, mask, pts, k, cam=g(cam, dev), pose=g(bt['pose'], dev), return_distance=True)
+    assert torch.equal(d1, d2)
+    assert torch.equal(i1, i2)
+
+
 def test_lift_gather_vs_oracle(dev):
     from mvpnet_amd.ops import lift_gather
     rs = np.random.RandomState(4)
