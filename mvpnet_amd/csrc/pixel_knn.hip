@@ -135,16 +135,14 @@ __global__ __launch_bounds__(kPKThreads) void pixel_knn_proj_kernel(const float*
       for (int uu = ulo; uu <= uhi; ++uu) eval_pixel<K>(xyz, msk, vi * hw + vv * w + uu, qx, qy, qz, bd, bi);
   }
 
-  // ---- phase 2: per view, widen to the radius the bound needs; scan only the ring ----
+  // ---- phase 2: per view, widen to the radius the bound needs; scan only the new ring ----
   for (int vi = 0; vi < nv; ++vi) {
     const ViewParam& V = vp[vi];
     const float dx = qx - V.t[0], dy = qy - V.t[1], dz = qz - V.t[2];
     const float zc = V.r[2] * dx + V.r[5] * dy + V.r[8] * dz;
-    // current k-th best distance, inflated: covers fp32 rounding of the distances, of the
-    // projection and of image_xyz itself (1e-3 relative + 10 um absolute)
-    const float dk = bd[K - 1] < INFINITY ? sqrtf(bd[K - 1]) * 1.001f + 1.0e-5f : INFINITY;
     if (!V.usable || !(zc > 0.05f)) {
       // no projective bound.  Every valid pixel has positive depth, so dist >= -zc for zc <= 0.
+      const float dk = bd[K - 1] < INFINITY ? sqrtf(bd[K - 1]) * 1.001f + 1.0e-5f : INFINITY;
       if (zc <= 0.f && -zc * 0.999f > dk) continue;
       for (int id = vi * hw; id < (vi + 1) * hw; ++id) eval_pixel<K>(xyz, msk, id, qx, qy, qz, bd, bi);
       continue;
@@ -154,27 +152,37 @@ __global__ __launch_bounds__(kPKThreads) void pixel_knn_proj_kernel(const float*
     const float u0 = V.fx * (xc / zc) + V.cx, v0 = V.fy * (yc / zc) + V.cy;
     const int uc = (int)rintf(fminf(fmaxf(u0, -1.0e6f), 1.0e6f));
     const int vc = (int)rintf(fminf(fmaxf(v0, -1.0e6f), 1.0e6f));
-    // need  zc * (wr + 0.45) * inv_scale > dk   (0.45 instead of 0.5: slack for u0,v0 rounding)
-    int wr;
-    if (dk < INFINITY) {
-      const float need = dk / (zc * V.inv_scale) - 0.45f;
-      wr = need < 0.f ? 0 : (need > 1.0e6f ? 1000000 : (int)ceilf(need));
-    } else {
-      wr = 1000000;
-    }
-    if (wr <= W0) continue;
-    const int ulo = max(uc - wr, 0), uhi = min(uc + wr, w - 1);
-    const int vlo = max(vc - wr, 0), vhi = min(vc + wr, h - 1);
-    const int iu0 = uc - W0, iu1 = uc + W0, iv0 = vc - W0, iv1 = vc + W0;  // probe window (already done)
-    for (int vv = vlo; vv <= vhi; ++vv) {
-      const bool inner_row = vv >= iv0 && vv <= iv1;
-      for (int uu = ulo; uu <= uhi; ++uu) {
-        if (inner_row && uu >= iu0 && uu <= iu1) {
-          uu = iu1;  // skip the probed span
-          continue;
-        }
-        eval_pixel<K>(xyz, msk, vi * hw + vv * w + uu, qx, qy, qz, bd, bi);
+    // radius beyond which the window already covers the whole image (nothing left to scan)
+    const int wfull = max(max(uc, w - 1 - uc), max(vc, h - 1 - vc));
+    int wdone = W0;  // [uc-wdone, uc+wdone] x [vc-wdone, vc+wdone] has been scanned
+    while (wdone < wfull) {
+      // current k-th best distance, inflated: covers fp32 rounding of the distances, of the
+      // projection and of image_xyz itself (1e-3 relative + 10 um absolute)
+      int wr;
+      if (bd[K - 1] < INFINITY) {
+        const float dk = sqrtf(bd[K - 1]) * 1.001f + 1.0e-5f;
+        // need  zc * (wr + 0.45) * inv_scale > dk   (0.45 instead of 0.5: slack for u0,v0 rounding)
+        const float need = dk / (zc * V.inv_scale) - 0.45f;
+        wr = need < 0.f ? 0 : (need > 1.0e6f ? 1000000 : (int)ceilf(need));
+        if (wr <= wdone) break;  // the bound already excludes everything outside the scanned window
+      } else {
+        wr = 2 * wdone + 2;  // fewer than k candidates so far: grow geometrically until some appear
       }
+      wr = min(wr, wfull);
+      const int ulo = max(uc - wr, 0), uhi = min(uc + wr, w - 1);
+      const int vlo = max(vc - wr, 0), vhi = min(vc + wr, h - 1);
+      const int iu0 = uc - wdone, iu1 = uc + wdone, iv0 = vc - wdone, iv1 = vc + wdone;  // already scanned
+      for (int vv = vlo; vv <= vhi; ++vv) {
+        const bool inner_row = vv >= iv0 && vv <= iv1;
+        for (int uu = ulo; uu <= uhi; ++uu) {
+          if (inner_row && uu >= iu0 && uu <= iu1) {
+            uu = iu1;  // skip the scanned span
+            continue;
+          }
+          eval_pixel<K>(xyz, msk, vi * hw + vv * w + uu, qx, qy, qz, bd, bi);
+        }
+      }
+      wdone = wr;
     }
   }
 

@@ -21,6 +21,18 @@ CFG = dict(num_centroids=(256, 64, 16, 4), radius=(0.1, 0.2, 0.4, 0.8), max_neig
 ATOL = {'eval': 1e-4, 'train': 1e-3}
 
 
+def assert_grad_close(actual, expected, mode):
+    """eval: element-wise.  train: batch-statistics BN + max-pool arg-max flips make single gradient
+    entries chaotic in fp32 -- measured on this fixture (tools/diag_grad.py): the CPU reference is 5.2 % of
+    the max gradient away from the float64 gradient of its own graph, the GPU path 0.5 %.  So train-mode
+    gradients are compared in the L2 norm."""
+    if mode == 'eval':
+        np.testing.assert_allclose(actual, expected, rtol=5e-3, atol=1e-5 * max(1.0, np.abs(expected).max()))
+    else:
+        rel = np.linalg.norm(actual.astype(np.float64) - expected) / max(np.linalg.norm(expected), 1e-30)
+        assert rel < 5e-2, 'relative L2 gradient error {:.3e}'.format(rel)
+
+
 @pytest.fixture(scope='module')
 def dev():
     assert torch.cuda.is_available()
@@ -81,10 +93,9 @@ def test_pn2ssg_small(dev, mode):
     params = dict(net.named_parameters())
     for pname in ('sa_modules.0.mlp.0.conv.weight', 'sa_modules.3.mlp.2.bn.weight', 'fp_modules.3.mlp.0.conv.weight',
                   'seg_logit.weight', 'seg_logit.bias'):
-        exp = g['{}_grad_{}'.format(mode, pname)]
-        np.testing.assert_allclose(params[pname].grad.cpu().numpy(), exp, rtol=5e-3, atol=(1e-5 if mode == 'eval' else 1e-3) * max(1.0, np.abs(exp).max()))
+        assert_grad_close(params[pname].grad.cpu().numpy(), g['{}_grad_{}'.format(mode, pname)], mode)
     norms = np.asarray([p.grad.norm().item() for p in net.parameters()])
-    np.testing.assert_allclose(norms, g[mode + '_grad_norms'], rtol=2e-3 if mode == 'eval' else 2e-2, atol=1e-6)
+    np.testing.assert_allclose(norms, g[mode + '_grad_norms'], rtol=2e-3 if mode == 'eval' else 5e-2, atol=1e-6)
     if mode == 'train':
         np.testing.assert_allclose(net.sa_modules[0].mlp[0].bn.running_mean.cpu().numpy(), g['train_running_mean_sa0_0'], rtol=1e-4, atol=1e-6)
 
@@ -144,10 +155,8 @@ def test_mvpnet3d_small(dev, mode):
     loss = SegLoss(weight=t(load_golden('pn2ssg_small')['log_weights']))(preds, {'seg_label': label})['seg_loss']
     np.testing.assert_allclose(loss.item(), g[mode + '_loss'], rtol=1e-5 if mode == 'eval' else 1e-4)
     loss.backward()
-    exp = g[mode + '_grad_feature_2d']  # backward of the lifting gather, (B*nv,C,h,w)
-    np.testing.assert_allclose(net2d.feature.grad.cpu().numpy(), exp, rtol=5e-3, atol=(1e-5 if mode == 'eval' else 1e-3) * np.abs(exp).max())
-    exp = g[mode + '_grad_aggr_w0']
-    np.testing.assert_allclose(model.feat_aggreg.mlp[0].conv.weight.grad.cpu().numpy(), exp, rtol=5e-3, atol=(1e-5 if mode == 'eval' else 1e-3) * np.abs(exp).max())
+    assert_grad_close(net2d.feature.grad.cpu().numpy(), g[mode + '_grad_feature_2d'], mode)  # bwd of the lifting gather
+    assert_grad_close(model.feat_aggreg.mlp[0].conv.weight.grad.cpu().numpy(), g[mode + '_grad_aggr_w0'], mode)
     # (b) lifting on the device from depth / intrinsics / pose: same logits
     if mode == 'eval':
         cam = np.stack([np.repeat(c['cam_matrix'][None, :3, :3], 2, 0) for c in chunks])
