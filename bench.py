@@ -73,35 +73,28 @@ def build_batch(rank, batch_size, dev):
 
 
 class TimedLifting:
-    """Wraps MVPNet3D.lift_inputs + ops.lift_gather with HIP events on the launch stream."""
+    """Brackets the mvp_lift_f32 call (2 launches: un-project, k-NN + gather) with HIP events recorded on
+    the stream the kernels are launched on (torch's current stream)."""
 
     def __init__(self):
         self.pairs = []
         self.enabled = False
 
     def install(self, model):
-        from mvpnet_amd import ops
-        import mvpnet_amd.mvpnet3d as M
-        orig_lift, orig_gather = model.lift_inputs, ops.lift_gather
+        from mvpnet_amd import _lib as L
+        orig_call = L.call
         timer = self
 
-        def lift_inputs(data_batch):
-            if timer.enabled:
-                s = torch.cuda.Event(enable_timing=True)
-                s.record()
-                timer._start = s
-            return orig_lift(data_batch)
+        def call(name, tensor_for_device, *args):
+            if name != 'mvp_lift_f32' or not timer.enabled:
+                return orig_call(name, tensor_for_device, *args)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig_call(name, tensor_for_device, *args)
+            e.record()
+            timer.pairs.append((s, e))
 
-        def lift_gather(*a, **k):
-            out = orig_gather(*a, **k)
-            if timer.enabled:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                timer.pairs.append((timer._start, e))
-            return out
-
-        model.lift_inputs = lift_inputs
-        M.ops.lift_gather = lift_gather
+        L.call = call
 
     def mean_ms(self):
         return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else float('nan')
@@ -229,7 +222,7 @@ def main():
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
                        'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
-            'roofline': {'bound': 'hbm', 'kernel': 'lifting = unproject_kernel + pixel_knn_proj_kernel + lift_gather_kernel',
+            'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = unproject_search_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': None, 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
         }

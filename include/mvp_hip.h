@@ -146,6 +146,19 @@ int mvp_lift_gather_f32(const float* feature, const float* image_xyz, const int6
 int mvp_lift_gather_backward_f32(const float* grad_gfeature, const int64_t* index, int64_t B, int64_t P, int64_t C,
                                  int64_t N, int64_t k, float* grad_feature, mvp_stream_t stream);
 
+/* fused lifting: un-projection + exact pixel k-NN + channels-last gather in two launches
+ * (replaces scannet_2d3d.py:254-313 + mvpnet_3d.py:99-109 end to end).
+ *   depth (B,nv,h,w) float32 metres (depth_is_u16 = 0) or uint16 millimetres (= 1); kinv, cam (B,nv,3,3);
+ *   pose (B,nv,4,4); box (B,4) or NULL; points (B,N,3); feature (B,nv,h,w,C) channels-last, C % 4 == 0
+ *   workspace: caller-owned device scratch of mvp_lift_workspace_bytes(B,nv,h,w,N) bytes, 16-byte aligned
+ *   -> knn_index (B,N,k) int64, gfeature (B,N,k,C) or NULL, gxyz (B,N,k,3) or NULL,
+ *      image_xyz (B,nv,h,w,3) or NULL, mask (B,nv,h,w) or NULL   (same values as the separate entry points). */
+int64_t mvp_lift_workspace_bytes(int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N);
+int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv, const float* cam, const float* pose,
+                 const float* box, const float* points, const float* feature, int64_t B, int64_t nv, int64_t h,
+                 int64_t w, int64_t N, int64_t C, int64_t k, void* workspace, int64_t* knn_index, float* gfeature,
+                 float* gxyz, float* image_xyz, uint8_t* mask, mvp_stream_t stream);
+
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.
  * accumulate: logit (n,C) rows of one chunk (row stride ld, so a (C,n) tensor can be passed

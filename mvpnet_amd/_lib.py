@@ -40,10 +40,12 @@ _SIGNATURES = {
     'mvp_pixel_knn_projective_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_lift_gather_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_lift_gather_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_lift_f32': [_ptr, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr,
+                     _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
 }
-EXPORTS = ['mvp_version', 'mvp_strerror'] + sorted(_SIGNATURES)
+EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -57,6 +59,8 @@ def lib():
         handle.mvp_version.restype = ctypes.c_char_p
         handle.mvp_strerror.restype = ctypes.c_char_p
         handle.mvp_strerror.argtypes = [ctypes.c_int]
+        handle.mvp_lift_workspace_bytes.restype = ctypes.c_int64
+        handle.mvp_lift_workspace_bytes.argtypes = [_i64, _i64, _i64, _i64, _i64]
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes

@@ -61,18 +61,14 @@ class MVPNet3D(nn.Module):
         self.net_3d = net_3d
 
     @staticmethod
-    def lift_inputs(data_batch):
-        """image_xyz (B,nv,h,w,3) and knn_indices (B,N,k): taken from the dict, or computed on the device."""
-        if 'knn_indices' in data_batch and 'image_xyz' in data_batch:
-            return data_batch['image_xyz'], data_batch['knn_indices']
-        cam = data_batch['cam_matrix']  # (B,nv,3,3) forward intrinsics, already scaled to (h,w)
-        pose = data_batch['pose']
+    def lift(feature_cl, data_batch):
+        """Device lifting from depth (B,nv,h,w), cam_matrix (B,nv,3,3 forward intrinsics already scaled to
+        (h,w)), pose (B,nv,4,4) [, kinv, pixel_box (B,4), k]: gathered feature, gathered xyz, knn_indices."""
+        cam = data_batch['cam_matrix']
         kinv = data_batch['kinv'] if 'kinv' in data_batch else torch.linalg.inv(cam)
-        points = data_batch['points'].transpose(1, 2).contiguous()
-        with torch.no_grad():
-            image_xyz, mask = ops.unproject(data_batch['depth'], kinv.contiguous(), pose, data_batch.get('pixel_box'))
-            knn = ops.pixel_knn(image_xyz, mask, points, int(data_batch.get('k', 3)), cam=cam.contiguous(), pose=pose)
-        return image_xyz, knn
+        points_nc = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
+        return ops.lift(feature_cl, data_batch['depth'], kinv, cam, data_batch['pose'], points_nc,
+                        k=int(data_batch.get('k', 3)), box=data_batch.get('pixel_box'))
 
     def forward(self, data_batch):
         images = data_batch['images']  # (B,nv,3,h,w)
@@ -81,9 +77,11 @@ class MVPNet3D(nn.Module):
         c = feature_2d.size(1)
         # channels-last view (B,nv,h,w,C); free when the 2D net already runs in torch.channels_last
         feature_cl = feature_2d.permute(0, 2, 3, 1).contiguous().view(b, nv, h, w, c)
-        image_xyz, knn_indices = self.lift_inputs(data_batch)
-        gfeat, gxyz = ops.lift_gather(feature_cl, image_xyz, knn_indices)  # (B,N,k,C), (B,N,k,3)
         points = data_batch['points']
+        if 'knn_indices' in data_batch and 'image_xyz' in data_batch:  # loader-supplied, as in the reference
+            gfeat, gxyz = ops.lift_gather(feature_cl, data_batch['image_xyz'], data_batch['knn_indices'])
+        else:  # device lifting: un-project + pixel k-NN + gather fused (mvp_lift_f32)
+            gfeat, gxyz = self.lift(feature_cl, data_batch)[:2]  # (B,N,k,C), (B,N,k,3)
         feature_2d3d = self.feat_aggreg(gxyz.permute(0, 3, 1, 2), points, gfeat.permute(0, 3, 1, 2))
         return self.net_3d({'points': points, 'feature': feature_2d3d})
 

@@ -6,10 +6,10 @@ from .ball_query import ball_query, ball_query_distance
 from .group_points import group_points
 from .knn_distance import knn_distance
 from .interpolate import feature_interpolate
-from .lifting import unproject, pixel_knn, lift_gather
+from .lifting import unproject, pixel_knn, lift_gather, lift
 
 __all__ = ['farthest_point_sample', 'ball_query', 'ball_query_distance', 'group_points', 'knn_distance',
-           'feature_interpolate', 'unproject', 'pixel_knn', 'lift_gather']
+           'feature_interpolate', 'unproject', 'pixel_knn', 'lift_gather', 'lift']
 
 
 def as_point_major(x, transpose):

@@ -96,3 +96,60 @@ def lift_gather(feature, image_xyz, knn_indices):
     if feature.dtype != torch.float32 or image_xyz.dtype != torch.float32 or knn_indices.dtype != torch.int64:
         raise RuntimeError('lift_gather: float32 feature/xyz and int64 indices expected')
     return LiftGatherFunction.apply(feature.contiguous(), image_xyz.contiguous(), knn_indices.contiguous())
+
+
+class LiftFunction(torch.autograd.Function):
+    """Fused un-project + pixel k-NN + channels-last gather (mvp_lift_f32, two launches).  Gradient flows to
+    the feature map only (scatter-add by the k-NN index)."""
+
+    @staticmethod
+    def forward(ctx, feature, depth, kinv, cam, pose, box, points, k, want_image_xyz):
+        L.require_gpu(feature, depth, kinv, cam, pose, box, points)
+        B, nv, h, w = depth.shape
+        N, C = points.size(1), feature.size(-1)
+        if depth.dtype == torch.float32:
+            is_u16 = 0
+        elif depth.dtype in (torch.int16, torch.uint16):
+            is_u16 = 1
+        else:
+            raise RuntimeError('lift: depth must be float32 (m) or (u)int16 (mm)')
+        ws = torch.empty(L.lib().mvp_lift_workspace_bytes(B, nv, h, w, N), dtype=torch.uint8, device=depth.device)
+        knn = torch.empty((B, N, k), dtype=torch.int64, device=depth.device)
+        gfeat = torch.empty((B, N, k, C), dtype=torch.float32, device=depth.device)
+        gxyz = torch.empty((B, N, k, 3), dtype=torch.float32, device=depth.device)
+        xyz = torch.empty((B, nv, h, w, 3), dtype=torch.float32, device=depth.device) if want_image_xyz else None
+        mask = torch.empty((B, nv, h, w), dtype=torch.uint8, device=depth.device) if want_image_xyz else None
+        L.call('mvp_lift_f32', depth, L.ptr(depth), is_u16, L.ptr(kinv), L.ptr(cam), L.ptr(pose), L.ptr(box), L.ptr(points),
+               L.ptr(feature), B, nv, h, w, N, C, k, L.ptr(ws), L.ptr(knn), L.ptr(gfeat), L.ptr(gxyz), L.ptr(xyz), L.ptr(mask))
+        ctx.save_for_backward(knn)
+        ctx.shape = tuple(feature.shape)
+        if want_image_xyz:
+            ctx.mark_non_differentiable(gxyz, knn, xyz, mask)
+            return gfeat, gxyz, knn, xyz, mask
+        ctx.mark_non_differentiable(gxyz, knn)
+        return gfeat, gxyz, knn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_gfeat, *unused):
+        (knn,) = ctx.saved_tensors
+        B, N, k = knn.shape
+        C = ctx.shape[-1]
+        P = 1
+        for s in ctx.shape[1:-1]:
+            P *= s
+        grad = torch.empty(ctx.shape, dtype=torch.float32, device=grad_gfeat.device)
+        g = grad_gfeat.contiguous()
+        L.call('mvp_lift_gather_backward_f32', g, L.ptr(g), L.ptr(knn), B, P, C, N, k, L.ptr(grad))
+        return (grad,) + (None,) * 8
+
+
+def lift(feature, depth, kinv, cam, pose, points, k=3, box=None, return_image_xyz=False):
+    """feature (B,nv,h,w,C) f32 channels-last; depth (B,nv,h,w) f32 m / int16 mm; kinv, cam (B,nv,3,3);
+    pose (B,nv,4,4); points (B,N,3) -> gathered feature (B,N,k,C), gathered xyz (B,N,k,3), knn_indices (B,N,k)
+    [, image_xyz (B,nv,h,w,3), image_mask (B,nv,h,w) uint8]."""
+    if feature.dtype != torch.float32 or points.dtype != torch.float32 or feature.size(-1) % 4:
+        raise RuntimeError('lift: float32 channels-last feature with C % 4 == 0 expected')
+    return LiftFunction.apply(feature.contiguous(), depth.contiguous(), kinv.contiguous(), cam.contiguous(),
+                              pose.contiguous(), None if box is None else box.contiguous(), points.contiguous(), int(k),
+                              bool(return_image_xyz))

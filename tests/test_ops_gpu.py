@@ -381,6 +381,44 @@ def test_lifting_properties_full_batch(dev):
     assert torch.equal(dd, d1)
 
 
+@pytest.mark.parametrize('kw,k', [(dict(nb_pts=1000, nv=2, h=30, w=40, channels=8), 3), (dict(nb_pts=2048, nv=3, h=60, w=80, channels=16), 5),
+                                   (dict(nb_pts=8192, nv=3, h=120, w=160, channels=64), 3)])
+@pytest.mark.parametrize('depth_kind', ['u16', 'f32'])
+def test_fused_lift_vs_oracle(dev, kw, k, depth_kind):
+    """mvp_lift_f32 (un-project + k-NN + gather, XCD-mapped) == oracle == the separate entry points;
+    B=11 exercises the partial last XCD group."""
+    from mvpnet_amd.ops import lift, unproject, pixel_knn, lift_gather
+    from mvpnet_amd.synthetic import make_batch
+    B = 11 if kw['nb_pts'] < 8192 else 3
+    bt = make_batch(700, B, **kw)
+    depth_m = bt['depth_mm'].astype(np.float32) / np.float32(1000.)
+    depth = g(bt['depth_mm'].astype(np.int16), dev) if depth_kind == 'u16' else g(depth_m, dev)
+    cam = g(np.repeat(bt['cam_matrix'][None, None, :3, :3], kw['nv'], 1).repeat(B, 0), dev)
+    feat = g(bt['feature_2d'], dev).requires_grad_(True)
+    gf, gx, knn, xyz, mask = lift(feat, depth, g(bt['kinv'], dev), cam, g(bt['pose'], dev), g(bt['points'], dev), k=k,
+                                  box=g(bt['pixel_box'], dev), return_image_xyz=True)
+    exyz, emask = O().unproject(depth_m, bt['kinv'], bt['pose'], bt['pixel_box'])
+    eknn = O().pixel_knn(exyz, emask, bt['points'], k)
+    egf, egx = O().lift_gather(bt['feature_2d'].reshape(B, -1, kw['channels']), exyz.reshape(B, -1, 3), eknn)
+    np.testing.assert_array_equal(xyz.cpu().numpy(), exyz)
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), emask)
+    np.testing.assert_array_equal(knn.cpu().numpy(), eknn)
+    np.testing.assert_array_equal(gf.detach().cpu().numpy(), egf)
+    np.testing.assert_array_equal(gx.cpu().numpy(), egx)
+    # separate entry points give the same tensors
+    xyz2, mask2 = unproject(depth, g(bt['kinv'], dev), g(bt['pose'], dev), g(bt['pixel_box'], dev))
+    knn2 = pixel_knn(xyz2, mask2, g(bt['points'], dev), k, cam=cam, pose=g(bt['pose'], dev))
+    gf2, gx2 = lift_gather(feat.detach(), xyz2, knn2)
+    assert torch.equal(knn2, knn) and torch.equal(gf2, gf.detach()) and torch.equal(gx2, gx)
+    # backward: scatter-add into the feature map
+    cot = torch.randn_like(gf)
+    gf.backward(cot)
+    ref = torch.zeros(B, feat[0].numel() // kw['channels'], kw['channels'], device=dev).index_put_(
+        (torch.arange(B, device=dev)[:, None].expand(B, knn[0].numel()).reshape(-1), knn.reshape(-1)),
+        cot.reshape(-1, kw['channels']), accumulate=True)
+    np.testing.assert_allclose(feat.grad.reshape(ref.shape).cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------ vote
 def test_vote_golden(dev):
     """mvpnet/test_mvpnet_3d.py:136-174 known answer; logits passed as (C,n) views like the model output."""

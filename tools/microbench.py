@@ -28,13 +28,14 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     dev = torch.device('cuda:0')
     print(torch.cuda.get_device_name(0), 'B =', B)
-    base = make_batch(0, min(B, 4))
-    rep = (B + 3) // 4
+    nu = min(B, 8)
+    base = make_batch(3000, nu, config=0)
+    rep = (B + nu - 1) // nu
     t = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * rep)[:B])).to(dev)
     depth = t(base['depth_mm'].astype(np.int16))
     kinv, pose, box, pts = t(base['kinv']), t(base['pose']), t(base['pixel_box']), t(base['points'])
     feat = t(base['feature_2d'])
-    cam = t(np.repeat(base['cam_matrix'][None, None, :3, :3], 3, 1).repeat(min(B, 4), 0))
+    cam = t(np.repeat(base['cam_matrix'][None, None, :3, :3], 3, 1).repeat(nu, 0))
     res = {}
     res['unproject'] = timeit(lambda: ops.unproject(depth, kinv, pose, box))
     xyz, mask = ops.unproject(depth, kinv, pose, box)
@@ -43,6 +44,7 @@ def main():
     res['pixel_knn_proj'] = timeit(lambda: ops.pixel_knn(xyz, mask, pts, 3, cam=cam, pose=pose), iters=5, warm=1)
     knn = ops.pixel_knn(xyz, mask, pts, 3, cam=cam, pose=pose)
     res['lift_gather'] = timeit(lambda: ops.lift_gather(feat, xyz, knn))
+    res['lift_fused(2 kernels)'] = timeit(lambda: ops.lift(feat, depth, kinv, cam, pose, pts, k=3, box=box))
     levels = [(8192, 2048, 0.1), (2048, 512, 0.2), (512, 128, 0.4), (128, 32, 0.8)]
     cur = pts
     xyzs = [pts]
