@@ -159,6 +159,38 @@ int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv, const f
                  int64_t w, int64_t N, int64_t C, int64_t k, void* workspace, int64_t* knn_index, float* gfeature,
                  float* gxyz, float* image_xyz, uint8_t* mask, mvp_stream_t stream);
 
+/* ---- channels-last ("rows") PointNet++ kernels ---------------------------------------------
+ * Same mathematics as the channel-major ops above with a point's C features stored as one
+ * contiguous row; these are what the model pipeline runs (mvpnet_amd/pn2.py).  All C, ld % 4 == 0.
+ * group_rows: replaces QueryGrouper.forward's two group_points + centre subtraction + cat
+ *   (mvpnet/models/pn2/modules.py:20-37): feature (B,N,C) [C may be 0], xyz (B,N,3) and center (B,M,3)
+ *   or both NULL, index (B,M,K) -> out (B,M,K,ld) = [feature row | xyz - center | zero pad].
+ * group_rows_backward: grad_out (B,M,K,ld) -> grad_feature (B,N,C) (zero-filled here; first C columns).
+ * interp_rows(_backward): feature_interpolate (mvpnet/ops/interpolate.py:5-34) on rows;
+ *   feature (B,N1,C), index/weight (B,N2,3) -> out (B,N2,ld) columns [0,C). */
+int mvp_group_rows_f32(const float* feature, const float* xyz, const float* center, const int64_t* index, int64_t B,
+                       int64_t N, int64_t C, int64_t M, int64_t K, int64_t ld, float* out, mvp_stream_t stream);
+int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t N, int64_t C, int64_t M,
+                                int64_t K, int64_t ld, float* grad_feature, mvp_stream_t stream);
+int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,
+                        int64_t N2, int64_t ld, float* out, mvp_stream_t stream);
+int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B, int64_t N1,
+                                 int64_t C, int64_t N2, int64_t ld, float* grad_feature, mvp_stream_t stream);
+/* BatchNorm (+ReLU) (+max over K consecutive rows) on a row matrix y (G*K, C): replaces the BN / ReLU /
+ * torch.max(dim=3) modules after each 1x1 conv (common/nn/modules/conv.py:41-51, pn2/modules.py:107-108).
+ * forward : training != 0: batch statistics (float64 accumulation) -> mean, invstd (outputs), running_* updated
+ *           (momentum, unbiased variance; may be NULL); training == 0: mean / invstd are INPUTS.
+ *           out (G,C) = max_k act(((y-mean)*invstd)*gamma+beta), arg (G,C) uint8 = first arg-max (K > 1 only).
+ *           stat: 2*C float64 scratch.
+ * backward: dsrc = d out (G,C) [K > 1] or d act (G*K,C) [K == 1] -> dy (G*K,C); on return
+ *           stat[0:C] = d beta, stat[C:2C] = d gamma (float64). */
+int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
+                            int training, float eps, float momentum, int relu, float* running_mean, float* running_var,
+                            double* stat, float* mean, float* invstd, float* out, uint8_t* arg, mvp_stream_t stream);
+int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
+                             int relu, double* stat, float* dy, mvp_stream_t stream);
+
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.
  * accumulate: logit (n,C) rows of one chunk (row stride ld, so a (C,n) tensor can be passed

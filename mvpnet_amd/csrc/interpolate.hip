@@ -4,7 +4,8 @@
 // mvpnet/ops/cuda/interpolate_kernel.cu:25-68, 131-174).  Reference layout ((B,C,N1) in,
 // (B,C,N2) out).  One lane per query point n, looping over a slice of channels: the three
 // (index, weight) pairs are loaded once and reused for every channel; stores are coalesced
-// along n.  out = (f[i0]*w0 + f[i1]*w1) + f[i2]*w2, each op rounded once.
+// along n.  out = (f[i0]*w0 + f[i1]*w1) + f[i2]*w2, each op rounded once.  Backward accumulates a
+// channel slice of the input gradient in LDS (ds_add) instead of global atomics.
 #include "common.h"
 
 namespace {
@@ -30,6 +31,41 @@ __global__ __launch_bounds__(kIPThreads) void interp_fwd_kernel(const T* __restr
   const T* fp = in + ((size_t)b * C + c0) * N1;
   T* op = out + ((size_t)b * C + c0) * N2 + n;
   for (int c = c0; c < c1; ++c, fp += N1, op += N2) *op = ok ? (fp[i0] * w0 + fp[i1] * w1) + fp[i2] * w2 : T(0);
+}
+
+constexpr int kIBThreads = 1024;
+
+// grad_in[b, c0:c0+CH, :] accumulated in LDS (ds_add), written once -- see group_points.hip.
+template <typename T>
+__global__ __launch_bounds__(kIBThreads) void interp_bwd_lds_kernel(const T* __restrict__ gout,
+                                                                    const int64_t* __restrict__ idx,
+                                                                    const T* __restrict__ w, int C, int N1, int N2,
+                                                                    int CH, T* __restrict__ gin) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* acc = reinterpret_cast<T*>(smem);
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int nc = min(CH, C - c0);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nc * N1; i += kIBThreads) acc[i] = T(0);
+  __syncthreads();
+  const T* gp = gout + ((size_t)b * C + c0) * N2;
+  for (int n = tid; n < N2; n += kIBThreads) {
+    const int64_t* ip = idx + ((size_t)b * N2 + n) * 3;
+    const T* wp = w + ((size_t)b * N2 + n) * 3;
+    const int64_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+    const T w0 = wp[0], w1 = wp[1], w2 = wp[2];
+    if (!(i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1)) continue;
+    for (int c = 0; c < nc; ++c) {
+      const T g = gp[(size_t)c * N2 + n];
+      atomicAdd(&acc[c * N1 + (int)i0], g * w0);
+      atomicAdd(&acc[c * N1 + (int)i1], g * w1);
+      atomicAdd(&acc[c * N1 + (int)i2], g * w2);
+    }
+  }
+  __syncthreads();
+  T* op = gin + ((size_t)b * C + c0) * N1;
+  for (int i = tid; i < nc * N1; i += kIBThreads) op[i] = acc[i];
 }
 
 template <typename T>
@@ -67,11 +103,27 @@ int interp_entry(const T* a, const int64_t* index, const T* weight, int64_t B, i
   MVP_REQUIRE(B >= 0 && C >= 0 && N1 > 0 && N2 >= 0);
   MVP_REQUIRE(B < 65536 && C < (1ll << 31) && N1 < (1ll << 31) && N2 < (1ll << 31));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0 || C == 0) return MVP_OK;
   if (BWD) {
+    constexpr int64_t kLdsBudget = 64 * 1024;
+    int64_t ch = kLdsBudget / ((int64_t)sizeof(T) * N1);
+    if (ch >= 1) {
+      if (ch > C) ch = C;
+      if (ch > 8) ch = 8;
+      const size_t bytes = (size_t)ch * N1 * sizeof(T);
+      auto k = interp_bwd_lds_kernel<T>;
+      if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+      }
+      dim3 grid((unsigned)cdiv(C, ch), (unsigned)B);
+      hipLaunchKernelGGL(k, grid, dim3(kIBThreads), bytes, s, a, index, weight, (int)C, (int)N1, (int)N2, (int)ch, o);
+      return mvp_launch_status();
+    }
     hipError_t e = hipMemsetAsync(o, 0, sizeof(T) * (size_t)(B * C * N1), s);
     if (e != hipSuccess) return (int)e;
   }
-  if (B == 0 || C == 0 || N2 == 0) return MVP_OK;
+  if (N2 == 0) return MVP_OK;
   dim3 grid((unsigned)cdiv(N2, kIPThreads), (unsigned)cdiv(C, kIPChanPerBlock), (unsigned)B);
   if (BWD)
     hipLaunchKernelGGL(interp_bwd_kernel<T>, grid, dim3(kIPThreads), 0, s, a, index, weight, (int)C, (int)N1, (int)N2, o);

@@ -1,0 +1,471 @@
+// rows.hip -- the channels-last ("rows") kernel family of the PointNet++ pipeline for gfx950.
+//
+// The reference keeps activations channel-major ((B,C,M,K), mvpnet/models/pn2/modules.py:20-37,
+// 100-108) which makes every gather / scatter touch C scattered 4-byte words per neighbour and
+// forces cuDNN/MIOpen layout transposes around each 1x1 convolution (common/nn/modules/conv.py:41-51).
+// Here a point's C features are one contiguous row: gathering a neighbour is one coalesced row read,
+// its backward is one coalesced row of atomics, a shared-MLP layer is a plain row-major GEMM, and
+// BatchNorm + ReLU (+ max over the K neighbours) are fused column-wise kernels over (rows, C).
+//
+//   group_rows          out[b,m,k,:] = [ feature[b,idx,:], xyz[b,idx]-center[b,m], 0-pad ]   (QueryGrouper.forward)
+//   group_rows_backward grad_feature[b,idx,:] += grad_out[b,m,k,:C]                          (group_points bwd)
+//   interp_rows         out[b,n,:] = sum_k w[b,n,k] * feature[b,idx[b,n,k],:]                (feature_interpolate)
+//   colstats / bn_finalize / bn_act / bn_act_bwd_*   training-mode BatchNorm(+ReLU)(+max over K) on rows
+//
+// Column mapping used everywhere: lane owns 4 consecutive channels (one float4), C/4 lanes per row,
+// 256/(C/4) rows per workgroup pass -> every global access is a full 16-byte-per-lane coalesced row.
+#include "common.h"
+
+namespace {
+
+constexpr int kRT = 256;  // threads per workgroup
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------------
+// group_rows: feature (B,N,C) [C % 4 == 0, may be 0], xyz (B,N,3) / center (B,M,3) optional,
+// index (B,M,K) -> out (B,M,K,ld), ld % 4 == 0, ld >= C + (xyz ? 3 : 0); pad columns are zeroed.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRT) void group_rows_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
+                                                         const float* __restrict__ center,
+                                                         const int64_t* __restrict__ idx, int N, int C, int M, int K,
+                                                         int ld, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int L4 = ld >> 2;
+  const int64_t E = (int64_t)M * K;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t e = t / L4;
+  const int c4 = (int)(t - e * L4);
+  if (e >= E) return;
+  const int64_t j = idx[(size_t)b * E + e];
+  const bool ok = j >= 0 && j < N;
+  const int c = c4 * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c + 4 <= C) {
+    if (ok) v = ld4(feat + ((size_t)b * N + j) * C + c);
+  } else if (xyz && ok) {
+    // the (up to) 4 columns starting at c straddle / follow the feature block: relative xyz, then zeros
+    const int m = (int)(e / K);
+    const float* p = xyz + ((size_t)b * N + j) * 3;
+    const float* q = center + ((size_t)b * M + m) * 3;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = c + i - C;  // 0..2 -> x,y,z
+      if (col >= 0 && col < 3) r[i] = p[col] - q[col];
+    }
+    v = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  st4(out + ((size_t)b * E + e) * ld + c, v);
+}
+
+// grad_feature (B,N,C) += grad_out[..., :C]; one lane per (row, channel): consecutive lanes hit
+// consecutive floats of one destination row, so each wave issues full-line atomics.
+__global__ __launch_bounds__(kRT) void group_rows_bwd_kernel(const float* __restrict__ gout,
+                                                             const int64_t* __restrict__ idx, int N, int C,
+                                                             int64_t E, int ld, float* __restrict__ gfeat) {
+  const int b = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t e = t / C;
+  const int c = (int)(t - e * C);
+  if (e >= E) return;
+  const int64_t j = idx[(size_t)b * E + e];
+  if (j < 0 || j >= N) return;
+  atomicAdd(gfeat + ((size_t)b * N + j) * C + c, gout[((size_t)b * E + e) * ld + c]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// interp_rows: feature (B,N1,C), index (B,N2,3), weight (B,N2,3) -> out (B,N2,ld) columns [0,C)
+// out = (f0*w0 + f1*w1) + f2*w2, each op rounded once (same order as the channel-major op).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRT) void interp_rows_kernel(const float* __restrict__ feat,
+                                                          const int64_t* __restrict__ idx,
+                                                          const float* __restrict__ w, int N1, int C, int N2, int ld,
+                                                          float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int C4 = C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t n = t / C4;
+  const int c = (int)(t - n * C4) * 4;
+  if (n >= N2) return;
+  const int64_t* ip = idx + ((size_t)b * N2 + n) * 3;
+  const float* wp = w + ((size_t)b * N2 + n) * 3;
+  const int64_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1) {
+    const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+    const float4 a = ld4(feat + ((size_t)b * N1 + i0) * C + c);
+    const float4 bb = ld4(feat + ((size_t)b * N1 + i1) * C + c);
+    const float4 cc = ld4(feat + ((size_t)b * N1 + i2) * C + c);
+    v.x = (a.x * w0 + bb.x * w1) + cc.x * w2;
+    v.y = (a.y * w0 + bb.y * w1) + cc.y * w2;
+    v.z = (a.z * w0 + bb.z * w1) + cc.z * w2;
+    v.w = (a.w * w0 + bb.w * w1) + cc.w * w2;
+  }
+  st4(out + ((size_t)b * N2 + n) * ld + c, v);
+}
+
+__global__ __launch_bounds__(kRT) void interp_rows_bwd_kernel(const float* __restrict__ gout,
+                                                              const int64_t* __restrict__ idx,
+                                                              const float* __restrict__ w, int N1, int C, int N2,
+                                                              int ld, float* __restrict__ gfeat) {
+  const int b = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t n = t / C;
+  const int c = (int)(t - n * C);
+  if (n >= N2) return;
+  const int64_t* ip = idx + ((size_t)b * N2 + n) * 3;
+  const float* wp = w + ((size_t)b * N2 + n) * 3;
+  const float g = gout[((size_t)b * N2 + n) * ld + c];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int64_t j = ip[k];
+    if (j >= 0 && j < N1) atomicAdd(gfeat + ((size_t)b * N1 + j) * C + c, g * wp[k]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Column statistics over rows: stat[0:C] += sum_r f(r,c), stat[C:2C] += sum_r g(r,c) in float64.
+// Each thread sums a short run of rows in fp32, workgroup partials are combined in fp64 through LDS
+// and one fp64 atomic per (workgroup, column, statistic) goes to global memory.
+// ---------------------------------------------------------------------------------------------------
+struct Plain {  // f = y, g = y*y : forward batch statistics
+  const float* y;
+  __device__ __forceinline__ void at(int64_t r, int c, int C, float4& f, float4& g) const {
+    f = ld4(y + (size_t)r * C + c);
+    g = make_float4(f.x * f.x, f.y * f.y, f.z * f.z, f.w * f.w);
+  }
+};
+struct BwdAct {  // f = dz, g = dz * xhat with dz = da * [bn(y) > 0] (relu) : BatchNorm backward sums
+  const float *da, *y, *mean, *invstd, *gamma, *beta;
+  int relu;
+  __device__ __forceinline__ void at(int64_t r, int c, int C, float4& f, float4& g) const {
+    const float4 yy = ld4(y + (size_t)r * C + c), d = ld4(da + (size_t)r * C + c);
+    const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+    const float xh[4] = {(yy.x - mu.x) * is.x, (yy.y - mu.y) * is.y, (yy.z - mu.z) * is.z, (yy.w - mu.w) * is.w};
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w}, dd[4] = {d.x, d.y, d.z, d.w};
+    float fo[4], go[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dz = (!relu || xh[i] * gg[i] + bb[i] > 0.f) ? dd[i] : 0.f;
+      fo[i] = dz;
+      go[i] = dz * xh[i];
+    }
+    f = make_float4(fo[0], fo[1], fo[2], fo[3]);
+    g = make_float4(go[0], go[1], go[2], go[3]);
+  }
+};
+struct BwdMax {  // rows are groups g; only the arg-max row of each (g, c) carries gradient
+  const float *dout, *out, *y, *mean, *invstd;
+  const uint8_t* arg;
+  int K, relu;
+  __device__ __forceinline__ void at(int64_t g, int c, int C, float4& f, float4& gg) const {
+    const float4 d = ld4(dout + (size_t)g * C + c), o = ld4(out + (size_t)g * C + c);
+    const float4 mu = ld4(mean + c), is = ld4(invstd + c);
+    const uint8_t* a = arg + (size_t)g * C + c;
+    const float dd[4] = {d.x, d.y, d.z, d.w}, oo[4] = {o.x, o.y, o.z, o.w};
+    const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
+    float fo[4], go[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dz = (!relu || oo[i] > 0.f) ? dd[i] : 0.f;  // relu'(0) = 0, like torch
+      const float yv = y[((size_t)g * K + a[i]) * C + c + i];
+      fo[i] = dz;
+      go[i] = dz * ((yv - mm[i]) * ii[i]);
+    }
+    f = make_float4(fo[0], fo[1], fo[2], fo[3]);
+    gg = make_float4(go[0], go[1], go[2], go[3]);
+  }
+};
+
+template <typename Src>
+__global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C, int64_t rows_per_block,
+                                                       double* __restrict__ stat) {
+  __shared__ double red[2][kRT][4];
+  const int C4 = C >> 2;
+  const int rpp = kRT / C4;
+  const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
+  const int c = c4 * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(R, r0 + rows_per_block);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  if (rg < rpp)
+    for (int64_t r = r0 + rg; r < r1; r += rpp) {
+      float4 f, g;
+      src.at(r, c, C, f, g);
+      s.x += f.x; s.y += f.y; s.z += f.z; s.w += f.w;
+      q.x += g.x; q.y += g.y; q.z += g.z; q.w += g.w;
+    }
+  double* a = red[0][threadIdx.x];
+  double* bq = red[1][threadIdx.x];
+  a[0] = s.x; a[1] = s.y; a[2] = s.z; a[3] = s.w;
+  bq[0] = q.x; bq[1] = q.y; bq[2] = q.z; bq[3] = q.w;
+  __syncthreads();
+  if (rg == 0) {
+    double ts[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0};
+    for (int g = 0; g < rpp; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ts[i] += red[0][g * C4 + c4][i];
+        tq[i] += red[1][g * C4 + c4][i];
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      atomicAdd(stat + c + i, ts[i]);
+      atomicAdd(stat + C + c + i, tq[i]);
+    }
+  }
+}
+
+// mean / invstd from the sums (biased variance for normalisation, unbiased for the running estimate:
+// torch.nn.BatchNorm semantics, common/nn/modules/conv.py:18,43 with momentum 0.1, eps 1e-5)
+__global__ void bn_finalize_kernel(const double* __restrict__ stat, int64_t R, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = stat[c] / (double)R;
+  double var = stat[C + c] / (double)R - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = R > 1 ? var * ((double)R / (double)(R - 1)) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+}
+
+// a = act(((y - mean) * invstd) * gamma + beta); K > 1: out[g] = max_k a[g,k], arg[g] = first arg-max
+template <bool RELU>
+__global__ __launch_bounds__(kRT) void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int64_t G, int K, int C,
+                                                     float* __restrict__ out, uint8_t* __restrict__ arg) {
+  const int C4 = C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t g = t / C4;
+  const int c = (int)(t - g * C4) * 4;
+  if (g >= G) return;
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bk[4] = {0, 0, 0, 0};
+  for (int k = 0; k < K; ++k) {
+    const float4 yy = ld4(y + ((size_t)g * K + k) * C + c);
+    float a[4] = {((yy.x - mu.x) * is.x) * ga.x + be.x, ((yy.y - mu.y) * is.y) * ga.y + be.y,
+                  ((yy.z - mu.z) * is.z) * ga.z + be.z, ((yy.w - mu.w) * is.w) * ga.w + be.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (RELU) a[i] = a[i] > 0.f ? a[i] : 0.f;
+      if (a[i] > best[i]) {
+        best[i] = a[i];
+        bk[i] = k;
+      }
+    }
+  }
+  st4(out + (size_t)g * C + c, make_float4(best[0], best[1], best[2], best[3]));
+  if (arg) {
+    uchar4 u;
+    u.x = (uint8_t)bk[0]; u.y = (uint8_t)bk[1]; u.z = (uint8_t)bk[2]; u.w = (uint8_t)bk[3];
+    *reinterpret_cast<uchar4*>(arg + (size_t)g * C + c) = u;
+  }
+}
+
+// dy = gamma*invstd * (dz - dbeta/R - xhat * dgamma/R);  dz from da (K == 1) or from (dout, arg) (K > 1)
+template <bool RELU>
+__global__ __launch_bounds__(kRT) void bn_act_bwd_kernel(const float* __restrict__ dsrc, const float* __restrict__ out,
+                                                         const uint8_t* __restrict__ arg, const float* __restrict__ y,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const double* __restrict__ stat, int64_t G, int K, int C,
+                                                         float* __restrict__ dy) {
+  const int C4 = C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t r = t / C4;  // row in [0, G*K)
+  const int c = (int)(t - r * C4) * 4;
+  const int64_t R = G * (int64_t)K;
+  if (r >= R) return;
+  const float4 yy = ld4(y + (size_t)r * C + c);
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+  const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
+  const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+  float dd[4];
+  if (K == 1) {
+    const float4 d = ld4(dsrc + (size_t)r * C + c);
+    dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
+  } else {
+    const int64_t g = r / K;
+    const int k = (int)(r - g * K);
+    const float4 d = ld4(dsrc + (size_t)g * C + c), o = ld4(out + (size_t)g * C + c);
+    const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (size_t)g * C + c);
+    dd[0] = (a.x == k && (!RELU || o.x > 0.f)) ? d.x : 0.f;
+    dd[1] = (a.y == k && (!RELU || o.y > 0.f)) ? d.y : 0.f;
+    dd[2] = (a.z == k && (!RELU || o.z > 0.f)) ? d.z : 0.f;
+    dd[3] = (a.w == k && (!RELU || o.w > 0.f)) ? d.w : 0.f;
+  }
+  float res[4];
+  const float invR = 1.0f / (float)R;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xh = (yv[i] - mm[i]) * ii[i];
+    float dz = dd[i];
+    if (K == 1 && RELU && !(xh * gg[i] + bb[i] > 0.f)) dz = 0.f;
+    const float db = (float)stat[c + i], dg = (float)stat[C + c + i];
+    res[i] = (gg[i] * ii[i]) * ((dz - db * invR) - xh * (dg * invR));
+  }
+  st4(dy + (size_t)r * C + c, make_float4(res[0], res[1], res[2], res[3]));
+}
+
+int check_rows(int64_t R, int64_t C) {
+  if (R < 0 || C <= 0 || C % 4 != 0 || C > 1024 || (kRT % (C / 4)) != 0) return MVP_EINVAL;
+  return MVP_OK;
+}
+
+template <typename Src>
+int launch_colstats(Src src, int64_t R, int64_t C, double* stat, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s);
+  if (e != hipSuccess) return (int)e;
+  if (R == 0) return MVP_OK;
+  const int rpp = kRT / (int)(C / 4);
+  int64_t rows_per_block = cdiv(R, 2048);
+  rows_per_block = cdiv(rows_per_block, rpp) * rpp;
+  if (rows_per_block > 64 * rpp) rows_per_block = 64 * rpp;  // at most 64 fp32 adds per thread before going fp64
+  hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)cdiv(R, rows_per_block)), dim3(kRT), 0, s, src, R, (int)C,
+                     rows_per_block, stat);
+  return mvp_launch_status();
+}
+
+}  // namespace
+
+MVP_API int mvp_group_rows_f32(const float* feature, const float* xyz, const float* center, const int64_t* index,
+                               int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, int64_t ld, float* out,
+                               mvp_stream_t stream) {
+  MVP_NONNULL(index);
+  MVP_NONNULL(out);
+  if (C > 0) MVP_NONNULL(feature);
+  if (xyz) MVP_NONNULL(center);
+  MVP_REQUIRE(B >= 0 && N > 0 && C >= 0 && M >= 0 && K >= 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C + (xyz ? 3 : 0) &&
+              ld > 0 && B < 65536);
+  if (B == 0 || M * K == 0) return MVP_OK;
+  dim3 grid((unsigned)cdiv(M * K * (ld / 4), kRT), (unsigned)B);
+  hipLaunchKernelGGL(group_rows_kernel, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), feature, xyz, center, index,
+                     (int)N, (int)C, (int)M, (int)K, (int)ld, out);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t N, int64_t C,
+                                        int64_t M, int64_t K, int64_t ld, float* grad_feature, mvp_stream_t stream) {
+  MVP_NONNULL(grad_out);
+  MVP_NONNULL(index);
+  MVP_NONNULL(grad_feature);
+  MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && M >= 0 && K >= 0 && ld >= C && B < 65536);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(grad_feature, 0, sizeof(float) * (size_t)(B * N * C), s);
+  if (e != hipSuccess) return (int)e;
+  if (B == 0 || M * K == 0) return MVP_OK;
+  dim3 grid((unsigned)cdiv(M * K * C, kRT), (unsigned)B);
+  hipLaunchKernelGGL(group_rows_bwd_kernel, grid, dim3(kRT), 0, s, grad_out, index, (int)N, (int)C, M * K, (int)ld,
+                     grad_feature);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1,
+                                int64_t C, int64_t N2, int64_t ld, float* out, mvp_stream_t stream) {
+  MVP_NONNULL(feature);
+  MVP_NONNULL(index);
+  MVP_NONNULL(weight);
+  MVP_NONNULL(out);
+  MVP_REQUIRE(B >= 0 && N1 > 0 && C > 0 && C % 4 == 0 && N2 >= 0 && ld >= C && ld % 4 == 0 && B < 65536);
+  if (B == 0 || N2 == 0) return MVP_OK;
+  dim3 grid((unsigned)cdiv(N2 * (C / 4), kRT), (unsigned)B);
+  hipLaunchKernelGGL(interp_rows_kernel, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), feature, index, weight,
+                     (int)N1, (int)C, (int)N2, (int)ld, out);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B,
+                                         int64_t N1, int64_t C, int64_t N2, int64_t ld, float* grad_feature,
+                                         mvp_stream_t stream) {
+  MVP_NONNULL(grad_out);
+  MVP_NONNULL(index);
+  MVP_NONNULL(weight);
+  MVP_NONNULL(grad_feature);
+  MVP_REQUIRE(B >= 0 && N1 > 0 && C > 0 && N2 >= 0 && ld >= C && B < 65536);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(grad_feature, 0, sizeof(float) * (size_t)(B * N1 * C), s);
+  if (e != hipSuccess) return (int)e;
+  if (B == 0 || N2 == 0) return MVP_OK;
+  dim3 grid((unsigned)cdiv(N2 * C, kRT), (unsigned)B);
+  hipLaunchKernelGGL(interp_rows_bwd_kernel, grid, dim3(kRT), 0, s, grad_out, index, weight, (int)N1, (int)C, (int)N2,
+                     (int)ld, grad_feature);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K,
+                                    int64_t C, int training, float eps, float momentum, int relu, float* running_mean,
+                                    float* running_var, double* stat, float* mean, float* invstd, float* out,
+                                    uint8_t* arg, mvp_stream_t stream) {
+  MVP_NONNULL(y);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(beta);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(out);
+  MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);
+  if (K > 1) MVP_NONNULL(arg);
+  int rc = check_rows(G * K, C);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t R = G * K;
+  if (training) {
+    MVP_NONNULL(stat);
+    rc = launch_colstats(Plain{y}, R, C, stat, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, stat, R, (int)C, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+  }  // eval: the caller passes mean = running_mean and invstd = 1/sqrt(running_var + eps)
+  if (R == 0) return mvp_launch_status();
+  dim3 grid((unsigned)cdiv(G * (C / 4), kRT));
+  if (relu)
+    hipLaunchKernelGGL(bn_act_kernel<true>, grid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, G, (int)K, (int)C, out, arg);
+  else
+    hipLaunchKernelGGL(bn_act_kernel<false>, grid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, G, (int)K, (int)C, out, arg);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     int64_t G, int64_t K, int64_t C, int relu, double* stat, float* dy,
+                                     mvp_stream_t stream) {
+  MVP_NONNULL(dsrc);
+  MVP_NONNULL(y);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(beta);
+  MVP_NONNULL(stat);
+  MVP_NONNULL(dy);
+  MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);
+  if (K > 1) {
+    MVP_NONNULL(out);
+    MVP_NONNULL(arg);
+  }
+  int rc = check_rows(G * K, C);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t R = G * K;
+  if (K == 1)
+    rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, s);
+  else
+    rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, arg, (int)K, relu}, G, C, stat, s);
+  if (rc || R == 0) return rc;
+  dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
+  if (relu)
+    hipLaunchKernelGGL(bn_act_bwd_kernel<true>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
+                       G, (int)K, (int)C, dy);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
+                       G, (int)K, (int)C, dy);
+  return mvp_launch_status();
+}

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .nn import SharedMLP, xavier_uniform
 from . import ops
+from . import rows as R
 
 
 class FeatureAggregation(nn.Module):
@@ -39,8 +40,27 @@ class FeatureAggregation(nn.Module):
     def reduction(self, x, dim):
         return torch.sum(x, dim) if self.reduction_name == 'sum' else torch.max(x, dim)[0]
 
-    def forward(self, src_xyz, tgt_xyz, feature):
-        """src_xyz (B,3,N,k), tgt_xyz (B,3,N), feature (B,C,N,k) -> (B,C_out,N)."""
+    def forward_rows(self, gxyz, points, gfeat):
+        """gxyz (B,N,k,3), points (B,N,3), gfeat (B,N,k,C) channels-last -> (B,N,C_out) rows."""
+        B, N, k, C = gfeat.shape
+        if self.mlp is None:
+            return gfeat.sum(2) if self.reduction_name == 'sum' else gfeat.max(2)[0]
+        x = gfeat
+        if self.use_relation:
+            diff = gxyz - points.unsqueeze(2)
+            x = torch.cat([gfeat, diff, torch.sum(diff ** 2, dim=3, keepdim=True)], dim=3)  # feature, diff, dist (:55-56)
+        if x.size(3) % 4:
+            x = torch.nn.functional.pad(x, (0, 4 - x.size(3) % 4))
+        if self.reduction_name == 'max':
+            return R.shared_mlp_rows(x.reshape(B * N * k, -1), self.mlp, K=k).view(B, N, -1)
+        y = R.shared_mlp_rows(x.reshape(B * N * k, -1), self.mlp)
+        return y.view(B, N, k, -1).sum(2)
+
+    def forward(self, src_xyz, tgt_xyz, feature, rows=False):
+        """src_xyz (B,3,N,k), tgt_xyz (B,3,N), feature (B,C,N,k) -> (B,C_out,N).
+        rows=True: channels-last (B,N,k,3), (B,N,3), (B,N,k,C) -> (B,N,C_out)."""
+        if rows:
+            return self.forward_rows(src_xyz, tgt_xyz, feature)
         if self.mlp is None:
             return self.reduction(feature, 3)
         x = feature
@@ -82,8 +102,8 @@ class MVPNet3D(nn.Module):
             gfeat, gxyz = ops.lift_gather(feature_cl, data_batch['image_xyz'], data_batch['knn_indices'])
         else:  # device lifting: un-project + pixel k-NN + gather fused (mvp_lift_f32)
             gfeat, gxyz = self.lift(feature_cl, data_batch)[:2]  # (B,N,k,C), (B,N,k,3)
-        feature_2d3d = self.feat_aggreg(gxyz.permute(0, 3, 1, 2), points, gfeat.permute(0, 3, 1, 2))
-        return self.net_3d({'points': points, 'feature': feature_2d3d})
+        feature_2d3d = self.feat_aggreg(gxyz, points.transpose(1, 2).contiguous(), gfeat, rows=True)  # (B,N,C) rows
+        return self.net_3d({'points': points, 'feature_rows': feature_2d3d})
 
 
 class SegLoss(nn.Module):

@@ -2,12 +2,18 @@
 `mvpnet.models.pn2` (modules.py:13-186, pn2ssg.py:22-137) -- same class names, constructor
 arguments, data-dict keys (`points`, `feature` -> `seg_logit`) and `state_dict` keys.
 All geometry (FPS, ball query, 3-NN, gathers, interpolation) runs in libmvp_hip.so.
+
+Internally activations are channels-last rows ((B,N,C): mvpnet_amd/rows.py, csrc/rows.hip): the
+reference's (B,C,M,K) tensors, its transposes and its separate conv / BN / ReLU / max kernels are
+replaced by coalesced row gathers, one row-major GEMM per layer and fused BN+ReLU(+max) kernels.
+The public `forward` signatures still take and return the reference's channel-major tensors.
 """
 import torch
 import torch.nn as nn
 
 from .nn import SharedMLP, SharedMLPDO, batch_index_select, xavier_uniform
 from . import ops
+from . import rows as R
 
 
 class QueryGrouper(nn.Module):
@@ -30,6 +36,13 @@ class QueryGrouper(nn.Module):
             group_feature = torch.cat([group_feature, group_xyz], dim=1)  # features first, then xyz (:33)
         return group_feature, group_xyz
 
+    def forward_rows(self, new_xyz, xyz, feature):
+        """new_xyz (B,M,3), xyz (B,N,3), feature (B,N,C) or None -> (B,M,K,round4(C+3)) rows
+        [feature | xyz - centre | 0-pad]  (same values as forward(), features first then xyz)."""
+        with torch.no_grad():
+            index = ops.ball_query(new_xyz, xyz, self.radius, self.max_neighbors, transpose=False)
+        return R.group_rows(feature, xyz, new_xyz, index)
+
     def extra_repr(self):
         return 'radius={}, max_neighbors={}'.format(self.radius, self.max_neighbors)
 
@@ -47,24 +60,43 @@ class SetAbstraction(nn.Module):
         self.mlp = SharedMLP(self.in_channels, mlp_channels, ndim=2, bn=True)
         self.grouper = None if num_centroids == 0 else QueryGrouper(radius, max_neighbors)
 
-    def forward(self, xyz, feature=None):
-        """xyz (B,3,N), feature (B,C,N) or None -> new_xyz (B,3,M), new_feature (B,C_out,M)."""
+    def forward_rows(self, xyz, feature=None):
+        """xyz (B,N,3), feature (B,N,C) or None -> new_xyz (B,M,3), new_feature (B,M,C_out)."""
+        B, N, _ = xyz.shape
+        use_feature = feature is not None
         if self.num_centroids == 0:  # one global group centred at the origin (modules.py:88-95)
-            assert feature is not None
-            new_xyz = xyz.new_zeros([xyz.size(0), 3, 1])
-            group_feature = feature.unsqueeze(2)
-            if self.use_xyz:
-                group_feature = torch.cat([group_feature, xyz.unsqueeze(2)], dim=1)
+            assert use_feature
+            new_xyz = xyz.new_zeros([B, 1, 3])
+            x = torch.cat([feature, xyz], dim=2) if self.use_xyz else feature
+            return new_xyz, R.shared_mlp_rows(x.reshape(B * N, -1), self.mlp, K=N).view(B, 1, -1)
+        if self.num_centroids == -1:  # every point is a centroid
+            new_xyz = xyz
         else:
-            if self.num_centroids == -1:  # every point is a centroid
-                new_xyz = xyz
-            else:
-                with torch.no_grad():
-                    index = ops.farthest_point_sample(xyz, self.num_centroids)
-                new_xyz = batch_index_select(xyz, index, dim=2)
-            group_feature, _ = self.grouper(new_xyz, xyz, feature, use_xyz=self.use_xyz)
-        new_feature = self.mlp(group_feature)
-        return new_xyz, new_feature.max(dim=3)[0]
+            with torch.no_grad():
+                index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False)
+            new_xyz = torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
+        M, K = new_xyz.size(1), self.max_neighbors
+        if use_feature and not self.use_xyz:
+            raise NotImplementedError('use_xyz=False with features is not on the rows path')
+        if use_feature and feature.size(2) % 4:
+            feature = torch.nn.functional.pad(feature, (0, 4 - feature.size(2) % 4))  # cannot happen with reference configs
+        group = self.grouper.forward_rows(new_xyz, xyz, feature if use_feature else None)  # (B,M,K,ld)
+        if use_feature and group.size(3) != self.in_channels:
+            # columns are [feature(C) | xyz(3) | pad]; the conv weight expects [feature(C_true) | xyz(3)]
+            c_true = self.in_channels - 3
+            if feature.size(2) != c_true:
+                group = torch.cat([group[..., :c_true], group[..., feature.size(2):feature.size(2) + 3]], dim=-1)
+        new_feature = R.shared_mlp_rows(group.view(B * M * K, group.size(3)), self.mlp, K=K)
+        return new_xyz, new_feature.view(B, M, -1)
+
+    def forward(self, xyz, feature=None, rows=False):
+        """xyz (B,3,N), feature (B,C,N) or None -> new_xyz (B,3,M), new_feature (B,C_out,M).
+        rows=True: channels-last in and out ((B,N,3), (B,N,C) -> (B,M,3), (B,M,C_out))."""
+        if rows:
+            return self.forward_rows(xyz, feature)
+        new_xyz, new_feature = self.forward_rows(xyz.transpose(1, 2).contiguous(),
+                                                 None if feature is None else feature.transpose(1, 2).contiguous())
+        return new_xyz.transpose(1, 2).contiguous(), new_feature.transpose(1, 2).contiguous()
 
     def extra_repr(self):
         return 'num_centroids={}, radius={}, max_neighbors={}, use_xyz={}'.format(
@@ -88,6 +120,18 @@ class FeatureInterpolator(nn.Module):
             return interpolated
         return torch.cat([interpolated, query_feature], dim=1)
 
+    def forward_rows(self, query_xyz, key_xyz, query_feature, key_feature):
+        """query_xyz (B,N1,3), key_xyz (B,N2,3), query_feature (B,N1,C1) or None, key_feature (B,N2,C2)
+        -> (B,N1,C2[+C1]) rows, interpolated features first (modules.py:145)."""
+        with torch.no_grad():
+            index, distance = ops.knn_distance(query_xyz, key_xyz, self.num_neighbors, transpose=False)
+            inv = 1.0 / torch.clamp(distance, min=self._eps)
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+        interpolated = R.interp_rows(key_feature, index, weight)
+        if query_feature is None:
+            return interpolated
+        return torch.cat([interpolated, query_feature], dim=2)
+
     def extra_repr(self):
         return 'num_neighbors={}'.format(self.num_neighbors)
 
@@ -107,13 +151,21 @@ class FeaturePropagation(nn.Module):
         else:
             raise ValueError('Expected value 3, but {} given.'.format(num_neighbors))
 
-    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature):
+    def forward_rows(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature):
+        """rows in / rows out: (B,N,3), (B,M,3), (B,N,C1) or None, (B,M,C2) -> (B,N,C_out)."""
+        B, N, _ = dense_xyz.shape
         if self.interpolator is None:  # broadcast a single global feature
-            assert sparse_xyz.size(2) == 1 and sparse_feature.size(2) == 1
-            new_feature = torch.cat([sparse_feature.expand(-1, -1, dense_xyz.size(2)), dense_feature], dim=1)
+            assert sparse_xyz.size(1) == 1 and sparse_feature.size(1) == 1
+            new_feature = torch.cat([sparse_feature.expand(-1, N, -1), dense_feature], dim=2)
         else:
-            new_feature = self.interpolator(dense_xyz, sparse_xyz, dense_feature, sparse_feature)
-        return self.mlp(new_feature)
+            new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature)
+        return R.shared_mlp_rows(new_feature.reshape(B * N, -1), self.mlp).view(B, N, -1)
+
+    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, rows=False):
+        if rows:
+            return self.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature)
+        t = lambda x: None if x is None else x.transpose(1, 2).contiguous()
+        return self.forward_rows(t(dense_xyz), t(sparse_xyz), t(dense_feature), t(sparse_feature)).transpose(1, 2).contiguous()
 
 
 class PN2SSG(nn.Module):
@@ -148,17 +200,27 @@ class PN2SSG(nn.Module):
         self.reset_parameters()
 
     def forward(self, data_batch):
-        xyz = data_batch['points']
-        feature = data_batch.get('feature', None)
+        """data_batch: 'points' (B,3,N) [+ 'feature' (B,C,N), or 'feature_rows' (B,N,C) channels-last]
+        -> {'seg_logit': (B,num_classes,N)}."""
+        xyz = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
+        if 'feature_rows' in data_batch:
+            feature = data_batch['feature_rows']
+        else:
+            feature = data_batch.get('feature', None)
+            feature = None if feature is None else feature.transpose(1, 2).contiguous()
+        B, N, _ = xyz.shape
         xyzs, feats = [xyz], [None]
         for sa in self.sa_modules:
-            xyz, feature = sa(xyz, feature)
+            xyz, feature = sa(xyz, feature, rows=True)
             xyzs.append(xyz)
             feats.append(feature)
         up = feats[-1]
         for level, fp in enumerate(self.fp_modules):
-            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up)
-        return {'seg_logit': self.seg_logit(self.mlp_seg(up))}
+            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True)
+        x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
+        w = self.seg_logit.weight.reshape(self.num_classes, -1)
+        logit = torch.addmm(self.seg_logit.bias, x, w.t())  # (B*N, classes)
+        return {'seg_logit': logit.view(B, N, self.num_classes).transpose(1, 2).contiguous()}
 
     def reset_parameters(self):
         for m in self.modules():

@@ -59,6 +59,11 @@ class StubNet2D(torch.nn.Module):
         return {'feature': self.feature}
 
 
+def cm(t):
+    """module outputs inside the pipeline are channels-last rows (B,N,C); goldens are channel-major (B,C,N)"""
+    return t.detach().transpose(1, 2).cpu().numpy()
+
+
 def hooks(model):
     rec = {}
     for i, m in enumerate(model.sa_modules):
@@ -83,9 +88,9 @@ def test_pn2ssg_small(dev, mode):
     preds = net({'points': points})
     for i in range(4):
         xyz, feat = rec['sa{}'.format(i)]
-        np.testing.assert_array_equal(xyz.cpu().numpy(), g['{}_sa{}_xyz'.format(mode, i)])  # FPS picks identical points
-        np.testing.assert_allclose(feat.detach().cpu().numpy(), g['{}_sa{}_feature'.format(mode, i)], rtol=1e-4, atol=ATOL[mode])
-        np.testing.assert_allclose(rec['fp{}'.format(i)].detach().cpu().numpy(), g['{}_fp{}_feature'.format(mode, i)], rtol=1e-4, atol=ATOL[mode])
+        np.testing.assert_array_equal(cm(xyz), g['{}_sa{}_xyz'.format(mode, i)])  # FPS picks identical points
+        np.testing.assert_allclose(cm(feat), g['{}_sa{}_feature'.format(mode, i)], rtol=1e-4, atol=ATOL[mode])
+        np.testing.assert_allclose(cm(rec['fp{}'.format(i)]), g['{}_fp{}_feature'.format(mode, i)], rtol=1e-4, atol=ATOL[mode])
     np.testing.assert_allclose(preds['seg_logit'].detach().cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])
     loss = SegLoss(weight=torch.from_numpy(g['log_weights']).to(dev))(preds, {'seg_label': label})['seg_loss']
     np.testing.assert_allclose(loss.item(), g[mode + '_loss'], rtol=1e-5 if mode == 'eval' else 1e-4)
@@ -150,7 +155,7 @@ def test_mvpnet3d_small(dev, mode):
     batch = {'images': torch.zeros(2, 2, 3, 30, 40, device=dev), 'image_xyz': t(g['image_xyz']),
              'knn_indices': t(g['knn_indices'].astype(np.int64)), 'points': points}
     preds = model(batch)
-    np.testing.assert_allclose(fa['o'].detach().cpu().numpy(), g[mode + '_feature_2d3d'], rtol=1e-4, atol=ATOL[mode])
+    np.testing.assert_allclose(cm(fa['o']), g[mode + '_feature_2d3d'], rtol=1e-4, atol=ATOL[mode])
     np.testing.assert_allclose(preds['seg_logit'].detach().cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])
     loss = SegLoss(weight=t(load_golden('pn2ssg_small')['log_weights']))(preds, {'seg_label': label})['seg_loss']
     np.testing.assert_allclose(loss.item(), g[mode + '_loss'], rtol=1e-5 if mode == 'eval' else 1e-4)

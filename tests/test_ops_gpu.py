@@ -460,3 +460,84 @@ def test_extension_modules_have_reference_names(dev):
         mod = importlib.import_module('mvpnet_dropin_test.' + name)
         for fn in fns:
             assert callable(getattr(mod, fn))
+
+
+# ------------------------------------------------------------------ channels-last rows kernels
+def test_group_rows_vs_channel_major(dev):
+    """rows.group_rows == cat[group_points(feature), group_points(xyz) - centre] of QueryGrouper (modules.py:20-37)."""
+    from mvpnet_amd import rows as R
+    from mvpnet_amd.ops import group_points
+    torch.manual_seed(0)
+    for C in (64, 0, 8):
+        xyz = torch.rand(3, 500, 3, device=dev)
+        center = torch.rand(3, 40, 3, device=dev)
+        idx = torch.randint(0, 500, (3, 40, 16), device=dev)
+        feat = torch.randn(3, 500, C, device=dev).requires_grad_(True) if C else None
+        out = R.group_rows(feat, xyz, center, idx)
+        gx = group_points(xyz.transpose(1, 2).contiguous(), idx) - center.transpose(1, 2).unsqueeze(-1)  # (B,3,M,K)
+        assert torch.equal(out[..., C:C + 3], gx.permute(0, 2, 3, 1))
+        assert (out[..., C + 3:] == 0).all()
+        if C:
+            gf = group_points(feat.detach().transpose(1, 2).contiguous(), idx)
+            assert torch.equal(out[..., :C].detach(), gf.permute(0, 2, 3, 1))
+            cot = torch.randn_like(out)
+            out.backward(cot)
+            ref = torch.zeros(3, 500, C, device=dev).index_put_(
+                (torch.arange(3, device=dev)[:, None].expand(3, 640).reshape(-1), idx.reshape(-1)), cot[..., :C].reshape(-1, C), accumulate=True)
+            np.testing.assert_allclose(feat.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_interp_rows_vs_channel_major(dev):
+    from mvpnet_amd import rows as R
+    from mvpnet_amd.ops import feature_interpolate
+    torch.manual_seed(1)
+    f = torch.randn(2, 300, 128, device=dev)
+    idx = torch.randint(0, 300, (2, 1000, 3), device=dev)
+    w = torch.rand(2, 1000, 3, device=dev)
+    w = w / w.sum(2, keepdim=True)
+    fr = f.clone().requires_grad_(True)
+    fc = f.transpose(1, 2).contiguous().requires_grad_(True)
+    o1 = R.interp_rows(fr, idx, w)
+    o2 = feature_interpolate(fc, idx, w)
+    assert torch.equal(o1.detach(), o2.detach().transpose(1, 2))
+    cot = torch.randn_like(o1)
+    o1.backward(cot)
+    o2.backward(cot.transpose(1, 2).contiguous())
+    np.testing.assert_allclose(fr.grad.cpu().numpy(), fc.grad.transpose(1, 2).cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('K,relu,train', [(1, True, True), (32, True, True), (1, False, True), (8, True, False), (1, True, False)])
+@pytest.mark.parametrize('C', [32, 64, 512])
+def test_bn_act_rows_vs_torch(dev, K, relu, train, C):
+    """Fused BatchNorm(+ReLU)(+max over K) on rows vs the torch fp32 modules it replaces
+    (nn.BatchNorm2d + ReLU + torch.max(dim=3), common/nn/modules/conv.py:41-51, pn2/modules.py:107-108)."""
+    from mvpnet_amd import rows as R
+    torch.manual_seed(C + K)
+    G = 777
+    y = (torch.randn(G * K, C, device=dev) * 2 + 0.5)
+    bn1, bn2 = torch.nn.BatchNorm1d(C).to(dev), torch.nn.BatchNorm1d(C).to(dev)
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            bn.running_mean.copy_(torch.linspace(-0.1, 0.4, C))
+            bn.running_var.copy_(torch.linspace(0.7, 3.0, C))
+    bn1.train(train)
+    bn2.train(train)
+    y1 = y.clone().requires_grad_(True)
+    y2 = y.clone().requires_grad_(True)
+    out = R.bn_act_rows(y1, bn1, relu=relu, K=K)
+    z = bn2(y2)
+    if relu:
+        z = torch.relu(z)
+    ref = z.view(G, K, C).max(dim=1)[0] if K > 1 else z
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(bn1.running_mean.cpu().numpy(), bn2.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn1.running_var.cpu().numpy(), bn2.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    cot = torch.randn_like(ref)
+    out.backward(cot)
+    ref.backward(cot)
+    scale = max(1.0, float(y2.grad.abs().max()))
+    np.testing.assert_allclose(y1.grad.cpu().numpy(), y2.grad.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(bn1.weight.grad.cpu().numpy(), bn2.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(bn2.weight.grad.abs().max()))
+    np.testing.assert_allclose(bn1.bias.grad.cpu().numpy(), bn2.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(bn2.bias.grad.abs().max()))
