@@ -183,13 +183,24 @@ int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, co
  *           out (G,C) = max_k act(((y-mean)*invstd)*gamma+beta), arg (G,C) uint8 = first arg-max (K > 1 only).
  *           stat: 2*C float64 scratch.
  * backward: dsrc = d out (G,C) [K > 1] or d act (G*K,C) [K == 1] -> dy (G*K,C); on return
- *           stat[0:C] = d beta, stat[C:2C] = d gamma (float64). */
+ *           stat[0:C] = d beta, stat[C:2C] = d gamma (float64).  training == 0: statistics were constants
+ *           (eval mode), the batch terms are dropped. */
 int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
                             int training, float eps, float momentum, int relu, float* running_mean, float* running_var,
                             double* stat, float* mean, float* invstd, float* out, uint8_t* arg, mvp_stream_t stream);
 int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
-                             int relu, double* stat, float* dy, mvp_stream_t stream);
+                             int relu, int training, double* stat, float* dy, mvp_stream_t stream);
+/* mean / invstd (+ running statistics update, may be NULL) from column sums stat = [sum y | sum y^2] over R rows */
+int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean, float* invstd,
+                        float* running_mean, float* running_var, mvp_stream_t stream);
+/* Shared-MLP layer on rows with fp32 MFMA (mlp.hip): Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias).
+ * act = identity when act_mean == NULL, else relu(((x-mean)*invstd)*gamma+beta) per input column: the previous
+ * layer's BatchNorm + ReLU fused into the load (common/nn/modules/conv.py:41-51), so that activation is never stored.
+ * stat != NULL: 2*Cout float64, receives the column sums of y and y^2 (this layer's batch statistics). */
+int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+                        const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                        const float* bias, float* Y, double* stat, mvp_stream_t stream);
 
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.

@@ -1,0 +1,208 @@
+// mlp.hip -- shared-MLP (pointwise conv) layers on row matrices with fp32 MFMA for gfx950.
+//
+// Replaces the Conv{1,2}d(k=1) + BatchNorm + ReLU module chain of the reference
+// (common/nn/modules/conv.py:29-51, mlp.py:38-75) for channels-last activations:
+//
+//   forward :  Y (R, Cout) = act(X) . W^T        act(x) = x                       (first layer)
+//                                                act(x) = relu(((x-mean)*invstd)*gamma+beta)
+//                                                         (the PREVIOUS layer's BatchNorm+ReLU, applied
+//                                                         while the tile is staged -- the activation
+//                                                         tensor is never written to HBM)
+//              epilogue: per-column sum(y), sum(y^2) in float64 -> batch statistics of THIS layer,
+//              so BatchNorm needs no extra pass over Y.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate -- an exact fp32 FMA chain, which is what keeps
+// the logits within 1e-4 of the fp32 reference; bf16 MFMA would not).  Tile: 128 rows x BN columns per
+// 256-thread workgroup, each wave owns 32 rows x BN columns (BN/32 accumulators of 32x32), K staged in
+// 32-wide slabs through LDS with +1 padding (row stride 33 words: the A/B fragment reads
+// As[row][k], Bs[col][k] with lane-consecutive rows are bank-conflict free).
+// The kernel is HBM-bound for the small layers (C = 32..64: 16 flop/B) and MFMA-bound for C >= 256.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMT = 256;   // threads
+constexpr int kBM = 128;   // rows per workgroup
+constexpr int kBK = 32;    // K slab
+constexpr int kLd = kBK + 1;
+
+struct InAct {  // previous layer's BatchNorm + ReLU, per input column (may be null = identity)
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+};
+
+template <int BN>
+__global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
+                                                      const float* __restrict__ W /* (Cout, ldw) */, int ldw, int Cout,
+                                                      InAct act, const float* __restrict__ bias,
+                                                      float* __restrict__ Y /* (R, Cout) */, double* __restrict__ stat) {
+  __shared__ float As[kBM * kLd];
+  __shared__ float Bs[BN * kLd];
+  __shared__ double sred[2][4][BN];
+  constexpr int NB = BN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * kBM;
+  const int col0 = blockIdx.y * BN;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // staging maps: 8 lanes cover one 32-float K slab of a row (float4 each) -> 32 rows per pass
+  const int kq = (tid & 7) * 4, rr = tid >> 3;
+  const bool x_vec = (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
+  const bool w_vec = (ldw % 4 == 0) && (((uintptr_t)W) % 16 == 0);
+
+  for (int k0 = 0; k0 < Cin; k0 += kBK) {
+    // ---- stage A slab (128 x 32) with the input activation applied ----
+    float pm[4], pi[4], pg[4], pb[4];
+    if (act.mean) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = min(k0 + kq + i, Cin - 1);
+        pm[i] = act.mean[k];
+        pi[i] = act.invstd[k];
+        pg[i] = act.gamma[k];
+        pb[i] = act.beta[k];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kBM / 32; ++p) {
+      const int m = rr + p * 32;
+      const int64_t r = row0 + m;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (r < R) {
+        const float* src = X + (size_t)r * ldx + k0 + kq;
+        if (x_vec && k0 + kq + 4 <= Cin) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k0 + kq + i < Cin) v[i] = src[i];
+        }
+        if (act.mean) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a = ((v[i] - pm[i]) * pi[i]) * pg[i] + pb[i];
+            v[i] = (k0 + kq + i < Cin && a > 0.f) ? a : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[m * kLd + kq + i] = v[i];
+    }
+    // ---- stage B slab (BN x 32): rows of W are output channels ----
+#pragma unroll
+    for (int p = 0; p < BN / 32; ++p) {
+      const int n = rr + p * 32;
+      const int co = col0 + n;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (co < Cout) {
+        const float* src = W + (size_t)co * ldw + k0 + kq;
+        if (w_vec && k0 + kq + 4 <= Cin) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k0 + kq + i < Cin) v[i] = src[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Bs[n * kLd + kq + i] = v[i];
+    }
+    __syncthreads();
+    // ---- 16 MFMA k-steps of 2 on this slab: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31] ----
+    const float* ap = As + (wave * 32 + (lane & 31)) * kLd + (lane >> 5);
+    const float* bp = Bs + (lane & 31) * kLd + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < kBK; kk += 2) {
+      const float a = ap[kk];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[j * 32 * kLd + kk], acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+  const int cl = lane & 31, rh = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int co = col0 + j * 32 + cl;
+    const float bv = (bias && co < Cout) ? bias[co] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = wave * 32 + (i & 3) + 8 * (i >> 2) + rh;
+      const int64_t r = row0 + m;
+      if (r < R && co < Cout) {
+        const float y = acc[j][i] + bv;
+        Y[(size_t)r * Cout + co] = y;
+        s += y;
+        q += y * y;
+      }
+    }
+    if (stat) {  // combine the two lane halves, then the four waves, one fp64 atomic pair per column
+      s += __shfl_xor(s, 32, kWave);
+      q += __shfl_xor(q, 32, kWave);
+      if (lane < 32) {
+        sred[0][wave][j * 32 + cl] = (double)s;
+        sred[1][wave][j * 32 + cl] = (double)q;
+      }
+    }
+  }
+  if (stat) {
+    __syncthreads();
+    for (int c = tid; c < BN; c += kMT) {
+      const int co = col0 + c;
+      if (co < Cout) {
+        atomicAdd(stat + co, sred[0][0][c] + sred[0][1][c] + sred[0][2][c] + sred[0][3][c]);
+        atomicAdd(stat + Cout + co, sred[1][0][c] + sred[1][1][c] + sred[1][2][c] + sred[1][3][c]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias); stat (2*Cout float64, zeroed here) =
+// column sums of y and y^2 when non-NULL.  act_* all NULL = identity, else the previous BatchNorm + ReLU.
+MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw,
+                                int64_t Cout, const float* act_mean, const float* act_invstd, const float* act_gamma,
+                                const float* act_beta, const float* bias, float* Y, double* stat, mvp_stream_t stream) {
+  MVP_NONNULL(X);
+  MVP_NONNULL(W);
+  MVP_NONNULL(Y);
+  MVP_REQUIRE(R >= 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldw >= Cin && Cin < (1 << 20) && Cout < (1 << 20));
+  if (act_mean) {
+    MVP_NONNULL(act_invstd);
+    MVP_NONNULL(act_gamma);
+    MVP_NONNULL(act_beta);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stat) {
+    hipError_t e = hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)Cout, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (R == 0) return MVP_OK;
+  InAct act{act_mean, act_invstd, act_gamma, act_beta};
+  const unsigned gx = (unsigned)cdiv(R, kBM);
+  if (Cout <= 32) {
+    hipLaunchKernelGGL(mlp_fwd_kernel<32>, dim3(gx, 1), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act,
+                       bias, Y, stat);
+  } else if (Cout <= 64) {
+    hipLaunchKernelGGL(mlp_fwd_kernel<64>, dim3(gx, 1), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act,
+                       bias, Y, stat);
+  } else {
+    hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(gx, (unsigned)cdiv(Cout, 128)), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W,
+                       (int)ldw, (int)Cout, act, bias, Y, stat);
+  }
+  return mvp_launch_status();
+}

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kRT) void bn_act_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const double* __restrict__ stat, int64_t G, int K, int C,
-                                                         float* __restrict__ dy) {
+                                                         int batch_terms, float* __restrict__ dy) {
   const int C4 = C >> 2;
   const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
   const int64_t r = t / C4;  // row in [0, G*K)
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kRT) void bn_act_bwd_kernel(const float* __restrict
     dd[3] = (a.w == k && (!RELU || o.w > 0.f)) ? d.w : 0.f;
   }
   float res[4];
-  const float invR = 1.0f / (float)R;
+  const float invR = batch_terms ? 1.0f / (float)R : 0.f;  // eval mode: statistics are constants
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float xh = (yv[i] - mm[i]) * ii[i];
@@ -436,7 +436,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
 
 MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y,
                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                     int64_t G, int64_t K, int64_t C, int relu, double* stat, float* dy,
+                                     int64_t G, int64_t K, int64_t C, int relu, int training, double* stat, float* dy,
                                      mvp_stream_t stream) {
   MVP_NONNULL(dsrc);
   MVP_NONNULL(y);
@@ -463,9 +463,20 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
   if (relu)
     hipLaunchKernelGGL(bn_act_bwd_kernel<true>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
-                       G, (int)K, (int)C, dy);
+                       G, (int)K, (int)C, training, dy);
   else
     hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
-                       G, (int)K, (int)C, dy);
+                       G, (int)K, (int)C, training, dy);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean,
+                                float* invstd, float* running_mean, float* running_var, mvp_stream_t stream) {
+  MVP_NONNULL(stat);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_REQUIRE(R > 0 && C > 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stat, R,
+                     (int)C, eps, momentum, mean, invstd, running_mean, running_var);
   return mvp_launch_status();
 }

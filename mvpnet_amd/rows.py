@@ -135,7 +135,7 @@ class BNActRows(torch.autograd.Function):
         stat = torch.empty(2 * C, dtype=torch.float64, device=y.device)
         dy = torch.empty_like(y)
         L.call('mvp_bn_rows_backward_f32', y, L.ptr(g), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
-               L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), L.ptr(stat), L.ptr(dy))
+               L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), 1, L.ptr(stat), L.ptr(dy))
         dbeta, dgamma = stat[:C].float(), stat[C:].float()
         return dy, dgamma, dbeta, None, None, None, None, None, None, None
 
@@ -153,11 +153,123 @@ def bn_act_rows(y, bn, relu=True, K=1):
                            relu, K)
 
 
+def _bn_backward(dsrc, out, arg, y, mean, invstd, gamma, beta, G, K, C, relu, training):
+    """-> dy (G*K,C), dgamma (C), dbeta (C) through mvp_bn_rows_backward_f32."""
+    stat = torch.empty(2 * C, dtype=torch.float64, device=y.device)
+    dy = torch.empty_like(y)
+    L.call('mvp_bn_rows_backward_f32', y, L.ptr(dsrc), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
+           L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), int(training), L.ptr(stat), L.ptr(dy))
+    return dy, stat[C:].float(), stat[:C].float()
+
+
+def _bn_apply(y, mean, invstd, gamma, beta, G, K, C, relu):
+    """act(bn(y)) with GIVEN statistics (+ max over K): the apply-only mode of mvp_bn_rows_forward_f32."""
+    out = torch.empty((G, C), dtype=torch.float32, device=y.device)
+    arg = torch.empty((G, C), dtype=torch.uint8, device=y.device) if K > 1 else None
+    L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, 0, 0.0, 0.0, int(relu), None, None, None,
+           L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg))
+    return out, arg
+
+
+class MLPChainRows(torch.autograd.Function):
+    """A whole SharedMLP (conv1x1 + BN + ReLU per layer, optional max over K after the last) as ONE autograd
+    node on rows.  Forward: one fp32-MFMA kernel per layer (mvp_mlp_forward_f32) that applies the previous
+    layer's BN+ReLU while loading and emits this layer's batch statistics from its epilogue, so only the
+    pre-BN outputs y_i ever reach HBM.  Backward re-creates each activation from y_i on the fly."""
+
+    @staticmethod
+    def forward(ctx, x0, training, K, eps_mom, bn_buffers, *params):
+        # params = (W_1, gamma_1, beta_1, ..., W_L, gamma_L, beta_L); bn_buffers = [(running_mean, running_var)] * L
+        nl = len(params) // 3
+        R = x0.size(0)
+        dev = x0.device
+        ys, means, invstds = [], [], []
+        act = (None, None, None, None)
+        x = x0
+        for i in range(nl):
+            w, gamma, beta = params[3 * i], params[3 * i + 1], params[3 * i + 2]
+            eps, mom = eps_mom[i]
+            cout, cin = w.size(0), w.size(1)
+            y = torch.empty((R, cout), dtype=torch.float32, device=dev)
+            stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
+            L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
+                   L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat))
+            rm, rv = bn_buffers[i]
+            if training:
+                mean = torch.empty(cout, dtype=torch.float32, device=dev)
+                invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+                L.call('mvp_bn_finalize_f32', y, L.ptr(stat), R, cout, float(eps), float(mom), L.ptr(mean), L.ptr(invstd),
+                       L.ptr(rm), L.ptr(rv))
+            else:
+                mean, invstd = rm, torch.rsqrt(rv + eps)
+            ys.append(y)
+            means.append(mean)
+            invstds.append(invstd)
+            act = (mean, invstd, gamma, beta)
+            x = y
+        cl = ys[-1].size(1)
+        G = R // K
+        out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True)
+        ctx.save_for_backward(x0, out, arg, *ys, *means, *invstds, *params)
+        ctx.cfg = (nl, training, K, R)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        nl, training, K, R = ctx.cfg
+        saved = ctx.saved_tensors
+        x0, out, arg = saved[0], saved[1], saved[2]
+        ys = saved[3:3 + nl]
+        means = saved[3 + nl:3 + 2 * nl]
+        invstds = saved[3 + 2 * nl:3 + 3 * nl]
+        params = saved[3 + 3 * nl:]
+        grads = [None] * (3 * nl)
+        g = grad_out.contiguous()
+        G = R // K
+        # last layer: through max-over-K + ReLU + BN
+        cl = ys[-1].size(1)
+        dy, dgam, dbet = _bn_backward(g, out, arg, ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, training)
+        dx0 = None
+        for i in range(nl - 1, -1, -1):
+            w = params[3 * i]
+            grads[3 * i + 1], grads[3 * i + 2] = dgam, dbet
+            if i == 0:
+                a_prev = x0[:, :w.size(1)] if x0.size(1) != w.size(1) else x0
+            else:
+                cp = ys[i - 1].size(1)
+                a_prev, _ = _bn_apply(ys[i - 1], means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1], R, 1, cp, True)
+            grads[3 * i] = dy.t() @ a_prev
+            if i > 0:
+                da = dy @ w
+                cp = ys[i - 1].size(1)
+                dy, dgam, dbet = _bn_backward(da, None, None, ys[i - 1], means[i - 1], invstds[i - 1], params[3 * i - 2],
+                                              params[3 * i - 1], R, 1, cp, True, training)
+            elif ctx.needs_input_grad[0]:
+                dx0 = dy @ w
+                if x0.size(1) != w.size(1):
+                    dx0 = F.pad(dx0, (0, x0.size(1) - w.size(1)))
+        return (dx0, None, None, None, None) + tuple(grads)
+
+
 def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
     K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108)."""
     n = len(mlp)
+    fused = dropout_p == 0 and all(l.bn is not None and l.relu is not None and l.conv.bias is None and
+                                   l.bn.running_mean is not None for l in mlp) and \
+        all(l.conv.weight.size(0) % 4 == 0 and 256 % (l.conv.weight.size(0) // 4) == 0 for l in mlp)
+    if fused:
+        bn_training = mlp[0].bn.training
+        params, buffers, eps_mom = [], [], []
+        for layer in mlp:
+            params += [layer.conv.weight.reshape(layer.conv.weight.size(0), -1), layer.bn.weight, layer.bn.bias]
+            buffers.append((layer.bn.running_mean, layer.bn.running_var))
+            eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
+            if bn_training and layer.bn.num_batches_tracked is not None:
+                layer.bn.num_batches_tracked.add_(1)
+        return MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, *params)
     for i, layer in enumerate(mlp):
         w = layer.conv.weight.reshape(layer.conv.weight.size(0), -1)  # (C_out, C_in)
         if x.size(1) != w.size(1):
