@@ -201,6 +201,10 @@ int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, flo
 int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
                         const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                         const float* bias, float* Y, double* stat, mvp_stream_t stream);
+/* dW (Cout,Cin) = dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue; dW is zero-filled here. */
+int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                            const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                            float* dW, mvp_stream_t stream);
 
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.

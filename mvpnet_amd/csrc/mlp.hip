@@ -170,6 +170,97 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient: dW (Cout, Cin) = dY^T (Cout, R) . act(X) (R, Cin), the reduction runs over the ROWS.
+// Both operands are consumed exactly as they lie in memory (row-major slabs of 32 rows): the MFMA
+// fragments A[i=co][k=r] = dY[r][co] and B[k=r][j=ci] = act(X)[r][ci] are lane-consecutive LDS reads,
+// no transpose anywhere.  act() re-creates the layer input from the previous layer's pre-BN output
+// on the fly (same prologue as the forward kernel), so that activation is not stored for backward
+// either.  Grid: (Cout/64, Cin/64, row splits); each workgroup keeps its 64x64 partial in MFMA
+// accumulators over its whole row range and flushes once with fp32 atomics.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kDT = 64;  // tile edge (Cout and Cin)
+
+__global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
+                                                     int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
+                                                     float* __restrict__ dW) {
+  __shared__ float Ds[kBK * kDT];
+  __shared__ float As[kBK * kDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.x * kDT, ci0 = blockIdx.y * kDT;
+  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_block;
+  const int64_t r_end = min(R, r_begin + rows_per_block);
+  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;  // 2 x 2 waves of 32 x 32
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  // staging: 16 lanes cover one 64-float row (float4 each) -> 16 rows per pass, 2 passes per slab
+  const int cq = (tid & 15) * 4, rr = tid >> 4;
+  float pm[4], pi[4], pg[4], pb[4];
+  if (act.mean) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = min(ci0 + cq + i, Cin - 1);
+      pm[i] = act.mean[k];
+      pi[i] = act.invstd[k];
+      pg[i] = act.gamma[k];
+      pb[i] = act.beta[k];
+    }
+  }
+  const bool d_vec = (Cout % 4 == 0) && (((uintptr_t)dY) % 16 == 0);
+  const bool x_vec = (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += kBK) {
+#pragma unroll
+    for (int p = 0; p < kBK / 16; ++p) {
+      const int m = rr + p * 16;
+      const int64_t r = r0 + m;
+      float d[4] = {0.f, 0.f, 0.f, 0.f}, a[4] = {0.f, 0.f, 0.f, 0.f};
+      if (r < r_end) {
+        const float* ds = dY + (size_t)r * Cout + co0 + cq;
+        if (d_vec && co0 + cq + 4 <= Cout) {
+          const float4 q = *reinterpret_cast<const float4*>(ds);
+          d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (co0 + cq + i < Cout) d[i] = ds[i];
+        }
+        const float* xs = X + (size_t)r * ldx + ci0 + cq;
+        if (x_vec && ci0 + cq + 4 <= Cin) {
+          const float4 q = *reinterpret_cast<const float4*>(xs);
+          a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (ci0 + cq + i < Cin) a[i] = xs[i];
+        }
+        if (act.mean) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = ((a[i] - pm[i]) * pi[i]) * pg[i] + pb[i];
+            a[i] = (ci0 + cq + i < Cin && v > 0.f) ? v : 0.f;
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(&Ds[m * kDT + cq]) = make_float4(d[0], d[1], d[2], d[3]);
+      *reinterpret_cast<float4*>(&As[m * kDT + cq]) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    __syncthreads();
+    const float* dp = Ds + (lane >> 5) * kDT + wco + (lane & 31);
+    const float* ap = As + (lane >> 5) * kDT + wci + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < kBK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[kk * kDT], ap[kk * kDT], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int ci = ci0 + wci + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int co = co0 + wco + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * Cin + ci, acc[i]);
+  }
+}
+
 }  // namespace
 
 // Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias); stat (2*Cout float64, zeroed here) =
@@ -204,5 +295,33 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
     hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(gx, (unsigned)cdiv(Cout, 128)), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W,
                        (int)ldw, (int)Cout, act, bias, Y, stat);
   }
+  return mvp_launch_status();
+}
+
+// dW (Cout,Cin) = dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]); dW is zero-filled here.  act as in mvp_mlp_forward_f32.
+MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                                    const float* act_mean, const float* act_invstd, const float* act_gamma,
+                                    const float* act_beta, float* dW, mvp_stream_t stream) {
+  MVP_NONNULL(dY);
+  MVP_NONNULL(X);
+  MVP_NONNULL(dW);
+  MVP_REQUIRE(R >= 0 && Cin > 0 && Cout > 0 && ldx >= Cin && Cin < (1 << 20) && Cout < (1 << 20));
+  if (act_mean) {
+    MVP_NONNULL(act_invstd);
+    MVP_NONNULL(act_gamma);
+    MVP_NONNULL(act_beta);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)(Cout * Cin), s);
+  if (e != hipSuccess) return (int)e;
+  if (R == 0) return MVP_OK;
+  const int64_t tiles = cdiv(Cout, kDT) * cdiv(Cin, kDT);
+  int64_t splits = cdiv(1024, tiles);                  // ~4 workgroups per CU in total
+  int64_t rows_per_block = cdiv(cdiv(R, splits), kBK) * kBK;
+  if (rows_per_block < 4 * kBK) rows_per_block = 4 * kBK;
+  splits = cdiv(R, rows_per_block);
+  InAct act{act_mean, act_invstd, act_gamma, act_beta};
+  dim3 grid((unsigned)cdiv(Cout, kDT), (unsigned)cdiv(Cin, kDT), (unsigned)splits);
+  hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW);
   return mvp_launch_status();
 }

@@ -231,24 +231,29 @@ class MLPChainRows(torch.autograd.Function):
         cl = ys[-1].size(1)
         dy, dgam, dbet = _bn_backward(g, out, arg, ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, training)
         dx0 = None
+        none4 = (None, None, None, None)
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
+            cout, cin = w.size(0), w.size(1)
             grads[3 * i + 1], grads[3 * i + 2] = dgam, dbet
-            if i == 0:
-                a_prev = x0[:, :w.size(1)] if x0.size(1) != w.size(1) else x0
-            else:
-                cp = ys[i - 1].size(1)
-                a_prev, _ = _bn_apply(ys[i - 1], means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1], R, 1, cp, True)
-            grads[3 * i] = dy.t() @ a_prev
-            if i > 0:
-                da = dy @ w
-                cp = ys[i - 1].size(1)
-                dy, dgam, dbet = _bn_backward(da, None, None, ys[i - 1], means[i - 1], invstds[i - 1], params[3 * i - 2],
-                                              params[3 * i - 1], R, 1, cp, True, training)
-            elif ctx.needs_input_grad[0]:
-                dx0 = dy @ w
-                if x0.size(1) != w.size(1):
-                    dx0 = F.pad(dx0, (0, x0.size(1) - w.size(1)))
+            # layer input = x0 (first layer) or relu(bn(y_{i-1})) re-created inside the kernels from y_{i-1}
+            src = x0 if i == 0 else ys[i - 1]
+            act = none4 if i == 0 else (means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1])
+            dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
+            L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
+                   L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw))
+            grads[3 * i] = dw
+            if i > 0 or ctx.needs_input_grad[0]:
+                # d(input) = dy . W  ==  the forward kernel with W^T
+                wt = w.t().contiguous()  # (cin, cout)
+                da = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
+                L.call('mvp_mlp_forward_f32', dy, L.ptr(dy), R, cout, cout, L.ptr(wt), cout, cin, None, None, None, None, None,
+                       L.ptr(da), None)
+                if i > 0:
+                    dy, dgam, dbet = _bn_backward(da, None, None, ys[i - 1], means[i - 1], invstds[i - 1], params[3 * i - 2],
+                                                  params[3 * i - 1], R, 1, cin, True, training)
+                else:
+                    dx0 = da if x0.size(1) == cin else F.pad(da, (0, x0.size(1) - cin))
         return (dx0, None, None, None, None) + tuple(grads)
 
 
