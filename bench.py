@@ -187,8 +187,23 @@ def main():
     timer = TimedLifting()
     timer.install(model)
 
+    from mvpnet_amd.mvpnet3d import prefetch_geometry
+
+    def fresh(b):
+        nb = dict(b)
+        nb.pop('geometry_plan', None)
+        return nb
+
+    state = {'cur': prefetch_geometry(model, fresh(batch))}
+
     def step():
-        return train_step(model, loss_fn, optimizer, batch, scheduler=scheduler, grad_sync=grad_sync)
+        # every step: (1) starts the geometry (FPS chain, ball queries, 3-NN) of the NEXT batch on the side
+        # stream, (2) runs forward + loss + backward + Adam on the current batch whose geometry was started one
+        # step earlier.  One geometry plan and one train step per timed step.
+        cur, nxt = state['cur'], fresh(batch)
+        out = train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=grad_sync, next_batch=nxt)
+        state['cur'] = nxt
+        return out
 
     for _ in range(args.warmup):
         step()

@@ -191,6 +191,10 @@ int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* bet
 int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
                              int relu, int training, double* stat, float* dy, mvp_stream_t stream);
+/* second half of the BatchNorm backward with known column sums stat = [sum dz | sum dz*xhat] (from mvp_mlp_input_grad_f32) */
+int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, int64_t R, int64_t C, int training,
+                                    const double* stat, float* dy, mvp_stream_t stream);
 /* mean / invstd (+ running statistics update, may be NULL) from column sums stat = [sum y | sum y^2] over R rows */
 int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, mvp_stream_t stream);
@@ -201,6 +205,12 @@ int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, flo
 int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
                         const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                         const float* bias, float* Y, double* stat, mvp_stream_t stream);
+/* d(input) with the previous layer's ReLU mask and BatchNorm-backward column sums fused into the epilogue:
+ * dZ (R,Cin) = (dY (R,Cout) . W) * [bn(y_prev) > 0], Wt = W^T (Cin,Cout) contiguous; stat (2*Cin float64) = [sum dZ | sum dZ*xhat].
+ * y_prev == NULL: plain dX = dY . W. */
+int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* Wt, int64_t Cin, const float* y_prev,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ,
+                           double* stat, mvp_stream_t stream);
 /* dW (Cout,Cin) = dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue; dW is zero-filled here. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                             const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,

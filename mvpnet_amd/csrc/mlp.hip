@@ -35,10 +35,22 @@ struct InAct {  // previous layer's BatchNorm + ReLU, per input column (may be n
   const float* beta;
 };
 
+// Optional backward epilogue (used when the kernel computes d(input) = dY . W): the result tile is the
+// gradient w.r.t. the previous layer's ACTIVATION; with the previous layer's pre-BN output y and BN
+// parameters it is turned, in registers, into dz = da * [relu'(bn(y))] and the two column sums BatchNorm's
+// backward needs (sum dz, sum dz * xhat) leave through the same epilogue reduction as the forward statistics.
+struct EpiBwd {
+  const float* y;  // (R, Cout_of_this_kernel) pre-BN output of the previous layer; null = plain forward epilogue
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+};
+
 template <int BN>
 __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
                                                       const float* __restrict__ W /* (Cout, ldw) */, int ldw, int Cout,
-                                                      InAct act, const float* __restrict__ bias,
+                                                      InAct act, const float* __restrict__ bias, EpiBwd epi,
                                                       float* __restrict__ Y /* (R, Cout) */, double* __restrict__ stat) {
   __shared__ float As[kBM * kLd];
   __shared__ float Bs[BN * kLd];
@@ -138,15 +150,29 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
     const int co = col0 + j * 32 + cl;
     const float bv = (bias && co < Cout) ? bias[co] : 0.f;
     float s = 0.f, q = 0.f;
+    float em = 0.f, ei = 0.f, eg = 0.f, eb = 0.f;
+    if (epi.y && co < Cout) {
+      em = epi.mean[co];
+      ei = epi.invstd[co];
+      eg = epi.gamma[co];
+      eb = epi.beta[co];
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int m = wave * 32 + (i & 3) + 8 * (i >> 2) + rh;
       const int64_t r = row0 + m;
       if (r < R && co < Cout) {
-        const float y = acc[j][i] + bv;
+        float y = acc[j][i] + bv;
+        if (epi.y) {
+          const float xh = (epi.y[(size_t)r * Cout + co] - em) * ei;
+          y = (xh * eg + eb > 0.f) ? y : 0.f;  // dz = da * relu'(bn(y_prev))
+          s += y;
+          q += y * xh;
+        } else {
+          s += y;
+          q += y * y;
+        }
         Y[(size_t)r * Cout + co] = y;
-        s += y;
-        q += y * y;
       }
     }
     if (stat) {  // combine the two lane halves, then the four waves, one fp64 atomic pair per column
@@ -287,13 +313,13 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
   const unsigned gx = (unsigned)cdiv(R, kBM);
   if (Cout <= 32) {
     hipLaunchKernelGGL(mlp_fwd_kernel<32>, dim3(gx, 1), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act,
-                       bias, Y, stat);
+                       bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat);
   } else if (Cout <= 64) {
     hipLaunchKernelGGL(mlp_fwd_kernel<64>, dim3(gx, 1), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act,
-                       bias, Y, stat);
+                       bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat);
   } else {
     hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(gx, (unsigned)cdiv(Cout, 128)), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W,
-                       (int)ldw, (int)Cout, act, bias, Y, stat);
+                       (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat);
   }
   return mvp_launch_status();
 }
@@ -323,5 +349,47 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
   InAct act{act_mean, act_invstd, act_gamma, act_beta};
   dim3 grid((unsigned)cdiv(Cout, kDT), (unsigned)cdiv(Cin, kDT), (unsigned)splits);
   hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW);
+  return mvp_launch_status();
+}
+
+// d(input) of a layer, fused with the first half of the previous layer's BatchNorm+ReLU backward:
+//   dZ (R,Cin) = (dY (R,Cout) . Wt^T) * [ bn(y_prev) > 0 ],   Wt (Cin,Cout) = W^T contiguous
+//   stat[0:Cin] = column sums of dZ (= d beta), stat[Cin:2Cin] = column sums of dZ * xhat (= d gamma)
+// y_prev == NULL: plain dX = dY . W (no masking, no statistics).
+MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* Wt, int64_t Cin,
+                                   const float* y_prev, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* dZ, double* stat, mvp_stream_t stream) {
+  MVP_NONNULL(dY);
+  MVP_NONNULL(Wt);
+  MVP_NONNULL(dZ);
+  MVP_REQUIRE(R >= 0 && Cin > 0 && Cout > 0 && Cin < (1 << 20) && Cout < (1 << 20));
+  if (y_prev) {
+    MVP_NONNULL(mean);
+    MVP_NONNULL(invstd);
+    MVP_NONNULL(gamma);
+    MVP_NONNULL(beta);
+    MVP_NONNULL(stat);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (y_prev) {
+    hipError_t e = hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)Cin, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (R == 0) return MVP_OK;
+  InAct act{nullptr, nullptr, nullptr, nullptr};
+  EpiBwd epi{y_prev, mean, invstd, gamma, beta};
+  double* st = y_prev ? stat : nullptr;
+  const unsigned gx = (unsigned)cdiv(R, kBM);
+  // roles: X = dY (R, Cout as the K dimension), W = Wt (Cin rows of length Cout), output columns = Cin
+  if (Cin <= 32) {
+    hipLaunchKernelGGL(mlp_fwd_kernel<32>, dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, Wt, (int)Cout, (int)Cin, act,
+                       nullptr, epi, dZ, st);
+  } else if (Cin <= 64) {
+    hipLaunchKernelGGL(mlp_fwd_kernel<64>, dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, Wt, (int)Cout, (int)Cin, act,
+                       nullptr, epi, dZ, st);
+  } else {
+    hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(gx, (unsigned)cdiv(Cin, 128)), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, Wt,
+                       (int)Cout, (int)Cin, act, nullptr, epi, dZ, st);
+  }
   return mvp_launch_status();
 }

@@ -480,3 +480,24 @@ MVP_API int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float 
                      (int)C, eps, momentum, mean, invstd, running_mean, running_var);
   return mvp_launch_status();
 }
+
+// Second half of BatchNorm's backward when the column sums are already known (they come out of the
+// epilogue of mvp_mlp_input_grad_f32): dy = gamma*invstd * (dz - stat[c]/R - xhat * stat[C+c]/R).
+MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd,
+                                            const float* gamma, const float* beta, int64_t R, int64_t C, int training,
+                                            const double* stat, float* dy, mvp_stream_t stream) {
+  MVP_NONNULL(dz);
+  MVP_NONNULL(y);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(beta);
+  MVP_NONNULL(stat);
+  MVP_NONNULL(dy);
+  int rc = check_rows(R, C);
+  if (rc || R == 0) return rc;
+  dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
+  hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), dz, nullptr, nullptr, y, mean,
+                     invstd, gamma, beta, stat, R, 1, (int)C, training, dy);
+  return mvp_launch_status();
+}

@@ -90,7 +90,18 @@ class MVPNet3D(nn.Module):
         return ops.lift(feature_cl, data_batch['depth'], kinv, cam, data_batch['pose'], points_nc,
                         k=int(data_batch.get('k', 3)), box=data_batch.get('pixel_box'))
 
+    def _side_stream(self, device):
+        if getattr(self, '_geo_stream', None) is None or self._geo_stream.device != device:
+            self._geo_stream = torch.cuda.Stream(device=device)
+        return self._geo_stream
+
     def forward(self, data_batch):
+        # coordinate-only work of the 3D network (FPS chain, ball queries, 3-NN) starts on a side stream
+        # now and overlaps the 2D network, the lifting and the aggregation MLP below.
+        plan = data_batch.get('geometry_plan')
+        if plan is None and hasattr(self.net_3d, 'plan_geometry') and data_batch['points'].is_cuda:
+            pts_rows = data_batch['points'].transpose(1, 2).contiguous()
+            plan = self.net_3d.plan_geometry(pts_rows, stream=self._side_stream(pts_rows.device))
         images = data_batch['images']  # (B,nv,3,h,w)
         b, nv, _, h, w = images.shape
         feature_2d = self.net_2d({'image': images.reshape(b * nv, *images.shape[2:])})['feature']  # (B*nv,C,h,w)
@@ -103,7 +114,7 @@ class MVPNet3D(nn.Module):
         else:  # device lifting: un-project + pixel k-NN + gather fused (mvp_lift_f32)
             gfeat, gxyz = self.lift(feature_cl, data_batch)[:2]  # (B,N,k,C), (B,N,k,3)
         feature_2d3d = self.feat_aggreg(gxyz, points.transpose(1, 2).contiguous(), gfeat, rows=True)  # (B,N,C) rows
-        return self.net_3d({'points': points, 'feature_rows': feature_2d3d})
+        return self.net_3d({'points': points, 'feature_rows': feature_2d3d, 'geometry_plan': plan})
 
 
 class SegLoss(nn.Module):
@@ -118,9 +129,24 @@ class SegLoss(nn.Module):
         return {'seg_loss': loss}
 
 
-def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None):
+def prefetch_geometry(model, data_batch):
+    """Start the coordinate-only work (FPS chain, ball queries, 3-NN) of `data_batch` on the model's side
+    stream and store the plan in the batch.  Called for batch i+1 before the forward of batch i, the ~3 ms
+    FPS dependency chain (which can only use B of the 256 CUs) runs under batch i's forward + backward --
+    the device-side counterpart of the reference's dataloader workers running ahead of the training loop."""
+    net = model.module if hasattr(model, 'module') else model
+    if 'geometry_plan' not in data_batch and hasattr(net, 'net_3d') and data_batch['points'].is_cuda:
+        pts_rows = data_batch['points'].transpose(1, 2).contiguous()
+        data_batch['geometry_plan'] = net.net_3d.plan_geometry(pts_rows, stream=net._side_stream(pts_rows.device))
+    return data_batch
+
+
+def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, next_batch=None):
     """One iteration of the reference loop (mvpnet/train_mvpnet_3d.py:158-180,287-288):
-    zero_grad -> forward -> SegLoss -> backward -> [grad all-reduce] -> [clip] -> step -> scheduler."""
+    zero_grad -> forward -> SegLoss -> backward -> [grad all-reduce] -> [clip] -> step -> scheduler.
+    next_batch: the batch of the NEXT iteration (already on the device); its geometry is prefetched."""
+    if next_batch is not None:
+        prefetch_geometry(model, next_batch)
     optimizer.zero_grad()
     preds = model(data_batch)
     loss = loss_fn(preds, data_batch)['seg_loss']

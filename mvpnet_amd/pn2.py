@@ -36,11 +36,12 @@ class QueryGrouper(nn.Module):
             group_feature = torch.cat([group_feature, group_xyz], dim=1)  # features first, then xyz (:33)
         return group_feature, group_xyz
 
-    def forward_rows(self, new_xyz, xyz, feature):
+    def forward_rows(self, new_xyz, xyz, feature, index=None):
         """new_xyz (B,M,3), xyz (B,N,3), feature (B,N,C) or None -> (B,M,K,round4(C+3)) rows
         [feature | xyz - centre | 0-pad]  (same values as forward(), features first then xyz)."""
-        with torch.no_grad():
-            index = ops.ball_query(new_xyz, xyz, self.radius, self.max_neighbors, transpose=False)
+        if index is None:
+            with torch.no_grad():
+                index = ops.ball_query(new_xyz, xyz, self.radius, self.max_neighbors, transpose=False)
         return R.group_rows(feature, xyz, new_xyz, index)
 
     def extra_repr(self):
@@ -60,7 +61,18 @@ class SetAbstraction(nn.Module):
         self.mlp = SharedMLP(self.in_channels, mlp_channels, ndim=2, bn=True)
         self.grouper = None if num_centroids == 0 else QueryGrouper(radius, max_neighbors)
 
-    def forward_rows(self, xyz, feature=None):
+    def geometry(self, xyz):
+        """Everything of this layer that depends on coordinates only: centroids + neighbour index."""
+        with torch.no_grad():
+            if self.num_centroids == -1:
+                new_xyz = xyz
+            else:
+                index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False)
+                new_xyz = torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
+            ball = ops.ball_query(new_xyz, xyz, self.radius, self.max_neighbors, transpose=False)
+        return new_xyz, ball
+
+    def forward_rows(self, xyz, feature=None, geometry=None):
         """xyz (B,N,3), feature (B,N,C) or None -> new_xyz (B,M,3), new_feature (B,M,C_out)."""
         B, N, _ = xyz.shape
         use_feature = feature is not None
@@ -69,18 +81,13 @@ class SetAbstraction(nn.Module):
             new_xyz = xyz.new_zeros([B, 1, 3])
             x = torch.cat([feature, xyz], dim=2) if self.use_xyz else feature
             return new_xyz, R.shared_mlp_rows(x.reshape(B * N, -1), self.mlp, K=N).view(B, 1, -1)
-        if self.num_centroids == -1:  # every point is a centroid
-            new_xyz = xyz
-        else:
-            with torch.no_grad():
-                index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False)
-            new_xyz = torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
+        new_xyz, ball = self.geometry(xyz) if geometry is None else geometry
         M, K = new_xyz.size(1), self.max_neighbors
         if use_feature and not self.use_xyz:
             raise NotImplementedError('use_xyz=False with features is not on the rows path')
         if use_feature and feature.size(2) % 4:
             feature = torch.nn.functional.pad(feature, (0, 4 - feature.size(2) % 4))  # cannot happen with reference configs
-        group = self.grouper.forward_rows(new_xyz, xyz, feature if use_feature else None)  # (B,M,K,ld)
+        group = self.grouper.forward_rows(new_xyz, xyz, feature if use_feature else None, index=ball)  # (B,M,K,ld)
         if use_feature and group.size(3) != self.in_channels:
             # columns are [feature(C) | xyz(3) | pad]; the conv weight expects [feature(C_true) | xyz(3)]
             c_true = self.in_channels - 3
@@ -89,11 +96,11 @@ class SetAbstraction(nn.Module):
         new_feature = R.shared_mlp_rows(group.view(B * M * K, group.size(3)), self.mlp, K=K)
         return new_xyz, new_feature.view(B, M, -1)
 
-    def forward(self, xyz, feature=None, rows=False):
+    def forward(self, xyz, feature=None, rows=False, geometry=None):
         """xyz (B,3,N), feature (B,C,N) or None -> new_xyz (B,3,M), new_feature (B,C_out,M).
         rows=True: channels-last in and out ((B,N,3), (B,N,C) -> (B,M,3), (B,M,C_out))."""
         if rows:
-            return self.forward_rows(xyz, feature)
+            return self.forward_rows(xyz, feature, geometry=geometry)
         new_xyz, new_feature = self.forward_rows(xyz.transpose(1, 2).contiguous(),
                                                  None if feature is None else feature.transpose(1, 2).contiguous())
         return new_xyz.transpose(1, 2).contiguous(), new_feature.transpose(1, 2).contiguous()
@@ -120,13 +127,18 @@ class FeatureInterpolator(nn.Module):
             return interpolated
         return torch.cat([interpolated, query_feature], dim=1)
 
-    def forward_rows(self, query_xyz, key_xyz, query_feature, key_feature):
-        """query_xyz (B,N1,3), key_xyz (B,N2,3), query_feature (B,N1,C1) or None, key_feature (B,N2,C2)
-        -> (B,N1,C2[+C1]) rows, interpolated features first (modules.py:145)."""
+    def geometry(self, query_xyz, key_xyz):
+        """3-NN index and inverse-squared-distance weights (coordinates only)."""
         with torch.no_grad():
             index, distance = ops.knn_distance(query_xyz, key_xyz, self.num_neighbors, transpose=False)
             inv = 1.0 / torch.clamp(distance, min=self._eps)
             weight = inv / torch.sum(inv, dim=2, keepdim=True)
+        return index, weight
+
+    def forward_rows(self, query_xyz, key_xyz, query_feature, key_feature, geometry=None):
+        """query_xyz (B,N1,3), key_xyz (B,N2,3), query_feature (B,N1,C1) or None, key_feature (B,N2,C2)
+        -> (B,N1,C2[+C1]) rows, interpolated features first (modules.py:145)."""
+        index, weight = self.geometry(query_xyz, key_xyz) if geometry is None else geometry
         interpolated = R.interp_rows(key_feature, index, weight)
         if query_feature is None:
             return interpolated
@@ -151,19 +163,19 @@ class FeaturePropagation(nn.Module):
         else:
             raise ValueError('Expected value 3, but {} given.'.format(num_neighbors))
 
-    def forward_rows(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature):
+    def forward_rows(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=None):
         """rows in / rows out: (B,N,3), (B,M,3), (B,N,C1) or None, (B,M,C2) -> (B,N,C_out)."""
         B, N, _ = dense_xyz.shape
         if self.interpolator is None:  # broadcast a single global feature
             assert sparse_xyz.size(1) == 1 and sparse_feature.size(1) == 1
             new_feature = torch.cat([sparse_feature.expand(-1, N, -1), dense_feature], dim=2)
         else:
-            new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature)
+            new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)
         return R.shared_mlp_rows(new_feature.reshape(B * N, -1), self.mlp).view(B, N, -1)
 
-    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, rows=False):
+    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, rows=False, geometry=None):
         if rows:
-            return self.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature)
+            return self.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)
         t = lambda x: None if x is None else x.transpose(1, 2).contiguous()
         return self.forward_rows(t(dense_xyz), t(sparse_xyz), t(dense_feature), t(sparse_feature)).transpose(1, 2).contiguous()
 
@@ -199,10 +211,44 @@ class PN2SSG(nn.Module):
         self.seg_logit = nn.Conv1d(seg_channels[-1], num_classes, 1, bias=True)
         self.reset_parameters()
 
+    def plan_geometry(self, xyz, stream=None):
+        """All coordinate-only work of the network -- 4 x (FPS, ball query) and 4 x (3-NN + weights) -- as a
+        plan that forward() consumes.  FPS is a chain of ~2700 dependent steps that occupies only B CUs; with
+        `stream` (a side HIP stream) it runs concurrently with the feature path (lifting, aggregation MLP) on
+        the caller's stream.  The plan records an event; forward() makes the current stream wait for it."""
+        cur = torch.cuda.current_stream(xyz.device)
+        if stream is not None:
+            stream.wait_stream(cur)
+        with torch.cuda.stream(stream if stream is not None else cur):
+            sa, xyzs = [], [xyz]
+            for m in self.sa_modules:
+                if m.num_centroids == 0:
+                    sa.append(None)
+                    xyzs.append(xyz.new_zeros([xyz.size(0), 1, 3]))
+                    continue
+                g = m.geometry(xyzs[-1])
+                sa.append(g)
+                xyzs.append(g[0])
+            fp = []
+            for level, m in enumerate(self.fp_modules):
+                fp.append(None if m.interpolator is None else m.interpolator.geometry(xyzs[-2 - level], xyzs[-1 - level]))
+            event = torch.cuda.Event()
+            event.record()
+        plan = {'sa': sa, 'fp': fp, 'event': event, 'stream': stream}
+        if stream is not None:  # tensors were allocated on the side stream but are consumed on the caller's
+            for g in sa + fp:
+                if g is not None:
+                    for t in g:
+                        t.record_stream(cur)
+        return plan
+
     def forward(self, data_batch):
         """data_batch: 'points' (B,3,N) [+ 'feature' (B,C,N), or 'feature_rows' (B,N,C) channels-last]
-        -> {'seg_logit': (B,num_classes,N)}."""
+        [+ 'geometry_plan' from plan_geometry()] -> {'seg_logit': (B,num_classes,N)}."""
         xyz = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
+        plan = data_batch.get('geometry_plan')
+        if plan is not None:
+            torch.cuda.current_stream(xyz.device).wait_event(plan['event'])
         if 'feature_rows' in data_batch:
             feature = data_batch['feature_rows']
         else:
@@ -210,13 +256,14 @@ class PN2SSG(nn.Module):
             feature = None if feature is None else feature.transpose(1, 2).contiguous()
         B, N, _ = xyz.shape
         xyzs, feats = [xyz], [None]
-        for sa in self.sa_modules:
-            xyz, feature = sa(xyz, feature, rows=True)
+        for level, sa in enumerate(self.sa_modules):
+            xyz, feature = sa(xyz, feature, rows=True, geometry=None if plan is None else plan['sa'][level])
             xyzs.append(xyz)
             feats.append(feature)
         up = feats[-1]
         for level, fp in enumerate(self.fp_modules):
-            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True)
+            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True,
+                    geometry=None if plan is None else plan['fp'][level])
         x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
         w = self.seg_logit.weight.reshape(self.num_classes, -1)
         logit = torch.addmm(self.seg_logit.bias, x, w.t())  # (B*N, classes)

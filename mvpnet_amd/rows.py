@@ -244,16 +244,21 @@ class MLPChainRows(torch.autograd.Function):
                    L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw))
             grads[3 * i] = dw
             if i > 0 or ctx.needs_input_grad[0]:
-                # d(input) = dy . W  ==  the forward kernel with W^T
                 wt = w.t().contiguous()  # (cin, cout)
-                da = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
-                L.call('mvp_mlp_forward_f32', dy, L.ptr(dy), R, cout, cout, L.ptr(wt), cout, cin, None, None, None, None, None,
-                       L.ptr(da), None)
+                dz = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
                 if i > 0:
-                    dy, dgam, dbet = _bn_backward(da, None, None, ys[i - 1], means[i - 1], invstds[i - 1], params[3 * i - 2],
-                                                  params[3 * i - 1], R, 1, cin, True, training)
+                    # d(input) = dy . W with the previous layer's ReLU mask and BN-backward column sums in the epilogue
+                    stat = torch.empty(2 * cin, dtype=torch.float64, device=dy.device)
+                    pm, pi, pg, pb = means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1]
+                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(wt), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
+                           L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat))
+                    dy_prev = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
+                    L.call('mvp_bn_rows_backward_finish_f32', dz, L.ptr(dz), L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb),
+                           R, cin, int(training), L.ptr(stat), L.ptr(dy_prev))
+                    dy, dgam, dbet = dy_prev, stat[cin:].float(), stat[:cin].float()
                 else:
-                    dx0 = da if x0.size(1) == cin else F.pad(da, (0, x0.size(1) - cin))
+                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(dz), None)
+                    dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
         return (dx0, None, None, None, None) + tuple(grads)
 
 
