@@ -265,8 +265,7 @@ class PN2SSG(nn.Module):
             up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True,
                     geometry=None if plan is None else plan['fp'][level])
         x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
-        w = self.seg_logit.weight.reshape(self.num_classes, -1)
-        logit = torch.addmm(self.seg_logit.bias, x, w.t())  # (B*N, classes)
+        logit = R.linear_rows(x, self.seg_logit.weight, self.seg_logit.bias)  # (B*N, classes)
         return {'seg_logit': logit.view(B, N, self.num_classes).transpose(1, 2).contiguous()}
 
     def reset_parameters(self):

@@ -262,6 +262,46 @@ class MLPChainRows(torch.autograd.Function):
         return (dx0, None, None, None, None) + tuple(grads)
 
 
+class LinearRows(torch.autograd.Function):
+    """y = x . W^T (+ bias) on rows with the fp32-MFMA kernels (forward, input gradient, weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        L.require_gpu(x, w, bias)
+        R, cin = x.shape
+        cout = w.size(0)
+        y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
+        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, cin, L.ptr(w), cin, cout, None, None, None, None, L.ptr(bias), L.ptr(y), None)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        R, cin = x.shape
+        cout = w.size(0)
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            wt = w.t().contiguous()
+            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(gx), None)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, cin, cin, None, None, None, None, L.ptr(gw))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+def linear_rows(x, weight, bias=None):
+    """x (R, C_in) float32, weight (C_out, C_in[,1[,1]]), bias (C_out) or None -> (R, C_out)."""
+    w = weight.reshape(weight.size(0), -1).contiguous()
+    return LinearRows.apply(x.contiguous(), w, bias)
+
+
 def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
@@ -284,7 +324,7 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False):
         w = layer.conv.weight.reshape(layer.conv.weight.size(0), -1)  # (C_out, C_in)
         if x.size(1) != w.size(1):
             w = F.pad(w, (0, x.size(1) - w.size(1)))
-        y = x @ w.t()
+        y = linear_rows(x, w)
         if layer.bn is not None:
             x = bn_act_rows(y, layer.bn, relu=layer.relu is not None, K=K if i == n - 1 else 1)
         else:
