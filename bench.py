@@ -237,7 +237,7 @@ def main():
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
                        'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
-            'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = unproject_search_kernel + lift_knn_gather_kernel',
+            'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': None, 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
         }

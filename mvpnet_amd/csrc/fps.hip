@@ -14,6 +14,8 @@
 // Semantics = the NumPy oracle (mvpnet/ops/tests/test_fps.py:7-37): idx[0] = 0, first
 // maximum wins (lowest index), squared distances with pinned rounding (common.h).
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -181,11 +183,158 @@ __global__ __launch_bounds__(NT) void fps_kernel(const T* __restrict__ pts, int 
   for (int i = tid; i < M; i += NT) o[i] = sout[i];
 }
 
+// ---- fp32 fast path ------------------------------------------------------------------------------
+// Same algorithm and results as fps_kernel<float,...>; differences are purely instruction count
+// (the loop is issue-bound: every wave of the workgroup pays the arg-max bookkeeping each iteration):
+//   * two points per instruction with packed fp32 math (v_pk_add/v_pk_mul; no FMA -> same rounding);
+//   * the scan tracks only the running MAX VALUE (v_max3_f32, half an instruction per point); the index
+//     of that maximum is recovered afterwards with one ballot per register slot, lowest slot first and
+//     lowest lane first = np.argmax's first maximum;
+//   * wave reduction on the value alone (6 DPP max steps), cross-wave on the packed (value : ~index) key.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float fmax_dpp(float v) {
+  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+  return fmaxf(v, o);
+}
+
+template <int D, int PPT, int NT, bool LDS_PTS>
+__global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ pts, int N, int M,
+                                                      int64_t* __restrict__ out) {
+  static_assert(PPT % 2 == 0, "points are processed in pairs");
+  constexpr int NW = NT / kWave;
+  constexpr int NP = PPT / 2;
+  using K = Key<float>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  K* part = reinterpret_cast<K*>(smem);
+  int* sout = reinterpret_cast<int*>(smem + 2 * 16 * 16);
+  float* sx = reinterpret_cast<float*>(smem + 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15));
+  float* sy = sx + (LDS_PTS ? N : 0);
+  float* sz = sy + (LDS_PTS ? N : 0);
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid / kWave;
+  const float* p = pts + (size_t)b * N * D;
+  int64_t* o = out + (size_t)b * M;
+
+  f32x2 px[NP], py[NP], pz[NP], md[NP];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int j = tid + i * NT;
+    float x = 0.f, y = 0.f, z = 0.f, m = -2.f;  // padding slot: never the maximum (real distances are >= 0)
+    if (j < N) {
+      x = p[(size_t)j * D + 0];
+      y = p[(size_t)j * D + 1];
+      z = D == 3 ? p[(size_t)j * D + 2] : 0.f;
+      m = INFINITY;
+      if (LDS_PTS) {
+        sx[j] = x;
+        sy[j] = y;
+        if (D == 3) sz[j] = z;
+      }
+    }
+    px[i >> 1][i & 1] = x;
+    py[i >> 1][i & 1] = y;
+    pz[i >> 1][i & 1] = z;
+    md[i >> 1][i & 1] = m;
+  }
+  float cx = p[0], cy = p[1], cz = D == 3 ? p[2] : 0.f;
+  if (tid == 0) sout[0] = 0;
+  if (LDS_PTS) __syncthreads();
+
+  for (int it = 1; it < M; ++it) {
+    const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+    float vmax = -3.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const f32x2 dx = px[i] - c2x, dy = py[i] - c2y;
+      f32x2 d = dx * dx + dy * dy;  // -ffp-contract=off: every packed op rounds once, like the scalar oracle
+      if (D == 3) {
+        const f32x2 dz = pz[i] - c2z;
+        d = d + dz * dz;
+      }
+      f32x2 m = md[i];
+      m[0] = fminf(m[0], d[0]);
+      m[1] = fminf(m[1], d[1]);
+      md[i] = m;
+      vmax = fmaxf(fmaxf(vmax, m[0]), m[1]);
+    }
+    // wave maximum (value only), lane 63 -> uniform
+    float wm = vmax;
+    wm = fmax_dpp<kDppXor1>(wm);
+    wm = fmax_dpp<kDppXor2>(wm);
+    wm = fmax_dpp<kDppHalfMirror>(wm);
+    wm = fmax_dpp<kDppMirror>(wm);
+    wm = fmax_dpp<kDppBcast15, 0xA>(wm);
+    wm = fmax_dpp<kDppBcast31, 0xC>(wm);
+    wm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 63));
+    // lowest index in this wave that attains it: slots ascend with the index, lanes ascend within a slot
+    int cand = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if (!found) {
+        const unsigned long long mk = __ballot(md[i >> 1][i & 1] == wm);
+        if (mk) {
+          cand = wave * kWave + (__ffsll((long long)mk) - 1) + i * NT;
+          found = true;
+        }
+      }
+    }
+    int win;
+    if (NW == 1) {
+      win = cand;
+    } else {
+      K k = wm >= 0.f ? K::make(wm, cand) : K::none();
+      K* cur = part + (it & 1) * 16;
+      if (lane == 0) cur[wave] = k;
+      __syncthreads();  // the only barrier of the iteration (partials are double buffered)
+      k = cur[lane & (NW - 1)];
+      key_max_row<K, NW>(k);
+      win = k.index();
+    }
+    if (tid == 0) sout[it] = win;
+    if (LDS_PTS) {
+      cx = sx[win];
+      cy = sy[win];
+      if (D == 3) cz = sz[win];
+    } else {
+      cx = p[(size_t)win * D + 0];
+      cy = p[(size_t)win * D + 1];
+      if (D == 3) cz = p[(size_t)win * D + 2];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < M; i += NT) o[i] = sout[i];
+}
+
 template <typename T, int D, int PPT, int NT>
 int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
   const size_t part_bytes = 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15);  // keys + output buffer
   const size_t pts_bytes = (size_t)N * 3 * sizeof(T);
   const bool lds = pts_bytes + part_bytes <= 150 * 1024;
+  if constexpr (std::is_same<T, float>::value && (PPT % 2 == 0)) {
+    if (lds) {
+      auto k = fps_fast_kernel<D, PPT, NT, true>;
+      size_t bytes = part_bytes + pts_bytes;
+      if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out);
+    } else {
+      auto k = fps_fast_kernel<D, PPT, NT, false>;
+      if (part_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_bytes);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), part_bytes, s, pts, (int)N, (int)M, out);
+    }
+    return mvp_launch_status();
+  }
   if (lds) {
     auto k = fps_kernel<T, D, PPT, NT, true>;
     size_t bytes = part_bytes + pts_bytes;
@@ -216,7 +365,12 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStr
   if (N <= 1024) return launch_cfg<T, D, 4, 256>(pts, B, N, M, out, s);
   if (N <= 2048) return launch_cfg<T, D, 8, 256>(pts, B, N, M, out, s);
   if (N <= 4096) return launch_cfg<T, D, 8, 512>(pts, B, N, M, out, s);
-  if (N <= 8192) return launch_cfg<T, D, 8, 1024>(pts, B, N, M, out, s);
+  if (N <= 8192) {
+    const char* e = getenv("MVP_FPS_CFG");  // tuning knob: threads per cloud for 4096 < N <= 8192
+    if (e && e[0] == '2') return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s);
+    if (e && e[0] == '5') return launch_cfg<T, D, 16, 512>(pts, B, N, M, out, s);
+    return launch_cfg<T, D, 8, 1024>(pts, B, N, M, out, s);
+  }
   if (N <= 16384) return launch_cfg<T, D, 16, 1024>(pts, B, N, M, out, s);
   if (N <= 32768) return launch_cfg<T, D, 32, 1024>(pts, B, N, M, out, s);
   return MVP_EUNSUPPORTED;  // > 32768 points per cloud: not covered by the register-resident kernel

@@ -18,7 +18,9 @@
 // phase is HBM-bound.  Three alternatives were built and measured: processing points in
 // Morton order (gather 57 -> 46 us from L2 re-use, but the per-chunk sort costs 14+ us), staging
 // per-view image windows in LDS (window bounding boxes of 256 points overflow a 48 KB budget) and
-// 8-lane cooperative probing (4x better TCP rate but 8x fewer loads in flight); none was a net win.
+// 8-lane cooperative probing (4x better TCP rate but 8x fewer loads in flight), and wave-specialised
+// software pipelining of k-NN and gather inside a workgroup (164 vs 132 us: the k-NN needs all the waves
+// it can get to hide L2 latency); none was a net win.
 // XCD-aware placement (workgroup L runs on XCD L % 8, observed, used for speed only) keeps each
 // chunk's 0.9 MB of records in ONE XCD's private 4 MB L2.
 #include "pixel_knn_core.h"
@@ -29,46 +31,68 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLFThreads = 256;
 constexpr int kXcds = 8;
 
-template <typename DepthT>
-__global__ __launch_bounds__(256) void lift_prepare_kernel(const DepthT* __restrict__ depth,
+// PX pixels per thread.  Measured: PX = 4 is slower than PX = 1 (15.1 vs 11.3 us, the 64-byte-strided
+// record stores of a wave no longer coalesce), so PX = 1 with large workgroups is used.
+constexpr int kPrepThreads = 1024;
+template <typename DepthT, int PX>
+__global__ __launch_bounds__(kPrepThreads) void lift_prepare_kernel(const DepthT* __restrict__ depth,
                                                            const float* __restrict__ kinv,
                                                            const float* __restrict__ pose,
                                                            const float* __restrict__ box, int B, int nv, int h, int w,
                                                            float4* __restrict__ rec, float* __restrict__ image_xyz,
                                                            uint8_t* __restrict__ mask) {
   const int bv = blockIdx.y;  // b * nv + view
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= h * w) return;
-  const int v = pix / w, u = pix - v * w;
+  const int pix0 = (blockIdx.x * kPrepThreads + threadIdx.x) * PX;
+  if (pix0 >= h * w) return;
   const float* Ki = kinv + (size_t)bv * 9;
   const float* Pm = pose + (size_t)bv * 16;
-  const size_t p = (size_t)bv * h * w + pix;
-  float df;
-  if constexpr (sizeof(DepthT) == 2)
-    df = __fdiv_rn((float)depth[p], 1000.0f);
-  else
-    df = depth[p];
-  // identical arithmetic to unproject_kernel (lifting.hip): float64, one rounding to float32
-  const double d = (double)df, du = (double)u, dv = (double)v;
-  const double rx = ((double)Ki[0] * du + (double)Ki[1] * dv) + (double)Ki[2];
-  const double ry = ((double)Ki[3] * du + (double)Ki[4] * dv) + (double)Ki[5];
-  const double rz = ((double)Ki[6] * du + (double)Ki[7] * dv) + (double)Ki[8];
-  const double xc = rx * d, yc = ry * d, zc = rz * d;
-  const double xw = ((xc * (double)Pm[0] + yc * (double)Pm[1]) + zc * (double)Pm[2]) + (double)Pm[3];
-  const double yw = ((xc * (double)Pm[4] + yc * (double)Pm[5]) + zc * (double)Pm[6]) + (double)Pm[7];
-  const double zw = ((xc * (double)Pm[8] + yc * (double)Pm[9]) + zc * (double)Pm[10]) + (double)Pm[11];
-  bool ok = zc > 0.0;
+  const double k0 = Ki[0], k1 = Ki[1], k2 = Ki[2], k3 = Ki[3], k4 = Ki[4], k5 = Ki[5], k6 = Ki[6], k7 = Ki[7], k8 = Ki[8];
+  const double p0 = Pm[0], p1 = Pm[1], p2 = Pm[2], p3 = Pm[3], p4 = Pm[4], p5 = Pm[5], p6 = Pm[6], p7 = Pm[7], p8 = Pm[8],
+               p9 = Pm[9], p10 = Pm[10], p11 = Pm[11];
+  float bx0 = 0.f, bx1 = 0.f, bx2 = 0.f, bx3 = 0.f;
   if (box) {
     const float* bx = box + (size_t)(bv / nv) * 4;
-    ok = ok && xw > (double)bx[0] && xw < (double)bx[2] && yw > (double)bx[1] && yw < (double)bx[3];
+    bx0 = bx[0]; bx1 = bx[1]; bx2 = bx[2]; bx3 = bx[3];
   }
-  rec[p] = make_float4((float)xw, (float)yw, (float)zw, ok ? 0.0f : INFINITY);
-  if (image_xyz) {
-    image_xyz[p * 3 + 0] = (float)xw;
-    image_xyz[p * 3 + 1] = (float)yw;
-    image_xyz[p * 3 + 2] = (float)zw;
+  const size_t base = (size_t)bv * h * w;
+  float df[PX];
+#pragma unroll
+  for (int i = 0; i < PX; ++i) {
+    const int pix = pix0 + i;
+    if (pix < h * w) {
+      if constexpr (sizeof(DepthT) == 2)
+        df[i] = __fdiv_rn((float)depth[base + pix], 1000.0f);
+      else
+        df[i] = depth[base + pix];
+    } else {
+      df[i] = 0.f;
+    }
   }
-  if (mask) mask[p] = ok ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < PX; ++i) {
+    const int pix = pix0 + i;
+    if (pix >= h * w) break;
+    const int v = pix / w, u = pix - v * w;
+    const size_t p = base + pix;
+    // identical arithmetic to unproject_kernel (lifting.hip): float64, one rounding to float32
+    const double d = (double)df[i], du = (double)u, dv = (double)v;
+    const double rx = (k0 * du + k1 * dv) + k2;
+    const double ry = (k3 * du + k4 * dv) + k5;
+    const double rz = (k6 * du + k7 * dv) + k8;
+    const double xc = rx * d, yc = ry * d, zc = rz * d;
+    const double xw = ((xc * p0 + yc * p1) + zc * p2) + p3;
+    const double yw = ((xc * p4 + yc * p5) + zc * p6) + p7;
+    const double zw = ((xc * p8 + yc * p9) + zc * p10) + p11;
+    bool ok = zc > 0.0;
+    if (box) ok = ok && xw > (double)bx0 && xw < (double)bx2 && yw > (double)bx1 && yw < (double)bx3;
+    rec[p] = make_float4((float)xw, (float)yw, (float)zw, ok ? 0.0f : INFINITY);
+    if (image_xyz) {
+      image_xyz[p * 3 + 0] = (float)xw;
+      image_xyz[p * 3 + 1] = (float)yw;
+      image_xyz[p * 3 + 2] = (float)zw;
+    }
+    if (mask) mask[p] = ok ? 1 : 0;
+  }
 }
 
 template <int K>
@@ -141,7 +165,10 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
   float4* ob = reinterpret_cast<float4*>(gfeat + ((size_t)b * N + (size_t)blk * kLFThreads) * K * C);
   // Output rows are written once and never re-read by this kernel: non-temporal stores keep them
   // from displacing the records / feature rows in L2 (measured 70 -> 57 us on the gather alone).
-  constexpr int U = 2;  // rows in flight per lane
+#ifndef MVP_GATHER_U
+#define MVP_GATHER_U 8
+#endif
+  constexpr int U = MVP_GATHER_U;  // rows in flight per lane
   for (int r = r0; r < rows; r += rpp * U) {
     float4 v[U];
 #pragma unroll
@@ -158,7 +185,11 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
       const int rr = r + u * rpp;
       if (rr < rows) {
         float4* dst = ob + (size_t)rr * C4 + c4;
+#ifdef MVP_GATHER_PLAIN_STORE
+        *dst = v[u];
+#else
         __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&v[u]), reinterpret_cast<f32x4*>(dst));
+#endif
       }
     }
   }
@@ -203,12 +234,13 @@ MVP_API int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv,
   if (B == 0) return MVP_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float4* rec = static_cast<float4*>(workspace);
-  dim3 grid((unsigned)cdiv(h * w, 256), (unsigned)(B * nv));
+  constexpr int PX = 1;
+  dim3 grid((unsigned)cdiv(cdiv(h * w, PX), kPrepThreads), (unsigned)(B * nv));
   if (depth_is_u16)
-    hipLaunchKernelGGL(lift_prepare_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(depth), kinv,
+    hipLaunchKernelGGL((lift_prepare_kernel<uint16_t, PX>), grid, dim3(kPrepThreads), 0, s, static_cast<const uint16_t*>(depth), kinv,
                        pose, box, (int)B, (int)nv, (int)h, (int)w, rec, image_xyz, mask);
   else
-    hipLaunchKernelGGL(lift_prepare_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(depth), kinv, pose,
+    hipLaunchKernelGGL((lift_prepare_kernel<float, PX>), grid, dim3(kPrepThreads), 0, s, static_cast<const float*>(depth), kinv, pose,
                        box, (int)B, (int)nv, (int)h, (int)w, rec, image_xyz, mask);
   int rc = mvp_launch_status();
   if (rc != MVP_OK || N == 0) return rc;

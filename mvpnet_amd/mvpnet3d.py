@@ -113,6 +113,9 @@ class MVPNet3D(nn.Module):
             gfeat, gxyz = ops.lift_gather(feature_cl, data_batch['image_xyz'], data_batch['knn_indices'])
         else:  # device lifting: un-project + pixel k-NN + gather fused (mvp_lift_f32)
             gfeat, gxyz = self.lift(feature_cl, data_batch)[:2]  # (B,N,k,C), (B,N,k,3)
+        nxt = data_batch.get('prefetch_next')
+        if nxt is not None:  # start the NEXT batch's FPS / ball query / 3-NN now: runs under this batch's MLPs
+            prefetch_geometry(self, nxt)
         feature_2d3d = self.feat_aggreg(gxyz, points.transpose(1, 2).contiguous(), gfeat, rows=True)  # (B,N,C) rows
         return self.net_3d({'points': points, 'feature_rows': feature_2d3d, 'geometry_plan': plan})
 
@@ -145,9 +148,9 @@ def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_n
     """One iteration of the reference loop (mvpnet/train_mvpnet_3d.py:158-180,287-288):
     zero_grad -> forward -> SegLoss -> backward -> [grad all-reduce] -> [clip] -> step -> scheduler.
     next_batch: the batch of the NEXT iteration (already on the device); its geometry is prefetched."""
-    if next_batch is not None:
-        prefetch_geometry(model, next_batch)
     optimizer.zero_grad()
+    if next_batch is not None:
+        data_batch = dict(data_batch, prefetch_next=next_batch)  # launched right after this batch's lifting
     preds = model(data_batch)
     loss = loss_fn(preds, data_batch)['seg_loss']
     loss.backward()

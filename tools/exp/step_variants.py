@@ -16,10 +16,18 @@ loss_fn = SegLoss(weight=torch.linspace(0.5, 1.5, 20, device=dev))
 opt = torch.optim.Adam(model.parameters(), lr=2e-3)
 def run(mode, n=10):
     plan = prefetch_geometry(model, dict(batch))['geometry_plan']
+    state = {'cur': prefetch_geometry(model, dict(batch))}
     def one():
         b = dict(batch)
         if mode == 'cached':
             b['geometry_plan'] = plan
+        if mode == 'prefetch':
+            cur, nxt = state['cur'], dict(batch)
+            out = train_step(model, loss_fn, opt, cur, next_batch=nxt)
+            state['cur'] = nxt
+            return out
+        if mode == 'inline':  # geometry on the main stream, no overlap at all
+            b['geometry_plan'] = model.net_3d.plan_geometry(b['points'].transpose(1, 2).contiguous(), stream=None)
         return train_step(model, loss_fn, opt, b)
     for _ in range(3): one()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -27,4 +35,4 @@ def run(mode, n=10):
     t_cpu = time.perf_counter() - t0
     torch.cuda.synchronize(); t = time.perf_counter() - t0
     print('B={} {:8s}: {:.2f} ms/step wall, CPU enqueue {:.2f} ms/step'.format(B, mode, t / n * 1e3, t_cpu / n * 1e3))
-run('normal'); run('cached')
+run('inline'); run('normal'); run('prefetch'); run('cached'); run('prefetch'); run('inline')
