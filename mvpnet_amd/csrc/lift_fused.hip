@@ -132,7 +132,10 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
       bi[s] = 0x7fffffff;
     }
     PackedSource src{crec};
-    projective_knn<K, 2>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
+#ifndef MVP_LIFT_W0
+#define MVP_LIFT_W0 2
+#endif
+    projective_knn<K, MVP_LIFT_W0>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
 #pragma unroll
     for (int s = 0; s < K; ++s) {
       const bool found = bd[s] < INFINITY;

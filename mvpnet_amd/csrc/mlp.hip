@@ -71,9 +71,47 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
   const bool x_vec = (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
   const bool w_vec = (ldw % 4 == 0) && (((uintptr_t)W) % 16 == 0);
 
-  for (int k0 = 0; k0 < Cin; k0 += kBK) {
-    // ---- stage A slab (128 x 32) with the input activation applied ----
-    float pm[4], pi[4], pg[4], pb[4];
+  // Software pipeline: the global loads of slab s+1 are issued before the MFMA loop of slab s and are
+  // only consumed (activation applied, written to LDS) after it, so HBM/L2 latency hides under the MFMAs.
+  float ra[kBM / 32][4], rb[BN / 32][4];
+  auto load_slab = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < kBM / 32; ++p) {
+      const int64_t r = row0 + rr + p * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[p][i] = 0.f;
+      if (r < R) {
+        const float* src = X + (size_t)r * ldx + k0 + kq;
+        if (x_vec && k0 + kq + 4 <= Cin) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          ra[p][0] = q.x; ra[p][1] = q.y; ra[p][2] = q.z; ra[p][3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k0 + kq + i < Cin) ra[p][i] = src[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < BN / 32; ++p) {
+      const int co = col0 + rr + p * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[p][i] = 0.f;
+      if (co < Cout) {
+        const float* src = W + (size_t)co * ldw + k0 + kq;
+        if (w_vec && k0 + kq + 4 <= Cin) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          rb[p][0] = q.x; rb[p][1] = q.y; rb[p][2] = q.z; rb[p][3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k0 + kq + i < Cin) rb[p][i] = src[i];
+        }
+      }
+    }
+  };
+  auto store_slab = [&](int k0) {  // registers -> LDS, with the input activation applied to A
+    float pm[4] = {0.f, 0.f, 0.f, 0.f}, pi[4] = {0.f, 0.f, 0.f, 0.f}, pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
     if (act.mean) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -87,50 +125,28 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int p = 0; p < kBM / 32; ++p) {
       const int m = rr + p * 32;
-      const int64_t r = row0 + m;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (r < R) {
-        const float* src = X + (size_t)r * ldx + k0 + kq;
-        if (x_vec && k0 + kq + 4 <= Cin) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
-          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
+      const bool row_ok = row0 + m < R;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (k0 + kq + i < Cin) v[i] = src[i];
-        }
+      for (int i = 0; i < 4; ++i) {
+        float v = ra[p][i];
         if (act.mean) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float a = ((v[i] - pm[i]) * pi[i]) * pg[i] + pb[i];
-            v[i] = (k0 + kq + i < Cin && a > 0.f) ? a : 0.f;
-          }
+          const float a = ((v - pm[i]) * pi[i]) * pg[i] + pb[i];
+          v = (row_ok && k0 + kq + i < Cin && a > 0.f) ? a : 0.f;
         }
+        As[m * kLd + kq + i] = v;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) As[m * kLd + kq + i] = v[i];
     }
-    // ---- stage B slab (BN x 32): rows of W are output channels ----
 #pragma unroll
-    for (int p = 0; p < BN / 32; ++p) {
-      const int n = rr + p * 32;
-      const int co = col0 + n;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (co < Cout) {
-        const float* src = W + (size_t)co * ldw + k0 + kq;
-        if (w_vec && k0 + kq + 4 <= Cin) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
-          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
+    for (int p = 0; p < BN / 32; ++p)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (k0 + kq + i < Cin) v[i] = src[i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Bs[n * kLd + kq + i] = v[i];
-    }
+      for (int i = 0; i < 4; ++i) Bs[(rr + p * 32) * kLd + kq + i] = rb[p][i];
+  };
+
+  load_slab(0);
+  for (int k0 = 0; k0 < Cin; k0 += kBK) {
+    store_slab(k0);
     __syncthreads();
+    if (k0 + kBK < Cin) load_slab(k0 + kBK);  // in flight during the MFMA loop below
     // ---- 16 MFMA k-steps of 2 on this slab: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31] ----
     const float* ap = As + (wave * 32 + (lane & 31)) * kLd + (lane >> 5);
     const float* bp = Bs + (lane & 31) * kLd + (lane >> 5);

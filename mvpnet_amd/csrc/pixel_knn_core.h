@@ -173,6 +173,34 @@ __device__ __forceinline__ void projective_knn(const Src& src, const ViewParam* 
         wr = 2 * wdone + 2;  // fewer than k candidates so far: grow geometrically until some appear
       }
       wr = min(wr, wfull);
+      if (W0 == 1 && wdone == 1) {
+        // Most points that need more than the 3x3 probe need exactly the next ring.  Scan it with 16
+        // independent loads (one memory round trip) instead of the generic row loop; lanes that do
+        // not need it are masked off and cost no L1 accesses.
+        float dd[16];
+        int ii[16];
+        int e = 0;
+#pragma unroll
+        for (int a = -2; a <= 2; ++a)
+#pragma unroll
+          for (int c = -2; c <= 2; ++c) {
+            if (a == -2 || a == 2 || c == -2 || c == 2) {
+              const int vv = vc + a, uu = uc + c;
+              const bool in = vv >= 0 && vv < h && uu >= 0 && uu < w;
+              const int cv = min(max(vv, 0), h - 1), cu = min(max(uu, 0), w - 1);
+              const int id = vi * hw + cv * w + cu;
+              const float d = src.dist2(vi, cv, cu, id, qx, qy, qz);
+              dd[e] = in ? d : INFINITY;
+              ii[e] = id;
+              ++e;
+            }
+          }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (dd[t] < INFINITY) topk_insert_id<K>(bd, bi, dd[t], ii[t]);
+        wdone = 2;
+        continue;
+      }
 #ifdef MVP_KNN_STATS
       bd_stats_rings += 1;
       bd_stats_pix += (2 * wr + 1) * (2 * wr + 1) - (2 * wdone + 1) * (2 * wdone + 1);

@@ -541,3 +541,56 @@ def test_bn_act_rows_vs_torch(dev, K, relu, train, C):
     np.testing.assert_allclose(y1.grad.cpu().numpy(), y2.grad.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(bn1.weight.grad.cpu().numpy(), bn2.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(bn2.weight.grad.abs().max()))
     np.testing.assert_allclose(bn1.bias.grad.cpu().numpy(), bn2.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(bn2.bias.grad.abs().max()))
+
+
+# ------------------------------------------------------------------ fp32-MFMA shared-MLP kernels
+@pytest.mark.parametrize('R,Cin,ldx,Cout', [(1000, 68, 68, 32), (4096, 64, 64, 64), (777, 131, 132, 128), (300, 259, 260, 256),
+                                            (129, 768, 768, 256), (5000, 32, 32, 20), (64, 3, 4, 32), (1, 128, 128, 512)])
+def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
+    """mvp_mlp_forward / weight_grad / input_grad (v_mfma_f32_32x32x2_f32) vs torch fp32 matmul on awkward shapes:
+    rows not a multiple of 128, K not a multiple of 32, padded leading dimension, Cout not a multiple of 32."""
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(R + Cin)
+    x = torch.randn(R, ldx, device=dev)
+    x[:, Cin:] = 7.0  # padding columns must be ignored
+    w = torch.randn(Cout, Cin, device=dev) * 0.2
+    bias = torch.randn(Cout, device=dev)
+    mean, invstd = torch.randn(Cin, device=dev) * 0.3, torch.rand(Cin, device=dev) + 0.5
+    gamma, beta = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.2
+    hi = torch.float64
+    for use_act in (False, True):
+        a = x[:, :Cin].to(hi)
+        if use_act:
+            a = torch.relu(((a - mean.to(hi)) * invstd.to(hi)) * gamma.to(hi) + beta.to(hi))
+        act = (mean, invstd, gamma, beta) if use_act else (None, None, None, None)
+        y = torch.empty(R, Cout, device=dev)
+        stat = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, ldx, L.ptr(w), Cin, Cout, *[L.ptr(t) for t in act], L.ptr(bias), L.ptr(y), L.ptr(stat))
+        ref = a @ w.to(hi).t() + bias.to(hi)
+        tol = 2e-5 * max(1.0, float(ref.abs().max()))
+        np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=tol)
+        np.testing.assert_allclose(stat[:Cout].cpu().numpy(), y.double().sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(stat[Cout:].cpu().numpy(), (y.double() ** 2).sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+        # weight gradient with the same prologue
+        dy = torch.randn(R, Cout, device=dev)
+        dw = torch.empty(Cout, Cin, device=dev)
+        L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, ldx, *[L.ptr(t) for t in act], L.ptr(dw))
+        refw = dy.to(hi).t() @ a
+        np.testing.assert_allclose(dw.cpu().numpy(), refw.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(refw.abs().max())))
+    # input gradient, plain and with the fused ReLU-mask / BN-backward sums epilogue
+    dy = torch.randn(R, Cout, device=dev)
+    wt = w.t().contiguous()
+    dz = torch.empty(R, Cin, device=dev)
+    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(wt), Cin, None, None, None, None, None, L.ptr(dz), None)
+    refx = dy.to(hi) @ w.to(hi)
+    np.testing.assert_allclose(dz.cpu().numpy(), refx.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(refx.abs().max())))
+    yprev = torch.randn(R, Cin, device=dev)
+    stat = torch.empty(2 * Cin, dtype=torch.float64, device=dev)
+    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(wt), Cin, L.ptr(yprev), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+           L.ptr(beta), L.ptr(dz), L.ptr(stat))
+    xh = (yprev - mean) * invstd
+    on = (xh * gamma + beta) > 0
+    refz = torch.where(on, refx, torch.zeros_like(refx))
+    np.testing.assert_allclose(dz.cpu().numpy(), refz.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(refx.abs().max())))
+    np.testing.assert_allclose(stat[:Cin].cpu().numpy(), refz.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(stat[Cin:].cpu().numpy(), (refz * xh.double()).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)

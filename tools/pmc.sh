@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools/pmc.sh <name> "<counters>" <python args...>  -> prints per-kernel mean counter values
+# usage: bash tools/pmc.sh <name> "<counters>" <python args...>  -> per-kernel mean counter values (top kernels)
 name=$1; ctrs=$2; shift; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$name
 cd /tmp && export TMPDIR=/tmp
@@ -9,10 +9,11 @@ import csv, collections
 rows=list(csv.DictReader(open('$out/p_counter_collection.csv')))
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+    acc[r['Kernel_Name'][:70]][r['Counter_Name']].append(float(r['Counter_Value']))
+keep=('mlp_','lift_','fps_','colstats','bn_act','group_rows','interp_rows')
 for k,v in acc.items():
-    if 'rocclr' in k or 'elementwise' in k: continue
-    print(k)
-    for c,vals in v.items():
-        print('    {:32s} mean {:16.1f}  (n={})'.format(c, sum(vals)/len(vals), len(vals)))
+    if not any(x in k for x in keep): continue
+    n=len(next(iter(v.values())))
+    print(k, ' n=%d'%n)
+    print('    '+'  '.join('{}={:.4g}'.format(c, sum(vals)/len(vals)) for c,vals in v.items()))
 PY
