@@ -204,13 +204,15 @@ int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, flo
  * stat != NULL: 2*Cout float64, receives the column sums of y and y^2 (this layer's batch statistics). */
 int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
                         const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
-                        const float* bias, float* Y, double* stat, mvp_stream_t stream);
+                        const float* bias, float* Y, double* stat, double* partial, mvp_stream_t stream);
+/* `partial` (both entry points below and above): optional scratch of ceil(R/128) * 2 * (output columns) float64; when
+ * given, the statistics are reduced without atomics (recommended for R >~ 1e5), otherwise with fp64 atomics. */
 /* d(input) with the previous layer's ReLU mask and BatchNorm-backward column sums fused into the epilogue:
  * dZ (R,Cin) = (dY (R,Cout) . W) * [bn(y_prev) > 0], Wt = W^T (Cin,Cout) contiguous; stat (2*Cin float64) = [sum dZ | sum dZ*xhat].
  * y_prev == NULL: plain dX = dY . W. */
 int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* Wt, int64_t Cin, const float* y_prev,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ,
-                           double* stat, mvp_stream_t stream);
+                           double* stat, double* partial, mvp_stream_t stream);
 /* dW (Cout,Cin) = dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue; dW is zero-filled here. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                             const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,

@@ -153,6 +153,13 @@ def bn_act_rows(y, bn, relu=True, K=1):
                            relu, K)
 
 
+def _partial(R, cols, device):
+    """Scratch for the atomics-free statistics reduction of the MFMA kernels (ceil(R/128) x 2 x cols float64)."""
+    if R < 65536:
+        return None  # few workgroups: fp64 atomics are cheaper than a second launch
+    return torch.empty(((R + 127) // 128) * 2 * cols, dtype=torch.float64, device=device)
+
+
 def _bn_backward(dsrc, out, arg, y, mean, invstd, gamma, beta, G, K, C, relu, training):
     """-> dy (G*K,C), dgamma (C), dbeta (C) through mvp_bn_rows_backward_f32."""
     stat = torch.empty(2 * C, dtype=torch.float64, device=y.device)
@@ -193,7 +200,7 @@ class MLPChainRows(torch.autograd.Function):
             y = torch.empty((R, cout), dtype=torch.float32, device=dev)
             stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
             L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
-                   L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat))
+                   L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None))
             rm, rv = bn_buffers[i]
             if training:
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -251,13 +258,13 @@ class MLPChainRows(torch.autograd.Function):
                     stat = torch.empty(2 * cin, dtype=torch.float64, device=dy.device)
                     pm, pi, pg, pb = means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1]
                     L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(wt), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
-                           L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat))
+                           L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat), L.ptr(_partial(R, cin, dy.device)))
                     dy_prev = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
                     L.call('mvp_bn_rows_backward_finish_f32', dz, L.ptr(dz), L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb),
                            R, cin, int(training), L.ptr(stat), L.ptr(dy_prev))
                     dy, dgam, dbet = dy_prev, stat[cin:].float(), stat[:cin].float()
                 else:
-                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(dz), None)
+                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(dz), None, None)
                     dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
         return (dx0, None, None, None, None) + tuple(grads)
 
@@ -271,7 +278,7 @@ class LinearRows(torch.autograd.Function):
         R, cin = x.shape
         cout = w.size(0)
         y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
-        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, cin, L.ptr(w), cin, cout, None, None, None, None, L.ptr(bias), L.ptr(y), None)
+        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, cin, L.ptr(w), cin, cout, None, None, None, None, L.ptr(bias), L.ptr(y), None, None)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y
@@ -287,7 +294,7 @@ class LinearRows(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             wt = w.t().contiguous()
-            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(gx), None)
+            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(gx), None, None)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, cin, cin, None, None, None, None, L.ptr(gw))

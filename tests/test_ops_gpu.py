@@ -565,7 +565,8 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
         act = (mean, invstd, gamma, beta) if use_act else (None, None, None, None)
         y = torch.empty(R, Cout, device=dev)
         stat = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
-        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, ldx, L.ptr(w), Cin, Cout, *[L.ptr(t) for t in act], L.ptr(bias), L.ptr(y), L.ptr(stat))
+        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, ldx, L.ptr(w), Cin, Cout, *[L.ptr(t) for t in act], L.ptr(bias), L.ptr(y), L.ptr(stat),
+               L.ptr(torch.empty(((R + 127) // 128) * 2 * Cout, dtype=torch.float64, device=dev)) if use_act else None)
         ref = a @ w.to(hi).t() + bias.to(hi)
         tol = 2e-5 * max(1.0, float(ref.abs().max()))
         np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=tol)
@@ -581,13 +582,13 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
     dy = torch.randn(R, Cout, device=dev)
     wt = w.t().contiguous()
     dz = torch.empty(R, Cin, device=dev)
-    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(wt), Cin, None, None, None, None, None, L.ptr(dz), None)
+    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(wt), Cin, None, None, None, None, None, L.ptr(dz), None, None)
     refx = dy.to(hi) @ w.to(hi)
     np.testing.assert_allclose(dz.cpu().numpy(), refx.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(refx.abs().max())))
     yprev = torch.randn(R, Cin, device=dev)
     stat = torch.empty(2 * Cin, dtype=torch.float64, device=dev)
     L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(wt), Cin, L.ptr(yprev), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-           L.ptr(beta), L.ptr(dz), L.ptr(stat))
+           L.ptr(beta), L.ptr(dz), L.ptr(stat), L.ptr(torch.empty(((R + 127) // 128) * 2 * Cin, dtype=torch.float64, device=dev)))
     xh = (yprev - mean) * invstd
     on = (xh * gamma + beta) > 0
     refz = torch.where(on, refx, torch.zeros_like(refx))
