@@ -100,6 +100,17 @@ class TimedLifting:
         return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else float('nan')
 
 
+def lift_traffic(batch):
+    """HBM bytes per mvp_lift_f32 launch from the PMC passes committed under profiles/ (measured at B = 32;
+    FETCH_SIZE doubled per the gfx950 calibration note); None for any other batch size."""
+    path = os.path.join(ROOT, 'profiles', 'r01_lift_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    return rec['hbm_bytes_per_launch'] if rec.get('batch') == batch else None
+
+
 def cpu_baseline(bt, batch_chunks=2):
     """fwd+bwd of the same step on the host with the CPU oracle ("port"): oracle lifting
     (reference loader arithmetic; scikit-learn ball tree like the reference when it is installed,
@@ -154,8 +165,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='chunks per GPU per step (yaml TRAIN.BATCH_SIZE = 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
+                                              'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml kept in tests/golden/configs.json')
+    ap.add_argument('--batch', type=int, default=0, help='chunks per GPU per step (default: TRAIN.BATCH_SIZE of the config = 32)')
     args = ap.parse_args()
 
     from mvpnet_amd import dist as D
@@ -172,17 +185,30 @@ def main():
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
 
+    # the experiment YAML drives model / optimiser / scheduler / batch size, unmodified (mvpnet_amd/config.py)
+    from mvpnet_amd import config as C
+    import yaml
+    if args.cfg:
+        cfg = C.load_cfg(path=args.cfg)
+        cfg_name = os.path.basename(args.cfg)
+    else:
+        with open(os.path.join(ROOT, 'tests', 'golden', 'configs.json')) as f:
+            cfg = C.load_cfg(text=yaml.safe_dump(json.load(f)['mvpnet_3d_unet_resnet34_pn2ssg']))
+        cfg_name = 'mvpnet_3d_unet_resnet34_pn2ssg.yaml'
+    ds = cfg.DATASET.ScanNet2D3DChunks
+    assert (ds.nb_pts, ds.num_rgbd_frames, tuple(ds.resize), ds.k) == (8192, 3, (160, 120), 3), 'bench shapes are the YAML shapes'
+    if args.batch <= 0:
+        args.batch = int(cfg.TRAIN.BATCH_SIZE)
     batch, feature, bt = build_batch(rank, args.batch, dev)
     torch.manual_seed(0)
     net2d = SuppliedFeature2D()
     net2d.feature = feature
-    model = MVPNet3D(net2d, '', PN2SSG(64, 20), in_channels=64, mlp_channels=(64, 64, 64), reduction='sum',
-                     use_relation=True).to(dev).train()  # reference defaults incl. dropout 0.5
+    model = C.build_model_mvpnet_3d(cfg, net2d).to(dev).train()  # reference defaults incl. dropout 0.5
     D.broadcast_parameters(model)
-    weights = torch.linspace(0.5, 1.5, 20, device=dev)  # stands in for the class log-weights file
+    weights = torch.linspace(0.5, 1.5, 20, device=dev)  # stands in for the class log-weights file (TRAIN.LABEL_WEIGHTS_PATH)
     loss_fn = SegLoss(weight=weights)
-    optimizer = torch.optim.Adam(model.parameters(), lr=2e-3, betas=(0.9, 0.999), weight_decay=0.0)
-    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=(24000, 32000), gamma=0.1)
+    optimizer = C.build_optimizer(cfg, model)
+    scheduler = C.build_scheduler(cfg, optimizer)
     grad_sync = D.GradSync(model.parameters()) if world > 1 else None
     timer = TimedLifting()
     timer.install(model)
@@ -235,11 +261,11 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[2]: MVPNet lifting (unproject + pixel k-NN + gather) + FeatureAggregation + '
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
-                       'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
+                       'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
+                         'traffic': lift_traffic(args.batch), 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(bt)

@@ -1,0 +1,181 @@
+"""Minimal configuration + factory layer so the reference's experiment YAMLs drive this package unmodified
+(`configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml`, `configs/scannet/3d_baselines/pn2ssg_chunk.yaml`).
+
+The reference uses yacs (absent here): defaults in `common/config/base.py:10-137`, task defaults in
+`mvpnet/config/mvpnet_3d.py:6-80` / `mvpnet/config/sem_seg_3d.py`, `purge_cfg` in
+`common/config/__init__.py:4-17`, factories in `mvpnet/models/build.py:8-47` and
+`common/solver/build.py:7-41`.  This is a PyYAML + `ast.literal_eval` work-alike of exactly what those
+need: nested attribute access, defaults, `merge_from_file` / `merge_from_list`, tuples written as strings
+("(160, 120)") evaluated like yacs does, and TYPE-keyed purge.  Only the hot path's knobs are defaulted;
+unknown keys from a YAML are accepted and kept (dataset, logging... are out of scope but must not fail).
+"""
+import ast
+import copy
+
+import yaml
+
+
+class CfgNode(dict):
+    """dict with attribute access (the subset of yacs.config.CfgNode the reference relies on)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    @staticmethod
+    def _convert(value):
+        if isinstance(value, dict):
+            node = CfgNode()
+            for k, v in value.items():
+                node[k] = CfgNode._convert(v)
+            return node
+        if isinstance(value, str):  # yacs literal_evals strings: "(160, 120)" -> (160, 120)
+            try:
+                return ast.literal_eval(value)
+            except (ValueError, SyntaxError):
+                return value
+        if isinstance(value, list):
+            return tuple(CfgNode._convert(v) for v in value)
+        return value
+
+    def merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), dict):
+                self[k].merge(v)
+            else:
+                self[k] = v
+        return self
+
+    def merge_from_file(self, path):
+        with open(path) as f:
+            return self.merge(CfgNode._convert(yaml.safe_load(f) or {}))
+
+    def merge_from_text(self, text):
+        return self.merge(CfgNode._convert(yaml.safe_load(text) or {}))
+
+    def merge_from_list(self, opts):
+        """['OPTIMIZER.BASE_LR', '0.001', ...] like the reference CLI overrides (train_mvpnet_3d.py:301-305)."""
+        assert len(opts) % 2 == 0
+        for key, value in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = key.split('.')
+            for p in parts[:-1]:
+                node = node.setdefault(p, CfgNode())
+            node[parts[-1]] = CfgNode._convert(value)
+        return self
+
+
+def _base():
+    """common/config/base.py:10-137 (the keys this package reads; the YAML may add others)."""
+    return CfgNode._convert({
+        'TASK': '', 'AUTO_RESUME': True, 'RESUME_STATES': True, 'RESUME_PATH': '',
+        'MODEL': {'TYPE': ''}, 'DATASET': {'TYPE': ''}, 'DATALOADER': {'NUM_WORKERS': 0, 'DROP_LAST': True},
+        'OPTIMIZER': {'TYPE': '', 'BASE_LR': 0.001, 'WEIGHT_DECAY': 0.0, 'MAX_GRAD_NORM': 0.0,
+                      'SGD': {'momentum': 0.9, 'dampening': 0.0}, 'Adam': {'betas': '(0.9, 0.999)'}},
+        'SCHEDULER': {'TYPE': '', 'MAX_ITERATION': 1, 'CLIP_LR': 0.0, 'StepLR': {'step_size': 0, 'gamma': 0.1},
+                      'MultiStepLR': {'milestones': '()', 'gamma': 0.1}},
+        'TRAIN': {'BATCH_SIZE': 1, 'CHECKPOINT_PERIOD': 0, 'LOG_PERIOD': 0, 'SUMMARY_PERIOD': 0, 'MAX_TO_KEEP': 0,
+                  'AUGMENTATION': '()', 'FROZEN_PATTERNS': '()', 'LABEL_WEIGHTS_PATH': ''},
+        'VAL': {'BATCH_SIZE': 1, 'PERIOD': 0, 'LOG_PERIOD': 0, 'METRIC': '', 'AUGMENTATION': '()', 'REPEATS': 1},
+        'OUTPUT_DIR': '@', 'RNG_SEED': -1,
+    })
+
+
+_PN2SSG = {'num_classes': 20, 'sa_channels': '((32, 32, 64), (64, 64, 128), (128, 128, 256), (256, 256, 512))',
+           'num_centroids': '(2048, 512, 128, 32)', 'radius': '(0.1, 0.2, 0.4, 0.8)', 'max_neighbors': '(32, 32, 32, 32)',
+           'fp_channels': '((256, 256), (256, 256), (256, 128), (128, 128, 128))', 'fp_neighbors': '(3, 3, 3, 3)',
+           'seg_channels': '(128,)', 'dropout_prob': 0.5, 'use_xyz': True}
+
+
+def get_cfg_mvpnet_3d():
+    """mvpnet/config/mvpnet_3d.py:6-80"""
+    cfg = _base()
+    cfg.merge(CfgNode._convert({
+        'TASK': 'mvpnet_3d', 'VAL': {'METRIC': 'seg_iou'},
+        'DATASET': {'TRAIN': '', 'VAL': '', 'ScanNet2D3DChunks': {
+            'cache_dir': '', 'image_dir': '', 'chunk_size': '(1.5, 1.5)', 'chunk_thresh': 0.3, 'chunk_margin': '(0.2, 0.2)',
+            'nb_pts': 8192, 'num_rgbd_frames': 3, 'resize': '(160, 120)', 'k': 3,
+            'image_normalizer': '((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))',
+            'augmentation': {'z_rot': '()', 'flip': 0.0, 'color_jitter': '()'}}},
+        'MODEL_3D': {'TYPE': '', 'PN2SSG': dict(_PN2SSG, in_channels=64)},
+        'MODEL_2D': {'TYPE': '', 'CKPT_PATH': '', 'UNetResNet34': {'num_classes': 20, 'p': 0.0}},
+        'FEAT_AGGR': {'in_channels': 64, 'mlp_channels': '(64, 64, 64)', 'reduction': 'sum', 'use_relation': True},
+    }))
+    return cfg
+
+
+def get_cfg_sem_seg_3d():
+    """mvpnet/config/sem_seg_3d.py (PN2SSG baseline: no input feature)"""
+    cfg = _base()
+    cfg.merge(CfgNode._convert({'TASK': 'sem_seg_3d', 'VAL': {'METRIC': 'seg_iou'},
+                                'MODEL': {'TYPE': '', 'PN2SSG': dict(_PN2SSG, in_channels=0)}}))
+    return cfg
+
+
+def load_cfg(path=None, text=None, opts=()):
+    """Defaults of the YAML's TASK + the YAML + `KEY VALUE` overrides, purged like the reference does."""
+    raw = CfgNode()
+    if path is not None:
+        raw.merge_from_file(path)
+    if text is not None:
+        raw.merge_from_text(text)
+    task = raw.get('TASK', 'mvpnet_3d')
+    cfg = {'mvpnet_3d': get_cfg_mvpnet_3d, 'sem_seg_3d': get_cfg_sem_seg_3d}[task]()
+    cfg.merge(raw)
+    cfg.merge_from_list(list(opts))
+    purge_cfg(cfg)
+    return cfg
+
+
+def purge_cfg(cfg):
+    """common/config/__init__.py:4-17: under a node with TYPE, drop sibling sub-nodes other than cfg[TYPE]."""
+    target = cfg.get('TYPE', None)
+    for k in [k for k, v in cfg.items() if isinstance(v, CfgNode)]:
+        if target is not None and k != target:
+            del cfg[k]
+        else:
+            purge_cfg(cfg[k])
+
+
+def build_model_sem_seg_3d(cfg):
+    """mvpnet/models/build.py:8-20 -> model (loss: mvpnet_amd.mvpnet3d.SegLoss)"""
+    from .pn2 import PN2SSG
+    assert cfg.TASK == 'sem_seg_3d' and cfg.MODEL.TYPE == 'PN2SSG', (cfg.TASK, cfg.MODEL.TYPE)
+    return PN2SSG(**dict(cfg.MODEL.get('PN2SSG', {})))
+
+
+def build_model_mvpnet_3d(cfg, net_2d, load_2d_ckpt=False):
+    """mvpnet/models/build.py:38-47.  `net_2d`: the 2D network instance (UNetResNet34 is out of scope here,
+    SURVEY.md sec.8f rank 2); everything else -- PN2SSG, FeatureAggregation, CKPT_PATH -- comes from cfg."""
+    from .pn2 import PN2SSG
+    from .mvpnet3d import MVPNet3D
+    assert cfg.TASK == 'mvpnet_3d' and cfg.MODEL_3D.TYPE == 'PN2SSG', (cfg.TASK, cfg.MODEL_3D.TYPE)
+    net_3d = PN2SSG(**dict(cfg.MODEL_3D.get('PN2SSG', {})))
+    return MVPNet3D(net_2d, cfg.MODEL_2D.get('CKPT_PATH', '') if load_2d_ckpt else '', net_3d, **dict(cfg.FEAT_AGGR))
+
+
+def build_optimizer(cfg, model):
+    """common/solver/build.py:7-22"""
+    import torch
+    name = cfg.OPTIMIZER.TYPE
+    if name == '':
+        return None
+    return getattr(torch.optim, name)(model.parameters(), lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY,
+                                      **dict(cfg.OPTIMIZER.get(name, {})))
+
+
+def build_scheduler(cfg, optimizer):
+    """common/solver/build.py:25-41 (without ClipLR)"""
+    import torch
+    name = cfg.SCHEDULER.TYPE
+    if name == '':
+        return None
+    return getattr(torch.optim.lr_scheduler, name)(optimizer, **dict(cfg.SCHEDULER.get(name, {})))

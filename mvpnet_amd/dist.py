@@ -50,33 +50,21 @@ class GradSync:
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = None
 
     def __call__(self):
         w = world_size()
         if w == 1 or not self.params:
             return
-        p0 = self.params[0]
-        if self.flat is None or self.flat.device != p0.device:
-            self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
-        off = 0
+        grads = []
         for p in self.params:
-            n = p.numel()
             if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(w)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        flat = torch.cat([g.reshape(-1) for g in grads])           # one kernel in, ...
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(w)
+        chunks = [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)]
+        torch._foreach_copy_(grads, chunks)                          # ... one multi-tensor kernel out
 
 
 def broadcast_parameters(module, src=0):

@@ -491,7 +491,22 @@ def gen_vote_trainstep():
     save('train_step', **out)
 
 
+def gen_configs():
+    """The two experiment YAMLs named in BASELINE.json, parsed (PyYAML) and stored as JSON data: what the
+    config loader (mvpnet_amd/config.py) must accept unmodified."""
+    import yaml
+    out = {}
+    for name, rel in [('mvpnet_3d_unet_resnet34_pn2ssg', 'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml'),
+                      ('pn2ssg_chunk', 'configs/scannet/3d_baselines/pn2ssg_chunk.yaml')]:
+        with open(os.path.join(REF, rel)) as f:
+            out[name] = yaml.safe_load(f)
+    with open(os.path.join(HERE, 'configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('configs.json')
+
+
 def main():
+    gen_configs()
     T = install_reference()
     gen_fps(T)
     gen_ball_query(T)
