@@ -251,6 +251,19 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = tmax.item()
 
+    # configs[1] (forward only, eval mode) on the same resident batch: reported as an extra field
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            model(dict(batch))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            model(dict(batch))
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) / 10 * 1e3
+    model.train()
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         lift_ms = timer.mean_ms()
@@ -263,6 +276,8 @@ def main():
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
                        'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
+            'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),
+                         'note': 'configs[1]: lifting + aggregation + PN2SSG forward, eval mode, same batch'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': lift_traffic(args.batch), 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
