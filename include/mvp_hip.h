@@ -172,6 +172,12 @@ int mvp_group_rows_f32(const float* feature, const float* xyz, const float* cent
                        int64_t N, int64_t C, int64_t M, int64_t K, int64_t ld, float* out, mvp_stream_t stream);
 int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t N, int64_t C, int64_t M,
                                 int64_t K, int64_t ld, float* grad_feature, mvp_stream_t stream);
+/* out (B,M,K,C) = z (B,N,C)[index] - sub (B,M,C): set-abstraction grouping AFTER the (linear) first shared-MLP layer,
+ * z = W1.[feature | xyz] per point, sub = W1_xyz . centre (same value as grouping first, 8x fewer conv rows). */
+int mvp_group_sub_rows_f32(const float* z, const float* sub, const int64_t* index, int64_t B, int64_t N, int64_t C, int64_t M,
+                           int64_t K, float* out, mvp_stream_t stream);
+/* column sums of y and y^2 over the R rows of y (R,C) -> stat (2*C float64, zero-filled here) */
+int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream);
 int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,
                         int64_t N2, int64_t ld, float* out, mvp_stream_t stream);
 int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B, int64_t N1,

@@ -60,6 +60,30 @@ __global__ __launch_bounds__(kRT) void group_rows_kernel(const float* __restrict
   st4(out + ((size_t)b * E + e) * ld + c, v);
 }
 
+// group_sub_rows: out[b,m,k,:] = z[b, idx[b,m,k], :] - sub[b,m,:]   (z (B,N,C), sub (B,M,C), C % 4 == 0)
+// Used with z = W1 . [feature | xyz] computed ONCE PER POINT and sub = W1_xyz . centre: the first shared-MLP
+// layer of a set-abstraction level is linear, so W1.[f(idx) | xyz(idx) - c] = z(idx) - W1_xyz.c and the 1x1 conv
+// runs on N rows instead of M*K = 8 N rows (the grouped tensor also shrinks from C+3 to C_1 columns).
+__global__ __launch_bounds__(kRT) void group_sub_rows_kernel(const float* __restrict__ z, const float* __restrict__ sub,
+                                                             const int64_t* __restrict__ idx, int N, int C, int M, int K,
+                                                             float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int C4 = C >> 2;
+  const int64_t E = (int64_t)M * K;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t e = t / C4;
+  const int c = (int)(t - e * C4) * 4;
+  if (e >= E) return;
+  const int64_t j = idx[(size_t)b * E + e];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j >= 0 && j < N) {
+    const float4 a = ld4(z + ((size_t)b * N + j) * C + c);
+    const float4 s = ld4(sub + ((size_t)b * M + e / K) * C + c);
+    v = make_float4(a.x - s.x, a.y - s.y, a.z - s.z, a.w - s.w);
+  }
+  st4(out + ((size_t)b * E + e) * C + c, v);
+}
+
 // grad_feature (B,N,C) += grad_out[..., :C]; one lane per (row, channel): consecutive lanes hit
 // consecutive floats of one destination row, so each wave issues full-line atomics.
 __global__ __launch_bounds__(kRT) void group_rows_bwd_kernel(const float* __restrict__ gout,
@@ -500,4 +524,27 @@ MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, con
   hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), dz, nullptr, nullptr, y, mean,
                      invstd, gamma, beta, stat, R, 1, (int)C, training, dy);
   return mvp_launch_status();
+}
+
+MVP_API int mvp_group_sub_rows_f32(const float* z, const float* sub, const int64_t* index, int64_t B, int64_t N, int64_t C,
+                                   int64_t M, int64_t K, float* out, mvp_stream_t stream) {
+  MVP_NONNULL(z);
+  MVP_NONNULL(sub);
+  MVP_NONNULL(index);
+  MVP_NONNULL(out);
+  MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && M >= 0 && K > 0 && B < 65536);
+  if (B == 0 || M == 0) return MVP_OK;
+  dim3 grid((unsigned)cdiv(M * K * (C / 4), kRT), (unsigned)B);
+  hipLaunchKernelGGL(group_sub_rows_kernel, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), z, sub, index, (int)N, (int)C,
+                     (int)M, (int)K, out);
+  return mvp_launch_status();
+}
+
+// column sums of y and y*y over R rows -> stat (2*C float64, zero-filled here)
+MVP_API int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream) {
+  MVP_NONNULL(y);
+  MVP_NONNULL(stat);
+  int rc = check_rows(R, C);
+  if (rc) return rc;
+  return launch_colstats(Plain{y}, R, C, stat, static_cast<hipStream_t>(stream));
 }

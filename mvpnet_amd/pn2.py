@@ -85,6 +85,24 @@ class SetAbstraction(nn.Module):
         M, K = new_xyz.size(1), self.max_neighbors
         if use_feature and not self.use_xyz:
             raise NotImplementedError('use_xyz=False with features is not on the rows path')
+        l0 = self.mlp[0]
+        c1 = l0.conv.weight.size(0)
+        if l0.bn is not None and l0.relu is not None and l0.conv.bias is None and l0.bn.running_mean is not None and c1 % 4 == 0:
+            # The first shared-MLP layer is linear, so it commutes with the grouping:
+            #   W1.[f(idx) | xyz(idx) - c] = (W1.[f | xyz])(idx) - W1_xyz.c
+            # -> one 1x1 conv over the N points instead of the M*K = 8N grouped rows, and the grouped tensor has
+            #    C_1 instead of C+3 columns (same mathematics as modules.py:20-37,107; differs by fp32 rounding only).
+            w1 = l0.conv.weight.reshape(c1, -1)                       # columns [feature (C) | xyz (3)]
+            p = torch.cat([feature, xyz], dim=2) if use_feature else xyz
+            pad = (-p.size(2)) % 4
+            if pad:
+                p = torch.nn.functional.pad(p, (0, pad))
+            w1p = torch.nn.functional.pad(w1, (0, pad)) if pad else w1
+            z = R.linear_rows(p.reshape(B * N, -1), w1p).view(B, N, c1)
+            cterm = torch.matmul(new_xyz, w1[:, -3:].t())              # (B,M,C_1) = W1_xyz . centre
+            y1 = R.group_sub_rows(z, cterm, ball)                      # (B,M,K,C_1): conv output of layer 1, grouped
+            new_feature = R.shared_mlp_rows(y1.view(B * M * K, c1), self.mlp, K=K, first_done=True)
+            return new_xyz, new_feature.view(B, M, -1)
         if use_feature and feature.size(2) % 4:
             feature = torch.nn.functional.pad(feature, (0, 4 - feature.size(2) % 4))  # cannot happen with reference configs
         group = self.grouper.forward_rows(new_xyz, xyz, feature if use_feature else None, index=ball)  # (B,M,K,ld)

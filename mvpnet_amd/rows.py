@@ -55,6 +55,36 @@ def group_rows(feature, xyz, center, index):
                            index.contiguous())
 
 
+class GroupSubRows(torch.autograd.Function):
+    """out[b,m,k,:] = z[b, index[b,m,k], :] - sub[b,m,:]; gradients to z (row scatter-add) and sub (-sum over k)."""
+
+    @staticmethod
+    def forward(ctx, z, sub, index):
+        L.require_gpu(z, sub, index)
+        B, N, C = z.shape
+        _, M, K = index.shape
+        out = torch.empty((B, M, K, C), dtype=torch.float32, device=z.device)
+        L.call('mvp_group_sub_rows_f32', z, L.ptr(z), L.ptr(sub), L.ptr(index), B, N, C, M, K, L.ptr(out))
+        ctx.save_for_backward(index)
+        ctx.dims = (B, N, C, M, K)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (index,) = ctx.saved_tensors
+        B, N, C, M, K = ctx.dims
+        g = grad_out.contiguous()
+        gz = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
+        L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
+        return gz, -g.view(B, M, K, C).sum(2), None
+
+
+def group_sub_rows(z, sub, index):
+    """z (B,N,C), sub (B,M,C), index (B,M,K) -> (B,M,K,C) = z[index] - sub."""
+    return GroupSubRows.apply(z.contiguous(), sub.contiguous(), index.contiguous())
+
+
 class InterpRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feature, index, weight):
@@ -196,11 +226,19 @@ class MLPChainRows(torch.autograd.Function):
         for i in range(nl):
             w, gamma, beta = params[3 * i], params[3 * i + 1], params[3 * i + 2]
             eps, mom = eps_mom[i]
-            cout, cin = w.size(0), w.size(1)
-            y = torch.empty((R, cout), dtype=torch.float32, device=dev)
-            stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
-            L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
-                   L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None))
+            if w is None:  # x0 already IS this layer's pre-BN output (the linear part ran before the grouping)
+                assert i == 0
+                cout = x0.size(1)
+                y = x0
+                stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
+                if training:
+                    L.call('mvp_colstats_f32', y, L.ptr(y), R, cout, L.ptr(stat))
+            else:
+                cout, cin = w.size(0), w.size(1)
+                y = torch.empty((R, cout), dtype=torch.float32, device=dev)
+                stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
+                L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
+                       L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None))
             rm, rv = bn_buffers[i]
             if training:
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -217,7 +255,8 @@ class MLPChainRows(torch.autograd.Function):
         cl = ys[-1].size(1)
         G = R // K
         out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True)
-        ctx.save_for_backward(x0, out, arg, *ys, *means, *invstds, *params)
+        ctx.first_linear = params[0] is not None
+        ctx.save_for_backward(x0, out, arg, *ys, *means, *invstds, *[p for p in params if p is not None])
         ctx.cfg = (nl, training, K, R)
         return out
 
@@ -230,7 +269,9 @@ class MLPChainRows(torch.autograd.Function):
         ys = saved[3:3 + nl]
         means = saved[3 + nl:3 + 2 * nl]
         invstds = saved[3 + 2 * nl:3 + 3 * nl]
-        params = saved[3 + 3 * nl:]
+        params = list(saved[3 + 3 * nl:])
+        if not ctx.first_linear:
+            params.insert(0, None)
         grads = [None] * (3 * nl)
         g = grad_out.contiguous()
         G = R // K
@@ -241,8 +282,11 @@ class MLPChainRows(torch.autograd.Function):
         none4 = (None, None, None, None)
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
-            cout, cin = w.size(0), w.size(1)
             grads[3 * i + 1], grads[3 * i + 2] = dgam, dbet
+            if w is None:  # i == 0: x0 was this layer's pre-BN output, its gradient is dy itself
+                dx0 = dy
+                break
+            cout, cin = w.size(0), w.size(1)
             # layer input = x0 (first layer) or relu(bn(y_{i-1})) re-created inside the kernels from y_{i-1}
             src = x0 if i == 0 else ys[i - 1]
             act = none4 if i == 0 else (means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1])
@@ -309,10 +353,12 @@ def linear_rows(x, weight, bias=None):
     return LinearRows.apply(x.contiguous(), w, bias)
 
 
-def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False):
+def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
-    K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108)."""
+    K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108).
+    first_done=True: x already is the first layer's conv output (the linear part was applied per point before
+    the grouping, see SetAbstraction.forward_rows); only its BatchNorm + ReLU and the remaining layers run here."""
     n = len(mlp)
     fused = dropout_p == 0 and all(l.bn is not None and l.relu is not None and l.conv.bias is None and
                                    l.bn.running_mean is not None for l in mlp) and \
@@ -320,13 +366,15 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False):
     if fused:
         bn_training = mlp[0].bn.training
         params, buffers, eps_mom = [], [], []
-        for layer in mlp:
-            params += [layer.conv.weight.reshape(layer.conv.weight.size(0), -1), layer.bn.weight, layer.bn.bias]
+        for li, layer in enumerate(mlp):
+            w = None if (first_done and li == 0) else layer.conv.weight.reshape(layer.conv.weight.size(0), -1)
+            params += [w, layer.bn.weight, layer.bn.bias]
             buffers.append((layer.bn.running_mean, layer.bn.running_var))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
             if bn_training and layer.bn.num_batches_tracked is not None:
                 layer.bn.num_batches_tracked.add_(1)
         return MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, *params)
+    assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     for i, layer in enumerate(mlp):
         w = layer.conv.weight.reshape(layer.conv.weight.size(0), -1)  # (C_out, C_in)
         if x.size(1) != w.size(1):
