@@ -172,10 +172,13 @@ int mvp_group_rows_f32(const float* feature, const float* xyz, const float* cent
                        int64_t N, int64_t C, int64_t M, int64_t K, int64_t ld, float* out, mvp_stream_t stream);
 int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t N, int64_t C, int64_t M,
                                 int64_t K, int64_t ld, float* grad_feature, mvp_stream_t stream);
-/* out (B,M,K,C) = z (B,N,C)[index] - sub (B,M,C): set-abstraction grouping AFTER the (linear) first shared-MLP layer,
- * z = W1.[feature | xyz] per point, sub = W1_xyz . centre (same value as grouping first, 8x fewer conv rows). */
-int mvp_group_sub_rows_f32(const float* z, const float* sub, const int64_t* index, int64_t B, int64_t N, int64_t C, int64_t M,
-                           int64_t K, float* out, mvp_stream_t stream);
+/* Set-abstraction grouping AFTER the feature part of the (linear) first shared-MLP layer (modules.py:20-37,107):
+ *   out (B,M,K,C) = zf (B,N,C)[index] + wxyz (C,3) . (xyz (B,N,3)[index] - centre (B,M,3))
+ * with zf = W1[:, :C_in] . feature evaluated once per point (8x fewer conv rows than grouping first) and the coordinate
+ * columns evaluated on the difference, as the reference does.  zf may be NULL (no input feature).  diff, if not NULL,
+ * receives the (B,M,K,4) rows [dx,dy,dz,0] (operand of the W1_xyz weight gradient). */
+int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
+                           int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, mvp_stream_t stream);
 /* column sums of y and y^2 over the R rows of y (R,C) -> stat (2*C float64, zero-filled here) */
 int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream);
 int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,

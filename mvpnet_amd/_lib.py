@@ -44,7 +44,7 @@ _SIGNATURES = {
                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_group_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_rows_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
-    'mvp_group_sub_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_lin_rows_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_colstats_f32': [_ptr, _i64, _i64, _ptr, _ptr],
     'mvp_interp_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interp_rows_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],

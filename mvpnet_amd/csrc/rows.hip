@@ -60,13 +60,17 @@ __global__ __launch_bounds__(kRT) void group_rows_kernel(const float* __restrict
   st4(out + ((size_t)b * E + e) * ld + c, v);
 }
 
-// group_sub_rows: out[b,m,k,:] = z[b, idx[b,m,k], :] - sub[b,m,:]   (z (B,N,C), sub (B,M,C), C % 4 == 0)
-// Used with z = W1 . [feature | xyz] computed ONCE PER POINT and sub = W1_xyz . centre: the first shared-MLP
-// layer of a set-abstraction level is linear, so W1.[f(idx) | xyz(idx) - c] = z(idx) - W1_xyz.c and the 1x1 conv
-// runs on N rows instead of M*K = 8 N rows (the grouped tensor also shrinks from C+3 to C_1 columns).
-__global__ __launch_bounds__(kRT) void group_sub_rows_kernel(const float* __restrict__ z, const float* __restrict__ sub,
+// group_lin_rows: out[b,m,k,:] = Wxyz . (xyz[b,j] - centre[b,m]) + zf[b,j,:],  j = idx[b,m,k]   (C % 4 == 0)
+// The first shared-MLP layer of a set-abstraction level is linear, so W1.[f(j) | xyz(j) - c] = (W1f.f)(j) + W1xyz.(xyz(j) - c):
+// the feature part zf = W1f.f is a 1x1 conv over the N points instead of the M*K = 8N grouped rows, and the
+// coordinate part (3 columns) is evaluated here on the DIFFERENCE -- first subtract, then multiply, as the
+// reference does (modules.py:27 then the conv) -- so no cancellation between W.xyz and W.centre is introduced.
+// zf == nullptr: no input feature (PN2SSG baseline, SA level 1).  diff != nullptr: also store [dx,dy,dz,0] rows
+// (the operand of the W1xyz weight gradient).  wxyz is (C,3) row-major.
+__global__ __launch_bounds__(kRT) void group_lin_rows_kernel(const float* __restrict__ zf, const float* __restrict__ xyz,
+                                                             const float* __restrict__ centre, const float* __restrict__ wxyz,
                                                              const int64_t* __restrict__ idx, int N, int C, int M, int K,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, float* __restrict__ diff) {
   const int b = blockIdx.y;
   const int C4 = C >> 2;
   const int64_t E = (int64_t)M * K;
@@ -76,12 +80,25 @@ __global__ __launch_bounds__(kRT) void group_sub_rows_kernel(const float* __rest
   if (e >= E) return;
   const int64_t j = idx[(size_t)b * E + e];
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dx = 0.f, dy = 0.f, dz = 0.f;
   if (j >= 0 && j < N) {
-    const float4 a = ld4(z + ((size_t)b * N + j) * C + c);
-    const float4 s = ld4(sub + ((size_t)b * M + e / K) * C + c);
-    v = make_float4(a.x - s.x, a.y - s.y, a.z - s.z, a.w - s.w);
+    const float* p = xyz + ((size_t)b * N + j) * 3;
+    const float* q = centre + ((size_t)b * M + e / K) * 3;
+    dx = p[0] - q[0];
+    dy = p[1] - q[1];
+    dz = p[2] - q[2];
+    const float* w = wxyz + (size_t)c * 3;
+    v.x = (w[0] * dx + w[1] * dy) + w[2] * dz;
+    v.y = (w[3] * dx + w[4] * dy) + w[5] * dz;
+    v.z = (w[6] * dx + w[7] * dy) + w[8] * dz;
+    v.w = (w[9] * dx + w[10] * dy) + w[11] * dz;
+    if (zf != nullptr) {
+      const float4 a = ld4(zf + ((size_t)b * N + j) * C + c);
+      v = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+    }
   }
   st4(out + ((size_t)b * E + e) * C + c, v);
+  if (diff != nullptr && c == 0) st4(diff + ((size_t)b * E + e) * 4, make_float4(dx, dy, dz, 0.f));
 }
 
 // grad_feature (B,N,C) += grad_out[..., :C]; one lane per (row, channel): consecutive lanes hit
@@ -526,17 +543,19 @@ MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, con
   return mvp_launch_status();
 }
 
-MVP_API int mvp_group_sub_rows_f32(const float* z, const float* sub, const int64_t* index, int64_t B, int64_t N, int64_t C,
-                                   int64_t M, int64_t K, float* out, mvp_stream_t stream) {
-  MVP_NONNULL(z);
-  MVP_NONNULL(sub);
+MVP_API int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
+                                   int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff,
+                                   mvp_stream_t stream) {
+  MVP_NONNULL(xyz);
+  MVP_NONNULL(centre);
+  MVP_NONNULL(wxyz);
   MVP_NONNULL(index);
   MVP_NONNULL(out);
   MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && M >= 0 && K > 0 && B < 65536);
   if (B == 0 || M == 0) return MVP_OK;
   dim3 grid((unsigned)cdiv(M * K * (C / 4), kRT), (unsigned)B);
-  hipLaunchKernelGGL(group_sub_rows_kernel, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), z, sub, index, (int)N, (int)C,
-                     (int)M, (int)K, out);
+  hipLaunchKernelGGL(group_lin_rows_kernel, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), zf, xyz, centre, wxyz, index,
+                     (int)N, (int)C, (int)M, (int)K, out, diff);
   return mvp_launch_status();
 }
 

@@ -88,19 +88,20 @@ class SetAbstraction(nn.Module):
         l0 = self.mlp[0]
         c1 = l0.conv.weight.size(0)
         if l0.bn is not None and l0.relu is not None and l0.conv.bias is None and l0.bn.running_mean is not None and c1 % 4 == 0:
-            # The first shared-MLP layer is linear, so it commutes with the grouping:
-            #   W1.[f(idx) | xyz(idx) - c] = (W1.[f | xyz])(idx) - W1_xyz.c
-            # -> one 1x1 conv over the N points instead of the M*K = 8N grouped rows, and the grouped tensor has
-            #    C_1 instead of C+3 columns (same mathematics as modules.py:20-37,107; differs by fp32 rounding only).
+            # The first shared-MLP layer is linear, so its feature columns commute with the grouping:
+            #   W1.[f(idx) | xyz(idx) - c] = (W1f.f)(idx) + W1xyz.(xyz(idx) - c)
+            # -> the 1x1 conv over the feature runs on the N points instead of the M*K = 8N grouped rows, and the
+            #    grouped tensor has C_1 instead of C+3 columns.  The 3 coordinate columns are applied to the difference
+            #    inside the grouping kernel (same operation order as modules.py:27 + conv; no cancellation).
             w1 = l0.conv.weight.reshape(c1, -1)                       # columns [feature (C) | xyz (3)]
-            p = torch.cat([feature, xyz], dim=2) if use_feature else xyz
-            pad = (-p.size(2)) % 4
-            if pad:
-                p = torch.nn.functional.pad(p, (0, pad))
-            w1p = torch.nn.functional.pad(w1, (0, pad)) if pad else w1
-            z = R.linear_rows(p.reshape(B * N, -1), w1p).view(B, N, c1)
-            cterm = torch.matmul(new_xyz, w1[:, -3:].t())              # (B,M,C_1) = W1_xyz . centre
-            y1 = R.group_sub_rows(z, cterm, ball)                      # (B,M,K,C_1): conv output of layer 1, grouped
+            zf = None
+            if use_feature:
+                cf = feature.size(2)
+                pad = (-cf) % 4
+                f = torch.nn.functional.pad(feature, (0, pad)) if pad else feature
+                w1f = torch.nn.functional.pad(w1[:, :cf], (0, pad)) if pad else w1[:, :cf]
+                zf = R.linear_rows(f.reshape(B * N, -1), w1f).view(B, N, c1)
+            y1 = R.group_lin_rows(zf, xyz, new_xyz, w1[:, -3:], ball)  # (B,M,K,C_1): conv output of layer 1, grouped
             new_feature = R.shared_mlp_rows(y1.view(B * M * K, c1), self.mlp, K=K, first_done=True)
             return new_xyz, new_feature.view(B, M, -1)
         if use_feature and feature.size(2) % 4:

@@ -55,34 +55,48 @@ def group_rows(feature, xyz, center, index):
                            index.contiguous())
 
 
-class GroupSubRows(torch.autograd.Function):
-    """out[b,m,k,:] = z[b, index[b,m,k], :] - sub[b,m,:]; gradients to z (row scatter-add) and sub (-sum over k)."""
+class GroupLinRows(torch.autograd.Function):
+    """out[b,m,k,:] = zf[b,j,:] + wxyz . (xyz[b,j] - centre[b,m]),  j = index[b,m,k]   (zf may be None).
+    Gradients: zf (row scatter-add) and wxyz (grad_out^T . diff rows); coordinates carry no gradient on this path
+    (the reference computes them under no_grad too: fps.py:11-13, modules.py:22-27 on leaf points)."""
 
     @staticmethod
-    def forward(ctx, z, sub, index):
-        L.require_gpu(z, sub, index)
-        B, N, C = z.shape
+    def forward(ctx, zf, xyz, centre, wxyz, index):
+        L.require_gpu(xyz, centre, wxyz, index)
+        B, N, _ = xyz.shape
         _, M, K = index.shape
-        out = torch.empty((B, M, K, C), dtype=torch.float32, device=z.device)
-        L.call('mvp_group_sub_rows_f32', z, L.ptr(z), L.ptr(sub), L.ptr(index), B, N, C, M, K, L.ptr(out))
-        ctx.save_for_backward(index)
+        C = wxyz.size(0)
+        need_w = wxyz.requires_grad
+        out = torch.empty((B, M, K, C), dtype=torch.float32, device=xyz.device)
+        diff = torch.empty((B, M, K, 4), dtype=torch.float32, device=xyz.device) if need_w else None
+        L.call('mvp_group_lin_rows_f32', xyz, L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(wxyz), L.ptr(index), B, N, C, M, K,
+               L.ptr(out), L.ptr(diff))
+        ctx.save_for_backward(index, diff)
         ctx.dims = (B, N, C, M, K)
+        ctx.has_zf = zf is not None
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        (index,) = ctx.saved_tensors
+        index, diff = ctx.saved_tensors
         B, N, C, M, K = ctx.dims
         g = grad_out.contiguous()
-        gz = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
-        L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
-        return gz, -g.view(B, M, K, C).sum(2), None
+        gz = gw = None
+        if ctx.has_zf and ctx.needs_input_grad[0]:
+            gz = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
+            L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
+        if diff is not None and ctx.needs_input_grad[3]:
+            gw4 = torch.empty((C, 4), dtype=torch.float32, device=g.device)
+            L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4))
+            gw = gw4[:, :3].contiguous()
+        return gz, None, None, gw, None
 
 
-def group_sub_rows(z, sub, index):
-    """z (B,N,C), sub (B,M,C), index (B,M,K) -> (B,M,K,C) = z[index] - sub."""
-    return GroupSubRows.apply(z.contiguous(), sub.contiguous(), index.contiguous())
+def group_lin_rows(zf, xyz, centre, wxyz, index):
+    """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3), index (B,M,K) -> (B,M,K,C)."""
+    return GroupLinRows.apply(None if zf is None else zf.contiguous(), xyz.contiguous(), centre.contiguous(), wxyz.contiguous(),
+                              index.contiguous())
 
 
 class InterpRows(torch.autograd.Function):
