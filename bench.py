@@ -166,6 +166,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-profile', action='store_true', help='cProfile the timed loop (host/launch cost), top entries to stderr')
     ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
                                               'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml kept in tests/golden/configs.json')
     ap.add_argument('--batch', type=int, default=0, help='chunks per GPU per step (default: TRAIN.BATCH_SIZE of the config = 32)')
@@ -237,9 +238,19 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    prof = None
+    if args.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(45)
+    host_elapsed = time.perf_counter() - t0      # python/launch time only (the queue is drained below)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -276,6 +287,7 @@ def main():
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
                        'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
+            'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
             'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),
                          'note': 'configs[1]: lifting + aggregation + PN2SSG forward, eval mode, same batch'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',

@@ -31,72 +31,235 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLFThreads = 256;
 constexpr int kXcds = 8;
 
-// PX pixels per thread.  Measured: PX = 4 is slower than PX = 1 (15.1 vs 11.3 us, the 64-byte-strided
-// record stores of a wave no longer coalesce), so PX = 1 with large workgroups is used.
+// Depth plane: next to the 16-byte records K1 writes ONE uint16 per pixel -- the camera-frame depth in units of 0.25 mm
+// (floor; 65535 = not a valid pixel, 65534 = 16.38 m or more) -- into a plane padded by kPlanePad rows / columns of
+// "invalid" on every side.  The k-NN kernel reads a 5-pixel window row with a single 16-byte load from it (8 pixels,
+// 4-byte aligned, never out of bounds thanks to the padding) and only fetches the records of the few candidates the
+// depth cannot exclude.
+constexpr int kPlanePad = 4;
+constexpr float kPlaneUnit = 2.5e-4f;  // metres per count
+constexpr unsigned kPlaneInvalid = 65535u, kPlaneSat = 65534u;
+__host__ __device__ inline int plane_pitch(int w) { return (w + 2 * kPlanePad + 4 + 1) & ~1; }  // even; >= w + 12
+__host__ __device__ inline int plane_rows(int h) { return h + 2 * kPlanePad; }
+
+// One thread per element of the padded plane (1 pixel per thread: 4 pixels per thread was measured slower, 15.1 vs
+// 11.3 us, because the 64-byte-strided record stores of a wave no longer coalesce).
 constexpr int kPrepThreads = 1024;
-template <typename DepthT, int PX>
+template <typename DepthT>
 __global__ __launch_bounds__(kPrepThreads) void lift_prepare_kernel(const DepthT* __restrict__ depth,
                                                            const float* __restrict__ kinv,
                                                            const float* __restrict__ pose,
                                                            const float* __restrict__ box, int B, int nv, int h, int w,
-                                                           float4* __restrict__ rec, float* __restrict__ image_xyz,
+                                                           int pitch, float4* __restrict__ rec,
+                                                           uint16_t* __restrict__ plane, float* __restrict__ image_xyz,
                                                            uint8_t* __restrict__ mask) {
   const int bv = blockIdx.y;  // b * nv + view
-  const int pix0 = (blockIdx.x * kPrepThreads + threadIdx.x) * PX;
-  if (pix0 >= h * w) return;
+  const int pp = blockIdx.x * kPrepThreads + threadIdx.x;
+  const int prow = plane_rows(h);
+  if (pp >= prow * pitch) return;
+  const int row = pp / pitch, col = pp - row * pitch;
+  const int v = row - kPlanePad, u = col - kPlanePad;
+  uint16_t* pl = plane + (size_t)bv * prow * pitch + pp;
+  if (v < 0 || v >= h || u < 0 || u >= w) {
+    *pl = (uint16_t)kPlaneInvalid;
+    return;
+  }
   const float* Ki = kinv + (size_t)bv * 9;
   const float* Pm = pose + (size_t)bv * 16;
   const double k0 = Ki[0], k1 = Ki[1], k2 = Ki[2], k3 = Ki[3], k4 = Ki[4], k5 = Ki[5], k6 = Ki[6], k7 = Ki[7], k8 = Ki[8];
   const double p0 = Pm[0], p1 = Pm[1], p2 = Pm[2], p3 = Pm[3], p4 = Pm[4], p5 = Pm[5], p6 = Pm[6], p7 = Pm[7], p8 = Pm[8],
                p9 = Pm[9], p10 = Pm[10], p11 = Pm[11];
-  float bx0 = 0.f, bx1 = 0.f, bx2 = 0.f, bx3 = 0.f;
+  const size_t p = (size_t)bv * h * w + (size_t)v * w + u;
+  float df;
+  if constexpr (sizeof(DepthT) == 2)
+    df = __fdiv_rn((float)depth[p], 1000.0f);
+  else
+    df = depth[p];
+  // identical arithmetic to unproject_kernel (lifting.hip): float64, one rounding to float32
+  const double d = (double)df, du = (double)u, dv = (double)v;
+  const double rx = (k0 * du + k1 * dv) + k2;
+  const double ry = (k3 * du + k4 * dv) + k5;
+  const double rz = (k6 * du + k7 * dv) + k8;
+  const double xc = rx * d, yc = ry * d, zc = rz * d;
+  const double xw = ((xc * p0 + yc * p1) + zc * p2) + p3;
+  const double yw = ((xc * p4 + yc * p5) + zc * p6) + p7;
+  const double zw = ((xc * p8 + yc * p9) + zc * p10) + p11;
+  bool ok = zc > 0.0;
   if (box) {
     const float* bx = box + (size_t)(bv / nv) * 4;
-    bx0 = bx[0]; bx1 = bx[1]; bx2 = bx[2]; bx3 = bx[3];
+    ok = ok && xw > (double)bx[0] && xw < (double)bx[2] && yw > (double)bx[1] && yw < (double)bx[3];
   }
-  const size_t base = (size_t)bv * h * w;
-  float df[PX];
+  rec[p] = make_float4((float)xw, (float)yw, (float)zw, ok ? 0.0f : INFINITY);
+  *pl = (uint16_t)(ok ? (unsigned)fminf(floorf((float)zc * (1.0f / kPlaneUnit)), (float)kPlaneSat) : kPlaneInvalid);
+  if (image_xyz) {
+    image_xyz[p * 3 + 0] = (float)xw;
+    image_xyz[p * 3 + 1] = (float)yw;
+    image_xyz[p * 3 + 2] = (float)zw;
+  }
+  if (mask) mask[p] = ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Filtered probe: the exact top-k of the 5x5 windows around the projections WITHOUT loading the 25 records per view.
+//
+// For a candidate pixel (u, v) of a pin-hole view with quantised camera depth z~ the camera-frame position
+// p~ = (z~ (u-cx)/fx, z~ (v-cy)/fy, z~) is within  e_i <= 1.0002 (E + 1e-4 s~)  of the stored point p_i, where s~ = |p~ - q_cam|
+// and  E = 0.125 mm * Rmax + 2e-4 z_q + 20 um + 4e-7 |t|_1  (quantisation; fp32 rounding of K^-1, of the pose and of the
+// stored world coordinates -- the same consistency of `cam` with `kinv` and rigidity of `pose` that the ring bound of
+// pixel_knn_core.h relies on; z_i <= z_q + |p_i - q|).  With (x +- y)^2 <=/>= (1 +- 0.1) x^2 +- (1/0.1 +- 1) y^2:
+//     lo = 0.8998 s~^2 - 9.05 E^2  <=  |p_i - q|^2  <=  1.1003 s~^2 + 11.05 E^2 = up.
+// U = k-th smallest `up` over the candidates seen so far is >= the true k-th smallest distance T, so every candidate that
+// can be in the top-k (|p_i - q|^2 <= T, ties included) has lo <= U, i.e. s~^2 <= (U + 9.05 E^2) / 0.8998: those survivors
+// (typically k + 1 or 2 of 75) are evaluated exactly from their records with the pinned arithmetic.
+// Invalid / padding pixels (65535) and depths of 16.38 m or more (65534) decode to z~ >= 16.38 m.  While U < 0.85 (16.38 - z_q)^2
+// such entries are neither among the k smallest `up` nor survivors, so they need no per-candidate test; a view where this
+// does not hold when it is processed (fewer than k candidates so far, z_q >= 16 m), or whose survivors overflow the lane's
+// list, is left pending and its whole window is evaluated from the records afterwards (rare).
+// L1 cost per point: 5 loads per view + one per survivor instead of 25 per view.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int kSurvCap = 24;
+
+template <int K>
+__device__ __forceinline__ void up_insert(float (&ub)[K], float v) {  // ub ascending; keeps the K smallest
 #pragma unroll
-  for (int i = 0; i < PX; ++i) {
-    const int pix = pix0 + i;
-    if (pix < h * w) {
-      if constexpr (sizeof(DepthT) == 2)
-        df[i] = __fdiv_rn((float)depth[base + pix], 1000.0f);
-      else
-        df[i] = depth[base + pix];
-    } else {
-      df[i] = 0.f;
+  for (int s = K - 1; s >= 1; --s) ub[s] = __builtin_amdgcn_fmed3f(ub[s - 1], ub[s], v);
+  ub[0] = fminf(ub[0], v);
+}
+
+template <int K>
+__device__ __forceinline__ void filtered_probe(const float4* __restrict__ crec, const uint16_t* __restrict__ cplane,
+                                               const ViewParam* __restrict__ vp, int nv, int h, int w, int pitch, float qx,
+                                               float qy, float qz, float (&bd)[K], int (&bi)[K], int* __restrict__ slist,
+                                               int tid) {
+  const int hw = h * w;
+  const size_t vstride = (size_t)plane_rows(h) * pitch;
+  float ub[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) ub[s] = INFINITY;
+  unsigned pend = 0;  // views (bit vi) to be probed from the records
+  int cnt = 0;
+  for (int vi = 0; vi < nv; ++vi) {
+    const ViewParam& V = vp[vi];
+    const float dx = qx - V.t[0], dy = qy - V.t[1], dz = qz - V.t[2];
+    const float zc = V.r[2] * dx + V.r[5] * dy + V.r[8] * dz;  // R^T (p - t)
+    if (!V.usable || !(zc > 0.05f)) continue;
+    const float xc = V.r[0] * dx + V.r[3] * dy + V.r[6] * dz;
+    const float yc = V.r[1] * dx + V.r[4] * dy + V.r[7] * dz;
+    const float u0 = V.fx * (xc / zc) + V.cx, v0 = V.fy * (yc / zc) + V.cy;
+    const int uc = (int)rintf(fminf(fmaxf(u0, -1.0e6f), 1.0e6f));
+    const int vc = (int)rintf(fminf(fmaxf(v0, -1.0e6f), 1.0e6f));
+    if (uc < -2 || uc > w + 1 || vc < -2 || vc > h + 1) continue;  // the window misses the image
+    const int sc = uc - 2 + kPlanePad;                              // padded column of the window's first pixel
+    const unsigned sh = (unsigned)(sc & 1) * 16u;
+    const uint16_t* p0 = cplane + vi * vstride + (size_t)(vc - 2 + kPlanePad) * pitch + (sc & ~1);
+    u32x4a rowv[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) rowv[a] = *reinterpret_cast<const u32x4a*>(p0 + (size_t)a * pitch);
+    const float E = 1.25e-4f * V.rmax + 2.0e-4f * zc + 2.0e-5f + 4.0e-7f * V.tabs;
+    const float cu = 11.05f * E * E, cl = 9.05f * E * E;
+    float ax[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) ax[c] = ((float)(uc - 2 + c) - V.cx) * V.ifx;
+    const float by0 = ((float)(vc - 2) - V.cy) * V.ify;
+    float s2[25];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const unsigned w0 = __builtin_amdgcn_alignbit(rowv[a].y, rowv[a].x, sh);
+      const unsigned w1 = __builtin_amdgcn_alignbit(rowv[a].z, rowv[a].y, sh);
+      const unsigned w2 = __builtin_amdgcn_alignbit(rowv[a].w, rowv[a].z, sh);
+      const float by = by0 + (float)a * V.ify;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const unsigned q16 = c == 0 ? (w0 & 0xffffu) : c == 1 ? (w0 >> 16) : c == 2 ? (w1 & 0xffffu) : c == 3 ? (w1 >> 16) : (w2 & 0xffffu);
+        const float z = fmaf((float)q16, kPlaneUnit, 0.5f * kPlaneUnit);
+        const float ddx = fmaf(z, ax[c], -xc), ddy = fmaf(z, by, -yc), ddz = z - zc;
+        const float v = fmaf(ddx, ddx, fmaf(ddy, ddy, ddz * ddz));
+        s2[a * 5 + c] = v;
+        up_insert<K>(ub, fmaf(v, 1.1003f, cu));
+      }
+    }
+    const float U = ub[K - 1];
+    const float far = 16.38f - zc;
+    const float thr = (U + cl) * 1.1115f;  // 1 / 0.8998 rounded up
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) m |= (s2[i] <= thr) ? (1u << i) : 0u;
+    // The filter is only sound while padding / invalid / saturated entries can be neither among the k smallest `up` nor
+    // survivors; a view where that does not hold yet, or whose survivors do not fit the list, is probed from its records.
+    if (!(zc < 16.0f) || !(U < 0.85f * far * far) || cnt + __popc(m) > kSurvCap) {
+      pend |= 1u << vi;
+      m = 0;
+    }
+    const int base = vi * hw + (vc - 2) * w + (uc - 2);
+    while (m != 0) {  // append this view's survivors to the lane's list (column tid of slist)
+      const int i = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int a = (i * 13) >> 6;  // i / 5 for 0 <= i < 25
+      slist[cnt * kLFThreads + tid] = base + a * w + (i - 5 * a);
+      ++cnt;
+    }
+  }
+  // (distance, id) packed into one 64-bit key: distances are >= +0, so their bit patterns order like the values and one
+  // unsigned compare is the lexicographic (distance, id) order.
+  unsigned long long kk[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) kk[s] = ~0ull;
+  auto key_insert = [&](unsigned long long x) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      const bool lt = x < kk[s];
+      const unsigned long long lo = lt ? x : kk[s];
+      x = lt ? kk[s] : x;
+      kk[s] = lo;
+    }
+  };
+  auto exact_key = [&](int id) -> unsigned long long {
+    const float4 r = crec[id];
+    const float d = dist2_3(r.x, r.y, r.z, qx, qy, qz) + r.w;  // pinned arithmetic; + inf marks an invalid pixel
+    return d < INFINITY ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id) : ~0ull;
+  };
+  // exact evaluation of the survivors, 4 records in flight per lane
+  for (int s0 = 0; __any(s0 < cnt); s0 += 4) {
+    unsigned long long key[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) key[j] = (s0 + j < cnt) ? exact_key(slist[(s0 + j) * kLFThreads + tid]) : ~0ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) key_insert(key[j]);
+  }
+  // views left pending: their whole 5x5 window from the records, one row (5 loads) in flight
+  while (__any(pend != 0)) {
+    if (pend != 0) {
+      const int vi = __ffs((int)pend) - 1;
+      pend &= pend - 1;
+      int uc, vc;
+      float zc;
+      if (project_point(vp[vi], qx, qy, qz, uc, vc, zc)) {
+        for (int a = 0; a < 5; ++a) {
+          const int vv = vc - 2 + a;
+          unsigned long long key[5];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            const int uu = uc - 2 + c;
+            key[c] = (vv >= 0 && vv < h && uu >= 0 && uu < w) ? exact_key(vi * hw + vv * w + uu) : ~0ull;
+          }
+#pragma unroll
+          for (int c = 0; c < 5; ++c) key_insert(key[c]);
+        }
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < PX; ++i) {
-    const int pix = pix0 + i;
-    if (pix >= h * w) break;
-    const int v = pix / w, u = pix - v * w;
-    const size_t p = base + pix;
-    // identical arithmetic to unproject_kernel (lifting.hip): float64, one rounding to float32
-    const double d = (double)df[i], du = (double)u, dv = (double)v;
-    const double rx = (k0 * du + k1 * dv) + k2;
-    const double ry = (k3 * du + k4 * dv) + k5;
-    const double rz = (k6 * du + k7 * dv) + k8;
-    const double xc = rx * d, yc = ry * d, zc = rz * d;
-    const double xw = ((xc * p0 + yc * p1) + zc * p2) + p3;
-    const double yw = ((xc * p4 + yc * p5) + zc * p6) + p7;
-    const double zw = ((xc * p8 + yc * p9) + zc * p10) + p11;
-    bool ok = zc > 0.0;
-    if (box) ok = ok && xw > (double)bx0 && xw < (double)bx2 && yw > (double)bx1 && yw < (double)bx3;
-    rec[p] = make_float4((float)xw, (float)yw, (float)zw, ok ? 0.0f : INFINITY);
-    if (image_xyz) {
-      image_xyz[p * 3 + 0] = (float)xw;
-      image_xyz[p * 3 + 1] = (float)yw;
-      image_xyz[p * 3 + 2] = (float)zw;
-    }
-    if (mask) mask[p] = ok ? 1 : 0;
+  for (int s = 0; s < K; ++s) {
+    const bool has = kk[s] != ~0ull;
+    bd[s] = has ? __uint_as_float((unsigned)(kk[s] >> 32)) : INFINITY;
+    bi[s] = has ? (int)(unsigned)kk[s] : 0x7fffffff;
   }
 }
 
 template <int K>
 __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float4* __restrict__ rec,
+                                                                     const uint16_t* __restrict__ plane, int pitch,
                                                                      const float* __restrict__ points,
                                                                      const float* __restrict__ cam,
                                                                      const float* __restrict__ pose,
@@ -107,6 +270,7 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
                                                                      float* __restrict__ gxyz) {
   __shared__ ViewParam vp[kMaxViews];
   __shared__ int sidx[kLFThreads * K];
+  __shared__ int slist[kLFThreads * kSurvCap];
   // XCD-aware chunk placement: L % 8 = XCD; chunks b with b % 8 == xcd live on that XCD.
   const int L = blockIdx.x;
   const int xcd = L % kXcds, jb = L / kXcds;
@@ -132,10 +296,8 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
       bi[s] = 0x7fffffff;
     }
     PackedSource src{crec};
-#ifndef MVP_LIFT_W0
-#define MVP_LIFT_W0 2
-#endif
-    projective_knn<K, MVP_LIFT_W0>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
+    filtered_probe<K>(crec, plane + (size_t)b * nv * plane_rows(h) * pitch, vp, nv, h, w, pitch, qx, qy, qz, bd, bi, slist, tid);
+    projective_rings<K, 2>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
 #pragma unroll
     for (int s = 0; s < K; ++s) {
       const bool found = bd[s] < INFINITY;
@@ -199,13 +361,13 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
 }
 
 template <int K>
-int launch_lift(const float4* rec, const float* points, const float* cam, const float* pose, const float* feature,
+int launch_lift(const float4* rec, const uint16_t* plane, int pitch, const float* points, const float* cam, const float* pose, const float* feature,
                 int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N, int64_t C, int64_t* knn_index, float* gfeat,
                 float* gxyz, hipStream_t s) {
   const int bpc = (int)cdiv(N, kLFThreads);
   const int64_t groups = cdiv(B, kXcds);  // chunks per XCD (rounded up; surplus workgroups exit at once)
   dim3 grid((unsigned)(kXcds * groups * bpc));
-  hipLaunchKernelGGL((lift_knn_gather_kernel<K>), grid, dim3(kLFThreads), 0, s, rec, points, cam, pose, feature,
+  hipLaunchKernelGGL((lift_knn_gather_kernel<K>), grid, dim3(kLFThreads), 0, s, rec, plane, pitch, points, cam, pose, feature,
                      (int)B, (int)nv, (int)h, (int)w, (int)N, (int)C, bpc, knn_index, gfeat, gxyz);
   return mvp_launch_status();
 }
@@ -214,7 +376,8 @@ int launch_lift(const float4* rec, const float* points, const float* cam, const 
 
 MVP_API int64_t mvp_lift_workspace_bytes(int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N) {
   if (B < 0 || nv < 0 || h < 0 || w < 0 || N < 0) return 0;
-  return B * nv * h * w * (int64_t)sizeof(float4);  // one search record per pixel (N reserved for future use)
+  // one 16-byte search record per pixel + the padded uint16 depth plane (N reserved for future use)
+  return B * nv * h * w * (int64_t)sizeof(float4) + ((B * nv * plane_rows((int)h) * plane_pitch((int)w) * 2 + 15) & ~(int64_t)15);
 }
 
 MVP_API int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv, const float* cam, const float* pose,
@@ -230,27 +393,28 @@ MVP_API int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv,
   MVP_NONNULL(knn_index);
   if (gfeature) MVP_NONNULL(feature);
   MVP_REQUIRE(B >= 0 && N >= 0 && nv > 0 && h > 0 && w > 0 && k >= 1 && k <= 8 && C >= 0);
-  MVP_REQUIRE(nv * h * w < (1ll << 31) && N < (1ll << 31) && B * (nv + 1) < 65536 && nv <= kMaxViews);
+  MVP_REQUIRE(nv * (h + 8) * (w + 14) < (1ll << 31) && N < (1ll << 31) && B * (nv + 1) < 65536 && nv <= kMaxViews);
   MVP_REQUIRE(((uintptr_t)workspace % 16) == 0);
   if (gfeature) MVP_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024 && (kLFThreads % (C / 4)) == 0 &&
                             ((uintptr_t)feature % 16) == 0 && ((uintptr_t)gfeature % 16) == 0);
   if (B == 0) return MVP_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float4* rec = static_cast<float4*>(workspace);
-  constexpr int PX = 1;
-  dim3 grid((unsigned)cdiv(cdiv(h * w, PX), kPrepThreads), (unsigned)(B * nv));
+  uint16_t* plane = reinterpret_cast<uint16_t*>(rec + B * nv * h * w);
+  const int pitch = plane_pitch((int)w);
+  dim3 grid((unsigned)cdiv((int64_t)plane_rows((int)h) * pitch, kPrepThreads), (unsigned)(B * nv));
   if (depth_is_u16)
-    hipLaunchKernelGGL((lift_prepare_kernel<uint16_t, PX>), grid, dim3(kPrepThreads), 0, s, static_cast<const uint16_t*>(depth), kinv,
-                       pose, box, (int)B, (int)nv, (int)h, (int)w, rec, image_xyz, mask);
+    hipLaunchKernelGGL((lift_prepare_kernel<uint16_t>), grid, dim3(kPrepThreads), 0, s, static_cast<const uint16_t*>(depth), kinv,
+                       pose, box, (int)B, (int)nv, (int)h, (int)w, pitch, rec, plane, image_xyz, mask);
   else
-    hipLaunchKernelGGL((lift_prepare_kernel<float, PX>), grid, dim3(kPrepThreads), 0, s, static_cast<const float*>(depth), kinv, pose,
-                       box, (int)B, (int)nv, (int)h, (int)w, rec, image_xyz, mask);
+    hipLaunchKernelGGL((lift_prepare_kernel<float>), grid, dim3(kPrepThreads), 0, s, static_cast<const float*>(depth), kinv, pose,
+                       box, (int)B, (int)nv, (int)h, (int)w, pitch, rec, plane, image_xyz, mask);
   int rc = mvp_launch_status();
   if (rc != MVP_OK || N == 0) return rc;
   switch (k) {
 #define MVP_CASE(KK) \
   case KK:           \
-    return launch_lift<KK>(rec, points, cam, pose, feature, B, nv, h, w, N, C, knn_index, gfeature, gxyz, s);
+    return launch_lift<KK>(rec, plane, pitch, points, cam, pose, feature, B, nv, h, w, N, C, knn_index, gfeature, gxyz, s);
     MVP_CASE(1) MVP_CASE(2) MVP_CASE(3) MVP_CASE(4) MVP_CASE(5) MVP_CASE(6) MVP_CASE(7) MVP_CASE(8)
 #undef MVP_CASE
   }

@@ -10,6 +10,9 @@ struct ViewParam {
   float t[3];   // camera centre in the world (pose[:3,3])
   float fx, fy, cx, cy;
   float inv_scale;  // 1 / (max(fx,fy) * Rmax): metres of guaranteed distance per (pixel * z)
+  float ifx, ify;   // 1/fx, 1/fy
+  float rmax;       // max over the image of |(a, b, 1)|, a = (u-cx)/fx, b = (v-cy)/fy
+  float tabs;       // |tx| + |ty| + |tz|
   int usable;       // pin-hole form K = [[fx,0,cx],[0,fy,cy],[0,0,1]] with fx,fy > 0
 };
 
@@ -56,6 +59,10 @@ __device__ __forceinline__ ViewParam make_view_param(const float* __restrict__ K
   const float am = fmaxf(a0, a1), bm = fmaxf(b0, b1);
   const float rmax = sqrtf(1.0f + am * am + bm * bm);
   v.inv_scale = v.usable ? 1.0f / (fmaxf(v.fx, v.fy) * rmax) : 0.f;
+  v.ifx = v.usable ? 1.0f / v.fx : 0.f;
+  v.ify = v.usable ? 1.0f / v.fy : 0.f;
+  v.rmax = rmax;
+  v.tabs = fabsf(v.t[0]) + fabsf(v.t[1]) + fabsf(v.t[2]);
   return v;
 }
 
@@ -93,14 +100,11 @@ __device__ __forceinline__ bool project_point(const ViewParam& V, float qx, floa
 }
 
 // The search itself.  vp: per-view parameters (LDS), bd/bi: sorted top-k (distance, flat pixel id).
+// ---- phase 1: probe window around the projection in every usable view (loads are independent) ----
 template <int K, int W0, typename Src>
-__device__ __forceinline__ void projective_knn(const Src& src, const ViewParam* __restrict__ vp, int nv, int h, int w,
-                                               float qx, float qy, float qz, float (&bd)[K], int (&bi)[K]) {
+__device__ __forceinline__ void projective_probe(const Src& src, const ViewParam* __restrict__ vp, int nv, int h, int w,
+                                                 float qx, float qy, float qz, float (&bd)[K], int (&bi)[K]) {
   const int hw = h * w;
-#ifdef MVP_KNN_STATS
-  int bd_stats_rings = 0, bd_stats_pix = 0;
-#endif
-  // ---- phase 1: probe window around the projection in every usable view (loads are independent) ----
   for (int vi = 0; vi < nv; ++vi) {
     const ViewParam& V = vp[vi];
     const float dx = qx - V.t[0], dy = qy - V.t[1], dz = qz - V.t[2];
@@ -130,8 +134,17 @@ __device__ __forceinline__ void projective_knn(const Src& src, const ViewParam* 
     for (int e = 0; e < S * S; ++e)
       if (dd[e] < INFINITY) topk_insert_id<K>(bd, bi, dd[e], ii[e]);
   }
+}
 
-  // ---- phase 2: per view, widen to the radius the bound needs; scan only the new ring ----
+// ---- phase 2: per view, widen to the radius the bound needs; scan only the new ring ----
+// Precondition: bd/bi hold the exact top-k of the (2 W0 + 1)^2 windows of all usable views.
+template <int K, int W0, typename Src>
+__device__ __forceinline__ void projective_rings(const Src& src, const ViewParam* __restrict__ vp, int nv, int h, int w,
+                                                 float qx, float qy, float qz, float (&bd)[K], int (&bi)[K]) {
+  const int hw = h * w;
+#ifdef MVP_KNN_STATS
+  int bd_stats_rings = 0, bd_stats_pix = 0;
+#endif
 #ifdef MVP_KNN_NOPHASE2
   return;
 #endif
@@ -237,3 +250,9 @@ __device__ __forceinline__ void projective_knn(const Src& src, const ViewParam* 
 #endif
 }
 
+template <int K, int W0, typename Src>
+__device__ __forceinline__ void projective_knn(const Src& src, const ViewParam* __restrict__ vp, int nv, int h, int w,
+                                               float qx, float qy, float qz, float (&bd)[K], int (&bi)[K]) {
+  projective_probe<K, W0>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
+  projective_rings<K, W0>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
+}
