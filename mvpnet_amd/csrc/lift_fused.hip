@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kPrepThreads) void lift_prepare_kernel(const DepthT
 // L1 cost per point: 5 loads per view + one per survivor instead of 25 per view.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-constexpr int kSurvCap = 24;
+constexpr int kSurvCap = 32;
 
 template <int K>
 __device__ __forceinline__ void up_insert(float (&ub)[K], float v) {  // ub ascending; keeps the K smallest
@@ -227,7 +227,8 @@ __device__ __forceinline__ void filtered_probe(const float4* __restrict__ crec, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) key_insert(key[j]);
   }
-  // views left pending: their whole 5x5 window from the records, one row (5 loads) in flight
+  // views left pending: their whole 5x5 window from the records, in two batches of independent loads (15 + 10).  Every
+  // wave of the launch is resident at once, so the kernel ends with its slowest wave: this tail has to be short.
   while (__any(pend != 0)) {
     if (pend != 0) {
       const int vi = __ffs((int)pend) - 1;
@@ -235,16 +236,19 @@ __device__ __forceinline__ void filtered_probe(const float4* __restrict__ crec, 
       int uc, vc;
       float zc;
       if (project_point(vp[vi], qx, qy, qz, uc, vc, zc)) {
-        for (int a = 0; a < 5; ++a) {
-          const int vv = vc - 2 + a;
-          unsigned long long key[5];
 #pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            const int uu = uc - 2 + c;
-            key[c] = (vv >= 0 && vv < h && uu >= 0 && uu < w) ? exact_key(vi * hw + vv * w + uu) : ~0ull;
+        for (int half = 0; half < 2; ++half) {
+          constexpr int kRows[2] = {3, 2};
+          unsigned long long key[15];
+#pragma unroll
+          for (int e = 0; e < 15; ++e) {
+            const int a = half * 3 + e / 5, c = e % 5;
+            const int vv = vc - 2 + a, uu = uc - 2 + c;
+            key[e] = (e < kRows[half] * 5 && vv >= 0 && vv < h && uu >= 0 && uu < w) ? exact_key(vi * hw + vv * w + uu) : ~0ull;
           }
 #pragma unroll
-          for (int c = 0; c < 5; ++c) key_insert(key[c]);
+          for (int e = 0; e < 15; ++e)
+            if (e < kRows[half] * 5) key_insert(key[e]);
         }
       }
     }

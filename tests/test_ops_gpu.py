@@ -336,6 +336,45 @@ def test_pixel_knn_projective_adversarial(dev, k):
     assert torch.equal(i1, i2)
 
 
+@pytest.mark.parametrize('k', [1, 3, 5, 8])
+@pytest.mark.parametrize('offset', [0.0, 700.0])
+def test_fused_lift_adversarial(dev, k, offset):
+    """mvp_lift_f32's depth-plane filter on inputs it is NOT tuned for: half the pixels invalid, a far plane beyond the
+    16.38 m range of the plane (saturated entries), depths of a few centimetres, depth edges, scene translated 700 m from
+    the origin (fp32 world coordinates lose 60 um), queries uniform in a huge box / behind cameras / at the camera
+    centres / exactly on pixels (ties) / 20 m away, one view with a skewed K (full scan).  Must equal the oracle's
+    exhaustive scan bit for bit."""
+    from mvpnet_amd.ops import lift
+    from mvpnet_amd.synthetic import make_batch
+    B, nv, h, w = 3, 3, 48, 64
+    bt = make_batch(400 + k, B, nb_pts=16, nv=nv, h=h, w=w, with_feature=False)
+    rs = np.random.RandomState(17 * k + int(offset))
+    depth = bt['depth_mm'].astype(np.float32) / np.float32(1000.)
+    depth[rs.rand(*depth.shape) < 0.5] = 0.0                                   # holes
+    far = rs.rand(*depth.shape) < 0.08
+    depth[far] = rs.uniform(16.0, 40.0, int(far.sum())).astype(np.float32)      # around / beyond the plane's range
+    near = rs.rand(*depth.shape) < 0.03
+    depth[near] = rs.uniform(0.02, 0.2, int(near.sum())).astype(np.float32)     # almost at the camera
+    depth[:, :, 20:24, :] += np.float32(0.7)                                    # depth edge
+    pose = bt['pose'].copy()
+    pose[..., :3, 3] += np.float32(offset)
+    exyz, emask = O().unproject(depth, bt['kinv'], pose, None)
+    pts = (rs.uniform(-2.0, 4.0, (B, 3000, 3)) + offset).astype(np.float32)
+    pts[:, :300] = bt['points'][:, rs.randint(0, 16, 300)] + np.float32(offset) + rs.normal(0, 0.02, (B, 300, 3)).astype(np.float32)
+    pts[:, 300:303] = pose[:, :, :3, 3]                                         # exactly at the camera centres
+    flat = exyz.reshape(B, -1, 3)
+    pts[:, 303:703] = flat[:, ::23][:, :400]                                    # exactly on pixels (valid and invalid ones)
+    pts[:, 703:800] = flat[:, 5::91][:, :97] + rs.normal(0, 0.3, (B, 97, 3)).astype(np.float32)
+    pts[:, 800:900] += np.float32(20.0)                                         # 20 m away from everything
+    cam = np.repeat(bt['cam_matrix'][None, None, :3, :3], nv, 1).repeat(B, 0).copy()
+    cam[1, 2, 0, 1] = 0.3                                                       # skewed K in one view
+    _, gx, knn = lift(torch.zeros(B, nv, h, w, 4, device=dev), g(depth, dev), g(bt['kinv'], dev), g(cam, dev), g(pose, dev), g(pts, dev), k=k)[:3]
+    eknn = O().pixel_knn(exyz, emask, pts, k)
+    np.testing.assert_array_equal(knn.cpu().numpy(), eknn)
+    sel = eknn >= 0
+    np.testing.assert_array_equal(gx.cpu().numpy()[sel], flat[np.nonzero(sel)[0], eknn[sel]])
+
+
 def test_lift_gather_vs_oracle(dev):
     from mvpnet_amd.ops import lift_gather
     rs = np.random.RandomState(4)
