@@ -166,6 +166,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train-only', action='store_true', help='skip the extra forward-only (configs[1]) measurement (profiling runs)')
     ap.add_argument('--host-profile', action='store_true', help='cProfile the timed loop (host/launch cost), top entries to stderr')
     ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
                                               'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml kept in tests/golden/configs.json')
@@ -265,14 +266,14 @@ def main():
     # configs[1] (forward only, eval mode) on the same resident batch: reported as an extra field
     model.eval()
     with torch.no_grad():
-        for _ in range(2):
+        for _ in range(0 if args.train_only else 2):
             model(dict(batch))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(0 if args.train_only else 10):
             model(dict(batch))
         torch.cuda.synchronize()
-        fwd_ms = (time.perf_counter() - t1) / 10 * 1e3
+        fwd_ms = (time.perf_counter() - t1) / 10 * 1e3 if not args.train_only else float('nan')
     model.train()
 
     if rank == 0:
