@@ -192,21 +192,23 @@ int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, co
  *           out (G,C) = max_k act(((y-mean)*invstd)*gamma+beta), arg (G,C) uint8 = first arg-max (K > 1 only).
  *           stat: 2*C float64 scratch.
  * backward: dsrc = d out (G,C) [K > 1] or d act (G*K,C) [K == 1] -> dy (G*K,C); on return
- *           stat[0:C] = d beta, stat[C:2C] = d gamma (float64).  training == 0: statistics were constants
- *           (eval mode), the batch terms are dropped. */
+ *           stat[0:C] = d beta, stat[C:2C] = d gamma (float64), also written as float32 to dgamma / dbeta when those
+ *           are not NULL.  training == 0: statistics were constants (eval mode), the batch terms are dropped. */
 int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
                             int training, float eps, float momentum, int relu, float* running_mean, float* running_var,
                             double* stat, float* mean, float* invstd, float* out, uint8_t* arg, mvp_stream_t stream);
 int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
-                             int relu, int training, double* stat, float* dy, mvp_stream_t stream);
+                             int relu, int training, double* stat, float* dy, float* dgamma, float* dbeta,
+                             mvp_stream_t stream);
 /* second half of the BatchNorm backward with known column sums stat = [sum dz | sum dz*xhat] (from mvp_mlp_input_grad_f32) */
 int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, int64_t R, int64_t C, int training,
-                                    const double* stat, float* dy, mvp_stream_t stream);
-/* mean / invstd (+ running statistics update, may be NULL) from column sums stat = [sum y | sum y^2] over R rows */
+                                    const double* stat, float* dy, float* dgamma, float* dbeta, mvp_stream_t stream);
+/* mean / invstd (+ running statistics update and num_batches_tracked += 1, each may be NULL) from column sums
+ * stat = [sum y | sum y^2] over R rows */
 int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean, float* invstd,
-                        float* running_mean, float* running_var, mvp_stream_t stream);
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
 /* Shared-MLP layer on rows with fp32 MFMA (mlp.hip): Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias).
  * act = identity when act_mean == NULL, else relu(((x-mean)*invstd)*gamma+beta) per input column: the previous
  * layer's BatchNorm + ReLU fused into the load (common/nn/modules/conv.py:41-51), so that activation is never stored.
@@ -217,9 +219,9 @@ int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, con
 /* `partial` (both entry points below and above): optional scratch of ceil(R/128) * 2 * (output columns) float64; when
  * given, the statistics are reduced without atomics (recommended for R >~ 1e5), otherwise with fp64 atomics. */
 /* d(input) with the previous layer's ReLU mask and BatchNorm-backward column sums fused into the epilogue:
- * dZ (R,Cin) = (dY (R,Cout) . W) * [bn(y_prev) > 0], Wt = W^T (Cin,Cout) contiguous; stat (2*Cin float64) = [sum dZ | sum dZ*xhat].
+ * dZ (R,Cin) = (dY (R,Cout) . W) * [bn(y_prev) > 0], W (Cout,Cin) as the forward uses it; stat (2*Cin float64) = [sum dZ | sum dZ*xhat].
  * y_prev == NULL: plain dX = dY . W. */
-int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* Wt, int64_t Cin, const float* y_prev,
+int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ,
                            double* stat, double* partial, mvp_stream_t stream);
 /* dW (Cout,Cin) = dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue; dW is zero-filled here. */

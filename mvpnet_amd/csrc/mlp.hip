@@ -48,9 +48,12 @@ struct EpiBwd {
   const float* beta;
 };
 
-template <int BN>
+// WT = false: W is (Cout, ldw) row-major, element (output column co, k) at W[co * ldw + k]   (forward: the conv weight)
+// WT = true : W is (Cin, ldw)  row-major, element (output column co, k) at W[k * ldw + co]   (input gradient: the SAME
+//             conv weight read across, so no transposed copy of it is ever made)
+template <int BN, bool WT = false>
 __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
-                                                      const float* __restrict__ W /* (Cout, ldw) */, int ldw, int Cout,
+                                                      const float* __restrict__ W, int ldw, int Cout,
                                                       InAct act, const float* __restrict__ bias, EpiBwd epi,
                                                       float* __restrict__ Y /* (R, Cout) */, double* __restrict__ stat,
                                                       double* __restrict__ partial) {
@@ -94,20 +97,41 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
         }
       }
     }
+    if constexpr (!WT) {
 #pragma unroll
-    for (int p = 0; p < BN / 32; ++p) {
-      const int co = col0 + rr + p * 32;
+      for (int p = 0; p < BN / 32; ++p) {
+        const int co = col0 + rr + p * 32;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[p][i] = 0.f;
-      if (co < Cout) {
-        const float* src = W + (size_t)co * ldw + k0 + kq;
-        if (w_vec && k0 + kq + 4 <= Cin) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
-          rb[p][0] = q.x; rb[p][1] = q.y; rb[p][2] = q.z; rb[p][3] = q.w;
-        } else {
+        for (int i = 0; i < 4; ++i) rb[p][i] = 0.f;
+        if (co < Cout) {
+          const float* src = W + (size_t)co * ldw + k0 + kq;
+          if (w_vec && k0 + kq + 4 <= Cin) {
+            const float4 q = *reinterpret_cast<const float4*>(src);
+            rb[p][0] = q.x; rb[p][1] = q.y; rb[p][2] = q.z; rb[p][3] = q.w;
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (k0 + kq + i < Cin) rb[p][i] = src[i];
+            for (int i = 0; i < 4; ++i)
+              if (k0 + kq + i < Cin) rb[p][i] = src[i];
+          }
+        }
+      }
+    } else {  // lane = one k of the slab, 4 consecutive output columns per lane (contiguous in the source row)
+      const int k = k0 + (tid & 31);
+#pragma unroll
+      for (int p = 0; p < BN / 32; ++p) {
+        const int co = col0 + p * 32 + (tid >> 5) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[p][i] = 0.f;
+        if (k < Cin && co < Cout) {
+          const float* src = W + (size_t)k * ldw + co;
+          if (w_vec && co + 4 <= Cout) {
+            const float4 q = *reinterpret_cast<const float4*>(src);
+            rb[p][0] = q.x; rb[p][1] = q.y; rb[p][2] = q.z; rb[p][3] = q.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (co + i < Cout) rb[p][i] = src[i];
+          }
         }
       }
     }
@@ -141,7 +165,12 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int p = 0; p < BN / 32; ++p)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) Bs[(rr + p * 32) * kLd + kq + i] = rb[p][i];
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (!WT)
+          Bs[(rr + p * 32) * kLd + kq + i] = rb[p][i];
+        else
+          Bs[(p * 32 + (tid >> 5) * 4 + i) * kLd + (tid & 31)] = rb[p][i];
+      }
   };
 
   load_slab(0);
@@ -417,14 +446,14 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
 }
 
 // d(input) of a layer, fused with the first half of the previous layer's BatchNorm+ReLU backward:
-//   dZ (R,Cin) = (dY (R,Cout) . Wt^T) * [ bn(y_prev) > 0 ],   Wt (Cin,Cout) = W^T contiguous
+//   dZ (R,Cin) = (dY (R,Cout) . W) * [ bn(y_prev) > 0 ],   W (Cout,Cin) = the layer's weight exactly as the forward uses it
 //   stat[0:Cin] = column sums of dZ (= d beta), stat[Cin:2Cin] = column sums of dZ * xhat (= d gamma)
 // y_prev == NULL: plain dX = dY . W (no masking, no statistics).
-MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* Wt, int64_t Cin,
+MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin,
                                    const float* y_prev, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, float* dZ, double* stat, double* partial, mvp_stream_t stream) {
   MVP_NONNULL(dY);
-  MVP_NONNULL(Wt);
+  MVP_NONNULL(W);
   MVP_NONNULL(dZ);
   MVP_REQUIRE(R >= 0 && Cin > 0 && Cout > 0 && Cin < (1 << 20) && Cout < (1 << 20));
   if (y_prev) {
@@ -444,16 +473,16 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
   EpiBwd epi{y_prev, mean, invstd, gamma, beta};
   double* st = y_prev ? stat : nullptr;
   const unsigned gx = (unsigned)cdiv(R, kBM);
-  // roles: X = dY (R, Cout as the K dimension), W = Wt (Cin rows of length Cout), output columns = Cin
+  // roles: X = dY (R, Cout as the K dimension), W read across (WT), output columns = Cin
   if (Cin <= 32) {
-    hipLaunchKernelGGL(mlp_fwd_kernel<32>, dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, Wt, (int)Cout, (int)Cin, act,
+    hipLaunchKernelGGL((mlp_fwd_kernel<32, true>), dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, W, (int)Cin, (int)Cin, act,
                        nullptr, epi, dZ, st, st ? partial : nullptr);
   } else if (Cin <= 64) {
-    hipLaunchKernelGGL(mlp_fwd_kernel<64>, dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, Wt, (int)Cout, (int)Cin, act,
+    hipLaunchKernelGGL((mlp_fwd_kernel<64, true>), dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, W, (int)Cin, (int)Cin, act,
                        nullptr, epi, dZ, st, st ? partial : nullptr);
   } else {
-    hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(gx, (unsigned)cdiv(Cin, 128)), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, Wt,
-                       (int)Cout, (int)Cin, act, nullptr, epi, dZ, st, st ? partial : nullptr);
+    hipLaunchKernelGGL((mlp_fwd_kernel<128, true>), dim3(gx, (unsigned)cdiv(Cin, 128)), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, W,
+                       (int)Cin, (int)Cin, act, nullptr, epi, dZ, st, st ? partial : nullptr);
   }
   if (st && partial)
     hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)std::min<int64_t>(128, cdiv(gx, 16))), dim3(256), 0, s, partial, (int64_t)gx,

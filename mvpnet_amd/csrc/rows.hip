@@ -284,9 +284,11 @@ __global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C
 // torch.nn.BatchNorm semantics, common/nn/modules/conv.py:18,43 with momentum 0.1, eps 1e-5)
 __global__ void bn_finalize_kernel(const double* __restrict__ stat, int64_t R, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   int64_t* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   const double m = stat[c] / (double)R;
   double var = stat[C + c] / (double)R - m * m;
   if (var < 0.0) var = 0.0;
@@ -341,8 +343,14 @@ __global__ __launch_bounds__(kRT) void bn_act_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const double* __restrict__ stat, int64_t G, int K, int C,
-                                                         int batch_terms, float* __restrict__ dy) {
+                                                         int batch_terms, float* __restrict__ dy,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int C4 = C >> 2;
+  if (blockIdx.x == 0 && dgamma)  // the parameter gradients are the two column sums themselves
+    for (int j = threadIdx.x; j < C; j += kRT) {
+      dbeta[j] = (float)stat[j];
+      dgamma[j] = (float)stat[C + j];
+    }
   const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
   const int64_t r = t / C4;  // row in [0, G*K)
   const int c = (int)(t - r * C4) * 4;
@@ -482,7 +490,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
     rc = launch_colstats(Plain{y}, R, C, stat, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, stat, R, (int)C, eps, momentum,
-                       mean, invstd, running_mean, running_var);
+                       mean, invstd, running_mean, running_var, static_cast<int64_t*>(nullptr));
   }  // eval: the caller passes mean = running_mean and invstd = 1/sqrt(running_var + eps)
   if (R == 0) return mvp_launch_status();
   dim3 grid((unsigned)cdiv(G * (C / 4), kRT));
@@ -496,7 +504,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
 MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y,
                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                                      int64_t G, int64_t K, int64_t C, int relu, int training, double* stat, float* dy,
-                                     mvp_stream_t stream) {
+                                     float* dgamma, float* dbeta, mvp_stream_t stream) {
   MVP_NONNULL(dsrc);
   MVP_NONNULL(y);
   MVP_NONNULL(mean);
@@ -505,6 +513,7 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   MVP_NONNULL(beta);
   MVP_NONNULL(stat);
   MVP_NONNULL(dy);
+  if (dgamma) MVP_NONNULL(dbeta);
   MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);
   if (K > 1) {
     MVP_NONNULL(out);
@@ -522,21 +531,22 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
   if (relu)
     hipLaunchKernelGGL(bn_act_bwd_kernel<true>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
-                       G, (int)K, (int)C, training, dy);
+                       G, (int)K, (int)C, training, dy, dgamma, dbeta);
   else
     hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
-                       G, (int)K, (int)C, training, dy);
+                       G, (int)K, (int)C, training, dy, dgamma, dbeta);
   return mvp_launch_status();
 }
 
 MVP_API int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean,
-                                float* invstd, float* running_mean, float* running_var, mvp_stream_t stream) {
+                                float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                mvp_stream_t stream) {
   MVP_NONNULL(stat);
   MVP_NONNULL(mean);
   MVP_NONNULL(invstd);
   MVP_REQUIRE(R > 0 && C > 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stat, R,
-                     (int)C, eps, momentum, mean, invstd, running_mean, running_var);
+                     (int)C, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
   return mvp_launch_status();
 }
 
@@ -544,7 +554,8 @@ MVP_API int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float 
 // epilogue of mvp_mlp_input_grad_f32): dy = gamma*invstd * (dz - stat[c]/R - xhat * stat[C+c]/R).
 MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd,
                                             const float* gamma, const float* beta, int64_t R, int64_t C, int training,
-                                            const double* stat, float* dy, mvp_stream_t stream) {
+                                            const double* stat, float* dy, float* dgamma, float* dbeta,
+                                            mvp_stream_t stream) {
   MVP_NONNULL(dz);
   MVP_NONNULL(y);
   MVP_NONNULL(mean);
@@ -557,7 +568,7 @@ MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, con
   if (rc || R == 0) return rc;
   dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
   hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), dz, nullptr, nullptr, y, mean,
-                     invstd, gamma, beta, stat, R, 1, (int)C, training, dy);
+                     invstd, gamma, beta, stat, R, 1, (int)C, training, dy, dgamma, dbeta);
   return mvp_launch_status();
 }
 

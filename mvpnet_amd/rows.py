@@ -178,10 +178,10 @@ class BNActRows(torch.autograd.Function):
             return dz * scale, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None, None
         stat = torch.empty(2 * C, dtype=torch.float64, device=y.device)
         dy = torch.empty_like(y)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
         L.call('mvp_bn_rows_backward_f32', y, L.ptr(g), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
-               L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), 1, L.ptr(stat), L.ptr(dy))
-        dbeta, dgamma = stat[:C].float(), stat[C:].float()
-        return dy, dgamma, dbeta, None, None, None, None, None, None, None
+               L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), 1, L.ptr(stat), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]))
+        return dy, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 def bn_act_rows(y, bn, relu=True, K=1):
@@ -208,9 +208,10 @@ def _bn_backward(dsrc, out, arg, y, mean, invstd, gamma, beta, G, K, C, relu, tr
     """-> dy (G*K,C), dgamma (C), dbeta (C) through mvp_bn_rows_backward_f32."""
     stat = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     dy = torch.empty_like(y)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
     L.call('mvp_bn_rows_backward_f32', y, L.ptr(dsrc), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
-           L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), int(training), L.ptr(stat), L.ptr(dy))
-    return dy, stat[C:].float(), stat[:C].float()
+           L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), int(training), L.ptr(stat), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]))
+    return dy, dgb[0], dgb[1]
 
 
 def _bn_apply(y, mean, invstd, gamma, beta, G, K, C, relu):
@@ -230,7 +231,7 @@ class MLPChainRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, training, K, eps_mom, bn_buffers, *params):
-        # params = (W_1, gamma_1, beta_1, ..., W_L, gamma_L, beta_L); bn_buffers = [(running_mean, running_var)] * L
+        # params = (W_1, gamma_1, beta_1, ..., W_L, gamma_L, beta_L); bn_buffers = [(running_mean, running_var, num_batches_tracked or None)] * L
         nl = len(params) // 3
         R = x0.size(0)
         dev = x0.device
@@ -253,12 +254,12 @@ class MLPChainRows(torch.autograd.Function):
                 stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
                 L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
                        L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None))
-            rm, rv = bn_buffers[i]
+            rm, rv, nbt = bn_buffers[i]
             if training:
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
                 invstd = torch.empty(cout, dtype=torch.float32, device=dev)
                 L.call('mvp_bn_finalize_f32', y, L.ptr(stat), R, cout, float(eps), float(mom), L.ptr(mean), L.ptr(invstd),
-                       L.ptr(rm), L.ptr(rv))
+                       L.ptr(rm), L.ptr(rv), L.ptr(nbt))
             else:
                 mean, invstd = rm, torch.rsqrt(rv + eps)
             ys.append(y)
@@ -309,20 +310,20 @@ class MLPChainRows(torch.autograd.Function):
                    L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw))
             grads[3 * i] = dw
             if i > 0 or ctx.needs_input_grad[0]:
-                wt = w.t().contiguous()  # (cin, cout)
                 dz = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
                 if i > 0:
                     # d(input) = dy . W with the previous layer's ReLU mask and BN-backward column sums in the epilogue
                     stat = torch.empty(2 * cin, dtype=torch.float64, device=dy.device)
                     pm, pi, pg, pb = means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1]
-                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(wt), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
+                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(w), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
                            L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat), L.ptr(_partial(R, cin, dy.device)))
                     dy_prev = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
+                    dgb = torch.empty((2, cin), dtype=torch.float32, device=dy.device)
                     L.call('mvp_bn_rows_backward_finish_f32', dz, L.ptr(dz), L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb),
-                           R, cin, int(training), L.ptr(stat), L.ptr(dy_prev))
-                    dy, dgam, dbet = dy_prev, stat[cin:].float(), stat[:cin].float()
+                           R, cin, int(training), L.ptr(stat), L.ptr(dy_prev), L.ptr(dgb[0]), L.ptr(dgb[1]))
+                    dy, dgam, dbet = dy_prev, dgb[0], dgb[1]
                 else:
-                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(dz), None, None)
+                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(dz), None, None)
                     dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
         return (dx0, None, None, None, None) + tuple(grads)
 
@@ -351,8 +352,7 @@ class LinearRows(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            wt = w.t().contiguous()
-            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(wt), cin, None, None, None, None, None, L.ptr(gx), None, None)
+            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, cin, cin, None, None, None, None, L.ptr(gw))
@@ -383,10 +383,8 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
         for li, layer in enumerate(mlp):
             w = None if (first_done and li == 0) else layer.conv.weight.reshape(layer.conv.weight.size(0), -1)
             params += [w, layer.bn.weight, layer.bn.bias]
-            buffers.append((layer.bn.running_mean, layer.bn.running_var))
+            buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
-            if bn_training and layer.bn.num_batches_tracked is not None:
-                layer.bn.num_batches_tracked.add_(1)
         return MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, *params)
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     for i, layer in enumerate(mlp):

@@ -619,14 +619,13 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
         np.testing.assert_allclose(dw.cpu().numpy(), refw.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(refw.abs().max())))
     # input gradient, plain and with the fused ReLU-mask / BN-backward sums epilogue
     dy = torch.randn(R, Cout, device=dev)
-    wt = w.t().contiguous()
     dz = torch.empty(R, Cin, device=dev)
-    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(wt), Cin, None, None, None, None, None, L.ptr(dz), None, None)
+    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(w), Cin, None, None, None, None, None, L.ptr(dz), None, None)
     refx = dy.to(hi) @ w.to(hi)
     np.testing.assert_allclose(dz.cpu().numpy(), refx.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(refx.abs().max())))
     yprev = torch.randn(R, Cin, device=dev)
     stat = torch.empty(2 * Cin, dtype=torch.float64, device=dev)
-    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(wt), Cin, L.ptr(yprev), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(w), Cin, L.ptr(yprev), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
            L.ptr(beta), L.ptr(dz), L.ptr(stat), L.ptr(torch.empty(((R + 127) // 128) * 2 * Cin, dtype=torch.float64, device=dev)))
     xh = (yprev - mean) * invstd
     on = (xh * gamma + beta) > 0

@@ -31,10 +31,10 @@ for name, G, K, C in SHAPES:
     t_f = timeit(lambda: L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1e-5, 0.1, 1, None, None,
                                 L.ptr(stat), L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg)))
     t_b = timeit(lambda: L.call('mvp_bn_rows_backward_f32', y, L.ptr(dsrc), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
-                                L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1, L.ptr(stat), L.ptr(dy)))
+                                L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1, L.ptr(stat), L.ptr(dy), None, None))
     dz = torch.randn(R, C, device=dev)
     t_bf = timeit(lambda: L.call('mvp_bn_rows_backward_finish_f32', y, L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                                 L.ptr(beta), R, C, 1, L.ptr(stat), L.ptr(dy)))
+                                 L.ptr(beta), R, C, 1, L.ptr(stat), L.ptr(dy), None, None))
     nb = R * C * 4
     gb = lambda byts, us: byts / us * 1e-3
     # minimal traffic: colstats reads y; fwd reads y twice (statistics, then apply) and writes out; bwd reads y (+dsrc) twice, writes dy
