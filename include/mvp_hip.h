@@ -179,7 +179,7 @@ int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* index, int
  * receives the (B,M,K,4) rows [dx,dy,dz,0] (operand of the W1_xyz weight gradient). */
 int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
                            int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, mvp_stream_t stream);
-/* column sums of y and y^2 over the R rows of y (R,C) -> stat (2*C float64, zero-filled here) */
+/* stat (2*C float64) += column sums of y and y^2 over the R rows of y (R,C); accumulated: the caller provides zeros */
 int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream);
 int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,
                         int64_t N2, int64_t ld, float* out, mvp_stream_t stream);
@@ -212,7 +212,9 @@ int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, flo
 /* Shared-MLP layer on rows with fp32 MFMA (mlp.hip): Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias).
  * act = identity when act_mean == NULL, else relu(((x-mean)*invstd)*gamma+beta) per input column: the previous
  * layer's BatchNorm + ReLU fused into the load (common/nn/modules/conv.py:41-51), so that activation is never stored.
- * stat != NULL: 2*Cout float64, receives the column sums of y and y^2 (this layer's batch statistics). */
+ * stat != NULL: 2*Cout float64, the column sums of y and y^2 (this layer's batch statistics) are ADDED to it -- in all
+ * three entry points `stat` and `dW` are accumulated into, so the caller provides zeros (one zeroed arena for a whole
+ * layer chain instead of a memset per call) or a running sum (gradient accumulation). */
 int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
                         const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                         const float* bias, float* Y, double* stat, double* partial, mvp_stream_t stream);
@@ -224,7 +226,7 @@ int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, con
 int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ,
                            double* stat, double* partial, mvp_stream_t stream);
-/* dW (Cout,Cin) = dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue; dW is zero-filled here. */
+/* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                             const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                             float* dW, mvp_stream_t stream);

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
 
 }  // namespace
 
-// Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias); stat (2*Cout float64, zeroed here) =
+// Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias); stat (2*Cout float64, accumulated into) +=
 // column sums of y and y^2 when non-NULL.  act_* all NULL = identity, else the previous BatchNorm + ReLU.
 MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw,
                                 int64_t Cout, const float* act_mean, const float* act_invstd, const float* act_gamma,
@@ -394,11 +394,7 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
     MVP_NONNULL(act_beta);
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (stat) {
-    hipError_t e = hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)Cout, s);
-    if (e != hipSuccess) return (int)e;
-  }
-  if (R == 0) return MVP_OK;
+  if (R == 0) return MVP_OK;  // stat / dW style outputs are ACCUMULATED into: the caller provides zeros
   InAct act{act_mean, act_invstd, act_gamma, act_beta};
   const unsigned gx = (unsigned)cdiv(R, kBM);
   if (Cout <= 32) {
@@ -417,7 +413,7 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
   return mvp_launch_status();
 }
 
-// dW (Cout,Cin) = dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]); dW is zero-filled here.  act as in mvp_mlp_forward_f32.
+// dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin])  (accumulated into dW: gradient-accumulation semantics).  act as in mvp_mlp_forward_f32.
 MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                                     const float* act_mean, const float* act_invstd, const float* act_gamma,
                                     const float* act_beta, float* dW, mvp_stream_t stream) {
@@ -431,8 +427,6 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
     MVP_NONNULL(act_beta);
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)(Cout * Cin), s);
-  if (e != hipSuccess) return (int)e;
   if (R == 0) return MVP_OK;
   const int64_t tiles = cdiv(Cout, kDT) * cdiv(Cin, kDT);
   int64_t splits = cdiv(1024, tiles);                  // ~4 workgroups per CU in total
@@ -464,10 +458,6 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
     MVP_NONNULL(stat);
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (y_prev) {
-    hipError_t e = hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)Cin, s);
-    if (e != hipSuccess) return (int)e;
-  }
   if (R == 0) return MVP_OK;
   InAct act{nullptr, nullptr, nullptr, nullptr};
   EpiBwd epi{y_prev, mean, invstd, gamma, beta};

@@ -394,8 +394,6 @@ int check_rows(int64_t R, int64_t C) {
 
 template <typename Src>
 int launch_colstats(Src src, int64_t R, int64_t C, double* stat, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s);
-  if (e != hipSuccess) return (int)e;
   if (R == 0) return MVP_OK;
   // one workgroup per ~512 KB of rows, between 16 and 256 of them
   const int64_t blocks = std::min<int64_t>(256, std::max<int64_t>(16, cdiv(R * C * 4, 512 * 1024)));
@@ -487,6 +485,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
   const int64_t R = G * K;
   if (training) {
     MVP_NONNULL(stat);
+    if (hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
     rc = launch_colstats(Plain{y}, R, C, stat, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, stat, R, (int)C, eps, momentum,
@@ -523,6 +522,7 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t R = G * K;
+  if (hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
   if (K == 1)
     rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, s);
   else
@@ -588,7 +588,7 @@ MVP_API int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const floa
   return mvp_launch_status();
 }
 
-// column sums of y and y*y over R rows -> stat (2*C float64, zero-filled here)
+// stat (2*C float64, accumulated into) += column sums of y and y*y over R rows
 MVP_API int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream) {
   MVP_NONNULL(y);
   MVP_NONNULL(stat);

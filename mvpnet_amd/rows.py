@@ -87,7 +87,7 @@ class GroupLinRows(torch.autograd.Function):
             gz = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
             L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
         if diff is not None and ctx.needs_input_grad[3]:
-            gw4 = torch.empty((C, 4), dtype=torch.float32, device=g.device)
+            gw4 = torch.zeros((C, 4), dtype=torch.float32, device=g.device)  # accumulated into
             L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4))
             gw = gw4[:, :3].contiguous()
         return gz, None, None, gw, None
@@ -238,20 +238,24 @@ class MLPChainRows(torch.autograd.Function):
         ys, means, invstds = [], [], []
         act = (None, None, None, None)
         x = x0
+        couts = [x0.size(1) if params[3 * i] is None else params[3 * i].size(0) for i in range(nl)]
+        # the kernels ADD their column sums to `stat`: one zeroed arena for the whole chain instead of a memset per layer
+        arena = torch.zeros(2 * sum(couts), dtype=torch.float64, device=dev) if training else None
+        off = 0
         for i in range(nl):
             w, gamma, beta = params[3 * i], params[3 * i + 1], params[3 * i + 2]
             eps, mom = eps_mom[i]
+            stat = arena[off:off + 2 * couts[i]] if training else None
+            off += 2 * couts[i]
             if w is None:  # x0 already IS this layer's pre-BN output (the linear part ran before the grouping)
                 assert i == 0
                 cout = x0.size(1)
                 y = x0
-                stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
                 if training:
                     L.call('mvp_colstats_f32', y, L.ptr(y), R, cout, L.ptr(stat))
             else:
                 cout, cin = w.size(0), w.size(1)
                 y = torch.empty((R, cout), dtype=torch.float32, device=dev)
-                stat = torch.empty(2 * cout, dtype=torch.float64, device=dev) if training else None
                 L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
                        L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None))
             rm, rv, nbt = bn_buffers[i]
@@ -295,6 +299,11 @@ class MLPChainRows(torch.autograd.Function):
         dy, dgam, dbet = _bn_backward(g, out, arg, ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, training)
         dx0 = None
         none4 = (None, None, None, None)
+        # `dW` and `stat` are accumulated into by the kernels: two zeroed arenas for the whole chain
+        w_numel = [0 if params[3 * i] is None else params[3 * i].numel() for i in range(nl)]
+        dw_arena = torch.zeros(sum(w_numel), dtype=torch.float32, device=g.device)
+        st_arena = torch.zeros(2 * sum(params[3 * i].size(1) for i in range(1, nl)), dtype=torch.float64, device=g.device)
+        dw_off, st_off = 0, 0
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
             grads[3 * i + 1], grads[3 * i + 2] = dgam, dbet
@@ -305,7 +314,8 @@ class MLPChainRows(torch.autograd.Function):
             # layer input = x0 (first layer) or relu(bn(y_{i-1})) re-created inside the kernels from y_{i-1}
             src = x0 if i == 0 else ys[i - 1]
             act = none4 if i == 0 else (means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1])
-            dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
+            dw = dw_arena[dw_off:dw_off + cout * cin].view(cout, cin)
+            dw_off += cout * cin
             L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
                    L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw))
             grads[3 * i] = dw
@@ -313,7 +323,8 @@ class MLPChainRows(torch.autograd.Function):
                 dz = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
                 if i > 0:
                     # d(input) = dy . W with the previous layer's ReLU mask and BN-backward column sums in the epilogue
-                    stat = torch.empty(2 * cin, dtype=torch.float64, device=dy.device)
+                    stat = st_arena[st_off:st_off + 2 * cin]
+                    st_off += 2 * cin
                     pm, pi, pg, pb = means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1]
                     L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(w), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
                            L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat), L.ptr(_partial(R, cin, dy.device)))
@@ -354,7 +365,7 @@ class LinearRows(torch.autograd.Function):
             gx = torch.empty_like(x)
             L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None)
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(w)
+            gw = torch.zeros_like(w)  # accumulated into
             L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, cin, cin, None, None, None, None, L.ptr(gw))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)

@@ -603,7 +603,7 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
             a = torch.relu(((a - mean.to(hi)) * invstd.to(hi)) * gamma.to(hi) + beta.to(hi))
         act = (mean, invstd, gamma, beta) if use_act else (None, None, None, None)
         y = torch.empty(R, Cout, device=dev)
-        stat = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+        stat = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)  # accumulated into
         L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, ldx, L.ptr(w), Cin, Cout, *[L.ptr(t) for t in act], L.ptr(bias), L.ptr(y), L.ptr(stat),
                L.ptr(torch.empty(((R + 127) // 128) * 2 * Cout, dtype=torch.float64, device=dev)) if use_act else None)
         ref = a @ w.to(hi).t() + bias.to(hi)
@@ -613,7 +613,7 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
         np.testing.assert_allclose(stat[Cout:].cpu().numpy(), (y.double() ** 2).sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
         # weight gradient with the same prologue
         dy = torch.randn(R, Cout, device=dev)
-        dw = torch.empty(Cout, Cin, device=dev)
+        dw = torch.zeros(Cout, Cin, device=dev)  # accumulated into
         L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, ldx, *[L.ptr(t) for t in act], L.ptr(dw))
         refw = dy.to(hi).t() @ a
         np.testing.assert_allclose(dw.cpu().numpy(), refw.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(refw.abs().max())))
@@ -624,7 +624,7 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
     refx = dy.to(hi) @ w.to(hi)
     np.testing.assert_allclose(dz.cpu().numpy(), refx.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(refx.abs().max())))
     yprev = torch.randn(R, Cin, device=dev)
-    stat = torch.empty(2 * Cin, dtype=torch.float64, device=dev)
+    stat = torch.zeros(2 * Cin, dtype=torch.float64, device=dev)
     L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(w), Cin, L.ptr(yprev), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
            L.ptr(beta), L.ptr(dz), L.ptr(stat), L.ptr(torch.empty(((R + 127) // 128) * 2 * Cin, dtype=torch.float64, device=dev)))
     xh = (yprev - mean) * invstd
