@@ -51,19 +51,38 @@ struct EpiBwd {
 // WT = false: W is (Cout, ldw) row-major, element (output column co, k) at W[co * ldw + k]   (forward: the conv weight)
 // WT = true : W is (Cin, ldw)  row-major, element (output column co, k) at W[k * ldw + co]   (input gradient: the SAME
 //             conv weight read across, so no transposed copy of it is ever made)
-template <int BN, bool WT = false>
+//
+// Data flow of one 128 x BN tile (256 threads, wave w owns rows 32 w .. 32 w + 31 and all BN columns):
+//   A (activations): global -> REGISTERS directly.  v_mfma_f32_32x32x2_f32 takes A[i = lane & 31][kk = lane >> 5]; which two
+//      k of the slab form a pair is free as long as A and B agree, so lane half h handles k = 8 t + 4 h + e (t, e = 0..3):
+//      each lane reads its row's slab as four 16-byte loads and the previous layer's BatchNorm + ReLU is applied in
+//      registers -- A never goes through LDS.
+//   B (weights, shared by the 4 waves): global -> registers -> LDS (row stride 36 words: 16-byte aligned and conflict-free
+//      for ds_read_b128 / ds_write_b128), double buffered: ONE barrier per K slab; fragments are read as b128
+//      (k = 8 t + 4 h .. + 3 of column j), 16 LDS reads per wave and slab instead of 80 scalar ones.
+//   The global loads of slab s + 1 (A, B) are issued before the 16 BN/32 MFMAs of slab s and consumed after them.
+constexpr int kMaxActCin = 512;    // input-activation parameters staged in LDS up to this many input channels
+
+// VEC: X and W rows are 16-byte aligned with lengths that are multiples of 4 (decided by the host; a run-time test in the
+// kernel makes the compiler issue both the scalar and the vector loads).
+template <int BN, int BK, bool WT, bool VEC>
 __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
                                                       const float* __restrict__ W, int ldw, int Cout,
                                                       InAct act, const float* __restrict__ bias, EpiBwd epi,
                                                       float* __restrict__ Y /* (R, Cout) */, double* __restrict__ stat,
                                                       double* __restrict__ partial) {
-  __shared__ float As[kBM * kLd];
-  __shared__ float Bs[BN * kLd];
-  __shared__ double sred[2][4][BN];
+  constexpr int kLdB = BK + 4;  // LDS row stride of the weight slab (words): 16-byte aligned rows, conflict-free b128 access
+  constexpr int NT = BK / 8;    // MFMA k-groups per slab (k = 8 t + 4 h + e)
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLdB];
+  __shared__ __attribute__((aligned(16))) float Ps[4][kMaxActCin];  // mean, invstd, gamma, beta of the input activation
+  // statistics scratch of the epilogue: aliases the weight slabs (dead after the last barrier of the K loop)
+  static_assert(sizeof(double) * 2 * 4 * BN <= sizeof(float) * 2 * BN * kLdB, "sred must fit in Bs");
+  double (*sred)[4][BN] = reinterpret_cast<double (*)[4][BN]>(&Bs[0][0]);
   constexpr int NB = BN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * kBM;
   const int col0 = blockIdx.y * BN;
+  const int li = lane & 31, lh = lane >> 5;
 
   f32x16 acc[NB];
 #pragma unroll
@@ -71,123 +90,183 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  // staging maps: 8 lanes cover one 32-float K slab of a row (float4 each) -> 32 rows per pass
-  const int kq = (tid & 7) * 4, rr = tid >> 3;
-  const bool x_vec = (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
-  const bool w_vec = (ldw % 4 == 0) && (((uintptr_t)W) % 16 == 0);
+  const bool has_act = act.mean != nullptr;
+  const bool act_lds = has_act && Cin <= kMaxActCin;
+  if (act_lds) {
+    for (int k = tid; k < min(kMaxActCin, (Cin + BK - 1) / BK * BK); k += kMT) {
+      const int kc = min(k, Cin - 1);
+      Ps[0][k] = act.mean[kc];
+      Ps[1][k] = act.invstd[kc];
+      Ps[2][k] = act.gamma[kc];
+      Ps[3][k] = act.beta[kc];
+    }
+  }
 
-  // Software pipeline: the global loads of slab s+1 are issued before the MFMA loop of slab s and are
-  // only consumed (activation applied, written to LDS) after it, so HBM/L2 latency hides under the MFMAs.
-  float ra[kBM / 32][4], rb[BN / 32][4];
-  auto load_slab = [&](int k0) {
+  // ---- A: this lane's row, 16 k-values of the slab in 4 x float4 ----
+  const int64_t arow = row0 + wave * 32 + li;
+  const bool arow_ok = arow < R;
+  const float* xrow = X + (size_t)(arow_ok ? arow : 0) * ldx;
+  // All loads are UNCONDITIONAL (addresses clamped into the tensor, masking happens when the values are consumed): a
+  // load inside a branch forces the compiler to wait for it at the join, i.e. before the MFMAs it is meant to overlap.
+  float4 an[NT];  // raw values of the NEXT slab
+  auto load_a = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < kBM / 32; ++p) {
-      const int64_t r = row0 + rr + p * 32;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ra[p][i] = 0.f;
-      if (r < R) {
-        const float* src = X + (size_t)r * ldx + k0 + kq;
-        if (x_vec && k0 + kq + 4 <= Cin) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
-          ra[p][0] = q.x; ra[p][1] = q.y; ra[p][2] = q.z; ra[p][3] = q.w;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (k0 + kq + i < Cin) ra[p][i] = src[i];
-        }
+    for (int t = 0; t < NT; ++t) {
+      const int k = k0 + 8 * t + 4 * lh;
+      if constexpr (VEC) {
+        an[t] = *reinterpret_cast<const float4*>(xrow + min(k, Cin - 4));
+      } else {
+        an[t].x = xrow[min(k + 0, Cin - 1)];
+        an[t].y = xrow[min(k + 1, Cin - 1)];
+        an[t].z = xrow[min(k + 2, Cin - 1)];
+        an[t].w = xrow[min(k + 3, Cin - 1)];
       }
     }
-    if constexpr (!WT) {
+  };
+  float ac[NT][4];  // activated values of the CURRENT slab
+  auto activate = [&](int k0) {
 #pragma unroll
-      for (int p = 0; p < BN / 32; ++p) {
-        const int co = col0 + rr + p * 32;
+    for (int t = 0; t < NT; ++t) {
+      const int k = k0 + 8 * t + 4 * lh;
+      float v[4] = {an[t].x, an[t].y, an[t].z, an[t].w};
+      if (has_act) {
+        float pm[4], pi[4], pg[4], pb[4];
+        if (act_lds) {
+          const float4 m4 = *reinterpret_cast<const float4*>(&Ps[0][k]), i4 = *reinterpret_cast<const float4*>(&Ps[1][k]);
+          const float4 g4 = *reinterpret_cast<const float4*>(&Ps[2][k]), b4 = *reinterpret_cast<const float4*>(&Ps[3][k]);
+          pm[0] = m4.x; pm[1] = m4.y; pm[2] = m4.z; pm[3] = m4.w;
+          pi[0] = i4.x; pi[1] = i4.y; pi[2] = i4.z; pi[3] = i4.w;
+          pg[0] = g4.x; pg[1] = g4.y; pg[2] = g4.z; pg[3] = g4.w;
+          pb[0] = b4.x; pb[1] = b4.y; pb[2] = b4.z; pb[3] = b4.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[p][i] = 0.f;
-        if (co < Cout) {
-          const float* src = W + (size_t)co * ldw + k0 + kq;
-          if (w_vec && k0 + kq + 4 <= Cin) {
-            const float4 q = *reinterpret_cast<const float4*>(src);
-            rb[p][0] = q.x; rb[p][1] = q.y; rb[p][2] = q.z; rb[p][3] = q.w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (k0 + kq + i < Cin) rb[p][i] = src[i];
+          for (int e = 0; e < 4; ++e) {
+            const int kc = min(k + e, Cin - 1);
+            pm[e] = act.mean[kc];
+            pi[e] = act.invstd[kc];
+            pg[e] = act.gamma[kc];
+            pb[e] = act.beta[kc];
           }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = ((v[e] - pm[e]) * pi[e]) * pg[e] + pb[e];
+          v[e] = a > 0.f ? a : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ac[t][e] = (arow_ok && k + e < Cin) ? v[e] : 0.f;
+    }
+  };
+
+  // ---- B: BN x 32 slab, 4096 * BN / 128 floats over 256 threads ----
+  constexpr int LPC = BK / 4;         // lanes that cover one column's K slab with one float4 each (contiguous in W: coalesced)
+  constexpr int CPP = kMT / LPC;      // columns per pass
+  constexpr int NV = BN / CPP;        // passes = float4 per thread
+  constexpr int KH = BK / 32;         // WT: 32-wide k groups per slab
+  float4 bn[WT ? NB * KH : NV];
+  auto load_b = [&](int k0) {
+    if constexpr (!WT) {
+      const int c = tid / LPC, k = k0 + (tid % LPC) * 4;
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const float* src = W + (size_t)min(col0 + u * CPP + c, Cout - 1) * ldw;
+        if constexpr (VEC) {
+          bn[u] = *reinterpret_cast<const float4*>(src + min(k, Cin - 4));
+        } else {
+          bn[u].x = src[min(k + 0, Cin - 1)];
+          bn[u].y = src[min(k + 1, Cin - 1)];
+          bn[u].z = src[min(k + 2, Cin - 1)];
+          bn[u].w = src[min(k + 3, Cin - 1)];
         }
       }
     } else {  // lane = one k of the slab, 4 consecutive output columns per lane (contiguous in the source row)
-      const int k = k0 + (tid & 31);
 #pragma unroll
-      for (int p = 0; p < BN / 32; ++p) {
-        const int co = col0 + p * 32 + (tid >> 5) * 4;
+      for (int g = 0; g < KH; ++g) {
+        const float* src = W + (size_t)min(k0 + 32 * g + (tid & 31), Cin - 1) * ldw;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[p][i] = 0.f;
-        if (k < Cin && co < Cout) {
-          const float* src = W + (size_t)k * ldw + co;
-          if (w_vec && co + 4 <= Cout) {
-            const float4 q = *reinterpret_cast<const float4*>(src);
-            rb[p][0] = q.x; rb[p][1] = q.y; rb[p][2] = q.z; rb[p][3] = q.w;
+        for (int p = 0; p < NB; ++p) {
+          const int co = col0 + p * 32 + (tid >> 5) * 4;
+          if constexpr (VEC) {
+            bn[g * NB + p] = *reinterpret_cast<const float4*>(src + min(co, Cout - 4));
           } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (co + i < Cout) rb[p][i] = src[i];
+            bn[g * NB + p].x = src[min(co + 0, Cout - 1)];
+            bn[g * NB + p].y = src[min(co + 1, Cout - 1)];
+            bn[g * NB + p].z = src[min(co + 2, Cout - 1)];
+            bn[g * NB + p].w = src[min(co + 3, Cout - 1)];
           }
         }
       }
     }
   };
-  auto store_slab = [&](int k0) {  // registers -> LDS, with the input activation applied to A
-    float pm[4] = {0.f, 0.f, 0.f, 0.f}, pi[4] = {0.f, 0.f, 0.f, 0.f}, pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (act.mean) {
+  auto store_b = [&](int buf, int k0) {  // registers -> LDS; entries outside (Cout, Cin) become zeros here
+    float* dst = Bs[buf];
+    if constexpr (!WT) {
+      const int c = tid / LPC, kq = (tid % LPC) * 4, k = k0 + kq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = min(k0 + kq + i, Cin - 1);
-        pm[i] = act.mean[k];
-        pi[i] = act.invstd[k];
-        pg[i] = act.gamma[k];
-        pb[i] = act.beta[k];
+      for (int u = 0; u < NV; ++u) {
+        const bool cok = col0 + u * CPP + c < Cout;
+        float4 v = bn[u];
+        v.x = (cok && k + 0 < Cin) ? v.x : 0.f;
+        v.y = (cok && k + 1 < Cin) ? v.y : 0.f;
+        v.z = (cok && k + 2 < Cin) ? v.z : 0.f;
+        v.w = (cok && k + 3 < Cin) ? v.w : 0.f;
+        *reinterpret_cast<float4*>(dst + (u * CPP + c) * kLdB + kq) = v;
       }
-    }
+    } else {
 #pragma unroll
-    for (int p = 0; p < kBM / 32; ++p) {
-      const int m = rr + p * 32;
-      const bool row_ok = row0 + m < R;
+      for (int g = 0; g < KH; ++g) {
+        const int kl = 32 * g + (tid & 31);
+        const bool kok = k0 + kl < Cin;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = ra[p][i];
-        if (act.mean) {
-          const float a = ((v - pm[i]) * pi[i]) * pg[i] + pb[i];
-          v = (row_ok && k0 + kq + i < Cin && a > 0.f) ? a : 0.f;
+        for (int p = 0; p < NB; ++p) {
+          const int c = p * 32 + (tid >> 5) * 4;
+          const int co = col0 + c;
+          dst[(c + 0) * kLdB + kl] = (kok && co + 0 < Cout) ? bn[g * NB + p].x : 0.f;
+          dst[(c + 1) * kLdB + kl] = (kok && co + 1 < Cout) ? bn[g * NB + p].y : 0.f;
+          dst[(c + 2) * kLdB + kl] = (kok && co + 2 < Cout) ? bn[g * NB + p].z : 0.f;
+          dst[(c + 3) * kLdB + kl] = (kok && co + 3 < Cout) ? bn[g * NB + p].w : 0.f;
         }
-        As[m * kLd + kq + i] = v;
       }
     }
-#pragma unroll
-    for (int p = 0; p < BN / 32; ++p)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (!WT)
-          Bs[(rr + p * 32) * kLd + kq + i] = rb[p][i];
-        else
-          Bs[(p * 32 + (tid >> 5) * 4 + i) * kLd + (tid & 31)] = rb[p][i];
-      }
   };
 
-  load_slab(0);
-  for (int k0 = 0; k0 < Cin; k0 += kBK) {
-    store_slab(k0);
-    __syncthreads();
-    if (k0 + kBK < Cin) load_slab(k0 + kBK);  // in flight during the MFMA loop below
-    // ---- 16 MFMA k-steps of 2 on this slab: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31] ----
-    const float* ap = As + (wave * 32 + (lane & 31)) * kLd + (lane >> 5);
-    const float* bp = Bs + (lane & 31) * kLd + (lane >> 5);
+  load_a(0);
+  load_b(0);
+  __syncthreads();  // Ps visible
+  store_b(0, 0);
+  activate(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < Cin; k0 += BK) {
+    const bool more = k0 + BK < Cin;
+    if (more) {  // in flight during the MFMAs below
+      load_a(k0 + BK);
+      load_b(k0 + BK);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the consumers of those loads BELOW the MFMAs
+    const float* bp = Bs[buf] + li * kLdB + 4 * lh;
 #pragma unroll
-    for (int kk = 0; kk < kBK; kk += 2) {
-      const float a = ap[kk];
+    for (int t = 0; t < NT; ++t) {
+      float4 bf[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[j * 32 * kLd + kk], acc[j], 0, 0, 0);
+      for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const float4*>(bp + j * 32 * kLdB + 8 * t);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][0], bf[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][1], bf[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][2], bf[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][3], bf[j].w, acc[j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      store_b(buf ^ 1, k0 + BK);  // last read in the previous iteration, which ended with a barrier
+      activate(k0 + BK);
     }
     __syncthreads();
+    buf ^= 1;
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
@@ -376,6 +455,27 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
   }
 }
 
+// Tile width by output columns, vector / scalar loads by alignment.
+template <bool WT>
+void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int ldw, int N, InAct act, const float* bias, EpiBwd epi,
+                float* Y, double* stat, double* partial, hipStream_t s) {
+  const unsigned gx = (unsigned)cdiv(R, kBM);
+  const bool vec = ldx % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && N % 4 == 0 && ((uintptr_t)X) % 16 == 0 && ((uintptr_t)W) % 16 == 0 &&
+                   K >= 4 && N >= 4;
+#define MVP_MLP_LAUNCH(BN, VEC)                                                                                                   \
+  /* K slab of 32: a 64-wide slab was measured slower (fewer slabs per tile expose the first load) */                                \
+  hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, ldw, N, act, \
+                     bias, epi, Y, stat, partial)
+  if (N <= 32) {
+    if (vec) MVP_MLP_LAUNCH(32, true); else MVP_MLP_LAUNCH(32, false);
+  } else if (N <= 64) {
+    if (vec) MVP_MLP_LAUNCH(64, true); else MVP_MLP_LAUNCH(64, false);
+  } else {
+    if (vec) MVP_MLP_LAUNCH(128, true); else MVP_MLP_LAUNCH(128, false);
+  }
+#undef MVP_MLP_LAUNCH
+}
+
 }  // namespace
 
 // Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias); stat (2*Cout float64, accumulated into) +=
@@ -397,16 +497,8 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
   if (R == 0) return MVP_OK;  // stat / dW style outputs are ACCUMULATED into: the caller provides zeros
   InAct act{act_mean, act_invstd, act_gamma, act_beta};
   const unsigned gx = (unsigned)cdiv(R, kBM);
-  if (Cout <= 32) {
-    hipLaunchKernelGGL(mlp_fwd_kernel<32>, dim3(gx, 1), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act,
-                       bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat, stat ? partial : nullptr);
-  } else if (Cout <= 64) {
-    hipLaunchKernelGGL(mlp_fwd_kernel<64>, dim3(gx, 1), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act,
-                       bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat, stat ? partial : nullptr);
-  } else {
-    hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(gx, (unsigned)cdiv(Cout, 128)), dim3(kMT), 0, s, X, R, (int)Cin, (int)ldx, W,
-                       (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat, stat ? partial : nullptr);
-  }
+  launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat,
+                    stat ? partial : nullptr, s);
   if (stat && partial)
     hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)std::min<int64_t>(128, cdiv(gx, 16))), dim3(256), 0, s, partial, (int64_t)gx,
                        (int)(2 * Cout), stat);
@@ -464,16 +556,7 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
   double* st = y_prev ? stat : nullptr;
   const unsigned gx = (unsigned)cdiv(R, kBM);
   // roles: X = dY (R, Cout as the K dimension), W read across (WT), output columns = Cin
-  if (Cin <= 32) {
-    hipLaunchKernelGGL((mlp_fwd_kernel<32, true>), dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, W, (int)Cin, (int)Cin, act,
-                       nullptr, epi, dZ, st, st ? partial : nullptr);
-  } else if (Cin <= 64) {
-    hipLaunchKernelGGL((mlp_fwd_kernel<64, true>), dim3(gx, 1), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, W, (int)Cin, (int)Cin, act,
-                       nullptr, epi, dZ, st, st ? partial : nullptr);
-  } else {
-    hipLaunchKernelGGL((mlp_fwd_kernel<128, true>), dim3(gx, (unsigned)cdiv(Cin, 128)), dim3(kMT), 0, s, dY, R, (int)Cout, (int)Cout, W,
-                       (int)Cin, (int)Cin, act, nullptr, epi, dZ, st, st ? partial : nullptr);
-  }
+  launch_mlp<true>(dY, R, (int)Cout, (int)Cout, W, (int)Cin, (int)Cin, act, nullptr, epi, dZ, st, st ? partial : nullptr, s);
   if (st && partial)
     hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)std::min<int64_t>(128, cdiv(gx, 16))), dim3(256), 0, s, partial, (int64_t)gx,
                        (int)(2 * Cin), stat);

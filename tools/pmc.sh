@@ -10,7 +10,7 @@ rows=list(csv.DictReader(open('$out/p_counter_collection.csv')))
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     acc[r['Kernel_Name'][:70]][r['Counter_Name']].append(float(r['Counter_Value']))
-keep=('mlp_','lift_','fps_','colstats','bn_act','group_rows','interp_rows')
+keep=('mlp_','Cijk','lift_','fps_','colstats','bn_act','group_rows','interp_rows')
 for k,v in acc.items():
     if not any(x in k for x in keep): continue
     n=len(next(iter(v.values())))
