@@ -373,85 +373,152 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restr
 // either.  Grid: (Cout/64, Cin/64, row splits); each workgroup keeps its 64x64 partial in MFMA
 // accumulators over its whole row range and flushes once with fp32 atomics.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kDT = 64;  // tile edge (Cout and Cin)
-
+// Tile TM (Cout side) x TN (Cin side), each 32 or 64.  The 4 waves cover the (TM/32) x (TN/32) output blocks; when there are fewer
+// than 4 blocks the spare waves split the ROWS of a slab between them (RS-way; the slab grows to 32 RS rows so every wave still
+// has 16 MFMAs per slab), so a 32 x 32 weight (the C = 32 layers over 2.1 M rows) keeps all four MFMA pipes busy instead of one.
+// Slabs are double buffered in LDS and the loads of slab s + 1 are issued (unconditionally, clamped) before the MFMAs of slab s:
+// one barrier per slab.  The RS partial tiles are summed through LDS and flushed with ONE fp32 atomic per element and
+// workgroup; the host bounds the number of row splits because those atomics queue per address (~90 ns each).
+template <int TM, int TN, bool VEC>
 __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
                                                      int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
                                                      float* __restrict__ dW) {
-  __shared__ float Ds[kBK * kDT];
-  __shared__ float As[kBK * kDT];
+  constexpr int NBLK = (TM / 32) * (TN / 32);  // output blocks of 32 x 32
+  constexpr int RS = 4 / NBLK;                 // waves per output block = row split of the slab
+  constexpr int BR = 32 * RS;                  // slab rows
+  __shared__ __attribute__((aligned(16))) float Ds[2][BR * TM];
+  __shared__ __attribute__((aligned(16))) float As[2][BR * TN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int co0 = blockIdx.x * kDT, ci0 = blockIdx.y * kDT;
+  const int co0 = blockIdx.x * TM, ci0 = blockIdx.y * TN;
   const int64_t r_begin = (int64_t)blockIdx.z * rows_per_block;
   const int64_t r_end = min(R, r_begin + rows_per_block);
-  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;  // 2 x 2 waves of 32 x 32
+  const int blk = wave % NBLK, rs = wave / NBLK;
+  const int wco = (blk / (TN / 32)) * 32, wci = (blk % (TN / 32)) * 32;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  // staging: 16 lanes cover one 64-float row (float4 each) -> 16 rows per pass, 2 passes per slab
-  const int cq = (tid & 15) * 4, rr = tid >> 4;
+  // staging: TM/4 (TN/4) lanes cover one row of the dY (X) tile with one float4 each
+  constexpr int LD = TM / 4, RD = kMT / LD, PD = BR / RD;  // lanes per row, rows per pass, passes
+  constexpr int LA = TN / 4, RA = kMT / LA, PA = BR / RA;
+  const int dq = (tid % LD) * 4, dr = tid / LD;
+  const int aq = (tid % LA) * 4, ar = tid / LA;
   float pm[4], pi[4], pg[4], pb[4];
-  if (act.mean) {
+  const bool has_act = act.mean != nullptr;
+  if (has_act) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = min(ci0 + cq + i, Cin - 1);
+      const int k = min(ci0 + aq + i, Cin - 1);
       pm[i] = act.mean[k];
       pi[i] = act.invstd[k];
       pg[i] = act.gamma[k];
       pb[i] = act.beta[k];
     }
   }
-  const bool d_vec = (Cout % 4 == 0) && (((uintptr_t)dY) % 16 == 0);
-  const bool x_vec = (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0);
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += kBK) {
+  float4 dn[PD], an[PA];
+  auto load = [&](int64_t r0) {  // unconditional, addresses clamped into the tensors
 #pragma unroll
-    for (int p = 0; p < kBK / 16; ++p) {
-      const int m = rr + p * 16;
-      const int64_t r = r0 + m;
-      float d[4] = {0.f, 0.f, 0.f, 0.f}, a[4] = {0.f, 0.f, 0.f, 0.f};
-      if (r < r_end) {
-        const float* ds = dY + (size_t)r * Cout + co0 + cq;
-        if (d_vec && co0 + cq + 4 <= Cout) {
-          const float4 q = *reinterpret_cast<const float4*>(ds);
-          d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (co0 + cq + i < Cout) d[i] = ds[i];
-        }
-        const float* xs = X + (size_t)r * ldx + ci0 + cq;
-        if (x_vec && ci0 + cq + 4 <= Cin) {
-          const float4 q = *reinterpret_cast<const float4*>(xs);
-          a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (ci0 + cq + i < Cin) a[i] = xs[i];
-        }
-        if (act.mean) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float v = ((a[i] - pm[i]) * pi[i]) * pg[i] + pb[i];
-            a[i] = (ci0 + cq + i < Cin && v > 0.f) ? v : 0.f;
-          }
-        }
+    for (int p = 0; p < PD; ++p) {
+      const float* src = dY + (size_t)min(r0 + dr + p * RD, R - 1) * Cout;
+      const int c = co0 + dq;
+      if constexpr (VEC) {
+        dn[p] = *reinterpret_cast<const float4*>(src + min(c, Cout - 4));
+      } else {
+        dn[p].x = src[min(c + 0, Cout - 1)];
+        dn[p].y = src[min(c + 1, Cout - 1)];
+        dn[p].z = src[min(c + 2, Cout - 1)];
+        dn[p].w = src[min(c + 3, Cout - 1)];
       }
-      *reinterpret_cast<float4*>(&Ds[m * kDT + cq]) = make_float4(d[0], d[1], d[2], d[3]);
-      *reinterpret_cast<float4*>(&As[m * kDT + cq]) = make_float4(a[0], a[1], a[2], a[3]);
     }
-    __syncthreads();
-    const float* dp = Ds + (lane >> 5) * kDT + wco + (lane & 31);
-    const float* ap = As + (lane >> 5) * kDT + wci + (lane & 31);
 #pragma unroll
-    for (int kk = 0; kk < kBK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[kk * kDT], ap[kk * kDT], acc, 0, 0, 0);
-    __syncthreads();
+    for (int p = 0; p < PA; ++p) {
+      const float* src = X + (size_t)min(r0 + ar + p * RA, R - 1) * ldx;
+      const int c = ci0 + aq;
+      if constexpr (VEC) {
+        an[p] = *reinterpret_cast<const float4*>(src + min(c, Cin - 4));
+      } else {
+        an[p].x = src[min(c + 0, Cin - 1)];
+        an[p].y = src[min(c + 1, Cin - 1)];
+        an[p].z = src[min(c + 2, Cin - 1)];
+        an[p].w = src[min(c + 3, Cin - 1)];
+      }
+    }
+  };
+  auto store = [&](int buf, int64_t r0) {  // registers -> LDS: masks (rows past r_end, columns past the tensor) and the activation
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int m = dr + p * RD;
+      const bool rok = r0 + m < r_end;
+      const int c = co0 + dq;
+      float4 v = dn[p];
+      v.x = (rok && c + 0 < Cout) ? v.x : 0.f;
+      v.y = (rok && c + 1 < Cout) ? v.y : 0.f;
+      v.z = (rok && c + 2 < Cout) ? v.z : 0.f;
+      v.w = (rok && c + 3 < Cout) ? v.w : 0.f;
+      *reinterpret_cast<float4*>(&Ds[buf][m * TM + dq]) = v;
+    }
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int m = ar + p * RA;
+      const bool rok = r0 + m < r_end;
+      const int c = ci0 + aq;
+      float a[4] = {an[p].x, an[p].y, an[p].z, an[p].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (has_act) {
+          const float v = ((a[i] - pm[i]) * pi[i]) * pg[i] + pb[i];
+          a[i] = v > 0.f ? v : 0.f;
+        }
+        a[i] = (rok && c + i < Cin) ? a[i] : 0.f;
+      }
+      *reinterpret_cast<float4*>(&As[buf][m * TN + aq]) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+  };
+
+  if (r_begin < r_end) {
+    load(r_begin);
+    store(0, r_begin);
   }
-  const int ci = ci0 + wci + (lane & 31);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += BR) {
+    const bool more = r0 + BR < r_end;
+    if (more) load(r0 + BR);
+    __builtin_amdgcn_sched_barrier(0);
+    // A[i = co][k = row], B[k = row][j = ci]: lane-consecutive LDS reads of the tiles exactly as they lie in memory
+    const float* dp = Ds[buf] + (rs * 32 + (lane >> 5)) * TM + wco + (lane & 31);
+    const float* ap = As[buf] + (rs * 32 + (lane >> 5)) * TN + wci + (lane & 31);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int co = co0 + wco + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-    if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * Cin + ci, acc[i]);
+    for (int kk = 0; kk < 32; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[kk * TM], ap[kk * TN], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store(buf ^ 1, r0 + BR);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // sum the RS partial tiles of each output block through LDS (the slabs are dead after the last barrier)
+  if constexpr (RS > 1) {
+    float* red = &Ds[0][0];  // RS x NBLK x 1024 floats <= 2 * BR * TM
+    static_assert(RS * NBLK * 1024 <= 2 * BR * TM, "reduction scratch must fit in the dY slabs");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[((rs * NBLK + blk) * 16 + i) * 64 + lane] = acc[i];
+    __syncthreads();
+    if (rs == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < RS; ++q) v += red[((q * NBLK + blk) * 16 + i) * 64 + lane];
+        acc[i] = v;
+      }
+    }
+  }
+  if (rs == 0) {
+    const int ci = ci0 + wci + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co0 + wco + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * Cin + ci, acc[i]);
+    }
   }
 }
 
@@ -520,14 +587,31 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (R == 0) return MVP_OK;
-  const int64_t tiles = cdiv(Cout, kDT) * cdiv(Cin, kDT);
-  int64_t splits = cdiv(1024, tiles);                  // ~4 workgroups per CU in total
-  int64_t rows_per_block = cdiv(cdiv(R, splits), kBK) * kBK;
-  if (rows_per_block < 4 * kBK) rows_per_block = 4 * kBK;
+  const int TM = Cout <= 32 ? 32 : 64, TN = Cin <= 32 ? 32 : 64;
+  const int64_t tiles = cdiv(Cout, TM) * cdiv(Cin, TN);
+  // ~4 workgroups per CU in total, but at most 512 row splits: each split queues one atomic on every dW element
+  int64_t splits = std::min<int64_t>(cdiv(1024, tiles), 512);
+  const int64_t slab = 32 * (4 / ((TM / 32) * (TN / 32)));
+  int64_t rows_per_block = cdiv(cdiv(R, splits), slab) * slab;
+  if (rows_per_block < 4 * slab) rows_per_block = 4 * slab;
   splits = cdiv(R, rows_per_block);
   InAct act{act_mean, act_invstd, act_gamma, act_beta};
-  dim3 grid((unsigned)cdiv(Cout, kDT), (unsigned)cdiv(Cin, kDT), (unsigned)splits);
-  hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW);
+  dim3 grid((unsigned)cdiv(Cout, TM), (unsigned)cdiv(Cin, TN), (unsigned)splits);
+  const bool vec = Cout % 4 == 0 && Cin % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dY) % 16 == 0 && ((uintptr_t)X) % 16 == 0;
+#define MVP_DW_LAUNCH(M_, N_)                                                                                                      \
+  do {                                                                                                                             \
+    if (vec)                                                                                                                       \
+      hipLaunchKernelGGL((mlp_dw_kernel<M_, N_, true>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
+                         rows_per_block, dW);                                                                                      \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((mlp_dw_kernel<M_, N_, false>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,        \
+                         rows_per_block, dW);                                                                                      \
+  } while (0)
+  if (TM == 32 && TN == 32) MVP_DW_LAUNCH(32, 32);
+  else if (TM == 32) MVP_DW_LAUNCH(32, 64);
+  else if (TN == 32) MVP_DW_LAUNCH(64, 32);
+  else MVP_DW_LAUNCH(64, 64);
+#undef MVP_DW_LAUNCH
   return mvp_launch_status();
 }
 
