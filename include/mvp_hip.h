@@ -176,9 +176,13 @@ int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* index, int
  *   out (B,M,K,C) = zf (B,N,C)[index] + wxyz (C,3) . (xyz (B,N,3)[index] - centre (B,M,3))
  * with zf = W1[:, :C_in] . feature evaluated once per point (8x fewer conv rows than grouping first) and the coordinate
  * columns evaluated on the difference, as the reference does.  zf may be NULL (no input feature).  diff, if not NULL,
- * receives the (B,M,K,4) rows [dx,dy,dz,0] (operand of the W1_xyz weight gradient). */
+ * receives the (B,M,K,4) rows [dx,dy,dz,0] (operand of the W1_xyz weight gradient).  stat, if not NULL (2*C float64,
+ * accumulated into): column sums of out and out^2 -- the layer's batch statistics without another pass; it needs the
+ * scratch `partial` of mvp_group_lin_partial_count(B,C,M,K) float64. */
+int64_t mvp_group_lin_partial_count(int64_t B, int64_t C, int64_t M, int64_t K);
 int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
-                           int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, mvp_stream_t stream);
+                           int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat,
+                           double* partial, mvp_stream_t stream);
 /* stat (2*C float64) += column sums of y and y^2 over the R rows of y (R,C); accumulated: the caller provides zeros */
 int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream);
 int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,

@@ -44,7 +44,7 @@ _SIGNATURES = {
                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_group_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_rows_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
-    'mvp_group_lin_rows_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_group_lin_rows_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_colstats_f32': [_ptr, _i64, _i64, _ptr, _ptr],
     'mvp_interp_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interp_rows_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
@@ -60,7 +60,7 @@ _SIGNATURES = {
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
 }
-EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes'] + sorted(_SIGNATURES)
+EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -76,6 +76,8 @@ def lib():
         handle.mvp_strerror.argtypes = [ctypes.c_int]
         handle.mvp_lift_workspace_bytes.restype = ctypes.c_int64
         handle.mvp_lift_workspace_bytes.argtypes = [_i64, _i64, _i64, _i64, _i64]
+        handle.mvp_group_lin_partial_count.restype = ctypes.c_int64
+        handle.mvp_group_lin_partial_count.argtypes = [_i64, _i64, _i64, _i64]
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes

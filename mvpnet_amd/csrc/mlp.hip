@@ -18,6 +18,7 @@
 // As[row][k], Bs[col][k] with lane-consecutive rows are bank-conflict free).
 // The kernel is HBM-bound for the small layers (C = 32..64: 16 flop/B) and MFMA-bound for C >= 256.
 #include "common.h"
+#include "stats_reduce.h"
 #include <algorithm>
 
 namespace {
@@ -329,41 +330,6 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
   }
 }
 
-// Sum the per-row-tile partial statistics (nblk x 2*Cout, written by the kernel above) into stat.
-// With one atomic pair per (workgroup, column) up to 16 k workgroups queued on the same 2*Cout
-// addresses (measured: 370 -> 215 us on a 2.1 M-row C=32 layer once that queue is gone).
-__global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restrict__ partial, int64_t nblk, int C2,
-                                                           double* __restrict__ stat) {
-  __shared__ double red[256];
-  const int64_t per = (nblk + gridDim.x - 1) / gridDim.x;
-  const int64_t t0 = (int64_t)blockIdx.x * per, t1 = min(nblk, t0 + per);
-  const int cpp = min(C2, 256);       // columns per pass; 256 / cpp row phases share a column
-  const int phases = 256 / cpp;
-  const int col = threadIdx.x % cpp, ph = threadIdx.x / cpp;
-  for (int cb = 0; cb < C2; cb += cpp) {
-    const int c = cb + col;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (ph < phases && c < C2) {
-      int64_t t = t0 + ph;
-      for (; t + 3 * phases < t1; t += 4 * phases) {  // 4 independent loads in flight
-        a0 += partial[(size_t)t * C2 + c];
-        a1 += partial[(size_t)(t + phases) * C2 + c];
-        a2 += partial[(size_t)(t + 2 * phases) * C2 + c];
-        a3 += partial[(size_t)(t + 3 * phases) * C2 + c];
-      }
-      for (; t < t1; t += phases) a0 += partial[(size_t)t * C2 + c];
-    }
-    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (ph == 0 && c < C2 && t1 > t0) {
-      double acc = 0.0;
-      for (int g = 0; g < phases; ++g) acc += red[g * cpp + col];
-      atomicAdd(stat + c, acc);
-    }
-    __syncthreads();
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Weight gradient: dW (Cout, Cin) = dY^T (Cout, R) . act(X) (R, Cin), the reduction runs over the ROWS.
 // Both operands are consumed exactly as they lie in memory (row-major slabs of 32 rows): the MFMA
@@ -567,8 +533,7 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
   launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat,
                     stat ? partial : nullptr, s);
   if (stat && partial)
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)std::min<int64_t>(128, cdiv(gx, 16))), dim3(256), 0, s, partial, (int64_t)gx,
-                       (int)(2 * Cout), stat);
+    launch_stats_reduce(partial, (int64_t)gx, (int)(2 * Cout), stat, s);
   return mvp_launch_status();
 }
 
@@ -642,7 +607,6 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
   // roles: X = dY (R, Cout as the K dimension), W read across (WT), output columns = Cin
   launch_mlp<true>(dY, R, (int)Cout, (int)Cout, W, (int)Cin, (int)Cin, act, nullptr, epi, dZ, st, st ? partial : nullptr, s);
   if (st && partial)
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)std::min<int64_t>(128, cdiv(gx, 16))), dim3(256), 0, s, partial, (int64_t)gx,
-                       (int)(2 * Cin), stat);
+    launch_stats_reduce(partial, (int64_t)gx, (int)(2 * Cin), stat, s);
   return mvp_launch_status();
 }

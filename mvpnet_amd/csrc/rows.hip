@@ -16,6 +16,7 @@
 // 256/(C/4) rows per workgroup pass -> every global access is a full 16-byte-per-lane coalesced row.
 #include <algorithm>
 #include "common.h"
+#include "stats_reduce.h"
 
 namespace {
 
@@ -68,38 +69,80 @@ __global__ __launch_bounds__(kRT) void group_rows_kernel(const float* __restrict
 // reference does (modules.py:27 then the conv) -- so no cancellation between W.xyz and W.centre is introduced.
 // zf == nullptr: no input feature (PN2SSG baseline, SA level 1).  diff != nullptr: also store [dx,dy,dz,0] rows
 // (the operand of the W1xyz weight gradient).  wxyz is (C,3) row-major.
+// A workgroup covers kGLIter * (1024 / C) consecutive rows of one chunk; with `partial` it also leaves the column sums of out
+// and out^2 over its rows in partial[workgroup][2*C] (float64) -- the batch statistics of this first layer without another
+// pass over the (B,M,K,C) tensor (reduced by stats_reduce_kernel).
+constexpr int kGLIter = 8;
 __global__ __launch_bounds__(kRT) void group_lin_rows_kernel(const float* __restrict__ zf, const float* __restrict__ xyz,
                                                              const float* __restrict__ centre, const float* __restrict__ wxyz,
                                                              const int64_t* __restrict__ idx, int N, int C, int M, int K,
-                                                             float* __restrict__ out, float* __restrict__ diff) {
+                                                             float* __restrict__ out, float* __restrict__ diff,
+                                                             double* __restrict__ partial) {
+  __shared__ float red[2][kRT][4];
   const int b = blockIdx.y;
   const int C4 = C >> 2;
+  const int rpp = kRT / C4;  // rows per pass
   const int64_t E = (int64_t)M * K;
-  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
-  const int64_t e = t / C4;
-  const int c = (int)(t - e * C4) * 4;
-  if (e >= E) return;
-  const int64_t j = idx[(size_t)b * E + e];
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dx = 0.f, dy = 0.f, dz = 0.f;
-  if (j >= 0 && j < N) {
-    const float* p = xyz + ((size_t)b * N + j) * 3;
-    const float* q = centre + ((size_t)b * M + e / K) * 3;
-    dx = p[0] - q[0];
-    dy = p[1] - q[1];
-    dz = p[2] - q[2];
-    const float* w = wxyz + (size_t)c * 3;
-    v.x = (w[0] * dx + w[1] * dy) + w[2] * dz;
-    v.y = (w[3] * dx + w[4] * dy) + w[5] * dz;
-    v.z = (w[6] * dx + w[7] * dy) + w[8] * dz;
-    v.w = (w[9] * dx + w[10] * dy) + w[11] * dz;
-    if (zf != nullptr) {
-      const float4 a = ld4(zf + ((size_t)b * N + j) * C + c);
-      v = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+  const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
+  const int c = c4 * 4;
+  const float* w = wxyz + (size_t)c * 3;
+  const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6], w7 = w[7], w8 = w[8], w9 = w[9],
+              w10 = w[10], w11 = w[11];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  int64_t jj[kGLIter];
+#pragma unroll
+  for (int it = 0; it < kGLIter; ++it) {
+    const int64_t e = ((int64_t)blockIdx.x * kGLIter + it) * rpp + rg;
+    jj[it] = (rg < rpp && e < E) ? idx[(size_t)b * E + e] : -1;
+  }
+#pragma unroll
+  for (int it = 0; it < kGLIter; ++it) {
+    const int64_t e = ((int64_t)blockIdx.x * kGLIter + it) * rpp + rg;
+    if (rg >= rpp || e >= E) continue;
+    const int64_t j = jj[it];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (j >= 0 && j < N) {
+      const float* p = xyz + ((size_t)b * N + j) * 3;
+      const float* qc = centre + ((size_t)b * M + e / K) * 3;
+      dx = p[0] - qc[0];
+      dy = p[1] - qc[1];
+      dz = p[2] - qc[2];
+      v.x = (w0 * dx + w1 * dy) + w2 * dz;
+      v.y = (w3 * dx + w4 * dy) + w5 * dz;
+      v.z = (w6 * dx + w7 * dy) + w8 * dz;
+      v.w = (w9 * dx + w10 * dy) + w11 * dz;
+      if (zf != nullptr) {
+        const float4 a = ld4(zf + ((size_t)b * N + j) * C + c);
+        v = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+      }
+    }
+    st4(out + ((size_t)b * E + e) * C + c, v);
+    if (diff != nullptr && c == 0) st4(diff + ((size_t)b * E + e) * 4, make_float4(dx, dy, dz, 0.f));
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  }
+  if (partial == nullptr) return;
+  float* a = red[0][threadIdx.x];
+  float* bq = red[1][threadIdx.x];
+  a[0] = s.x; a[1] = s.y; a[2] = s.z; a[3] = s.w;
+  bq[0] = q.x; bq[1] = q.y; bq[2] = q.z; bq[3] = q.w;
+  __syncthreads();
+  if (rg == 0) {
+    double ts[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0};
+    for (int g = 0; g < rpp; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ts[i] += (double)red[0][g * C4 + c4][i];
+        tq[i] += (double)red[1][g * C4 + c4][i];
+      }
+    double* dst = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dst[c + i] = ts[i];
+      dst[C + c + i] = tq[i];
     }
   }
-  st4(out + ((size_t)b * E + e) * C + c, v);
-  if (diff != nullptr && c == 0) st4(diff + ((size_t)b * E + e) * 4, make_float4(dx, dy, dz, 0.f));
 }
 
 // grad_feature (B,N,C) += grad_out[..., :C]; one lane per (row, channel): consecutive lanes hit
@@ -572,19 +615,28 @@ MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, con
   return mvp_launch_status();
 }
 
+MVP_API int64_t mvp_group_lin_partial_count(int64_t B, int64_t C, int64_t M, int64_t K) {
+  if (B < 0 || C <= 0 || C % 4 != 0 || (kRT % (C / 4)) != 0 || M < 0 || K < 0) return 0;
+  return B * cdiv(M * K, (int64_t)kGLIter * (kRT / (C / 4))) * 2 * C;
+}
+
 MVP_API int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
-                                   int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff,
-                                   mvp_stream_t stream) {
+                                   int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat,
+                                   double* partial, mvp_stream_t stream) {
   MVP_NONNULL(xyz);
   MVP_NONNULL(centre);
   MVP_NONNULL(wxyz);
   MVP_NONNULL(index);
   MVP_NONNULL(out);
-  MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && M >= 0 && K > 0 && B < 65536);
+  if (stat) MVP_NONNULL(partial);
+  MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && C <= 1024 && (kRT % (C / 4)) == 0 && M >= 0 && K > 0 && B < 65536);
   if (B == 0 || M == 0) return MVP_OK;
-  dim3 grid((unsigned)cdiv(M * K * (C / 4), kRT), (unsigned)B);
-  hipLaunchKernelGGL(group_lin_rows_kernel, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), zf, xyz, centre, wxyz, index,
-                     (int)N, (int)C, (int)M, (int)K, out, diff);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t gx = cdiv(M * K, (int64_t)kGLIter * (kRT / (C / 4)));
+  dim3 grid((unsigned)gx, (unsigned)B);
+  hipLaunchKernelGGL(group_lin_rows_kernel, grid, dim3(kRT), 0, s, zf, xyz, centre, wxyz, index, (int)N, (int)C, (int)M, (int)K, out,
+                     diff, stat ? partial : nullptr);
+  if (stat) launch_stats_reduce(partial, gx * B, (int)(2 * C), stat, s);
   return mvp_launch_status();
 }
 

@@ -1,0 +1,48 @@
+// stats_reduce.h -- reduction of per-workgroup partial column statistics (shared by mlp.hip and rows.hip).
+#pragma once
+#include "common.h"
+
+namespace {
+
+// Sum the per-row-tile partial statistics (nblk x 2*Cout, written by the producing kernel) into stat.
+// With one atomic pair per (workgroup, column) up to 16 k workgroups queued on the same 2*Cout
+// addresses (measured: 370 -> 215 us on a 2.1 M-row C=32 layer once that queue is gone).
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restrict__ partial, int64_t nblk, int C2,
+                                                           double* __restrict__ stat) {
+  __shared__ double red[256];
+  const int64_t per = (nblk + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * per, t1 = min(nblk, t0 + per);
+  const int cpp = min(C2, 256);       // columns per pass; 256 / cpp row phases share a column
+  const int phases = 256 / cpp;
+  const int col = threadIdx.x % cpp, ph = threadIdx.x / cpp;
+  for (int cb = 0; cb < C2; cb += cpp) {
+    const int c = cb + col;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (ph < phases && c < C2) {
+      int64_t t = t0 + ph;
+      for (; t + 3 * phases < t1; t += 4 * phases) {  // 4 independent loads in flight
+        a0 += partial[(size_t)t * C2 + c];
+        a1 += partial[(size_t)(t + phases) * C2 + c];
+        a2 += partial[(size_t)(t + 2 * phases) * C2 + c];
+        a3 += partial[(size_t)(t + 3 * phases) * C2 + c];
+      }
+      for (; t < t1; t += phases) a0 += partial[(size_t)t * C2 + c];
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ph == 0 && c < C2 && t1 > t0) {
+      double acc = 0.0;
+      for (int g = 0; g < phases; ++g) acc += red[g * cpp + col];
+      atomicAdd(stat + c, acc);
+    }
+    __syncthreads();
+  }
+}
+
+
+static inline void launch_stats_reduce(const double* partial, int64_t nblk, int C2, double* stat, hipStream_t s) {
+  const int64_t blocks = nblk < 16 ? 1 : (nblk / 16 > 128 ? 128 : nblk / 16);
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, nblk, C2, stat);
+}
+
+}  // namespace

@@ -101,8 +101,12 @@ class SetAbstraction(nn.Module):
                 f = torch.nn.functional.pad(feature, (0, pad)) if pad else feature
                 w1f = torch.nn.functional.pad(w1[:, :cf], (0, pad)) if pad else w1[:, :cf]
                 zf = R.linear_rows(f.reshape(B * N, -1), w1f).view(B, N, c1)
-            y1 = R.group_lin_rows(zf, xyz, new_xyz, w1[:, -3:], ball)  # (B,M,K,C_1): conv output of layer 1, grouped
-            new_feature = R.shared_mlp_rows(y1.view(B * M * K, c1), self.mlp, K=K, first_done=True)
+            bn_training = l0.bn.training
+            y1 = R.group_lin_rows(zf, xyz, new_xyz, w1[:, -3:], ball, want_stat=bn_training)  # (B,M,K,C_1): conv output of layer 1
+            stat1 = None
+            if bn_training:
+                y1, stat1 = y1
+            new_feature = R.shared_mlp_rows(y1.view(B * M * K, c1), self.mlp, K=K, first_done=True, first_stat=stat1)
             return new_xyz, new_feature.view(B, M, -1)
         if use_feature and feature.size(2) % 4:
             feature = torch.nn.functional.pad(feature, (0, 4 - feature.size(2) % 4))  # cannot happen with reference configs

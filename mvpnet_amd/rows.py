@@ -57,28 +57,35 @@ def group_rows(feature, xyz, center, index):
 
 class GroupLinRows(torch.autograd.Function):
     """out[b,m,k,:] = zf[b,j,:] + wxyz . (xyz[b,j] - centre[b,m]),  j = index[b,m,k]   (zf may be None).
-    Gradients: zf (row scatter-add) and wxyz (grad_out^T . diff rows); coordinates carry no gradient on this path
-    (the reference computes them under no_grad too: fps.py:11-13, modules.py:22-27 on leaf points)."""
+    want_stat: also return the float64 column sums [sum out | sum out^2] (the BatchNorm batch statistics of this layer,
+    computed by the same kernel).  Gradients: zf (row scatter-add) and wxyz (grad_out^T . diff rows); coordinates carry no
+    gradient on this path (the reference computes them under no_grad too: fps.py:11-13, modules.py:22-27 on leaf points)."""
 
     @staticmethod
-    def forward(ctx, zf, xyz, centre, wxyz, index):
+    def forward(ctx, zf, xyz, centre, wxyz, index, want_stat):
         L.require_gpu(xyz, centre, wxyz, index)
         B, N, _ = xyz.shape
         _, M, K = index.shape
         C = wxyz.size(0)
         need_w = wxyz.requires_grad
-        out = torch.empty((B, M, K, C), dtype=torch.float32, device=xyz.device)
-        diff = torch.empty((B, M, K, 4), dtype=torch.float32, device=xyz.device) if need_w else None
+        dev = xyz.device
+        out = torch.empty((B, M, K, C), dtype=torch.float32, device=dev)
+        diff = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_w else None
+        stat = torch.zeros(2 * C, dtype=torch.float64, device=dev) if want_stat else None
+        partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, M, K), dtype=torch.float64, device=dev) if want_stat else None
         L.call('mvp_group_lin_rows_f32', xyz, L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(wxyz), L.ptr(index), B, N, C, M, K,
-               L.ptr(out), L.ptr(diff))
+               L.ptr(out), L.ptr(diff), L.ptr(stat), L.ptr(partial))
         ctx.save_for_backward(index, diff)
         ctx.dims = (B, N, C, M, K)
         ctx.has_zf = zf is not None
+        if want_stat:
+            ctx.mark_non_differentiable(stat)
+            return out, stat
         return out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, *unused):
         index, diff = ctx.saved_tensors
         B, N, C, M, K = ctx.dims
         g = grad_out.contiguous()
@@ -90,13 +97,13 @@ class GroupLinRows(torch.autograd.Function):
             gw4 = torch.zeros((C, 4), dtype=torch.float32, device=g.device)  # accumulated into
             L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4))
             gw = gw4[:, :3].contiguous()
-        return gz, None, None, gw, None
+        return gz, None, None, gw, None, None
 
 
-def group_lin_rows(zf, xyz, centre, wxyz, index):
-    """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3), index (B,M,K) -> (B,M,K,C)."""
+def group_lin_rows(zf, xyz, centre, wxyz, index, want_stat=False):
+    """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3), index (B,M,K) -> (B,M,K,C) [, stat (2C) float64]."""
     return GroupLinRows.apply(None if zf is None else zf.contiguous(), xyz.contiguous(), centre.contiguous(), wxyz.contiguous(),
-                              index.contiguous())
+                              index.contiguous(), bool(want_stat))
 
 
 class InterpRows(torch.autograd.Function):
@@ -230,7 +237,7 @@ class MLPChainRows(torch.autograd.Function):
     pre-BN outputs y_i ever reach HBM.  Backward re-creates each activation from y_i on the fly."""
 
     @staticmethod
-    def forward(ctx, x0, training, K, eps_mom, bn_buffers, *params):
+    def forward(ctx, x0, training, K, eps_mom, bn_buffers, first_stat, *params):
         # params = (W_1, gamma_1, beta_1, ..., W_L, gamma_L, beta_L); bn_buffers = [(running_mean, running_var, num_batches_tracked or None)] * L
         nl = len(params) // 3
         R = x0.size(0)
@@ -251,7 +258,9 @@ class MLPChainRows(torch.autograd.Function):
                 assert i == 0
                 cout = x0.size(1)
                 y = x0
-                if training:
+                if training and first_stat is not None:
+                    stat = first_stat  # the grouping kernel already summed the columns
+                elif training:
                     L.call('mvp_colstats_f32', y, L.ptr(y), R, cout, L.ptr(stat))
             else:
                 cout, cin = w.size(0), w.size(1)
@@ -336,7 +345,7 @@ class MLPChainRows(torch.autograd.Function):
                 else:
                     L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(dz), None, None)
                     dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
-        return (dx0, None, None, None, None) + tuple(grads)
+        return (dx0, None, None, None, None, None) + tuple(grads)
 
 
 class LinearRows(torch.autograd.Function):
@@ -378,7 +387,7 @@ def linear_rows(x, weight, bias=None):
     return LinearRows.apply(x.contiguous(), w, bias)
 
 
-def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False):
+def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
     K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108).
@@ -396,7 +405,7 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             params += [w, layer.bn.weight, layer.bn.bias]
             buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
-        return MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, *params)
+        return MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, *params)
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     for i, layer in enumerate(mlp):
         w = layer.conv.weight.reshape(layer.conv.weight.size(0), -1)  # (C_out, C_in)
