@@ -1,28 +1,18 @@
 // lift_fused.hip -- the whole 2D->3D lifting step in two launches for gfx950:
 //
-//   K1  lift_prepare_kernel     : depth -> one 16-byte search record per pixel (x, y, z, w),
-//                                 w = 0 valid / +inf invalid (optionally also the public image_xyz +
-//                                 mask tensors of mvp_unproject_*).
-//   K2  lift_knn_gather_kernel  : per workgroup of 256 chunk points:
-//                                 exact projective pixel k-NN on the records (pixel_knn_core.h),
-//                                 one point per lane, 25 independent probes per view; then the
-//                                 workgroup gathers the k x 256 neighbour rows of the channels-last
-//                                 feature map (16 lanes x 16 B per 256-byte row, full-line loads,
-//                                 non-temporal full-line stores) and the neighbours' xyz.
+//   K1  lift_prepare_kernel     : depth -> one 16-byte search record per pixel (x, y, z, w), w = 0 valid / +inf invalid, plus a
+//                                 padded uint16 depth plane (and optionally the public image_xyz + mask tensors of mvp_unproject_*).
+//   K2  lift_knn_gather_kernel  : per workgroup of 256 chunk points: exact projective pixel k-NN, one point per lane -- the 5x5
+//                                 windows are filtered through the depth plane (5 row loads per view), only the few candidates
+//                                 that can be in the top-k are evaluated exactly from their records, then ring growth
+//                                 (pixel_knn_core.h); the workgroup then gathers the k x 256 neighbour rows of the channels-last
+//                                 feature map (16 lanes x 16 B per 256-byte row, full-line loads, non-temporal full-line stores)
+//                                 and the neighbours' xyz.
 //
-// Replaces, on the device, scannet_2d3d.py:254-313 (loader workers) + mvpnet_3d.py:99-109
-// (two channel-major group_points calls and a full transpose copy).
-//
-// Measured on MI355X (profiles/): the k-NN phase is bound by the per-CU vector-L1 (TCP) rate of
-// ~0.75 scattered 16-byte lane-accesses/clk (21 M accesses per launch), not by bytes; the gather
-// phase is HBM-bound.  Three alternatives were built and measured: processing points in
-// Morton order (gather 57 -> 46 us from L2 re-use, but the per-chunk sort costs 14+ us), staging
-// per-view image windows in LDS (window bounding boxes of 256 points overflow a 48 KB budget) and
-// 8-lane cooperative probing (4x better TCP rate but 8x fewer loads in flight), and wave-specialised
-// software pipelining of k-NN and gather inside a workgroup (164 vs 132 us: the k-NN needs all the waves
-// it can get to hide L2 latency); none was a net win.
-// XCD-aware placement (workgroup L runs on XCD L % 8, observed, used for speed only) keeps each
-// chunk's 0.9 MB of records in ONE XCD's private 4 MB L2.
+// Replaces, on the device, scannet_2d3d.py:254-313 (loader workers) + mvpnet_3d.py:99-109 (two channel-major group_points
+// calls and a full transpose copy).  Measurements, ablations and the alternatives that were built and dropped: DESIGN.md 4.1.
+// XCD-aware placement (workgroup L runs on XCD L % 8, observed, used for speed only) keeps each chunk's 0.9 MB of records in ONE
+// XCD's private 4 MB L2.
 #include "pixel_knn_core.h"
 
 namespace {
