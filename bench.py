@@ -182,6 +182,7 @@ def main():
     _lib.lib()
     rank, world, local = D.init_from_env()
     assert world == args.gpus, 'WORLD_SIZE ({}) != --gpus ({})'.format(world, args.gpus)
+    local = int(os.environ.get('MVP_DEVICE', local))  # debugging aid: several ranks on one GPU (with MVP_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     torch.backends.cudnn.allow_tf32 = False

@@ -1,0 +1,122 @@
+"""The one-process-per-GPU path with the REAL kernels: two ranks (both on cuda:0, gloo transport because RCCL refuses two ranks
+on one device) run the sharded train step of mvpnet_amd.mvpnet3d.train_step with dist.GradSync, and the sharded whole-scene
+inference (shard_chunks -> forward -> all_gather_logits -> vote_scene).  Checks: parameters stay identical across ranks, the
+averaged gradient equals the single-process gradient of the full batch (eval-mode BatchNorm, so the batch split does not
+change the statistics), every rank votes the same scene labels as the single-process run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+KW = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
+CFG = dict(num_centroids=(256, 64, 16, 4), radius=(0.1, 0.2, 0.4, 0.8), max_neighbors=(32, 32, 32, 32))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Feature2D(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.feature = None
+
+    def forward(self, data):
+        return {'feature': self.feature}
+
+
+def _model(dev):
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D
+    torch.manual_seed(3)
+    return MVPNet3D(_Feature2D(), '', PN2SSG(16, 20, dropout_prob=0.0, **CFG), in_channels=16, mlp_channels=(16, 16, 16)).to(dev)
+
+
+def _batch(ids, dev):
+    from mvpnet_amd.synthetic import make_chunk
+    cs = [make_chunk(500 + i, **KW) for i in ids]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    st = lambda k: np.stack([c[k] for c in cs])
+    nv = KW['nv']
+    batch = {'images': torch.zeros(len(ids), nv, 3, KW['h'], KW['w'], device=dev), 'points': t(st('points').transpose(0, 2, 1)),
+             'seg_label': t(np.maximum(st('seg_label'), 0)),  # no ignored labels: every rank's mean loss has the same weight
+ 'depth': t(st('depth_mm').astype(np.int16)),
+             'cam_matrix': t(np.stack([np.repeat(c['cam_matrix'][None, :3, :3], nv, 0) for c in cs])), 'kinv': t(st('kinv')),
+             'pose': t(st('pose')), 'pixel_box': t(st('pixel_box')), 'k': 3}
+    feature = t(st('feature_2d')).view(len(ids) * nv, KW['h'], KW['w'], KW['channels']).permute(0, 3, 1, 2)
+    return batch, feature
+
+
+def _step(model, ids, dev, grad_sync):
+    from mvpnet_amd.mvpnet3d import SegLoss, train_step
+    batch, feature = _batch(ids, dev)
+    model.net_2d.feature = feature
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)  # lr 0: the parameters must not move, only the gradients matter
+    train_step(model, SegLoss(), opt, batch, grad_sync=grad_sync)
+    return [p.grad.detach().clone().cpu() for p in model.parameters() if p.grad is not None]
+
+
+def _infer(model, ids, dev):
+    batch, feature = _batch(ids, dev)
+    model.net_2d.feature = feature
+    with torch.no_grad():
+        return model(batch)['seg_logit']
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      MVP_DIST_BACKEND='gloo')
+    from mvpnet_amd import dist as D
+    dev = torch.device('cuda:0')
+    D.init_from_env()
+    model = _model(dev).eval()  # eval-mode BatchNorm: per-rank batches give the statistics of the full batch
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.5)  # diverge on purpose; broadcast must repair it
+    D.broadcast_parameters(model)
+    sync = D.GradSync(model.parameters())
+    grads = _step(model, [2 * rank, 2 * rank + 1], dev, sync)
+    # whole-scene inference over 5 chunks: rank r owns r, r + 2, ...
+    mine = D.shard_chunks(5, rank, world)
+    logits = D.all_gather_logits(_infer(model, mine, dev), 5)
+    rs = np.random.RandomState(9)
+    chunk_inds = [torch.from_numpy(rs.choice(3000, 1024 - 17 * i, replace=False)).to(dev) for i in range(5)]
+    mean, label, cnt = D.vote_scene(logits, chunk_inds, 3000)
+    torch.save({'grads': grads, 'label': label.cpu(), 'mean': mean.cpu(), 'params': [p.detach().cpu() for p in model.parameters()]},
+               os.path.join(tmp, 'r{}.pt'.format(rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [torch.load(os.path.join(str(tmp_path), 'r{}.pt'.format(r))) for r in range(2)]
+    for a, b in zip(r0['params'], r1['params']):
+        assert torch.equal(a, b)
+    for a, b in zip(r0['grads'], r1['grads']):
+        assert torch.equal(a, b)
+    assert torch.equal(r0['label'], r1['label']) and torch.equal(r0['mean'], r1['mean'])
+    # single process, full batch / all chunks
+    from mvpnet_amd import dist as D
+    dev = torch.device('cuda:0')
+    model = _model(dev).eval()
+    ref = _step(model, [0, 1, 2, 3], dev, None)
+    for g, e in zip(r0['grads'], ref):
+        np.testing.assert_allclose(g.numpy(), e.numpy(), rtol=2e-3, atol=1e-5 * max(1.0, float(e.abs().max())))
+    logits = _infer(model, list(range(5)), dev)
+    rs = np.random.RandomState(9)
+    chunk_inds = [torch.from_numpy(rs.choice(3000, 1024 - 17 * i, replace=False)).to(dev) for i in range(5)]
+    mean, label, cnt = D.vote_scene(logits, chunk_inds, 3000)
+    np.testing.assert_allclose(r0['mean'].numpy(), mean.cpu().numpy(), rtol=0, atol=1e-5)
+    assert (r0['label'] == label.cpu()).float().mean() > 0.999
