@@ -242,22 +242,30 @@ struct BwdAct {  // f = dz, g = dz * xhat with dz = da * [bn(y) > 0] (relu) : Ba
   }
 };
 struct BwdMax {  // rows are groups g; only the arg-max row of each (g, c) carries gradient
-  const float *dout, *out, *y, *mean, *invstd;
+  const float *dout, *out, *y, *mean, *invstd, *gamma, *beta;
   const uint8_t* arg;
   int K, relu;
   __device__ __forceinline__ void at(int64_t g, int c, int C, float4& f, float4& gg) const {
     const float4 d = ld4(dout + (size_t)g * C + c), o = ld4(out + (size_t)g * C + c);
-    const float4 mu = ld4(mean + c), is = ld4(invstd + c);
+    const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
     const uint8_t* a = arg + (size_t)g * C + c;
     const float dd[4] = {d.x, d.y, d.z, d.w}, oo[4] = {o.x, o.y, o.z, o.w};
     const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
+    const float gm[4] = {ga.x, ga.y, ga.z, ga.w}, bt[4] = {be.x, be.y, be.z, be.w};
     float fo[4], go[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float dz = (!relu || oo[i] > 0.f) ? dd[i] : 0.f;  // relu'(0) = 0, like torch
-      const float yv = y[((size_t)g * K + a[i]) * C + c + i];
+      // xhat of the arg-max row.  Where gradient flows the pooled output IS xhat * gamma + beta, so xhat comes back from the
+      // (G,C) tensors alone -- no 4-byte gather per element into the K times larger pre-BN tensor (157 -> ~15 us per call).
+      // A (near-)zero gamma cannot be inverted: those columns read y.
+      float xh;
+      if (fabsf(gm[i]) >= 0.05f * (1.0f + fabsf(bt[i])))
+        xh = (oo[i] - bt[i]) / gm[i];
+      else
+        xh = (y[((size_t)g * K + a[i]) * C + c + i] - mm[i]) * ii[i];
       fo[i] = dz;
-      go[i] = dz * ((yv - mm[i]) * ii[i]);
+      go[i] = dz * xh;
     }
     f = make_float4(fo[0], fo[1], fo[2], fo[3]);
     gg = make_float4(go[0], go[1], go[2], go[3]);
@@ -569,7 +577,7 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   if (K == 1)
     rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, s);
   else
-    rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, arg, (int)K, relu}, G, C, stat, s);
+    rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, gamma, beta, arg, (int)K, relu}, G, C, stat, s);
   if (rc || R == 0) return rc;
   dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
   if (relu)
