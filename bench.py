@@ -281,6 +281,35 @@ def main():
             cur = nxt
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / 10 * 1e3 if not args.train_only else float('nan')
+    # configs[3]: whole-scene inference -- 64 chunks of one synthetic scene sharded over the ranks, ONE all-gather of the per-chunk
+    # logits, vote on the device (mvpnet_amd/scene.py).  Extra field; the chunk inputs are the resident batch, tiled.
+    scene = None
+    if not args.train_only:
+        from mvpnet_amd.scene import infer_scene
+        from mvpnet_amd.synthetic import make_scene
+        n_scene_pts, n_scene_chunks = 200000, 64
+        chunk_inds = [torch.from_numpy(a).to(dev) for a in make_scene(0, n_scene_pts, n_scene_chunks, 8192)]
+        mine = D.shard_chunks(n_scene_chunks, rank, world)
+        per = min(args.batch, len(mine))
+        sub = {k: (v[:per] if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == args.batch else v) for k, v in batch.items()}
+        net2d.feature = feature[:per * 3]
+        batches = [dict(sub) for _ in range(len(mine) // per)]
+        if len(mine) == per * len(batches):
+            infer_scene(model, batches, chunk_inds, n_scene_pts)
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                mean_logit, label, cnt = infer_scene(model, batches, chunk_inds, n_scene_pts)
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            scene_ms = (time.perf_counter() - t2) / 3 * 1e3
+            scene = {'chunks_per_s': round(n_scene_chunks / (scene_ms * 1e-3), 1), 'ms_per_scene': round(scene_ms, 3),
+                     'note': 'configs[3]: {} chunks of a {}-point scene sharded over {} rank(s), all-gather of logits + device vote'.format(
+                         n_scene_chunks, n_scene_pts, world)}
+        net2d.feature = feature
     model.train()
 
     if rank == 0:
@@ -296,6 +325,7 @@ def main():
                        'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
+            'scene_inference': scene,
             'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),
                          'note': 'configs[1]: lifting + aggregation + PN2SSG forward, eval mode, same batch, next batch geometry prefetched'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
