@@ -187,6 +187,12 @@ int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centr
 int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream);
 int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,
                         int64_t N2, int64_t ld, float* out, mvp_stream_t stream);
+/* out (B,N2,C) = 3-point interpolation of feature (B,N1,C) (+ add (B,N2,C) if not NULL): feature propagation with the (linear)
+ * first shared-MLP layer applied before the interpolation (pn2/modules.py:135-145,178-186):
+ *   W.[interp(f_sparse) | skip] = interp(Wa.f_sparse) + Wb.skip.
+ * stat (2*C float64, accumulated into) / partial (mvp_group_lin_partial_count(B,C,N2,1) float64) as in mvp_group_lin_rows_f32. */
+int mvp_interp_add_rows_f32(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B, int64_t N1,
+                            int64_t C, int64_t N2, float* out, double* stat, double* partial, mvp_stream_t stream);
 int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B, int64_t N1,
                                  int64_t C, int64_t N2, int64_t ld, float* grad_feature, mvp_stream_t stream);
 /* BatchNorm (+ReLU) (+max over K consecutive rows) on a row matrix y (G*K, C): replaces the BN / ReLU /

@@ -191,6 +191,70 @@ __global__ __launch_bounds__(kRT) void interp_rows_kernel(const float* __restric
   st4(out + ((size_t)b * N2 + n) * ld + c, v);
 }
 
+// interp_add_rows: out[b,n,:] = (f[i0]*w0 + f[i1]*w1) + f[i2]*w2 (+ add[b,n,:]); with `partial` also the column sums of out and
+// out^2 per workgroup (same row blocking and reduction as group_lin_rows_kernel).  Feature propagation applies its (linear) first
+// shared-MLP layer BEFORE the interpolation: W.[interp(f_sparse) | skip] = interp(Wa.f_sparse) + Wb.skip, so the large GEMM runs on
+// the 4x fewer sparse points and this kernel produces the layer's pre-BN output and its batch statistics in one pass.
+__global__ __launch_bounds__(kRT) void interp_add_rows_kernel(const float* __restrict__ feat, const int64_t* __restrict__ idx,
+                                                              const float* __restrict__ w, const float* __restrict__ add, int N1,
+                                                              int C, int N2, float* __restrict__ out,
+                                                              double* __restrict__ partial) {
+  __shared__ float red[2][kRT][4];
+  const int b = blockIdx.y;
+  const int C4 = C >> 2;
+  const int rpp = kRT / C4;
+  const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
+  const int c = c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+#pragma unroll
+  for (int it = 0; it < kGLIter; ++it) {
+    const int64_t n = ((int64_t)blockIdx.x * kGLIter + it) * rpp + rg;
+    if (rg >= rpp || n >= N2) continue;
+    const int64_t* ip = idx + ((size_t)b * N2 + n) * 3;
+    const float* wp = w + ((size_t)b * N2 + n) * 3;
+    const int64_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1) {
+      const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+      const float4 a = ld4(feat + ((size_t)b * N1 + i0) * C + c);
+      const float4 bb = ld4(feat + ((size_t)b * N1 + i1) * C + c);
+      const float4 cc = ld4(feat + ((size_t)b * N1 + i2) * C + c);
+      v.x = (a.x * w0 + bb.x * w1) + cc.x * w2;
+      v.y = (a.y * w0 + bb.y * w1) + cc.y * w2;
+      v.z = (a.z * w0 + bb.z * w1) + cc.z * w2;
+      v.w = (a.w * w0 + bb.w * w1) + cc.w * w2;
+    }
+    if (add != nullptr) {
+      const float4 e = ld4(add + ((size_t)b * N2 + n) * C + c);
+      v = make_float4(v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w);
+    }
+    st4(out + ((size_t)b * N2 + n) * C + c, v);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  }
+  if (partial == nullptr) return;
+  float* a = red[0][threadIdx.x];
+  float* bq = red[1][threadIdx.x];
+  a[0] = s.x; a[1] = s.y; a[2] = s.z; a[3] = s.w;
+  bq[0] = q.x; bq[1] = q.y; bq[2] = q.z; bq[3] = q.w;
+  __syncthreads();
+  if (rg == 0) {
+    double ts[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0};
+    for (int g = 0; g < rpp; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ts[i] += (double)red[0][g * C4 + c4][i];
+        tq[i] += (double)red[1][g * C4 + c4][i];
+      }
+    double* dst = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dst[c + i] = ts[i];
+      dst[C + c + i] = tq[i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kRT) void interp_rows_bwd_kernel(const float* __restrict__ gout,
                                                               const int64_t* __restrict__ idx,
                                                               const float* __restrict__ w, int N1, int C, int N2,
@@ -497,6 +561,24 @@ MVP_API int mvp_interp_rows_f32(const float* feature, const int64_t* index, cons
   dim3 grid((unsigned)cdiv(N2 * (C / 4), kRT), (unsigned)B);
   hipLaunchKernelGGL(interp_rows_kernel, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), feature, index, weight,
                      (int)N1, (int)C, (int)N2, (int)ld, out);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_interp_add_rows_f32(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B,
+                                    int64_t N1, int64_t C, int64_t N2, float* out, double* stat, double* partial,
+                                    mvp_stream_t stream) {
+  MVP_NONNULL(feature);
+  MVP_NONNULL(index);
+  MVP_NONNULL(weight);
+  MVP_NONNULL(out);
+  if (stat) MVP_NONNULL(partial);
+  MVP_REQUIRE(B >= 0 && N1 > 0 && C > 0 && C % 4 == 0 && C <= 1024 && (kRT % (C / 4)) == 0 && N2 >= 0 && B < 65536);
+  if (B == 0 || N2 == 0) return MVP_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t gx = cdiv(N2, (int64_t)kGLIter * (kRT / (C / 4)));
+  hipLaunchKernelGGL(interp_add_rows_kernel, dim3((unsigned)gx, (unsigned)B), dim3(kRT), 0, s, feature, index, weight, add, (int)N1,
+                     (int)C, (int)N2, out, stat ? partial : nullptr);
+  if (stat) launch_stats_reduce(partial, gx * B, (int)(2 * C), stat, s);
   return mvp_launch_status();
 }
 

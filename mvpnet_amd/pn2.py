@@ -193,6 +193,28 @@ class FeaturePropagation(nn.Module):
             assert sparse_xyz.size(1) == 1 and sparse_feature.size(1) == 1
             new_feature = torch.cat([sparse_feature.expand(-1, N, -1), dense_feature], dim=2)
         else:
+            l0 = self.mlp[0]
+            c1 = l0.conv.weight.size(0)
+            c2 = sparse_feature.size(2)
+            if l0.bn is not None and l0.relu is not None and l0.conv.bias is None and l0.bn.running_mean is not None and \
+                    c1 % 4 == 0 and 256 % (c1 // 4) == 0 and c2 % 4 == 0:
+                # The first shared-MLP layer is linear and so is the interpolation:
+                #   W1.[interp(f_sparse) | f_dense] = interp(W1a.f_sparse) + W1b.f_dense
+                # -> the wide GEMM runs on the M = N/4 sparse points; the interpolation kernel adds the skip part and emits
+                #    the layer's pre-BN output together with its batch statistics (modules.py:135-145,178-186; fp32 rounding only).
+                M = sparse_xyz.size(1)
+                index, weight = self.interpolator.geometry(dense_xyz, sparse_xyz) if geometry is None else geometry
+                w1 = l0.conv.weight.reshape(c1, -1)                    # columns [interpolated (C2) | skip (C1)]
+                z = R.linear_rows(sparse_feature.reshape(B * M, c2), w1[:, :c2]).view(B, M, c1)
+                zs = None
+                if dense_feature is not None:
+                    zs = R.linear_rows(dense_feature.reshape(B * N, -1), w1[:, c2:]).view(B, N, c1)
+                bn_training = l0.bn.training
+                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=bn_training)
+                stat1 = None
+                if bn_training:
+                    y1, stat1 = y1
+                return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1).view(B, N, -1)
             new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)
         return R.shared_mlp_rows(new_feature.reshape(B * N, -1), self.mlp).view(B, N, -1)
 

@@ -136,6 +136,49 @@ def interp_rows(feature, index, weight):
     return InterpRows.apply(feature.contiguous(), index.contiguous(), weight.contiguous())
 
 
+class InterpAddRows(torch.autograd.Function):
+    """out = interp(feature; index, weight) (+ add); want_stat: also the float64 column sums [sum out | sum out^2]."""
+
+    @staticmethod
+    def forward(ctx, feature, index, weight, add, want_stat):
+        L.require_gpu(feature, index, weight, add)
+        B, N1, C = feature.shape
+        N2 = index.size(1)
+        dev = feature.device
+        out = torch.empty((B, N2, C), dtype=torch.float32, device=dev)
+        stat = torch.zeros(2 * C, dtype=torch.float64, device=dev) if want_stat else None
+        partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, N2, 1), dtype=torch.float64, device=dev) if want_stat else None
+        L.call('mvp_interp_add_rows_f32', feature, L.ptr(feature), L.ptr(index), L.ptr(weight), L.ptr(add), B, N1, C, N2, L.ptr(out),
+               L.ptr(stat), L.ptr(partial))
+        ctx.save_for_backward(index, weight)
+        ctx.dims = (B, N1, C, N2)
+        ctx.has_add = add is not None
+        if want_stat:
+            ctx.mark_non_differentiable(stat)
+            return out, stat
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out, *unused):
+        index, weight = ctx.saved_tensors
+        B, N1, C, N2 = ctx.dims
+        g = grad_out.contiguous()
+        grad = None
+        if ctx.needs_input_grad[0]:
+            grad = torch.empty((B, N1, C), dtype=torch.float32, device=g.device)
+            L.call('mvp_interp_rows_backward_f32', g, L.ptr(g), L.ptr(index), L.ptr(weight), B, N1, C, N2, C, L.ptr(grad))
+        return grad, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None), None
+
+
+def interp_add_rows(feature, index, weight, add=None, want_stat=False):
+    """feature (B,N1,C), index / weight (B,N2,3), add (B,N2,C) or None -> (B,N2,C) [, stat (2C) float64]."""
+    if feature.dtype != torch.float32 or feature.size(2) % 4:
+        raise RuntimeError('interp_add_rows: float32 feature with C % 4 == 0 expected')
+    return InterpAddRows.apply(feature.contiguous(), index.contiguous(), weight.contiguous(), None if add is None else add.contiguous(),
+                               bool(want_stat))
+
+
 class BNActRows(torch.autograd.Function):
     """BatchNorm (+ReLU) (+max over K consecutive rows) on y (G*K, C); one fused forward and backward."""
 
