@@ -167,6 +167,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-only', action='store_true', help='skip the extra forward-only (configs[1]) measurement (profiling runs)')
+    ap.add_argument('--graph', action='store_true', help='replay forward + backward from ONE captured HIP graph (mvpnet3d.GraphedTrainStep) instead '
+                                                         'of ~400 eager launches; same GPU time on an idle host, immune to a busy one')
     ap.add_argument('--host-profile', action='store_true', help='cProfile the timed loop (host/launch cost), top entries to stderr')
     ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
                                               'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml kept in tests/golden/configs.json')
@@ -225,14 +227,28 @@ def main():
 
     state = {'cur': prefetch_geometry(model, fresh(batch))}
 
-    def step():
-        # every step: (1) starts the geometry (FPS chain, ball queries, 3-NN) of the NEXT batch on the side
-        # stream, (2) runs forward + loss + backward + Adam on the current batch whose geometry was started one
-        # step earlier.  One geometry plan and one train step per timed step.
+    def eager_step():
         cur, nxt = state['cur'], fresh(batch)
         out = train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=grad_sync, next_batch=nxt)
         state['cur'] = nxt
         return out
+
+    if not args.graph:
+
+        def step():
+            # every step: (1) starts the geometry (FPS chain, ball queries, 3-NN) of the NEXT batch on the side
+            # stream, (2) runs forward + loss + backward + Adam on the current batch whose geometry was started one
+            # step earlier.  One geometry plan and one train step per timed step.
+            return eager_step()
+    else:
+        # the same iteration with forward + loss + backward captured in ONE HIP graph (mvpnet3d.GraphedTrainStep):
+        # lifting -> fork: next batch's geometry -> aggregation + PointNet++ -> loss -> backward -> join;
+        # gradient all-reduce, Adam and the scheduler run eagerly after each replay.
+        from mvpnet_amd.mvpnet3d import GraphedTrainStep
+        graphed = GraphedTrainStep(model, loss_fn, optimizer, fresh(batch), fresh(batch), scheduler=scheduler, grad_sync=grad_sync)
+
+        def step():
+            return graphed.step(batch, batch)
 
     for _ in range(args.warmup):
         step()
@@ -257,6 +273,10 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    if args.graph:  # python does not run per replay: time the lifting call in a few eager steps right after the timed region
+        for _ in range(5):
+            eager_step()
+        torch.cuda.synchronize()
     timer.enabled = False
     assert torch.isfinite(loss).item()
     if world > 1:
@@ -323,7 +343,8 @@ def main():
             'config': {'workload': 'configs[2]: MVPNet lifting (unproject + pixel k-NN + gather) + FeatureAggregation + '
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
                        'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
-                       'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world)},
+                       'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world),
+                       'launch': 'hip graph (forward + backward), optimizer eager' if args.graph else 'eager'},
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
             'scene_inference': scene,
             'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),

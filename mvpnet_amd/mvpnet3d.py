@@ -162,3 +162,74 @@ def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_n
     if scheduler is not None:
         scheduler.step()
     return loss.detach(), preds
+
+
+def _plan_tensors(plan):
+    """The tensors of a geometry plan (PN2SSG.plan_geometry) in a fixed order."""
+    return [t for g in plan['sa'] + plan['fp'] if g is not None for t in g]
+
+
+class GraphedTrainStep:
+    """The training iteration of `train_step` with forward + loss + backward captured ONCE in a HIP graph
+    (torch.cuda.CUDAGraph): ~400 kernel launches per step become one graph launch, so the step no longer depends on the
+    host keeping up (8 ranks per node share the CPU) and the launch gaps between the many small kernels disappear.
+
+    The graph holds, for fixed shapes: lifting of batch i -> FORK: FPS / ball query / 3-NN of batch i+1 on the side stream ->
+    aggregation + PointNet++ of batch i with the geometry computed by the PREVIOUS replay -> loss -> backward -> JOIN -> copy
+    of the new geometry into the static plan.  Gradient all-reduce, clipping, optimizer and scheduler stay eager after the
+    replay (they are a handful of multi-tensor launches, and RCCL stays out of the capture).
+
+    step(batch, next_batch) copies the two batches into the static input tensors (keys of the reference's data dict; the 2D
+    feature map is produced inside the graph by model.net_2d) and replays.  Batches must arrive in sequence: `batch` of call
+    i is `next_batch` of call i-1, as with train_step(..., next_batch=...)."""
+
+    COPY_KEYS = ('images', 'points', 'seg_label', 'depth', 'cam_matrix', 'kinv', 'pose', 'pixel_box', 'image_xyz', 'knn_indices')
+
+    def __init__(self, model, loss_fn, optimizer, batch, next_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, warmup=3):
+        self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
+        self.scheduler, self.max_grad_norm, self.grad_sync = scheduler, max_grad_norm, grad_sync
+        net = model.module if hasattr(model, 'module') else model
+        self.static = {k: (v.clone() if torch.is_tensor(v) and k in self.COPY_KEYS else v) for k, v in batch.items()
+                       if k not in ('geometry_plan', 'prefetch_next')}
+        self.static_next = {'points': next_batch['points'].clone()}
+        dev = self.static['points'].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # eager warm-up off the default stream (allocator, lazy module state)
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                loss = loss_fn(model(dict(self.static)), self.static)['seg_loss']
+                loss.backward()
+            plan = net.net_3d.plan_geometry(self.static['points'].transpose(1, 2).contiguous())
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.plan = {'sa': plan['sa'], 'fp': plan['fp'], 'event': None, 'stream': None}  # static geometry of the CURRENT batch
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            nxt = dict(self.static_next)
+            preds = model(dict(self.static, geometry_plan=self.plan, prefetch_next=nxt))
+            self.loss = loss_fn(preds, self.static)['seg_loss']
+            self.loss.backward()
+            new_plan = nxt['geometry_plan']
+            torch.cuda.current_stream(dev).wait_event(new_plan['event'])  # join the side stream
+            for dst, src in zip(_plan_tensors(self.plan), _plan_tensors(new_plan)):
+                dst.copy_(src)
+            self.preds = preds
+
+    def step(self, batch=None, next_batch=None):
+        if batch is not None:
+            for k, v in batch.items():
+                if k in self.COPY_KEYS and torch.is_tensor(v) and v.data_ptr() != self.static[k].data_ptr():
+                    self.static[k].copy_(v)
+        if next_batch is not None and next_batch['points'].data_ptr() != self.static_next['points'].data_ptr():
+            self.static_next['points'].copy_(next_batch['points'])
+        self.graph.replay()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        if self.max_grad_norm > 0:
+            nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_grad_norm)
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return self.loss.detach(), self.preds

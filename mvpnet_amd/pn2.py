@@ -279,8 +279,12 @@ class PN2SSG(nn.Module):
                 fp.append(None if m.interpolator is None else m.interpolator.geometry(xyzs[-2 - level], xyzs[-1 - level]))
             event = torch.cuda.Event()
             event.record()
-        plan = {'sa': sa, 'fp': fp, 'event': event, 'stream': stream}
-        if stream is not None:  # tensors were allocated on the side stream but are consumed on the caller's
+        # `xyz` is read by the side stream long after this function returns (ball query / 3-NN of level 1 run after the 2.4 ms
+        # FPS): the plan keeps it alive, otherwise the caller's stream may recycle its memory while it is still being read.
+        plan = {'sa': sa, 'fp': fp, 'event': event, 'stream': stream, 'xyz': xyz}
+        if stream is not None and not torch.cuda.is_current_stream_capturing():
+            xyz.record_stream(stream)
+        if stream is not None and not torch.cuda.is_current_stream_capturing():  # tensors were allocated on the side stream but are consumed on the caller's
             for g in sa + fp:
                 if g is not None:
                     for t in g:
@@ -292,7 +296,7 @@ class PN2SSG(nn.Module):
         [+ 'geometry_plan' from plan_geometry()] -> {'seg_logit': (B,num_classes,N)}."""
         xyz = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
         plan = data_batch.get('geometry_plan')
-        if plan is not None:
+        if plan is not None and plan.get('event') is not None:
             torch.cuda.current_stream(xyz.device).wait_event(plan['event'])
         if 'feature_rows' in data_batch:
             feature = data_batch['feature_rows']
