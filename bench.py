@@ -330,6 +330,39 @@ def main():
                      'note': 'configs[3]: {} chunks of a {}-point scene sharded over {} rank(s), all-gather of logits + device vote'.format(
                          n_scene_chunks, n_scene_pts, world)}
         net2d.feature = feature
+    # True end-to-end step: the frozen 2D network (UNetResNet34 built from the YAML, BatchNorm folded, channels_last, MIOpen
+    # convolutions) produces the feature map from images every step instead of the resident one.  Extra field only: the 2D network
+    # is outside the hot path and runs on the vendor convolution library.
+    e2e = None
+    if not args.train_only:
+        torch.manual_seed(0)
+        model2 = C.build_model_mvpnet_3d(cfg).to(dev).train()
+        model2.net_2d.eval()
+        opt2 = C.build_optimizer(cfg, model2)
+        b2 = dict(batch, images=torch.randn(args.batch, 3, 3, 120, 160, device=dev))
+        e2e = {}
+        for tag, ctx in (('fp32', None), ('bf16_2d_net', torch.bfloat16)):
+            fwd2d = model2.net_2d.forward
+            if ctx is not None:  # autocast only around the frozen 2D network; lifting / PointNet++ stay fp32
+                def cast_forward(data, _f=fwd2d):
+                    with torch.autocast('cuda', dtype=torch.bfloat16):
+                        out = _f(data)
+                    return {'feature': out['feature'].float()}
+                model2.net_2d.forward = cast_forward
+            cur2 = prefetch_geometry(model2, fresh(b2))
+            for i in range(7):
+                if i == 2:
+                    torch.cuda.synchronize()
+                    t3 = time.perf_counter()
+                nxt2 = fresh(b2)
+                train_step(model2, loss_fn, opt2, cur2, next_batch=nxt2)
+                cur2 = nxt2
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t3) / 5 * 1e3
+            e2e[tag] = {'chunks_per_s_per_gpu': round(args.batch / (ms2 * 1e-3), 1), 'ms_per_step': round(ms2, 3)}
+            model2.net_2d.forward = fwd2d
+        e2e['note'] = 'full train step INCLUDING the frozen UNetResNet34 forward on 3x160x120 images (mvpnet_amd/unet_resnet34.py)'
+        del model2, opt2
     model.train()
 
     if rank == 0:
@@ -346,6 +379,7 @@ def main():
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world),
                        'launch': 'hip graph (forward + backward), optimizer eager' if args.graph else 'eager'},
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
+            'with_2d_network': e2e,
             'scene_inference': scene,
             'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),
                          'note': 'configs[1]: lifting + aggregation + PN2SSG forward, eval mode, same batch, next batch geometry prefetched'},

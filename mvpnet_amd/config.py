@@ -152,14 +152,24 @@ def build_model_sem_seg_3d(cfg):
     return PN2SSG(**dict(cfg.MODEL.get('PN2SSG', {})))
 
 
-def build_model_mvpnet_3d(cfg, net_2d, load_2d_ckpt=False):
-    """mvpnet/models/build.py:38-47.  `net_2d`: the 2D network instance (UNetResNet34 is out of scope here,
-    SURVEY.md sec.8f rank 2); everything else -- PN2SSG, FeatureAggregation, CKPT_PATH -- comes from cfg."""
+def build_model_mvpnet_3d(cfg, net_2d=None, load_2d_ckpt=False, freeze_2d=True):
+    """mvpnet/models/build.py:23-47.  net_2d=None: built from cfg.MODEL_2D (TYPE UNetResNet34, mvpnet_amd/unet_resnet34.py);
+    with freeze_2d (the reference trains MVPNet with the 2D branch frozen, train_mvpnet_3d.py FROZEN_PATTERNS) it is put in
+    folded channels-last inference form AFTER an optional CKPT_PATH load.  A module instance can be supplied instead (e.g. a
+    feature provider); PN2SSG, FeatureAggregation and CKPT_PATH always come from cfg."""
     from .pn2 import PN2SSG
     from .mvpnet3d import MVPNet3D
     assert cfg.TASK == 'mvpnet_3d' and cfg.MODEL_3D.TYPE == 'PN2SSG', (cfg.TASK, cfg.MODEL_3D.TYPE)
+    built_here = net_2d is None
+    if built_here:
+        from .unet_resnet34 import UNetResNet34
+        assert cfg.MODEL_2D.TYPE == 'UNetResNet34', cfg.MODEL_2D.TYPE
+        net_2d = UNetResNet34(**dict(cfg.MODEL_2D.get('UNetResNet34', {})))
     net_3d = PN2SSG(**dict(cfg.MODEL_3D.get('PN2SSG', {})))
-    return MVPNet3D(net_2d, cfg.MODEL_2D.get('CKPT_PATH', '') if load_2d_ckpt else '', net_3d, **dict(cfg.FEAT_AGGR))
+    model = MVPNet3D(net_2d, cfg.MODEL_2D.get('CKPT_PATH', '') if load_2d_ckpt else '', net_3d, **dict(cfg.FEAT_AGGR))
+    if built_here and freeze_2d:
+        model.net_2d = net_2d.frozen_inference()
+    return model
 
 
 def build_optimizer(cfg, model):

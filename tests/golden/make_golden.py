@@ -505,6 +505,34 @@ def gen_configs():
     print('configs.json')
 
 
+def gen_unet():
+    """UNetResNet34 (mvpnet/models/unet_resnet34.py): the REFERENCE class run on CPU.  torchvision is not installed here, so
+    `torchvision.models.resnet.resnet34` is provided by this repo's restatement of the standard ResNet-34 encoder
+    (mvpnet_amd/unet_resnet34.py::resnet34); what the fixture pins is the reference's own code: key names, the stride-1 stem,
+    padding to multiples of 16, skip concatenation order, decoder, crop, outputs.  Seeded weights, eval mode."""
+    from mvpnet_amd import unet_resnet34 as mine
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tvr = types.ModuleType('torchvision.models.resnet')
+    tvr.resnet34 = lambda pretrained=False: mine.ResNet34()
+    tv.models, tvm.resnet = tvm, tvr
+    sys.modules.update({'torchvision': tv, 'torchvision.models': tvm, 'torchvision.models.resnet': tvr})
+    from mvpnet.models.unet_resnet34 import UNetResNet34 as Ref
+    ref = Ref(20, p=0.0, pretrained=False)
+    shapes = load_into(ref, 404)
+    ref.eval()
+    out = {'state_keys': json.dumps([[k, list(v)] for k, v in shapes.items()])}
+    rs = np.random.RandomState(405)
+    for name, (h, w) in (('a', (48, 64)), ('b', (30, 40))):  # multiples of 16 / padded + cropped
+        x = rs.standard_normal((2, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            pr = ref({'image': torch.from_numpy(x)})
+        out[name + '_image'] = x
+        out[name + '_feature'] = pr['feature'].numpy()
+        out[name + '_seg_logit'] = pr['seg_logit'].numpy()
+    save('unet_resnet34', **out)
+
+
 def main():
     gen_configs()
     T = install_reference()
@@ -516,6 +544,7 @@ def main():
     lifting = gen_lifting()
     gen_modules(lifting)
     gen_vote_trainstep()
+    gen_unet()
     import sklearn
     manifest = dict(numpy=np.__version__, torch=torch.__version__, sklearn=sklearn.__version__,
                     reference='/root/reference (maxjaritz/mvpnet @ v0)', generator='tests/golden/make_golden.py')

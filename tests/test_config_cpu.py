@@ -30,6 +30,12 @@ def test_mvpnet_3d_yaml():
     sched = C.build_scheduler(cfg, opt)
     assert isinstance(opt, torch.optim.Adam) and opt.defaults['lr'] == 0.002 and opt.defaults['betas'] == (0.9, 0.999)
     assert isinstance(sched, torch.optim.lr_scheduler.MultiStepLR) and sorted(sched.milestones) == [24000, 32000]
+    # the whole model from the YAML alone: MODEL_2D.TYPE UNetResNet34, frozen (folded BatchNorm, channels-last)
+    full = C.build_model_mvpnet_3d(cfg)
+    assert type(full.net_2d).__name__ == 'UNetResNet34' and full.net_2d.num_classes == 20
+    assert not any(p.requires_grad for p in full.net_2d.parameters())
+    trainable = sum(p.numel() for p in full.parameters() if p.requires_grad)
+    assert trainable == 967092 + 12928
 
 
 def test_pn2ssg_chunk_yaml():

@@ -252,3 +252,24 @@ def test_graphed_train_step_matches_eager(dev):
         graphed.append(float(g.step(seq[i], seq[i + 1])[0]))
     np.testing.assert_allclose(graphed[:2], eager[:2], rtol=1e-5)
     np.testing.assert_allclose(graphed[2], eager[2], rtol=2e-3)
+
+
+def test_unet_resnet34_frozen_channels_last(dev):
+    """UNetResNet34 in its frozen form on the GPU (BatchNorm folded, channels_last, MIOpen convolutions) against the golden
+    vectors of the imported reference class, and feeding MVPNet3D's device lifting without a layout copy."""
+    import collections
+    import json
+    from mvpnet_amd.unet_resnet34 import UNetResNet34
+    g = load_golden('unet_resnet34')
+    net = UNetResNet34(20)
+    keys = collections.OrderedDict((k, tuple(s)) for k, s in json.loads(str(g['state_keys'])))
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in fill_state_dict(keys, 404).items()})
+    net = net.frozen_inference().to(dev)
+    for name in ('a', 'b'):
+        x = torch.from_numpy(g[name + '_image']).to(dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            out = net({'image': x})
+        assert out['feature'].permute(0, 2, 3, 1).is_contiguous()
+        np.testing.assert_allclose(out['feature'].cpu().numpy(), g[name + '_feature'], rtol=0, atol=1e-4 * np.abs(g[name + '_feature']).max())
+        np.testing.assert_allclose(out['seg_logit'].cpu().numpy(), g[name + '_seg_logit'], rtol=0,
+                                   atol=1e-4 * np.abs(g[name + '_seg_logit']).max())

@@ -1,0 +1,46 @@
+"""UNetResNet34 against the golden vectors of the imported reference class (decoder, padding, crop,
+key names; the ResNet-34 encoder blocks are this repo's restatement -- see the module docstring).  Pure torch, runs on CPU."""
+import collections
+import json
+
+import numpy as np
+import torch
+
+from mvpnet_amd.unet_resnet34 import UNetResNet34
+from tests.conftest import load_golden
+from tests.golden.weights import fill_state_dict
+
+
+def _load(model, g, seed=404):
+    ref_keys = [(k, tuple(s)) for k, s in json.loads(str(g['state_keys']))]
+    mine = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert mine == ref_keys, 'state_dict keys / shapes differ from the reference (checkpoints would not load)'
+    sd = fill_state_dict(collections.OrderedDict(ref_keys), seed)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return model.eval()
+
+
+def test_unet_matches_reference():
+    g = load_golden('unet_resnet34')
+    model = _load(UNetResNet34(20), g)
+    # torchvision's resnet34 has 21 797 672 parameters, 513 000 of them in the fc layer the U-Net drops; decoder + head: 2 330 900
+    assert sum(p.numel() for p in model.parameters()) == 21_797_672 - 513_000 + 2_330_900
+    for name in ('a', 'b'):
+        with torch.no_grad():
+            out = model({'image': torch.from_numpy(g[name + '_image'])})
+        np.testing.assert_allclose(out['feature'].numpy(), g[name + '_feature'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out['seg_logit'].numpy(), g[name + '_seg_logit'], rtol=1e-4, atol=1e-5)
+
+
+def test_unet_folded_channels_last():
+    g = load_golden('unet_resnet34')
+    model = _load(UNetResNet34(20), g).frozen_inference()
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in model.modules())
+    assert not any(p.requires_grad for p in model.parameters())
+    x = torch.from_numpy(g['b_image']).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        out = model({'image': x})
+    assert out['feature'].permute(0, 2, 3, 1).is_contiguous()  # (B*nv, h, w, C) rows, as the lifting kernel reads them
+    scale = np.abs(g['b_feature']).max()
+    np.testing.assert_allclose(out['feature'].numpy(), g['b_feature'], rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(out['seg_logit'].numpy(), g['b_seg_logit'], rtol=0, atol=2e-5 * np.abs(g['b_seg_logit']).max())
