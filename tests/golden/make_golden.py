@@ -533,6 +533,39 @@ def gen_unet():
     save('unet_resnet34', **out)
 
 
+def gen_chunker():
+    """scene2chunks_legacy (mvpnet/utils/chunk_util.py:4-53, imported) and select_frames (scannet_2d3d.py:20-30; that module
+    imports open3d, so its 9 lines are re-typed here) on seeded synthetic scenes."""
+    from mvpnet.utils.chunk_util import scene2chunks_legacy
+
+    def select_frames(rgbd_overlap, num_rgbd_frames):  # scannet_2d3d.py:20-30
+        selected_frames = []
+        rgbd_overlap = rgbd_overlap.copy()
+        for i in range(num_rgbd_frames):
+            frame_idx = rgbd_overlap.sum(0).argmax()
+            selected_frames.append(frame_idx)
+            rgbd_overlap[rgbd_overlap[:, frame_idx]] = False
+        return selected_frames
+
+    out = {}
+    for ci, (n, ext, stride, thresh) in enumerate([(20000, (6.0, 5.0, 2.5), 0.5, 500), (3000, (2.0, 1.2, 2.0), 0.75, 200),
+                                                   (50000, (9.3, 7.7, 3.0), 1.0, 1000)]):
+        rs = np.random.RandomState(900 + ci)
+        pts = (rs.uniform(0, 1, (n, 3)) * np.array(ext) + rs.uniform(-3, 3, 3)).astype(np.float32)
+        idx, boxes = scene2chunks_legacy(pts, (1.5, 1.5), stride, thresh=thresh, margin=(0.2, 0.2), return_bbox=True)
+        out['c%d_points' % ci] = pts
+        out['c%d_args' % ci] = np.array([stride, thresh], np.float64)
+        out['c%d_lengths' % ci] = np.array([len(i) for i in idx], np.int64)
+        out['c%d_indices' % ci] = np.concatenate(idx).astype(np.int64) if idx else np.zeros(0, np.int64)
+        out['c%d_boxes' % ci] = np.stack(boxes).astype(np.float64) if boxes else np.zeros((0, 6))
+    for ci, (npts, nfr, p) in enumerate([(500, 40, 0.1), (64, 7, 0.5), (300, 25, 0.02)]):
+        rs = np.random.RandomState(950 + ci)
+        ov = rs.uniform(size=(npts, nfr)) < p
+        out['f%d_overlap' % ci] = ov
+        out['f%d_selected' % ci] = np.array(select_frames(ov, 3), np.int64)
+    save('chunker', **out)
+
+
 def main():
     gen_configs()
     T = install_reference()
@@ -545,6 +578,7 @@ def main():
     gen_modules(lifting)
     gen_vote_trainstep()
     gen_unet()
+    gen_chunker()
     import sklearn
     manifest = dict(numpy=np.__version__, torch=torch.__version__, sklearn=sklearn.__version__,
                     reference='/root/reference (maxjaritz/mvpnet @ v0)', generator='tests/golden/make_golden.py')
