@@ -187,6 +187,18 @@ int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centr
 int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream);
 int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,
                         int64_t N2, int64_t ld, float* out, mvp_stream_t stream);
+/* Transposed index of a gather out[b,e] = f[b, index[b,e]] (index (B,E) int64, values outside [0,N) are ignored):
+ *   offsets (B,N+1) int32, slots (B,E) int32: the positions e that read point j are slots[b][offsets[b][j] .. offsets[b][j+1]).
+ * cursor: (B,N) int32 scratch.  With it the scatter-add backward of group_points / feature_interpolate
+ * (group_points_kernel.cu:50-89, interpolate_kernel.cu:131-174: one atomicAdd per element) is a gather:
+ *   grad_feature (B,N,C) = sum over the slots p of point j of weight[b,p] * grad_out[b, slot / S, :]
+ * (weight NULL = 1; S = slots per grad_out row: 1 for the grouping with E = M*K rows, 3 for the 3-NN interpolation with E = 3*N2).
+ * No atomics on the data, no zero fill, reproducible up to the order of the slots inside one point's list. */
+int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots, int32_t* cursor,
+                      mvp_stream_t stream);
+int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_t* offsets, const int32_t* slots, const float* weight,
+                                     int64_t B, int64_t N, int64_t C, int64_t E, int64_t S, int64_t ld, float* grad_feature,
+                                     mvp_stream_t stream);
 /* out (B,N2,C) = 3-point interpolation of feature (B,N1,C) (+ add (B,N2,C) if not NULL): feature propagation with the (linear)
  * first shared-MLP layer applied before the interpolation (pn2/modules.py:135-145,178-186):
  *   W.[interp(f_sparse) | skip] = interp(Wa.f_sparse) + Wb.skip.

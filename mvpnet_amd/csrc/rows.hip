@@ -275,6 +275,91 @@ __global__ __launch_bounds__(kRT) void interp_rows_bwd_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Transposed index ("who references point j"): the scatter-add backward of a gather, out[e] = f[idx[e]], as a GATHER.
+//   offsets (B, N+1) int32: slots of point j are slots[b][offsets[j] .. offsets[j+1])
+//   slots   (B, E)   int32: positions e, grouped by idx[e] (order inside a group: arrival order of the fill atomics)
+// Built by counting sort (count atomics -> per-chunk scan -> fill atomics on 4-byte cursors); the row-wide float atomics of the
+// scatter (67 M per call at SA level 1: 399 us) become plain coalesced row reads, and the result needs no zero fill.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRT) void csr_count_kernel(const int64_t* __restrict__ idx, int64_t E, int N, int* __restrict__ counts) {
+  const int b = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  if (e >= E) return;
+  const int64_t j = idx[(size_t)b * E + e];
+  if (j >= 0 && j < N) atomicAdd(counts + (size_t)b * (N + 1) + j + 1, 1);
+}
+
+// one workgroup per chunk: inclusive scan of counts[1..N] in place (counts[0] = 0) -> offsets; cursor = copy of the starts
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int* __restrict__ offsets, int* __restrict__ cursor, int N) {
+  __shared__ int part[1024];
+  int* o = offsets + (size_t)blockIdx.x * (N + 1);
+  int* cur = cursor + (size_t)blockIdx.x * N;
+  const int per = (N + 1023) / 1024;
+  const int j0 = threadIdx.x * per;
+  int sum = 0;
+  for (int i = 0; i < per; ++i)
+    if (j0 + i < N) sum += o[j0 + i + 1];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele over the 1024 partial sums
+    const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  if (threadIdx.x == 0) o[0] = 0;
+  for (int i = 0; i < per; ++i)
+    if (j0 + i < N) {
+      cur[j0 + i] = run;
+      run += o[j0 + i + 1];
+      o[j0 + i + 1] = run;
+    }
+}
+
+__global__ __launch_bounds__(kRT) void csr_fill_kernel(const int64_t* __restrict__ idx, int64_t E, int N, int* __restrict__ cursor,
+                                                       int* __restrict__ slots) {
+  const int b = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  if (e >= E) return;
+  const int64_t j = idx[(size_t)b * E + e];
+  if (j >= 0 && j < N) slots[(size_t)b * E + atomicAdd(cursor + (size_t)b * N + j, 1)] = (int)e;
+}
+
+// grad_feature[b,j,:] = sum over the slots p of point j of  w[p] * grad_out[b, slot / S, :]   (w == nullptr: 1; S = slots per row:
+// 1 for the grouping, 3 for the 3-NN interpolation).  One lane per (point, 4 channels).
+__global__ __launch_bounds__(kRT) void gather_bwd_csr_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
+                                                             const int* __restrict__ slots, const float* __restrict__ w, int N,
+                                                             int C, int64_t E, int S, int ld, float* __restrict__ gfeat) {
+  const int b = blockIdx.y;
+  const int C4 = C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t j = t / C4;
+  const int c = (int)(t - j * C4) * 4;
+  if (j >= N) return;
+  const int* o = offsets + (size_t)b * (N + 1) + j;
+  const int p0 = o[0], p1 = o[1];
+  const int* sl = slots + (size_t)b * E;
+  const float* g = gout + (size_t)b * (E / S) * ld;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = p0;
+  for (; p + 1 < p1; p += 2) {  // two independent row loads in flight
+    const int e0 = sl[p], e1 = sl[p + 1];
+    const float4 a = ld4(g + (size_t)(e0 / S) * ld + c), bb = ld4(g + (size_t)(e1 / S) * ld + c);
+    const float w0 = w ? w[(size_t)b * E + e0] : 1.f, w1 = w ? w[(size_t)b * E + e1] : 1.f;
+    acc.x += a.x * w0; acc.y += a.y * w0; acc.z += a.z * w0; acc.w += a.w * w0;
+    acc.x += bb.x * w1; acc.y += bb.y * w1; acc.z += bb.z * w1; acc.w += bb.w * w1;
+  }
+  if (p < p1) {
+    const int e0 = sl[p];
+    const float4 a = ld4(g + (size_t)(e0 / S) * ld + c);
+    const float w0 = w ? w[(size_t)b * E + e0] : 1.f;
+    acc.x += a.x * w0; acc.y += a.y * w0; acc.z += a.z * w0; acc.w += a.w * w0;
+  }
+  st4(gfeat + ((size_t)b * N + j) * C + c, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Column statistics over rows: stat[0:C] += sum_r f(r,c), stat[C:2C] += sum_r g(r,c) in float64.
 // Each thread sums a short run of rows in fp32, workgroup partials are combined in fp64 through LDS
 // and one fp64 atomic per (workgroup, column, statistic) goes to global memory.
@@ -547,6 +632,37 @@ MVP_API int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* in
   dim3 grid((unsigned)cdiv(M * K * C, kRT), (unsigned)B);
   hipLaunchKernelGGL(group_rows_bwd_kernel, grid, dim3(kRT), 0, s, grad_out, index, (int)N, (int)C, M * K, (int)ld,
                      grad_feature);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots,
+                              int32_t* cursor, mvp_stream_t stream) {
+  MVP_NONNULL(index);
+  MVP_NONNULL(offsets);
+  MVP_NONNULL(slots);
+  MVP_NONNULL(cursor);
+  MVP_REQUIRE(B >= 0 && E >= 0 && N > 0 && B < 65536 && E < (1ll << 31) && N < (1ll << 30));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0) return MVP_OK;
+  hipError_t e = hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)(B * (N + 1)), s);
+  if (e != hipSuccess) return (int)e;
+  if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)cdiv(E, kRT), (unsigned)B), dim3(kRT), 0, s, index, E, (int)N, offsets);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3((unsigned)B), dim3(1024), 0, s, offsets, cursor, (int)N);
+  if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)cdiv(E, kRT), (unsigned)B), dim3(kRT), 0, s, index, E, (int)N, cursor, slots);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_t* offsets, const int32_t* slots, const float* weight,
+                                             int64_t B, int64_t N, int64_t C, int64_t E, int64_t S, int64_t ld, float* grad_feature,
+                                             mvp_stream_t stream) {
+  MVP_NONNULL(grad_out);
+  MVP_NONNULL(offsets);
+  MVP_NONNULL(slots);
+  MVP_NONNULL(grad_feature);
+  MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && E >= 0 && S >= 1 && E % S == 0 && ld >= C && ld % 4 == 0 && B < 65536);
+  if (B == 0) return MVP_OK;
+  hipLaunchKernelGGL(gather_bwd_csr_kernel, dim3((unsigned)cdiv(N * (C / 4), kRT), (unsigned)B), dim3(kRT), 0,
+                     static_cast<hipStream_t>(stream), grad_out, offsets, slots, weight, (int)N, (int)C, E, (int)S, (int)ld, grad_feature);
   return mvp_launch_status();
 }
 

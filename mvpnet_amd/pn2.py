@@ -61,8 +61,9 @@ class SetAbstraction(nn.Module):
         self.mlp = SharedMLP(self.in_channels, mlp_channels, ndim=2, bn=True)
         self.grouper = None if num_centroids == 0 else QueryGrouper(radius, max_neighbors)
 
-    def geometry(self, xyz):
-        """Everything of this layer that depends on coordinates only: centroids + neighbour index."""
+    def geometry(self, xyz, with_csr=False):
+        """Everything of this layer that depends on coordinates only: centroids + neighbour index
+        [+ with_csr: the transposed index (offsets, slots) the backward of the grouping gathers through]."""
         with torch.no_grad():
             if self.num_centroids == -1:
                 new_xyz = xyz
@@ -70,6 +71,8 @@ class SetAbstraction(nn.Module):
                 index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False)
                 new_xyz = torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
             ball = ops.ball_query(new_xyz, xyz, self.radius, self.max_neighbors, transpose=False)
+            if with_csr:
+                return (new_xyz, ball) + R.build_csr(ball, xyz.size(1))
         return new_xyz, ball
 
     def forward_rows(self, xyz, feature=None, geometry=None):
@@ -81,7 +84,9 @@ class SetAbstraction(nn.Module):
             new_xyz = xyz.new_zeros([B, 1, 3])
             x = torch.cat([feature, xyz], dim=2) if self.use_xyz else feature
             return new_xyz, R.shared_mlp_rows(x.reshape(B * N, -1), self.mlp, K=N).view(B, 1, -1)
-        new_xyz, ball = self.geometry(xyz) if geometry is None else geometry
+        geometry = self.geometry(xyz) if geometry is None else geometry
+        new_xyz, ball = geometry[0], geometry[1]
+        csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
         M, K = new_xyz.size(1), self.max_neighbors
         if use_feature and not self.use_xyz:
             raise NotImplementedError('use_xyz=False with features is not on the rows path')
@@ -102,7 +107,7 @@ class SetAbstraction(nn.Module):
                 w1f = torch.nn.functional.pad(w1[:, :cf], (0, pad)) if pad else w1[:, :cf]
                 zf = R.linear_rows(f.reshape(B * N, -1), w1f).view(B, N, c1)
             bn_training = l0.bn.training
-            y1 = R.group_lin_rows(zf, xyz, new_xyz, w1[:, -3:], ball, want_stat=bn_training)  # (B,M,K,C_1): conv output of layer 1
+            y1 = R.group_lin_rows(zf, xyz, new_xyz, w1[:, -3:], ball, want_stat=bn_training, csr=csr)  # (B,M,K,C_1): conv output of layer 1
             stat1 = None
             if bn_training:
                 y1, stat1 = y1
@@ -150,18 +155,21 @@ class FeatureInterpolator(nn.Module):
             return interpolated
         return torch.cat([interpolated, query_feature], dim=1)
 
-    def geometry(self, query_xyz, key_xyz):
-        """3-NN index and inverse-squared-distance weights (coordinates only)."""
+    def geometry(self, query_xyz, key_xyz, with_csr=False):
+        """3-NN index and inverse-squared-distance weights (coordinates only) [+ with_csr: the transposed index]."""
         with torch.no_grad():
             index, distance = ops.knn_distance(query_xyz, key_xyz, self.num_neighbors, transpose=False)
             inv = 1.0 / torch.clamp(distance, min=self._eps)
             weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            if with_csr:
+                return (index, weight) + R.build_csr(index, key_xyz.size(1))
         return index, weight
 
     def forward_rows(self, query_xyz, key_xyz, query_feature, key_feature, geometry=None):
         """query_xyz (B,N1,3), key_xyz (B,N2,3), query_feature (B,N1,C1) or None, key_feature (B,N2,C2)
         -> (B,N1,C2[+C1]) rows, interpolated features first (modules.py:145)."""
-        index, weight = self.geometry(query_xyz, key_xyz) if geometry is None else geometry
+        geometry = self.geometry(query_xyz, key_xyz) if geometry is None else geometry
+        index, weight = geometry[0], geometry[1]
         interpolated = R.interp_rows(key_feature, index, weight)
         if query_feature is None:
             return interpolated
@@ -203,14 +211,16 @@ class FeaturePropagation(nn.Module):
                 # -> the wide GEMM runs on the M = N/4 sparse points; the interpolation kernel adds the skip part and emits
                 #    the layer's pre-BN output together with its batch statistics (modules.py:135-145,178-186; fp32 rounding only).
                 M = sparse_xyz.size(1)
-                index, weight = self.interpolator.geometry(dense_xyz, sparse_xyz) if geometry is None else geometry
+                geometry = self.interpolator.geometry(dense_xyz, sparse_xyz) if geometry is None else geometry
+                index, weight = geometry[0], geometry[1]
+                csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
                 w1 = l0.conv.weight.reshape(c1, -1)                    # columns [interpolated (C2) | skip (C1)]
                 z = R.linear_rows(sparse_feature.reshape(B * M, c2), w1[:, :c2]).view(B, M, c1)
                 zs = None
                 if dense_feature is not None:
                     zs = R.linear_rows(dense_feature.reshape(B * N, -1), w1[:, c2:]).view(B, N, c1)
                 bn_training = l0.bn.training
-                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=bn_training)
+                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=bn_training, csr=csr)
                 stat1 = None
                 if bn_training:
                     y1, stat1 = y1
@@ -256,27 +266,31 @@ class PN2SSG(nn.Module):
         self.seg_logit = nn.Conv1d(seg_channels[-1], num_classes, 1, bias=True)
         self.reset_parameters()
 
-    def plan_geometry(self, xyz, stream=None):
+    def plan_geometry(self, xyz, stream=None, with_csr=None):
         """All coordinate-only work of the network -- 4 x (FPS, ball query) and 4 x (3-NN + weights) -- as a
         plan that forward() consumes.  FPS is a chain of ~2700 dependent steps that occupies only B CUs; with
         `stream` (a side HIP stream) it runs concurrently with the feature path (lifting, aggregation MLP) on
-        the caller's stream.  The plan records an event; forward() makes the current stream wait for it."""
+        the caller's stream.  The plan records an event; forward() makes the current stream wait for it.
+        with_csr (default: training with gradients enabled): also the transposed ball / 3-NN indices, so the backward of
+        the grouping and of the interpolation gathers instead of scattering with atomics."""
+        if with_csr is None:
+            with_csr = self.training and torch.is_grad_enabled()
         cur = torch.cuda.current_stream(xyz.device)
         if stream is not None:
             stream.wait_stream(cur)
         with torch.cuda.stream(stream if stream is not None else cur):
             sa, xyzs = [], [xyz]
-            for m in self.sa_modules:
+            for level, m in enumerate(self.sa_modules):
                 if m.num_centroids == 0:
                     sa.append(None)
                     xyzs.append(xyz.new_zeros([xyz.size(0), 1, 3]))
                     continue
-                g = m.geometry(xyzs[-1])
+                g = m.geometry(xyzs[-1], with_csr=with_csr and (level > 0 or self.in_channels > 0))
                 sa.append(g)
                 xyzs.append(g[0])
             fp = []
             for level, m in enumerate(self.fp_modules):
-                fp.append(None if m.interpolator is None else m.interpolator.geometry(xyzs[-2 - level], xyzs[-1 - level]))
+                fp.append(None if m.interpolator is None else m.interpolator.geometry(xyzs[-2 - level], xyzs[-1 - level], with_csr=with_csr))
             event = torch.cuda.Event()
             event.record()
         # `xyz` is read by the side stream long after this function returns (ball query / 3-NN of level 1 run after the 2.4 ms

@@ -55,6 +55,20 @@ def group_rows(feature, xyz, center, index):
                            index.contiguous())
 
 
+def build_csr(index, N):
+    """index (B, ...) int64 positions into N points -> (offsets (B,N+1) int32, slots (B,E) int32): for every point the list of
+    flattened positions that read it (mvp_csr_build_i64).  Turns the scatter-add backward of a gather into a gather."""
+    B = index.size(0)
+    flat = index.reshape(B, -1)
+    E = flat.size(1)
+    dev = index.device
+    offsets = torch.empty((B, N + 1), dtype=torch.int32, device=dev)
+    slots = torch.empty((B, E), dtype=torch.int32, device=dev)
+    cursor = torch.empty((B, N), dtype=torch.int32, device=dev)
+    L.call('mvp_csr_build_i64', flat, L.ptr(flat), B, E, N, L.ptr(offsets), L.ptr(slots), L.ptr(cursor))
+    return offsets, slots
+
+
 class GroupLinRows(torch.autograd.Function):
     """out[b,m,k,:] = zf[b,j,:] + wxyz . (xyz[b,j] - centre[b,m]),  j = index[b,m,k]   (zf may be None).
     want_stat: also return the float64 column sums [sum out | sum out^2] (the BatchNorm batch statistics of this layer,
@@ -62,7 +76,7 @@ class GroupLinRows(torch.autograd.Function):
     gradient on this path (the reference computes them under no_grad too: fps.py:11-13, modules.py:22-27 on leaf points)."""
 
     @staticmethod
-    def forward(ctx, zf, xyz, centre, wxyz, index, want_stat):
+    def forward(ctx, zf, xyz, centre, wxyz, index, want_stat, offsets=None, slots=None):
         L.require_gpu(xyz, centre, wxyz, index)
         B, N, _ = xyz.shape
         _, M, K = index.shape
@@ -75,9 +89,11 @@ class GroupLinRows(torch.autograd.Function):
         partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, M, K), dtype=torch.float64, device=dev) if want_stat else None
         L.call('mvp_group_lin_rows_f32', xyz, L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(wxyz), L.ptr(index), B, N, C, M, K,
                L.ptr(out), L.ptr(diff), L.ptr(stat), L.ptr(partial))
-        ctx.save_for_backward(index, diff)
-        ctx.dims = (B, N, C, M, K)
         ctx.has_zf = zf is not None
+        if offsets is None and ctx.has_zf and zf.requires_grad:  # not supplied by the geometry plan: build it here
+            offsets, slots = build_csr(index, N)
+        ctx.save_for_backward(index, diff, offsets, slots)
+        ctx.dims = (B, N, C, M, K)
         if want_stat:
             ctx.mark_non_differentiable(stat)
             return out, stat
@@ -86,24 +102,29 @@ class GroupLinRows(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out, *unused):
-        index, diff = ctx.saved_tensors
+        index, diff, offsets, slots = ctx.saved_tensors
         B, N, C, M, K = ctx.dims
         g = grad_out.contiguous()
         gz = gw = None
         if ctx.has_zf and ctx.needs_input_grad[0]:
             gz = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
-            L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
+            if offsets is not None:  # gather through the transposed index: no atomics, no zero fill
+                L.call('mvp_gather_rows_backward_csr_f32', g, L.ptr(g), L.ptr(offsets), L.ptr(slots), None, B, N, C, M * K, 1, C, L.ptr(gz))
+            else:
+                L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
         if diff is not None and ctx.needs_input_grad[3]:
             gw4 = torch.zeros((C, 4), dtype=torch.float32, device=g.device)  # accumulated into
             L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4))
             gw = gw4[:, :3].contiguous()
-        return gz, None, None, gw, None, None
+        return gz, None, None, gw, None, None, None, None
 
 
-def group_lin_rows(zf, xyz, centre, wxyz, index, want_stat=False):
-    """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3), index (B,M,K) -> (B,M,K,C) [, stat (2C) float64]."""
+def group_lin_rows(zf, xyz, centre, wxyz, index, want_stat=False, csr=None):
+    """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3), index (B,M,K) -> (B,M,K,C) [, stat (2C) float64].
+    csr: (offsets, slots) of build_csr(index, N) when the geometry plan already holds it."""
+    offsets, slots = csr if csr is not None else (None, None)
     return GroupLinRows.apply(None if zf is None else zf.contiguous(), xyz.contiguous(), centre.contiguous(), wxyz.contiguous(),
-                              index.contiguous(), bool(want_stat))
+                              index.contiguous(), bool(want_stat), offsets, slots)
 
 
 class InterpRows(torch.autograd.Function):
@@ -140,7 +161,7 @@ class InterpAddRows(torch.autograd.Function):
     """out = interp(feature; index, weight) (+ add); want_stat: also the float64 column sums [sum out | sum out^2]."""
 
     @staticmethod
-    def forward(ctx, feature, index, weight, add, want_stat):
+    def forward(ctx, feature, index, weight, add, want_stat, offsets=None, slots=None):
         L.require_gpu(feature, index, weight, add)
         B, N1, C = feature.shape
         N2 = index.size(1)
@@ -150,7 +171,9 @@ class InterpAddRows(torch.autograd.Function):
         partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, N2, 1), dtype=torch.float64, device=dev) if want_stat else None
         L.call('mvp_interp_add_rows_f32', feature, L.ptr(feature), L.ptr(index), L.ptr(weight), L.ptr(add), B, N1, C, N2, L.ptr(out),
                L.ptr(stat), L.ptr(partial))
-        ctx.save_for_backward(index, weight)
+        if offsets is None and feature.requires_grad:
+            offsets, slots = build_csr(index, N1)
+        ctx.save_for_backward(index, weight, offsets, slots)
         ctx.dims = (B, N1, C, N2)
         ctx.has_add = add is not None
         if want_stat:
@@ -161,22 +184,28 @@ class InterpAddRows(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out, *unused):
-        index, weight = ctx.saved_tensors
+        index, weight, offsets, slots = ctx.saved_tensors
         B, N1, C, N2 = ctx.dims
         g = grad_out.contiguous()
         grad = None
         if ctx.needs_input_grad[0]:
             grad = torch.empty((B, N1, C), dtype=torch.float32, device=g.device)
-            L.call('mvp_interp_rows_backward_f32', g, L.ptr(g), L.ptr(index), L.ptr(weight), B, N1, C, N2, C, L.ptr(grad))
-        return grad, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None), None
+            if offsets is not None:
+                L.call('mvp_gather_rows_backward_csr_f32', g, L.ptr(g), L.ptr(offsets), L.ptr(slots), L.ptr(weight), B, N1, C, 3 * N2, 3, C,
+                       L.ptr(grad))
+            else:
+                L.call('mvp_interp_rows_backward_f32', g, L.ptr(g), L.ptr(index), L.ptr(weight), B, N1, C, N2, C, L.ptr(grad))
+        return grad, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None), None, None, None
 
 
-def interp_add_rows(feature, index, weight, add=None, want_stat=False):
-    """feature (B,N1,C), index / weight (B,N2,3), add (B,N2,C) or None -> (B,N2,C) [, stat (2C) float64]."""
+def interp_add_rows(feature, index, weight, add=None, want_stat=False, csr=None):
+    """feature (B,N1,C), index / weight (B,N2,3), add (B,N2,C) or None -> (B,N2,C) [, stat (2C) float64].
+    csr: (offsets, slots) of build_csr(index, N1) when the geometry plan already holds it."""
     if feature.dtype != torch.float32 or feature.size(2) % 4:
         raise RuntimeError('interp_add_rows: float32 feature with C % 4 == 0 expected')
+    offsets, slots = csr if csr is not None else (None, None)
     return InterpAddRows.apply(feature.contiguous(), index.contiguous(), weight.contiguous(), None if add is None else add.contiguous(),
-                               bool(want_stat))
+                               bool(want_stat), offsets, slots)
 
 
 class BNActRows(torch.autograd.Function):
