@@ -633,3 +633,74 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
     np.testing.assert_allclose(dz.cpu().numpy(), refz.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(refx.abs().max())))
     np.testing.assert_allclose(stat[:Cin].cpu().numpy(), refz.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(stat[Cin:].cpu().numpy(), (refz * xh.double()).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------ rows kernels added for the linear-first factorisations
+@pytest.mark.parametrize('B,N,M,K,C,with_zf', [(2, 300, 50, 16, 32, True), (3, 1000, 129, 32, 64, True), (1, 64, 8, 4, 128, False)])
+def test_group_lin_rows_vs_torch(dev, B, N, M, K, C, with_zf):
+    """out = zf[idx] + Wxyz.(xyz[idx] - centre), its column statistics, and both gradients (gather through the transposed
+    index for zf, MFMA weight gradient on the difference rows for Wxyz) against plain torch."""
+    from mvpnet_amd import rows as R
+    rs = np.random.RandomState(B * 7 + C)
+    xyz = g(rs.rand(B, N, 3).astype(np.float32), dev)
+    centre = g(rs.rand(B, M, 3).astype(np.float32), dev)
+    idx = g(rs.randint(0, N, (B, M, K)), dev)
+    zf = g(rs.randn(B, N, C).astype(np.float32), dev).requires_grad_(True) if with_zf else None
+    w = g(rs.randn(C, 3).astype(np.float32), dev).requires_grad_(True)
+    out, stat = R.group_lin_rows(zf, xyz, centre, w, idx, want_stat=True)
+    bi = torch.arange(B, device=dev)[:, None, None]
+    diff = xyz[bi, idx] - centre[:, :, None]
+    ref = diff @ w.detach().t() + (zf.detach()[bi, idx] if with_zf else 0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    flat = ref.reshape(-1, C).double()
+    np.testing.assert_allclose(stat[:C].cpu().numpy(), flat.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(stat[C:].cpu().numpy(), (flat ** 2).sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    cot = torch.randn_like(out)
+    out.backward(cot)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), torch.einsum('bmkc,bmkd->cd', cot, diff).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    if with_zf:
+        refz = torch.zeros(B, N, C, device=dev).index_put_((bi.expand(B, M, K).reshape(-1), idx.reshape(-1)), cot.reshape(-1, C), accumulate=True)
+        np.testing.assert_allclose(zf.grad.cpu().numpy(), refz.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('B,N1,N2,C,with_add', [(2, 40, 300, 32, True), (3, 128, 1000, 128, False), (1, 4, 17, 256, True)])
+def test_interp_add_rows_vs_torch(dev, B, N1, N2, C, with_add):
+    from mvpnet_amd import rows as R
+    rs = np.random.RandomState(N2 + C)
+    f = g(rs.randn(B, N1, C).astype(np.float32), dev).requires_grad_(True)
+    idx = g(rs.randint(0, N1, (B, N2, 3)), dev)
+    wt = g(rs.rand(B, N2, 3).astype(np.float32), dev)
+    add = g(rs.randn(B, N2, C).astype(np.float32), dev).requires_grad_(True) if with_add else None
+    out, stat = R.interp_add_rows(f, idx, wt, add, want_stat=True)
+    bi = torch.arange(B, device=dev)[:, None, None]
+    ref = (f.detach()[bi, idx] * wt[..., None]).sum(2) + (add.detach() if with_add else 0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    flat = ref.reshape(-1, C).double()
+    np.testing.assert_allclose(stat[:C].cpu().numpy(), flat.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(stat[C:].cpu().numpy(), (flat ** 2).sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    cot = torch.randn_like(out)
+    out.backward(cot)
+    reff = torch.zeros(B, N1, C, device=dev).index_put_((bi.expand(B, N2, 3).reshape(-1), idx.reshape(-1)),
+                                                        (cot[:, :, None] * wt[..., None]).reshape(-1, C), accumulate=True)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), reff.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    if with_add:
+        assert torch.equal(add.grad, cot)
+
+
+def test_csr_build(dev):
+    """mvp_csr_build_i64: every position appears exactly once in the list of the point it reads; negative / out-of-range
+    entries are dropped; empty lists for unreferenced points."""
+    from mvpnet_amd import rows as R
+    rs = np.random.RandomState(3)
+    B, E, N = 3, 5000, 700
+    idx = rs.randint(-2, N + 2, (B, E)).astype(np.int64)
+    offsets, slots = R.build_csr(g(idx, dev), N)
+    offsets, slots = offsets.cpu().numpy(), slots.cpu().numpy()
+    for b in range(B):
+        valid = (idx[b] >= 0) & (idx[b] < N)
+        assert offsets[b, 0] == 0 and offsets[b, N] == valid.sum()
+        np.testing.assert_array_equal(np.diff(offsets[b]), np.bincount(idx[b][valid], minlength=N))
+        used = slots[b, :offsets[b, N]]
+        assert sorted(used.tolist()) == np.nonzero(valid)[0].tolist()
+        owner = np.repeat(np.arange(N), np.diff(offsets[b]))
+        np.testing.assert_array_equal(idx[b][used], owner)
