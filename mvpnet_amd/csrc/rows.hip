@@ -536,58 +536,71 @@ __global__ __launch_bounds__(kRT) void bn_act_kernel(const float* __restrict__ y
   }
 }
 
-// dy = gamma*invstd * (dz - dbeta/R - xhat * dgamma/R);  dz from da (K == 1) or from (dout, arg) (K > 1)
+// dy = gamma*invstd * (dz - dbeta/R - xhat * dgamma/R);  dz from da (K == 1: bn_rows_bwd_kernel) or from (dout, arg) (K > 1:
+// bn_pool_bwd_kernel).
+// K == 1 variant with kBwdRows consecutive rows per lane: the parameters and the two statistics are loaded once per lane
+// instead of once per 16 streamed bytes.
+constexpr int kBwdRows = 8;
 template <bool RELU>
-__global__ __launch_bounds__(kRT) void bn_act_bwd_kernel(const float* __restrict__ dsrc, const float* __restrict__ out,
-                                                         const uint8_t* __restrict__ arg, const float* __restrict__ y,
-                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const double* __restrict__ stat, int64_t G, int K, int C,
-                                                         int batch_terms, float* __restrict__ dy,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(kRT) void bn_rows_bwd_kernel(const float* __restrict__ dsrc, const float* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const double* __restrict__ stat, int64_t R, int C, int batch_terms,
+                                                          float* __restrict__ dy, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
   const int C4 = C >> 2;
-  if (blockIdx.x == 0 && dgamma)  // the parameter gradients are the two column sums themselves
+  if (blockIdx.x == 0 && dgamma)
     for (int j = threadIdx.x; j < C; j += kRT) {
       dbeta[j] = (float)stat[j];
       dgamma[j] = (float)stat[C + j];
     }
   const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
-  const int64_t r = t / C4;  // row in [0, G*K)
-  const int c = (int)(t - r * C4) * 4;
-  const int64_t R = G * (int64_t)K;
-  if (r >= R) return;
-  const float4 yy = ld4(y + (size_t)r * C + c);
+  const int64_t rg = t / C4;
+  const int c = (int)(t - rg * C4) * 4;
+  const int64_t r0 = rg * kBwdRows;
+  if (r0 >= R) return;
   const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
-  const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
+  const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
   const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-  float dd[4];
-  if (K == 1) {
-    const float4 d = ld4(dsrc + (size_t)r * C + c);
-    dd[0] = d.x; dd[1] = d.y; dd[2] = d.z; dd[3] = d.w;
-  } else {
-    const int64_t g = r / K;
-    const int k = (int)(r - g * K);
-    const float4 d = ld4(dsrc + (size_t)g * C + c), o = ld4(out + (size_t)g * C + c);
-    const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (size_t)g * C + c);
-    dd[0] = (a.x == k && (!RELU || o.x > 0.f)) ? d.x : 0.f;
-    dd[1] = (a.y == k && (!RELU || o.y > 0.f)) ? d.y : 0.f;
-    dd[2] = (a.z == k && (!RELU || o.z > 0.f)) ? d.z : 0.f;
-    dd[3] = (a.w == k && (!RELU || o.w > 0.f)) ? d.w : 0.f;
-  }
-  float res[4];
-  const float invR = batch_terms ? 1.0f / (float)R : 0.f;  // eval mode: statistics are constants
+  const float invR = batch_terms ? 1.0f / (float)R : 0.f;
+  float sc[4], db[4], dg[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float xh = (yv[i] - mm[i]) * ii[i];
-    float dz = dd[i];
-    if (K == 1 && RELU && !(xh * gg[i] + bb[i] > 0.f)) dz = 0.f;
-    const float db = (float)stat[c + i], dg = (float)stat[C + c + i];
-    res[i] = (gg[i] * ii[i]) * ((dz - db * invR) - xh * (dg * invR));
+    sc[i] = gg[i] * ii[i];
+    db[i] = (float)stat[c + i] * invR;
+    dg[i] = (float)stat[C + c + i] * invR;
   }
-  st4(dy + (size_t)r * C + c, make_float4(res[0], res[1], res[2], res[3]));
+#pragma unroll
+  for (int h = 0; h < kBwdRows; h += 4) {
+    float4 yy[4], dd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + h + u;
+      yy[u] = dd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < R) {
+        yy[u] = ld4(y + (size_t)r * C + c);
+        dd[u] = ld4(dsrc + (size_t)r * C + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + h + u;
+      if (r >= R) break;
+      const float yv[4] = {yy[u].x, yy[u].y, yy[u].z, yy[u].w}, dv[4] = {dd[u].x, dd[u].y, dd[u].z, dd[u].w};
+      float res[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (yv[i] - mm[i]) * ii[i];
+        float dz = dv[i];
+        if (RELU && !(xh * gg[i] + bb[i] > 0.f)) dz = 0.f;
+        res[i] = sc[i] * ((dz - db[i]) - xh * dg[i]);
+      }
+      st4(dy + (size_t)r * C + c, make_float4(res[0], res[1], res[2], res[3]));
+    }
+  }
 }
 
-// Same as bn_act_bwd_kernel for K > 1 (gradient through max-over-K), one lane per (GROUP, 4 channels): the per-column
+// K > 1 (gradient through max-over-K), one lane per (GROUP, 4 channels): the per-column
 // parameters, the two statistics and the group's dout / out / arg are loaded once and the K rows of the group are streamed
 // (4 loads in flight).  The row-per-lane version re-read ~100 bytes of parameters and group data through the vector L1 for
 // every 16 bytes it streamed: 360 -> ~200 us on the 2.1 M x 64 tensor of set-abstraction level 1.
@@ -845,13 +858,13 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
                          (int)C, training, dy, dgamma, dbeta);
     return mvp_launch_status();
   }
-  dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
+  dim3 grid((unsigned)cdiv(cdiv(R, kBwdRows) * (C / 4), kRT));
   if (relu)
-    hipLaunchKernelGGL(bn_act_bwd_kernel<true>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
-                       G, (int)K, (int)C, training, dy, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_rows_bwd_kernel<true>, grid, dim3(kRT), 0, s, dsrc, y, mean, invstd, gamma, beta, stat, R, (int)C, training,
+                       dy, dgamma, dbeta);
   else
-    hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat,
-                       G, (int)K, (int)C, training, dy, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_rows_bwd_kernel<false>, grid, dim3(kRT), 0, s, dsrc, y, mean, invstd, gamma, beta, stat, R, (int)C, training,
+                       dy, dgamma, dbeta);
   return mvp_launch_status();
 }
 
@@ -883,9 +896,9 @@ MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, con
   MVP_NONNULL(dy);
   int rc = check_rows(R, C);
   if (rc || R == 0) return rc;
-  dim3 grid((unsigned)cdiv(R * (C / 4), kRT));
-  hipLaunchKernelGGL(bn_act_bwd_kernel<false>, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), dz, nullptr, nullptr, y, mean,
-                     invstd, gamma, beta, stat, R, 1, (int)C, training, dy, dgamma, dbeta);
+  dim3 grid((unsigned)cdiv(cdiv(R, kBwdRows) * (C / 4), kRT));
+  hipLaunchKernelGGL(bn_rows_bwd_kernel<false>, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), dz, y, mean, invstd, gamma, beta,
+                     stat, R, (int)C, training, dy, dgamma, dbeta);
   return mvp_launch_status();
 }
 
