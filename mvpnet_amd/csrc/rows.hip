@@ -536,6 +536,37 @@ __global__ __launch_bounds__(kRT) void bn_act_kernel(const float* __restrict__ y
   }
 }
 
+// K == 1 form of bn_act_kernel with 8 consecutive rows per lane (parameters loaded once per lane, 4 loads in flight)
+template <bool RELU>
+__global__ __launch_bounds__(kRT) void bn_act_rows_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int64_t R, int C, float* __restrict__ out) {
+  const int C4 = C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t rg = t / C4;
+  const int c = (int)(t - rg * C4) * 4;
+  const int64_t r0 = rg * 8;
+  if (r0 >= R) return;
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+#pragma unroll
+  for (int h = 0; h < 8; h += 4) {
+    float4 yy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) yy[u] = (r0 + h + u < R) ? ld4(y + (size_t)(r0 + h + u) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r0 + h + u >= R) break;
+      float a[4] = {((yy[u].x - mu.x) * is.x) * ga.x + be.x, ((yy[u].y - mu.y) * is.y) * ga.y + be.y,
+                    ((yy[u].z - mu.z) * is.z) * ga.z + be.z, ((yy[u].w - mu.w) * is.w) * ga.w + be.w};
+      if (RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = a[i] > 0.f ? a[i] : 0.f;
+      }
+      st4(out + (size_t)(r0 + h + u) * C + c, make_float4(a[0], a[1], a[2], a[3]));
+    }
+  }
+}
+
 // dy = gamma*invstd * (dz - dbeta/R - xhat * dgamma/R);  dz from da (K == 1: bn_rows_bwd_kernel) or from (dout, arg) (K > 1:
 // bn_pool_bwd_kernel).
 // K == 1 variant with kBwdRows consecutive rows per lane: the parameters and the two statistics are loaded once per lane
@@ -812,6 +843,14 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
                        mean, invstd, running_mean, running_var, static_cast<int64_t*>(nullptr));
   }  // eval: the caller passes mean = running_mean and invstd = 1/sqrt(running_var + eps)
   if (R == 0) return mvp_launch_status();
+  if (K == 1) {
+    dim3 rgrid((unsigned)cdiv(cdiv(R, 8) * (C / 4), kRT));
+    if (relu)
+      hipLaunchKernelGGL(bn_act_rows_kernel<true>, rgrid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, R, (int)C, out);
+    else
+      hipLaunchKernelGGL(bn_act_rows_kernel<false>, rgrid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, R, (int)C, out);
+    return mvp_launch_status();
+  }
   dim3 grid((unsigned)cdiv(G * (C / 4), kRT));
   if (relu)
     hipLaunchKernelGGL(bn_act_kernel<true>, grid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, G, (int)K, (int)C, out, arg);
