@@ -364,27 +364,43 @@ __global__ __launch_bounds__(kRT) void gather_bwd_csr_kernel(const float* __rest
 // Each thread sums a short run of rows in fp32, workgroup partials are combined in fp64 through LDS
 // and one fp64 atomic per (workgroup, column, statistic) goes to global memory.
 // ---------------------------------------------------------------------------------------------------
+struct NoParams {};
 struct Plain {  // f = y, g = y*y : forward batch statistics
   const float* y;
-  __device__ __forceinline__ void at(int64_t r, int c, int C, float4& f, float4& g) const {
+  typedef NoParams Params;
+  __device__ __forceinline__ Params params(int) const { return Params(); }
+  __device__ __forceinline__ void at(const Params&, int64_t r, int c, int C, float4& f, float4& g) const {
     f = ld4(y + (size_t)r * C + c);
     g = make_float4(f.x * f.x, f.y * f.y, f.z * f.z, f.w * f.w);
   }
 };
+struct ColParams {  // per-column constants of a lane, loaded once (not once per row)
+  float mm[4], ii[4], gg[4], bb[4];
+};
+__device__ __forceinline__ ColParams load_col_params(const float* mean, const float* invstd, const float* gamma, const float* beta, int c) {
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+  ColParams p;
+  p.mm[0] = mu.x; p.mm[1] = mu.y; p.mm[2] = mu.z; p.mm[3] = mu.w;
+  p.ii[0] = is.x; p.ii[1] = is.y; p.ii[2] = is.z; p.ii[3] = is.w;
+  p.gg[0] = ga.x; p.gg[1] = ga.y; p.gg[2] = ga.z; p.gg[3] = ga.w;
+  p.bb[0] = be.x; p.bb[1] = be.y; p.bb[2] = be.z; p.bb[3] = be.w;
+  return p;
+}
 struct BwdAct {  // f = dz, g = dz * xhat with dz = da * [bn(y) > 0] (relu) : BatchNorm backward sums
   const float *da, *y, *mean, *invstd, *gamma, *beta;
   int relu;
-  __device__ __forceinline__ void at(int64_t r, int c, int C, float4& f, float4& g) const {
+  typedef ColParams Params;
+  __device__ __forceinline__ Params params(int c) const { return load_col_params(mean, invstd, gamma, beta, c); }
+  __device__ __forceinline__ void at(const Params& p, int64_t r, int c, int C, float4& f, float4& g) const {
     const float4 yy = ld4(y + (size_t)r * C + c), d = ld4(da + (size_t)r * C + c);
-    const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
-    const float xh[4] = {(yy.x - mu.x) * is.x, (yy.y - mu.y) * is.y, (yy.z - mu.z) * is.z, (yy.w - mu.w) * is.w};
-    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w}, dd[4] = {d.x, d.y, d.z, d.w};
+    const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, dd[4] = {d.x, d.y, d.z, d.w};
     float fo[4], go[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float dz = (!relu || xh[i] * gg[i] + bb[i] > 0.f) ? dd[i] : 0.f;
+      const float xh = (yv[i] - p.mm[i]) * p.ii[i];
+      const float dz = (!relu || xh * p.gg[i] + p.bb[i] > 0.f) ? dd[i] : 0.f;
       fo[i] = dz;
-      go[i] = dz * xh[i];
+      go[i] = dz * xh;
     }
     f = make_float4(fo[0], fo[1], fo[2], fo[3]);
     g = make_float4(go[0], go[1], go[2], go[3]);
@@ -394,13 +410,13 @@ struct BwdMax {  // rows are groups g; only the arg-max row of each (g, c) carri
   const float *dout, *out, *y, *mean, *invstd, *gamma, *beta;
   const uint8_t* arg;
   int K, relu;
-  __device__ __forceinline__ void at(int64_t g, int c, int C, float4& f, float4& gg) const {
+  typedef ColParams Params;
+  __device__ __forceinline__ Params params(int c) const { return load_col_params(mean, invstd, gamma, beta, c); }
+  __device__ __forceinline__ void at(const Params& p, int64_t g, int c, int C, float4& f, float4& gg) const {
     const float4 d = ld4(dout + (size_t)g * C + c), o = ld4(out + (size_t)g * C + c);
-    const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
     const uint8_t* a = arg + (size_t)g * C + c;
     const float dd[4] = {d.x, d.y, d.z, d.w}, oo[4] = {o.x, o.y, o.z, o.w};
-    const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w};
-    const float gm[4] = {ga.x, ga.y, ga.z, ga.w}, bt[4] = {be.x, be.y, be.z, be.w};
+    const float *mm = p.mm, *ii = p.ii, *gm = p.gg, *bt = p.bb;
     float fo[4], go[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C
   const int64_t stride = (int64_t)gridDim.x * rpp;
   double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
   if (rg < rpp) {
+    const typename Src::Params prm = src.params(c);
     int64_t r = (int64_t)blockIdx.x * rpp + rg;
     while (r < R) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C
         for (int u = 0; u < 4; ++u) {
           f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           g[u] = f[u];
-          if (r + u * stride < R) src.at(r + u * stride, c, C, f[u], g[u]);
+          if (r + u * stride < R) src.at(prm, r + u * stride, c, C, f[u], g[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
