@@ -466,7 +466,8 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
     first_done=True: x already is the first layer's conv output (the linear part was applied per point before
     the grouping, see SetAbstraction.forward_rows); only its BatchNorm + ReLU and the remaining layers run here."""
     n = len(mlp)
-    fused = dropout_p == 0 and all(l.bn is not None and l.relu is not None and l.conv.bias is None and
+    # dropout follows EVERY layer of a SharedMLPDO (mlp.py:86-92): a single-layer chain can still be fused, dropout on its output
+    fused = (dropout_p == 0 or n == 1) and all(l.bn is not None and l.relu is not None and l.conv.bias is None and
                                    l.bn.running_mean is not None for l in mlp) and \
         all(l.conv.weight.size(0) % 4 == 0 and 256 % (l.conv.weight.size(0) // 4) == 0 for l in mlp)
     if fused:
@@ -477,7 +478,8 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             params += [w, layer.bn.weight, layer.bn.bias]
             buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
-        return MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, *params)
+        out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, *params)
+        return F.dropout(out, p=dropout_p, training=training, inplace=False) if dropout_p > 0 else out
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     for i, layer in enumerate(mlp):
         w = layer.conv.weight.reshape(layer.conv.weight.size(0), -1)  # (C_out, C_in)
