@@ -211,7 +211,9 @@ int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, co
  * torch.max(dim=3) modules after each 1x1 conv (common/nn/modules/conv.py:41-51, pn2/modules.py:107-108).
  * forward : training != 0: batch statistics (float64 accumulation) -> mean, invstd (outputs), running_* updated
  *           (momentum, unbiased variance; may be NULL); training == 0: mean / invstd are INPUTS.
- *           out (G,C) = max_k act(((y-mean)*invstd)*gamma+beta), arg (G,C) uint8 = first arg-max (K > 1 only).
+ *           out (G,C) = max_k act(((y-mean)*invstd)*gamma+beta), arg (G,C) uint8 = first arg-max (K > 1 only);
+ *           K > 1 with arg == NULL: out = SUM over k instead (FeatureAggregation reduction='sum', mvpnet_3d.py:40-41,59),
+ *           backward likewise (out is then unused).
  *           stat: 2*C float64 scratch.
  * backward: dsrc = d out (G,C) [K > 1] or d act (G*K,C) [K == 1] -> dy (G*K,C); on return
  *           stat[0:C] = d beta, stat[C:2C] = d gamma (float64), also written as float32 to dgamma / dbeta when those

@@ -437,6 +437,27 @@ struct BwdMax {  // rows are groups g; only the arg-max row of each (g, c) carri
   }
 };
 
+struct BwdSum {  // rows r = g*K + k; every row of group g receives dout[g] (gradient of a SUM over K), masked by its own ReLU
+  const float *dout, *y, *mean, *invstd, *gamma, *beta;
+  int K, relu;
+  typedef ColParams Params;
+  __device__ __forceinline__ Params params(int c) const { return load_col_params(mean, invstd, gamma, beta, c); }
+  __device__ __forceinline__ void at(const Params& p, int64_t r, int c, int C, float4& f, float4& g) const {
+    const float4 yy = ld4(y + (size_t)r * C + c), d = ld4(dout + (size_t)(r / K) * C + c);
+    const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, dd[4] = {d.x, d.y, d.z, d.w};
+    float fo[4], go[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (yv[i] - p.mm[i]) * p.ii[i];
+      const float dz = (!relu || xh * p.gg[i] + p.bb[i] > 0.f) ? dd[i] : 0.f;
+      fo[i] = dz;
+      go[i] = dz * xh;
+    }
+    f = make_float4(fo[0], fo[1], fo[2], fo[3]);
+    g = make_float4(go[0], go[1], go[2], go[3]);
+  }
+};
+
 // Persistent, grid-stride: a few hundred workgroups walk the rows with 4 independent 16-byte loads in flight per lane,
 // sum runs of <= 64 rows in fp32 and carry the run totals in fp64 registers.  The number of workgroups is the number of
 // fp64 atomics that queue on each of the 2*C result addresses (~90 ns each, measured: with 2048 workgroups that queue
@@ -530,7 +551,9 @@ __global__ __launch_bounds__(kRT) void bn_act_kernel(const float* __restrict__ y
   const int c = (int)(t - g * C4) * 4;
   if (g >= G) return;
   const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+  const bool sum = K > 1 && arg == nullptr;  // no arg-max requested over K rows: the reduction is a SUM (feature aggregation)
   float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  if (sum) best[0] = best[1] = best[2] = best[3] = 0.f;
   int bk[4] = {0, 0, 0, 0};
   for (int k = 0; k < K; ++k) {
     const float4 yy = ld4(y + ((size_t)g * K + k) * C + c);
@@ -539,7 +562,9 @@ __global__ __launch_bounds__(kRT) void bn_act_kernel(const float* __restrict__ y
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (RELU) a[i] = a[i] > 0.f ? a[i] : 0.f;
-      if (a[i] > best[i]) {
+      if (sum) {
+        best[i] += a[i];
+      } else if (a[i] > best[i]) {
         best[i] = a[i];
         bk[i] = k;
       }
@@ -656,9 +681,10 @@ template <bool RELU>
 __global__ __launch_bounds__(kRT) void bn_pool_bwd_kernel(const float* __restrict__ dsrc, const float* __restrict__ out,
                                                           const uint8_t* __restrict__ arg, const float* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          const float* __restrict__ gamma, const double* __restrict__ stat,
-                                                          int64_t G, int K, int C, int batch_terms, float* __restrict__ dy,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const double* __restrict__ stat, int64_t G, int K, int C,
+                                                          int batch_terms, float* __restrict__ dy, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
   const int C4 = C >> 2;
   if (blockIdx.x == 0 && dgamma)
     for (int j = threadIdx.x; j < C; j += kRT) {
@@ -669,10 +695,14 @@ __global__ __launch_bounds__(kRT) void bn_pool_bwd_kernel(const float* __restric
   const int64_t g = t / C4;
   const int c = (int)(t - g * C4) * 4;
   if (g >= G) return;
-  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
-  const float4 d = ld4(dsrc + (size_t)g * C + c), o = ld4(out + (size_t)g * C + c);
-  const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (size_t)g * C + c);
+  const bool sum = arg == nullptr;  // gradient of a sum over K: every row gets dout[g], masked by its own ReLU
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+  const float4 d = ld4(dsrc + (size_t)g * C + c);
+  const float4 o = sum ? make_float4(1.f, 1.f, 1.f, 1.f) : ld4(out + (size_t)g * C + c);
+  uchar4 a = make_uchar4(0, 0, 0, 0);
+  if (!sum) a = *reinterpret_cast<const uchar4*>(arg + (size_t)g * C + c);
   const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w};
+  const float bb[4] = {be.x, be.y, be.z, be.w};
   const float invR = batch_terms ? 1.0f / (float)(G * (int64_t)K) : 0.f;  // eval mode: statistics are constants
   float sc[4], db[4], dg[4], dd[4];
   const int aa[4] = {a.x, a.y, a.z, a.w};
@@ -682,7 +712,7 @@ __global__ __launch_bounds__(kRT) void bn_pool_bwd_kernel(const float* __restric
     sc[i] = gg[i] * ii[i];
     db[i] = (float)stat[c + i] * invR;
     dg[i] = (float)stat[C + c + i] * invR;
-    dd[i] = (!RELU || ov[i] > 0.f) ? dv[i] : 0.f;
+    dd[i] = (sum || !RELU || ov[i] > 0.f) ? dv[i] : 0.f;
   }
   const float* yp = y + (size_t)g * K * C + c;
   float* dp = dy + (size_t)g * K * C + c;
@@ -698,7 +728,7 @@ __global__ __launch_bounds__(kRT) void bn_pool_bwd_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float xh = (yv[i] - mm[i]) * ii[i];
-        const float dz = (aa[i] == k0 + u) ? dd[i] : 0.f;
+        const float dz = sum ? ((!RELU || xh * gg[i] + bb[i] > 0.f) ? dd[i] : 0.f) : ((aa[i] == k0 + u) ? dd[i] : 0.f);
         res[i] = sc[i] * ((dz - db[i]) - xh * dg[i]);
       }
       st4(dp + (size_t)(k0 + u) * C, make_float4(res[0], res[1], res[2], res[3]));
@@ -845,8 +875,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
   MVP_NONNULL(mean);
   MVP_NONNULL(invstd);
   MVP_NONNULL(out);
-  MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);
-  if (K > 1) MVP_NONNULL(arg);
+  MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);  // K > 1: arg != NULL -> max over K with arg-max, arg == NULL -> sum over K
   int rc = check_rows(G * K, C);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -890,10 +919,7 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   MVP_NONNULL(dy);
   if (dgamma) MVP_NONNULL(dbeta);
   MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);
-  if (K > 1) {
-    MVP_NONNULL(out);
-    MVP_NONNULL(arg);
-  }
+  if (K > 1 && arg) MVP_NONNULL(out);  // K > 1 with arg == NULL: backward of the SUM over K
   int rc = check_rows(G * K, C);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -901,17 +927,19 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   if (hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
   if (K == 1)
     rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, s);
+  else if (arg == nullptr)
+    rc = launch_colstats(BwdSum{dsrc, y, mean, invstd, gamma, beta, (int)K, relu}, R, C, stat, s);
   else
     rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, gamma, beta, arg, (int)K, relu}, G, C, stat, s);
   if (rc || R == 0) return rc;
   if (K > 1) {  // through the max over K: one lane per group streams its K rows
     dim3 pgrid((unsigned)cdiv(G * (C / 4), kRT));
     if (relu)
-      hipLaunchKernelGGL(bn_pool_bwd_kernel<true>, pgrid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, stat, G, (int)K,
-                         (int)C, training, dy, dgamma, dbeta);
+      hipLaunchKernelGGL(bn_pool_bwd_kernel<true>, pgrid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat, G,
+                         (int)K, (int)C, training, dy, dgamma, dbeta);
     else
-      hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, pgrid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, stat, G, (int)K,
-                         (int)C, training, dy, dgamma, dbeta);
+      hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, pgrid, dim3(kRT), 0, s, dsrc, out, arg, y, mean, invstd, gamma, beta, stat, G,
+                         (int)K, (int)C, training, dy, dgamma, dbeta);
     return mvp_launch_status();
   }
   dim3 grid((unsigned)cdiv(cdiv(R, kBwdRows) * (C / 4), kRT));

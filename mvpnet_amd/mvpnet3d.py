@@ -51,10 +51,8 @@ class FeatureAggregation(nn.Module):
             x = torch.cat([gfeat, diff, torch.sum(diff ** 2, dim=3, keepdim=True)], dim=3)  # feature, diff, dist (:55-56)
         if x.size(3) % 4:
             x = torch.nn.functional.pad(x, (0, 4 - x.size(3) % 4))
-        if self.reduction_name == 'max':
-            return R.shared_mlp_rows(x.reshape(B * N * k, -1), self.mlp, K=k).view(B, N, -1)
-        y = R.shared_mlp_rows(x.reshape(B * N * k, -1), self.mlp)
-        return y.view(B, N, k, -1).sum(2)
+        # the reduction over the k neighbours (max or sum, :40-41,59) is folded into the last layer's BatchNorm + ReLU kernel
+        return R.shared_mlp_rows(x.reshape(B * N * k, -1), self.mlp, K=k, reduce=self.reduction_name).view(B, N, -1)
 
     def forward(self, src_xyz, tgt_xyz, feature, rows=False):
         """src_xyz (B,3,N,k), tgt_xyz (B,3,N), feature (B,C,N,k) -> (B,C_out,N).

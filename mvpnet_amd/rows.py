@@ -293,10 +293,11 @@ def _bn_backward(dsrc, out, arg, y, mean, invstd, gamma, beta, G, K, C, relu, tr
     return dy, dgb[0], dgb[1]
 
 
-def _bn_apply(y, mean, invstd, gamma, beta, G, K, C, relu):
-    """act(bn(y)) with GIVEN statistics (+ max over K): the apply-only mode of mvp_bn_rows_forward_f32."""
+def _bn_apply(y, mean, invstd, gamma, beta, G, K, C, relu, pool_sum=False):
+    """act(bn(y)) with GIVEN statistics (+ max, or with pool_sum the sum, over K): the apply-only mode of
+    mvp_bn_rows_forward_f32 (no arg-max buffer = sum)."""
     out = torch.empty((G, C), dtype=torch.float32, device=y.device)
-    arg = torch.empty((G, C), dtype=torch.uint8, device=y.device) if K > 1 else None
+    arg = torch.empty((G, C), dtype=torch.uint8, device=y.device) if (K > 1 and not pool_sum) else None
     L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, 0, 0.0, 0.0, int(relu), None, None, None,
            L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg))
     return out, arg
@@ -309,7 +310,7 @@ class MLPChainRows(torch.autograd.Function):
     pre-BN outputs y_i ever reach HBM.  Backward re-creates each activation from y_i on the fly."""
 
     @staticmethod
-    def forward(ctx, x0, training, K, eps_mom, bn_buffers, first_stat, *params):
+    def forward(ctx, x0, training, K, eps_mom, bn_buffers, first_stat, pool_sum, *params):
         # params = (W_1, gamma_1, beta_1, ..., W_L, gamma_L, beta_L); bn_buffers = [(running_mean, running_var, num_batches_tracked or None)] * L
         nl = len(params) // 3
         R = x0.size(0)
@@ -354,7 +355,7 @@ class MLPChainRows(torch.autograd.Function):
             x = y
         cl = ys[-1].size(1)
         G = R // K
-        out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True)
+        out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, pool_sum)
         ctx.first_linear = params[0] is not None
         ctx.save_for_backward(x0, out, arg, *ys, *means, *invstds, *[p for p in params if p is not None])
         ctx.cfg = (nl, training, K, R)
@@ -417,7 +418,7 @@ class MLPChainRows(torch.autograd.Function):
                 else:
                     L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(dz), None, None)
                     dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
-        return (dx0, None, None, None, None, None) + tuple(grads)
+        return (dx0, None, None, None, None, None, None) + tuple(grads)
 
 
 class LinearRows(torch.autograd.Function):
@@ -459,10 +460,11 @@ def linear_rows(x, weight, bias=None):
     return LinearRows.apply(x.contiguous(), w, bias)
 
 
-def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None):
+def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max'):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
-    K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108).
+    K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108), or their sum with reduce='sum'
+    (FeatureAggregation, mvpnet_3d.py:40-41,59).
     first_done=True: x already is the first layer's conv output (the linear part was applied per point before
     the grouping, see SetAbstraction.forward_rows); only its BatchNorm + ReLU and the remaining layers run here."""
     n = len(mlp)
@@ -478,7 +480,8 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             params += [w, layer.bn.weight, layer.bn.bias]
             buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
-        out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, *params)
+        out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None,
+                                 reduce == 'sum' and K > 1, *params)
         return F.dropout(out, p=dropout_p, training=training, inplace=False) if dropout_p > 0 else out
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     for i, layer in enumerate(mlp):
@@ -487,13 +490,15 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             w = F.pad(w, (0, x.size(1) - w.size(1)))
         y = linear_rows(x, w)
         if layer.bn is not None:
-            x = bn_act_rows(y, layer.bn, relu=layer.relu is not None, K=K if i == n - 1 else 1)
+            x = bn_act_rows(y, layer.bn, relu=layer.relu is not None, K=K if (i == n - 1 and reduce != 'sum') else 1)
+            if K > 1 and i == n - 1 and reduce == 'sum':
+                x = x.view(-1, K, x.size(1)).sum(dim=1)
         else:
             if layer.conv.bias is not None:
                 y = y + layer.conv.bias
             x = F.relu(y) if layer.relu is not None else y
             if K > 1 and i == n - 1:
-                x = x.view(-1, K, x.size(1)).max(dim=1)[0]
+                x = x.view(-1, K, x.size(1)).sum(dim=1) if reduce == 'sum' else x.view(-1, K, x.size(1)).max(dim=1)[0]
         if dropout_p > 0:
             x = F.dropout(x, p=dropout_p, training=training, inplace=False)
     return x
