@@ -62,6 +62,12 @@ struct EpiBwd {
 //      for ds_read_b128 / ds_write_b128), double buffered: ONE barrier per K slab; fragments are read as b128
 //      (k = 8 t + 4 h .. + 3 of column j), 16 LDS reads per wave and slab instead of 80 scalar ones.
 //   The global loads of slab s + 1 (A, B) are issued before the 16 BN/32 MFMAs of slab s and consumed after them.
+#ifndef MVP_MFMA_PRIO
+#define MVP_MFMA_PRIO 2
+#endif
+#ifndef MVP_DW_PRIO
+#define MVP_DW_PRIO 2
+#endif
 constexpr int kMaxActCin = 512;    // input-activation parameters staged in LDS up to this many input channels
 
 // VEC: X and W rows are 16-byte aligned with lengths that are multiples of 4 (decided by the host; a run-time test in the
@@ -246,6 +252,7 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
       load_b(k0 + BK);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the consumers of those loads BELOW the MFMAs
+    __builtin_amdgcn_s_setprio(MVP_MFMA_PRIO);  // waves inside their MFMA block win the issue arbitration over waves that stage / store
     const float* bp = Bs[buf] + li * kLdB + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][3], bf[j].w, acc[j], 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (more) {
       store_b(buf ^ 1, k0 + BK);  // last read in the previous iteration, which ended with a barrier
@@ -451,11 +459,13 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
     const bool more = r0 + BR < r_end;
     if (more) load(r0 + BR);
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(MVP_DW_PRIO);
     // A[i = co][k = row], B[k = row][j = ci]: lane-consecutive LDS reads of the tiles exactly as they lie in memory
     const float* dp = Ds[buf] + (rs * 32 + (lane >> 5)) * TM + wco + (lane & 31);
     const float* ap = As[buf] + (rs * 32 + (lane >> 5)) * TN + wci + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < 32; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[kk * TM], ap[kk * TN], acc, 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (more) store(buf ^ 1, r0 + BR);
     __syncthreads();
