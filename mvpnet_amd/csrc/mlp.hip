@@ -296,6 +296,21 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
       eb = epi.beta[co];
     }
     float yst[16];
+    if constexpr (VEC) {
+      if (epi.y) {  // y_prev tile: 16-byte row loads into the wave's LDS tile, read back in the accumulator layout below
+        float* st = Ss[wave];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const int row = pp * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+          const int64_t r = row0 + wave * 32 + row;
+          const int cc = col0 + j * 32 + c4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (r < R && cc < Cout) v = *reinterpret_cast<const f32x4*>(epi.y + (size_t)r * Cout + cc);
+          *reinterpret_cast<f32x4*>(st + row * kLdS + c4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int m = wave * 32 + (i & 3) + 8 * (i >> 2) + rh;
@@ -304,7 +319,8 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
       if (r < R && co < Cout) {
         float y = acc[j][i] + bv;
         if (epi.y) {
-          const float xh = (epi.y[(size_t)r * Cout + co] - em) * ei;
+          const float yp = VEC ? Ss[wave][((i & 3) + 8 * (i >> 2) + rh) * kLdS + cl] : epi.y[(size_t)r * Cout + co];
+          const float xh = (yp - em) * ei;
           y = (xh * eg + eb > 0.f) ? y : 0.f;  // dz = da * relu'(bn(y_prev))
           s += y;
           q += y * xh;
@@ -317,6 +333,7 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
       }
     }
     if constexpr (VEC) {
+      if (epi.y) __builtin_amdgcn_wave_barrier();  // the y_prev tile has been read
       // Output through a wave-private LDS tile: the accumulator layout has one COLUMN per lane (4-byte stores, two 128-byte
       // segments per instruction); transposed, every lane stores 16 bytes and one instruction covers eight full 128-byte rows.
       float* st = Ss[wave];
