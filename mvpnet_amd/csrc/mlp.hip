@@ -550,9 +550,12 @@ void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int l
   /* K slab of 32: a 64-wide slab was measured slower (fewer slabs per tile expose the first load) */                                \
   hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, ldw, N, act, \
                      bias, epi, Y, stat, partial)
-  if (N <= 32) {
+  // Few rows (the 128- and 512-point levels): narrower column tiles until the launch has a workgroup for each of the 256 CUs.
+  int bn = N <= 32 ? 32 : N <= 64 ? 64 : 128;
+  while (bn > 32 && (int64_t)gx * cdiv(N, bn) < 256) bn >>= 1;
+  if (bn == 32) {
     if (vec) MVP_MLP_LAUNCH(32, true); else MVP_MLP_LAUNCH(32, false);
-  } else if (N <= 64) {
+  } else if (bn == 64) {
     if (vec) MVP_MLP_LAUNCH(64, true); else MVP_MLP_LAUNCH(64, false);
   } else {
     if (vec) MVP_MLP_LAUNCH(128, true); else MVP_MLP_LAUNCH(128, false);

@@ -94,6 +94,10 @@ class MVPNet3D(nn.Module):
         return self._geo_stream
 
     def forward(self, data_batch):
+        with R.zero_pool.step(data_batch['points'].device):  # one zero fill for all accumulators of this step (rows.ZeroPool)
+            return self._forward(data_batch)
+
+    def _forward(self, data_batch):
         # coordinate-only work of the 3D network (FPS chain, ball queries, 3-NN) starts on a side stream
         # now and overlaps the 2D network, the lifting and the aggregation MLP below.
         plan = data_batch.get('geometry_plan')

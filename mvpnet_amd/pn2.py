@@ -308,6 +308,10 @@ class PN2SSG(nn.Module):
     def forward(self, data_batch):
         """data_batch: 'points' (B,3,N) [+ 'feature' (B,C,N), or 'feature_rows' (B,N,C) channels-last]
         [+ 'geometry_plan' from plan_geometry()] -> {'seg_logit': (B,num_classes,N)}."""
+        with R.zero_pool.step(data_batch['points'].device):  # one zero fill for all accumulators of this step
+            return self._forward(data_batch)
+
+    def _forward(self, data_batch):
         xyz = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
         plan = data_batch.get('geometry_plan')
         if plan is not None and plan.get('event') is not None:

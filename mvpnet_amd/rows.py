@@ -55,6 +55,60 @@ def group_rows(feature, xyz, center, index):
                            index.contiguous())
 
 
+class ZeroPool:
+    """One zero fill per training step instead of one per accumulator.
+
+    The statistics / weight-gradient kernels ACCUMULATE into their outputs (include/mvp_hip.h), so every shared-MLP chain
+    needs zeroed arenas in forward and in backward: ~90 `torch.zeros` fills of a few KB per step, 4-5 us of device time
+    each and all on the critical stream.  `step()` (entered by the top-level model forward) allocates ONE zeroed
+    buffer sized by the previous step's demand; `zeros()` hands out disjoint 256-byte aligned views of it, each exactly
+    once -- a request that does not fit (first step, changed shapes, a second forward before the first backward) falls
+    back to `torch.zeros`.  The buffer is never recycled by the pool: the views (e.g. the parameters' .grad) keep it alive."""
+
+    def __init__(self):
+        self.buf = None
+        self.cursor = 0
+        self.demand = 0
+        self.capacity = 0
+        self.depth = 0
+
+    class _Step:
+        def __init__(self, pool, dev):
+            self.pool, self.dev = pool, dev
+
+        def __enter__(self):
+            p = self.pool
+            if p.depth == 0:
+                p.capacity = max(p.demand, p.cursor)  # what the last step asked for in total
+                p.buf = torch.zeros(p.capacity // 8, dtype=torch.float64, device=self.dev) if p.capacity else None
+                p.cursor = p.demand = 0
+            p.depth += 1
+
+        def __exit__(self, *exc):
+            self.pool.depth -= 1
+
+    def step(self, dev):
+        return ZeroPool._Step(self, dev)
+
+    def zeros(self, shape, dtype, dev):
+        if isinstance(shape, int):
+            shape = (shape,)
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        nbytes = (numel * torch.empty(0, dtype=dtype).element_size() + 255) // 256 * 256
+        self.demand += nbytes
+        buf = self.buf
+        if buf is None or buf.device != dev or self.cursor + nbytes > self.capacity or numel == 0:
+            return torch.zeros(shape, dtype=dtype, device=dev)
+        view = buf[self.cursor // 8:(self.cursor + nbytes) // 8].view(dtype)[:numel].view(shape)
+        self.cursor += nbytes
+        return view
+
+
+zero_pool = ZeroPool()
+
+
 def build_csr(index, N):
     """index (B, ...) int64 positions into N points -> (offsets (B,N+1) int32, slots (B,E) int32): for every point the list of
     flattened positions that read it (mvp_csr_build_i64).  Turns the scatter-add backward of a gather into a gather."""
@@ -85,7 +139,7 @@ class GroupLinRows(torch.autograd.Function):
         dev = xyz.device
         out = torch.empty((B, M, K, C), dtype=torch.float32, device=dev)
         diff = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_w else None
-        stat = torch.zeros(2 * C, dtype=torch.float64, device=dev) if want_stat else None
+        stat = zero_pool.zeros(2 * C, torch.float64, dev) if want_stat else None
         partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, M, K), dtype=torch.float64, device=dev) if want_stat else None
         L.call('mvp_group_lin_rows_f32', xyz, L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(wxyz), L.ptr(index), B, N, C, M, K,
                L.ptr(out), L.ptr(diff), L.ptr(stat), L.ptr(partial))
@@ -113,7 +167,7 @@ class GroupLinRows(torch.autograd.Function):
             else:
                 L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
         if diff is not None and ctx.needs_input_grad[3]:
-            gw4 = torch.zeros((C, 4), dtype=torch.float32, device=g.device)  # accumulated into
+            gw4 = zero_pool.zeros((C, 4), torch.float32, g.device)  # accumulated into
             L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4))
             gw = gw4[:, :3].contiguous()
         return gz, None, None, gw, None, None, None, None
@@ -167,7 +221,7 @@ class InterpAddRows(torch.autograd.Function):
         N2 = index.size(1)
         dev = feature.device
         out = torch.empty((B, N2, C), dtype=torch.float32, device=dev)
-        stat = torch.zeros(2 * C, dtype=torch.float64, device=dev) if want_stat else None
+        stat = zero_pool.zeros(2 * C, torch.float64, dev) if want_stat else None
         partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, N2, 1), dtype=torch.float64, device=dev) if want_stat else None
         L.call('mvp_interp_add_rows_f32', feature, L.ptr(feature), L.ptr(index), L.ptr(weight), L.ptr(add), B, N1, C, N2, L.ptr(out),
                L.ptr(stat), L.ptr(partial))
@@ -320,7 +374,7 @@ class MLPChainRows(torch.autograd.Function):
         x = x0
         couts = [x0.size(1) if params[3 * i] is None else params[3 * i].size(0) for i in range(nl)]
         # the kernels ADD their column sums to `stat`: one zeroed arena for the whole chain instead of a memset per layer
-        arena = torch.zeros(2 * sum(couts), dtype=torch.float64, device=dev) if training else None
+        arena = zero_pool.zeros(2 * sum(couts), torch.float64, dev) if training else None
         off = 0
         for i in range(nl):
             w, gamma, beta = params[3 * i], params[3 * i + 1], params[3 * i + 2]
@@ -383,8 +437,8 @@ class MLPChainRows(torch.autograd.Function):
         none4 = (None, None, None, None)
         # `dW` and `stat` are accumulated into by the kernels: two zeroed arenas for the whole chain
         w_numel = [0 if params[3 * i] is None else params[3 * i].numel() for i in range(nl)]
-        dw_arena = torch.zeros(sum(w_numel), dtype=torch.float32, device=g.device)
-        st_arena = torch.zeros(2 * sum(params[3 * i].size(1) for i in range(1, nl)), dtype=torch.float64, device=g.device)
+        dw_arena = zero_pool.zeros(sum(w_numel), torch.float32, g.device)
+        st_arena = zero_pool.zeros(2 * sum(params[3 * i].size(1) for i in range(1, nl)), torch.float64, g.device)
         dw_off, st_off = 0, 0
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
@@ -447,7 +501,7 @@ class LinearRows(torch.autograd.Function):
             gx = torch.empty_like(x)
             L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros_like(w)  # accumulated into
+            gw = zero_pool.zeros(tuple(w.shape), torch.float32, w.device)  # accumulated into
             L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, cin, cin, None, None, None, None, L.ptr(gw))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
