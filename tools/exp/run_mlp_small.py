@@ -9,7 +9,7 @@ def bench(R, Cin, Cout, n=50):
     stat = torch.zeros(2 * Cout, dtype=torch.float64, device=dev); part = torch.empty(((R + 127) // 128) * 2 * Cout, dtype=torch.float64, device=dev)
     dy = torch.randn(R, Cout, device=dev); dx = torch.empty(R, Cin, device=dev)
     def f(): L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, Cin, L.ptr(w), Cin, Cout, None, None, None, None, None, L.ptr(y), L.ptr(stat), L.ptr(part))
-    def g(): L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(w), Cin, None, None, None, None, None, None, L.ptr(dx), None, None)
+    def g(): L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(w), Cin, None, None, None, None, None, L.ptr(dx), None, None)
     def h(): torch.mm(x, w.t(), out=y)
     res = []
     for fn in (f, g, h):
