@@ -184,7 +184,11 @@ int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centr
                            int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat,
                            double* partial, mvp_stream_t stream);
 /* stat (2*C float64) += column sums of y and y^2 over the R rows of y (R,C); accumulated: the caller provides zeros */
-int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream);
+int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, double* partial, mvp_stream_t stream);
+/* `partial` of mvp_colstats_f32 / mvp_bn_rows_forward_f32 / mvp_bn_rows_backward_f32: optional scratch of
+ * mvp_colstats_partial_count(G*K rows, C) float64.  With it the column sums are reduced through per-workgroup slots by up to 2048
+ * workgroups; without it (NULL) by at most 256 workgroups with fp64 atomics, which queue per result address. */
+int64_t mvp_colstats_partial_count(int64_t R, int64_t C);
 int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float* weight, int64_t B, int64_t N1, int64_t C,
                         int64_t N2, int64_t ld, float* out, mvp_stream_t stream);
 /* Transposed index of a gather out[b,e] = f[b, index[b,e]] (index (B,E) int64, values outside [0,N) are ignored):
@@ -220,10 +224,11 @@ int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, co
  *           are not NULL.  training == 0: statistics were constants (eval mode), the batch terms are dropped. */
 int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
                             int training, float eps, float momentum, int relu, float* running_mean, float* running_var,
-                            double* stat, float* mean, float* invstd, float* out, uint8_t* arg, mvp_stream_t stream);
+                            double* stat, float* mean, float* invstd, float* out, uint8_t* arg, double* partial,
+                            mvp_stream_t stream);
 int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
-                             int relu, int training, double* stat, float* dy, float* dgamma, float* dbeta,
+                             int relu, int training, double* stat, float* dy, float* dgamma, float* dbeta, double* partial,
                              mvp_stream_t stream);
 /* second half of the BatchNorm backward with known column sums stat = [sum dz | sum dz*xhat] (from mvp_mlp_input_grad_f32) */
 int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd,

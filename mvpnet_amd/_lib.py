@@ -45,16 +45,16 @@ _SIGNATURES = {
     'mvp_group_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_rows_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_lin_rows_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr],
-    'mvp_colstats_f32': [_ptr, _i64, _i64, _ptr, _ptr],
+    'mvp_colstats_f32': [_ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_interp_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_csr_build_i64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_gather_rows_backward_csr_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interp_add_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_interp_rows_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_bn_rows_forward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, ctypes.c_int, _f32, _f32, ctypes.c_int, _ptr, _ptr, _ptr, _ptr,
-                                _ptr, _ptr, _ptr, _ptr],
+                                _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_rows_backward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, _ptr,
-                                 _ptr, _ptr, _ptr, _ptr],
+                                 _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_rows_backward_finish_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_finalize_f32': [_ptr, _i64, _i64, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -63,7 +63,7 @@ _SIGNATURES = {
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
 }
-EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count'] + sorted(_SIGNATURES)
+EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -81,6 +81,8 @@ def lib():
         handle.mvp_lift_workspace_bytes.argtypes = [_i64, _i64, _i64, _i64, _i64]
         handle.mvp_group_lin_partial_count.restype = ctypes.c_int64
         handle.mvp_group_lin_partial_count.argtypes = [_i64, _i64, _i64, _i64]
+        handle.mvp_colstats_partial_count.restype = ctypes.c_int64
+        handle.mvp_colstats_partial_count.argtypes = [_i64, _i64]
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes

@@ -463,7 +463,8 @@ struct BwdSum {  // rows r = g*K + k; every row of group g receives dout[g] (gra
 // fp64 atomics that queue on each of the 2*C result addresses (~90 ns each, measured: with 2048 workgroups that queue
 // alone cost 180 us per call whatever the tensor size), so it is kept small and scales with the tensor.
 template <typename Src>
-__global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C, double* __restrict__ stat) {
+__global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C, double* __restrict__ stat,
+                                                       double* __restrict__ partial) {
   __shared__ double red[2][kRT][4];
   const int C4 = C >> 2;
   const int rpp = kRT / C4;
@@ -510,10 +511,19 @@ __global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C
         ts[i] += red[0][g * C4 + c4][i];
         tq[i] += red[1][g * C4 + c4][i];
       }
+    if (partial) {  // one private slot per workgroup, summed by stats_reduce_kernel: no atomics, so many workgroups are free
+      double* slot = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      atomicAdd(stat + c + i, ts[i]);
-      atomicAdd(stat + C + c + i, tq[i]);
+      for (int i = 0; i < 4; ++i) {
+        slot[c + i] = ts[i];
+        slot[C + c + i] = tq[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        atomicAdd(stat + c + i, ts[i]);
+        atomicAdd(stat + C + c + i, tq[i]);
+      }
     }
   }
 }
@@ -741,12 +751,23 @@ int check_rows(int64_t R, int64_t C) {
   return MVP_OK;
 }
 
+// Workgroups of the scratch-buffer variant: one per ~32 KB of rows (a handful of 4-deep load rounds per lane), 16 .. 2048.
+inline int64_t colstats_blocks_partial(int64_t R, int64_t C) {
+  return std::min<int64_t>(2048, std::max<int64_t>(16, cdiv(R * C * 4, 32 * 1024)));
+}
+
 template <typename Src>
-int launch_colstats(Src src, int64_t R, int64_t C, double* stat, hipStream_t s) {
+int launch_colstats(Src src, int64_t R, int64_t C, double* stat, double* partial, hipStream_t s) {
   if (R == 0) return MVP_OK;
-  // one workgroup per ~512 KB of rows, between 16 and 256 of them
+  if (partial) {
+    const int64_t blocks = colstats_blocks_partial(R, C);
+    hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)blocks), dim3(kRT), 0, s, src, R, (int)C, stat, partial);
+    launch_stats_reduce(partial, blocks, (int)(2 * C), stat, s);
+    return mvp_launch_status();
+  }
+  // fp64 atomics: one workgroup per ~512 KB of rows, between 16 and 256 of them (they queue per result address)
   const int64_t blocks = std::min<int64_t>(256, std::max<int64_t>(16, cdiv(R * C * 4, 512 * 1024)));
-  hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)blocks), dim3(kRT), 0, s, src, R, (int)C, stat);
+  hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)blocks), dim3(kRT), 0, s, src, R, (int)C, stat, static_cast<double*>(nullptr));
   return mvp_launch_status();
 }
 
@@ -868,7 +889,7 @@ MVP_API int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* i
 MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K,
                                     int64_t C, int training, float eps, float momentum, int relu, float* running_mean,
                                     float* running_var, double* stat, float* mean, float* invstd, float* out,
-                                    uint8_t* arg, mvp_stream_t stream) {
+                                    uint8_t* arg, double* partial, mvp_stream_t stream) {
   MVP_NONNULL(y);
   MVP_NONNULL(gamma);
   MVP_NONNULL(beta);
@@ -883,7 +904,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
   if (training) {
     MVP_NONNULL(stat);
     if (hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
-    rc = launch_colstats(Plain{y}, R, C, stat, s);
+    rc = launch_colstats(Plain{y}, R, C, stat, partial, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, stat, R, (int)C, eps, momentum,
                        mean, invstd, running_mean, running_var, static_cast<int64_t*>(nullptr));
@@ -908,7 +929,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
 MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y,
                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                                      int64_t G, int64_t K, int64_t C, int relu, int training, double* stat, float* dy,
-                                     float* dgamma, float* dbeta, mvp_stream_t stream) {
+                                     float* dgamma, float* dbeta, double* partial, mvp_stream_t stream) {
   MVP_NONNULL(dsrc);
   MVP_NONNULL(y);
   MVP_NONNULL(mean);
@@ -926,11 +947,11 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   const int64_t R = G * K;
   if (hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
   if (K == 1)
-    rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, s);
+    rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, partial, s);
   else if (arg == nullptr)
-    rc = launch_colstats(BwdSum{dsrc, y, mean, invstd, gamma, beta, (int)K, relu}, R, C, stat, s);
+    rc = launch_colstats(BwdSum{dsrc, y, mean, invstd, gamma, beta, (int)K, relu}, R, C, stat, partial, s);
   else
-    rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, gamma, beta, arg, (int)K, relu}, G, C, stat, s);
+    rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, gamma, beta, arg, (int)K, relu}, G, C, stat, partial, s);
   if (rc || R == 0) return rc;
   if (K > 1) {  // through the max over K: one lane per group streams its K rows
     dim3 pgrid((unsigned)cdiv(G * (C / 4), kRT));
@@ -1012,10 +1033,16 @@ MVP_API int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const floa
 }
 
 // stat (2*C float64, accumulated into) += column sums of y and y*y over R rows
-MVP_API int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, mvp_stream_t stream) {
+MVP_API int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, double* partial, mvp_stream_t stream) {
   MVP_NONNULL(y);
   MVP_NONNULL(stat);
   int rc = check_rows(R, C);
   if (rc) return rc;
-  return launch_colstats(Plain{y}, R, C, stat, static_cast<hipStream_t>(stream));
+  return launch_colstats(Plain{y}, R, C, stat, partial, static_cast<hipStream_t>(stream));
+}
+
+// float64 elements of the optional `partial` scratch of the column-statistics passes over R rows of C columns
+MVP_API int64_t mvp_colstats_partial_count(int64_t R, int64_t C) {
+  if (R <= 0 || C <= 0) return 0;
+  return colstats_blocks_partial(R, C) * 2 * C;
 }

@@ -282,7 +282,8 @@ class BNActRows(torch.autograd.Function):
             invstd = torch.rsqrt(running_var + eps)
         L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, int(training), float(eps),
                float(momentum), int(relu), L.ptr(running_mean) if training else None,
-               L.ptr(running_var) if training else None, L.ptr(stat), L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg))
+               L.ptr(running_var) if training else None, L.ptr(stat), L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg),
+               L.ptr(_cs_partial(R, C, dev)) if training else None)
         ctx.save_for_backward(y, gamma, beta, mean, invstd, out, arg)
         ctx.cfg = (G, K, C, bool(relu), bool(training))
         return out
@@ -313,7 +314,8 @@ class BNActRows(torch.autograd.Function):
         dy = torch.empty_like(y)
         dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
         L.call('mvp_bn_rows_backward_f32', y, L.ptr(g), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
-               L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), 1, L.ptr(stat), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]))
+               L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), 1, L.ptr(stat), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]),
+               L.ptr(_cs_partial(G * K, C, y.device)))
         return dy, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
@@ -337,13 +339,19 @@ def _partial(R, cols, device):
     return torch.empty(((R + 127) // 128) * 2 * cols, dtype=torch.float64, device=device)
 
 
+def _cs_partial(R, C, device):
+    """Scratch of the column-statistics passes (mvp_colstats_partial_count): lets them run on up to 2048 workgroups."""
+    return torch.empty(L.lib().mvp_colstats_partial_count(R, C), dtype=torch.float64, device=device)
+
+
 def _bn_backward(dsrc, out, arg, y, mean, invstd, gamma, beta, G, K, C, relu, training):
     """-> dy (G*K,C), dgamma (C), dbeta (C) through mvp_bn_rows_backward_f32."""
     stat = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     dy = torch.empty_like(y)
     dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
     L.call('mvp_bn_rows_backward_f32', y, L.ptr(dsrc), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
-           L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), int(training), L.ptr(stat), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]))
+           L.ptr(gamma), L.ptr(beta), G, K, C, int(relu), int(training), L.ptr(stat), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]),
+           L.ptr(_cs_partial(G * K, C, y.device)))
     return dy, dgb[0], dgb[1]
 
 
@@ -353,7 +361,7 @@ def _bn_apply(y, mean, invstd, gamma, beta, G, K, C, relu, pool_sum=False):
     out = torch.empty((G, C), dtype=torch.float32, device=y.device)
     arg = torch.empty((G, C), dtype=torch.uint8, device=y.device) if (K > 1 and not pool_sum) else None
     L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, 0, 0.0, 0.0, int(relu), None, None, None,
-           L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg))
+           L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg), None)
     return out, arg
 
 
@@ -388,7 +396,7 @@ class MLPChainRows(torch.autograd.Function):
                 if training and first_stat is not None:
                     stat = first_stat  # the grouping kernel already summed the columns
                 elif training:
-                    L.call('mvp_colstats_f32', y, L.ptr(y), R, cout, L.ptr(stat))
+                    L.call('mvp_colstats_f32', y, L.ptr(y), R, cout, L.ptr(stat), L.ptr(_cs_partial(R, cout, dev)))
             else:
                 cout, cin = w.size(0), w.size(1)
                 y = torch.empty((R, cout), dtype=torch.float32, device=dev)

@@ -635,6 +635,44 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
     np.testing.assert_allclose(stat[Cin:].cpu().numpy(), (refz * xh.double()).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize('G,K,C,pool', [(5000, 1, 64, 'none'), (700, 32, 32, 'max'), (3000, 3, 64, 'sum'), (40000, 1, 128, 'none')])
+def test_column_statistics_scratch_variant(dev, G, K, C, pool):
+    """The `partial` scratch (per-workgroup slots + stats_reduce, up to 2048 workgroups) and the fp64-atomics variant of the
+    column-statistics passes give the same sums, forward and backward, and match a float64 torch reduction."""
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(G + K)
+    R = G * K
+    y = torch.randn(R, C, device=dev) * 2 + 0.5
+    gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3
+    n = L.lib().mvp_colstats_partial_count(R, C)
+    assert n >= 16 * 2 * C and n % (2 * C) == 0
+    res = []
+    for use in (False, True):
+        part = torch.full((n,), float('nan'), dtype=torch.float64, device=dev) if use else None
+        st = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        L.call('mvp_colstats_f32', y, L.ptr(y), R, C, L.ptr(st), L.ptr(part))
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        out = torch.empty(G, C, device=dev)
+        arg = torch.empty(G, C, dtype=torch.uint8, device=dev) if pool == 'max' else None
+        st2 = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1e-5, 0.1, 1, None, None, L.ptr(st2),
+               L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg), L.ptr(part))
+        dsrc = torch.randn(G, C, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        dy = torch.empty(R, C, device=dev)
+        st3 = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        L.call('mvp_bn_rows_backward_f32', y, L.ptr(dsrc), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+               L.ptr(beta), G, K, C, 1, 1, L.ptr(st3), L.ptr(dy), None, None, L.ptr(part))
+        res.append((st, st2, mean, invstd, out, st3, dy))
+    a, b = res
+    ref = torch.cat([y.double().sum(0), (y.double() ** 2).sum(0)])
+    for t in (a[0], b[0], a[1], b[1]):
+        np.testing.assert_allclose(t.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6, atol=1e-3)
+    for i in (2, 3, 4):
+        np.testing.assert_allclose(b[i].cpu().numpy(), a[i].cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(b[5].cpu().numpy(), a[5].cpu().numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(b[6].cpu().numpy(), a[6].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 # ------------------------------------------------------------------ rows kernels added for the linear-first factorisations
 @pytest.mark.parametrize('B,N,M,K,C,with_zf', [(2, 300, 50, 16, 32, True), (3, 1000, 129, 32, 64, True), (1, 64, 8, 4, 128, False)])
 def test_group_lin_rows_vs_torch(dev, B, N, M, K, C, with_zf):

@@ -27,16 +27,20 @@ for name, G, K, C in SHAPES:
     arg = torch.empty(G, C, dtype=torch.uint8, device=dev)
     dsrc = torch.randn(G, C, device=dev)
     dy = torch.empty(R, C, device=dev)
-    t_cs = timeit(lambda: L.call('mvp_colstats_f32', y, L.ptr(y), R, C, L.ptr(stat)))
-    t_f = timeit(lambda: L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1e-5, 0.1, 1, None, None,
-                                L.ptr(stat), L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg)))
-    t_b = timeit(lambda: L.call('mvp_bn_rows_backward_f32', y, L.ptr(dsrc), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
-                                L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1, L.ptr(stat), L.ptr(dy), None, None))
+    part = torch.empty(L.lib().mvp_colstats_partial_count(R, C), dtype=torch.float64, device=dev)
+    t_cs = timeit(lambda: L.call('mvp_colstats_f32', y, L.ptr(y), R, C, L.ptr(stat), L.ptr(part)))
+    t_cs0 = timeit(lambda: L.call('mvp_colstats_f32', y, L.ptr(y), R, C, L.ptr(stat), None))
+    fwd = lambda p: L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1e-5, 0.1, 1, None, None,
+                           L.ptr(stat), L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg), L.ptr(p))
+    bwd = lambda p: L.call('mvp_bn_rows_backward_f32', y, L.ptr(dsrc), L.ptr(out), L.ptr(arg), L.ptr(y), L.ptr(mean), L.ptr(invstd),
+                           L.ptr(gamma), L.ptr(beta), G, K, C, 1, 1, L.ptr(stat), L.ptr(dy), None, None, L.ptr(p))
+    t_f, t_f0 = timeit(lambda: fwd(part)), timeit(lambda: fwd(None))
+    t_b, t_b0 = timeit(lambda: bwd(part)), timeit(lambda: bwd(None))
     dz = torch.randn(R, C, device=dev)
     t_bf = timeit(lambda: L.call('mvp_bn_rows_backward_finish_f32', y, L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
                                  L.ptr(beta), R, C, 1, L.ptr(stat), L.ptr(dy), None, None))
     nb = R * C * 4
     gb = lambda byts, us: byts / us * 1e-3
     # minimal traffic: colstats reads y; fwd reads y twice (statistics, then apply) and writes out; bwd reads y (+dsrc) twice, writes dy
-    print('%-6s %9d %3d %4d | %10.1f (%8.0f) | %10.1f (%8.0f) | %10.1f (%8.0f) | %10.1f (%8.0f)' % (
-        name, G, K, C, t_cs, gb(nb, t_cs), t_f, gb(2 * nb + nb // K, t_f), t_b, gb(3 * nb if K > 1 else 5 * nb, t_b), t_bf, gb(3 * nb, t_bf)))
+    print('%-6s %9d %3d %4d | %10.1f (%8.0f) | %10.1f (%8.0f) | %10.1f (%8.0f) | %10.1f (%8.0f) | atomics: %6.1f %6.1f %6.1f' % (
+        name, G, K, C, t_cs, gb(nb, t_cs), t_f, gb(2 * nb + nb // K, t_f), t_b, gb(3 * nb if K > 1 else 5 * nb, t_b), t_bf, gb(3 * nb, t_bf), t_cs0, t_f0, t_b0))
