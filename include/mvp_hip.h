@@ -270,6 +270,26 @@ int mvp_vote_accumulate_f32(const float* logit, int64_t ld_r, int64_t ld_c, cons
 int mvp_vote_finish_f32(const float* sum, const int32_t* count, int64_t n_pts, int64_t C, float* mean, int64_t* label,
                         mvp_stream_t stream);
 
+/* ---- segmentation loss and confusion matrix (the step after the path) -------------
+ * Logits are addressed as element (b,c,n) at logit[b*ld_b + c*ld_c + n*ld_n]: the reference's (B,C,N) tensor
+ * (ld_b = C*N, ld_c = N, ld_n = 1) or channels-last rows (B = 1, N = rows, ld_n = C, ld_c = 1).  label (B*N) int64;
+ * points whose label is ignore_index (or outside [0,C)) are skipped.
+ * mvp_seg_loss_f32: replaces F.cross_entropy(logit, label, weight, ignore_index) of mvpnet/models/loss.py:5-21 (mean
+ *   reduction: sum w[y]*nll / sum w[y]).  acc: 3 float64, ZEROED by the caller ([sum w*nll, sum w, ticket]); loss: 1 float,
+ *   written by the last workgroup (nan when no point is valid, as torch).  weight may be NULL.
+ * mvp_seg_loss_backward_f32: grad_logit (own strides gld_*) = *grad_out * w[y]/acc[1] * (softmax - onehot), 0 for skipped
+ *   points; acc as left by the forward, grad_out = 1 float on the device.
+ * mvp_seg_confusion_f32: mat (C,C) int64 += 1 at [label][argmax_c logit] (first maximum), i.e. the argmax + mask +
+ *   bincount of mvpnet/models/metric.py:13-24,38-53 in one pass; accumulated into (the caller zeroes / keeps a running matrix). */
+int mvp_seg_loss_f32(const float* logit, int64_t B, int64_t C, int64_t N, int64_t ld_b, int64_t ld_c, int64_t ld_n,
+                     const int64_t* label, const float* weight, int64_t ignore_index, double* acc, float* loss, mvp_stream_t stream);
+int mvp_seg_loss_backward_f32(const float* logit, int64_t B, int64_t C, int64_t N, int64_t ld_b, int64_t ld_c, int64_t ld_n,
+                              const int64_t* label, const float* weight, int64_t ignore_index, const double* acc,
+                              const float* grad_out, float* grad_logit, int64_t gld_b, int64_t gld_c, int64_t gld_n,
+                              mvp_stream_t stream);
+int mvp_seg_confusion_f32(const float* logit, int64_t B, int64_t C, int64_t N, int64_t ld_b, int64_t ld_c, int64_t ld_n,
+                          const int64_t* label, int64_t ignore_index, int64_t* mat, mvp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .nn import SharedMLP, xavier_uniform
 from . import ops
+from . import _lib as L
 from . import rows as R
 
 
@@ -122,15 +123,51 @@ class MVPNet3D(nn.Module):
         return self.net_3d({'points': points, 'feature_rows': feature_2d3d, 'geometry_plan': plan})
 
 
+class _SegLossFn(torch.autograd.Function):
+    """F.cross_entropy(logit (B,C,N), label (B,N), weight, ignore_index) in one forward and one backward kernel
+    (mvp_seg_loss_f32 / mvp_seg_loss_backward_f32): no (B,C,N) log-probability tensor, no nll_loss fill + scatter."""
+
+    @staticmethod
+    def forward(ctx, logit, label, weight, ignore_index):
+        L.require_gpu(label, weight)
+        B, C, N = logit.shape
+        acc = R.zero_pool.zeros(3, torch.float64, logit.device)  # [sum w*nll, sum w, ticket]
+        loss = torch.empty((), dtype=torch.float32, device=logit.device)
+        sb, sc, sn = logit.stride()
+        L.call('mvp_seg_loss_f32', logit, L.ptr(logit), B, C, N, sb, sc, sn, L.ptr(label), L.ptr(weight), int(ignore_index), L.ptr(acc),
+               L.ptr(loss))
+        ctx.save_for_backward(logit, label, weight, acc)
+        ctx.ignore_index = int(ignore_index)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        logit, label, weight, acc = ctx.saved_tensors
+        B, C, N = logit.shape
+        g = grad_out.contiguous().to(torch.float32)
+        grad = torch.empty((B, C, N), dtype=torch.float32, device=logit.device)
+        sb, sc, sn = logit.stride()
+        L.call('mvp_seg_loss_backward_f32', logit, L.ptr(logit), B, C, N, sb, sc, sn, L.ptr(label), L.ptr(weight), ctx.ignore_index,
+               L.ptr(acc), L.ptr(g), L.ptr(grad), C * N, N, 1)
+        return grad, None, None, None
+
+
 class SegLoss(nn.Module):
-    """Weighted cross entropy with ignore_index (loss.py:5-21)."""
+    """Weighted cross entropy with ignore_index (loss.py:5-21).  fp32 (B,C,N) logits on the GPU go through the fused HIP
+    kernels (logits in any strides); everything else (host tensors, other dtypes / ranks) through F.cross_entropy, which is
+    what the reference calls."""
 
     def __init__(self, weight=None, ignore_index=-100):
         super().__init__()
         self.weight, self.ignore_index = weight, ignore_index
 
     def forward(self, preds, labels):
-        loss = F.cross_entropy(preds['seg_logit'], labels['seg_label'], weight=self.weight, ignore_index=self.ignore_index)
+        logit, label = preds['seg_logit'], labels['seg_label']
+        if logit.is_cuda and logit.dtype == torch.float32 and logit.dim() == 3 and label.dtype == torch.int64:
+            weight = None if self.weight is None else self.weight.to(device=logit.device, dtype=torch.float32).contiguous()
+            loss = _SegLossFn.apply(logit, label.contiguous(), weight, self.ignore_index)
+        else:
+            loss = F.cross_entropy(logit, label, weight=self.weight, ignore_index=self.ignore_index)
         return {'seg_loss': loss}
 
 

@@ -24,6 +24,7 @@ import collections
 import hashlib
 import importlib.util
 import json
+import logging
 import os
 import sys
 import types
@@ -566,7 +567,136 @@ def gen_chunker():
     save('chunker', **out)
 
 
+def gen_metrics():
+    """Meters, evaluator, loss and checkpoint files from the imported reference classes (mvpnet/models/metric.py,
+    mvpnet/models/loss.py, mvpnet/evaluate_3d.py, common/utils/{metric_logger,checkpoint}.py) on seeded inputs."""
+    import io
+    import shutil
+    import tempfile
+    from mvpnet.models.metric import SegAccuracy, SegIoU
+    from mvpnet.models.loss import SegLoss
+    from mvpnet.evaluate_3d import Evaluator, CLASS_NAMES, EVAL_CLASS_IDS
+    from common.utils.metric_logger import MetricLogger
+    from common.utils.checkpoint import Checkpointer, CheckpointerV2
+    from mvpnet_amd import metric as mine_metric
+    from mvpnet_amd import checkpoint as mine_ckpt
+
+    out = {}
+    rs = np.random.RandomState(4242)
+    B, C, N = 2, 20, 700
+    acc, iou = SegAccuracy(), SegIoU(C)
+    weight = torch.from_numpy(np.linspace(0.5, 2.0, C).astype(np.float32))
+    crit = SegLoss(weight=weight)
+    logger = MetricLogger(delimiter='  ')
+    logger.add_meters([acc, iou])
+    lines = []
+    for it in range(3):
+        logit = torch.from_numpy((rs.randn(B, C, N) * 2).astype(np.float32)).requires_grad_(True)
+        label = rs.randint(0, C, (B, N)).astype(np.int64)
+        label[rs.uniform(size=(B, N)) < 0.15] = -100
+        if it == 1:
+            label[0] = -100  # a fully ignored chunk
+        label = torch.from_numpy(label)
+        # make some predictions correct so the diagonal is populated
+        with torch.no_grad():
+            hit = torch.from_numpy(rs.uniform(size=(B, N)) < 0.4) & (label >= 0)
+            bump = torch.zeros(B, C, N)
+            bump.scatter_(1, label.clamp(min=0).unsqueeze(1), 8.0)
+            logit.data += bump * hit.unsqueeze(1)
+        loss = crit({'seg_logit': logit}, {'seg_label': label})['seg_loss']
+        loss.backward()
+        acc.update_dict({'seg_logit': logit.detach()}, {'seg_label': label})
+        iou.update_dict({'seg_logit': logit.detach()}, {'seg_label': label})
+        logger.update(loss=loss.detach(), lr=0.002 / (it + 1))
+        lines.append(str(logger) + ' || ' + logger.summary_str)
+        out['m%d_logit' % it], out['m%d_label' % it] = logit.detach().numpy(), label.numpy()
+        out['m%d_loss' % it], out['m%d_grad' % it] = np.float64(loss.item()), logit.grad.numpy()
+        out['m%d_acc' % it] = np.array([acc.global_avg, acc.avg], np.float64)
+        out['m%d_mat' % it], out['m%d_iou' % it] = iou.mat.numpy().copy(), iou.iou.numpy().copy()
+    out['loss_weight'] = weight.numpy()
+    out['logger_lines'] = np.asarray(json.dumps(lines))
+    # whole-scene evaluator: raw ScanNet ids and contiguous ids, ignored ground truth, "unlabelled" predictions
+    ev = Evaluator(CLASS_NAMES)
+    ev_raw = Evaluator(CLASS_NAMES, EVAL_CLASS_IDS)
+    for sc in range(3):
+        n = 1500 + 300 * sc
+        gt = rs.randint(0, 20, n).astype(np.int64)
+        pred = np.where(rs.uniform(size=n) < 0.6, gt, rs.randint(0, 21, n)).astype(np.int64)  # 20 = unlabelled prediction
+        gt[rs.uniform(size=n) < 0.1] = -100
+        if sc == 2:
+            gt[gt == 7] = 3  # a class absent from the ground truth (nan IoU unless predicted)
+        ids = np.array(EVAL_CLASS_IDS + [0])
+        out['e%d_gt' % sc], out['e%d_pred' % sc] = gt.copy(), pred.copy()
+        ev.update(pred.copy(), gt.copy())
+        ev_raw.update(ids[pred], np.where(gt >= 0, ids[np.clip(gt, 0, 19)], -100))
+    ev.update(np.zeros(5, np.int64), np.full(5, -100, np.int64))  # "Invalid label." scene: skipped
+    for name, e in (('ev', ev), ('evraw', ev_raw)):
+        out[name + '_cm'] = e.confusion_matrix.copy()
+        out[name + '_overall'] = np.array([e.overall_acc, e.overall_iou], np.float64)
+        out[name + '_class_iou'] = np.array(e.class_iou, np.float64)
+        out[name + '_class_acc'] = np.array(e.class_seg_acc, np.float64)
+    out['ev_table'] = np.asarray(ev.print_table())
+    tmp = tempfile.mkdtemp()
+    try:
+        ev.save_table(os.path.join(tmp, 't.tsv'))
+        out['ev_tsv'] = np.asarray(open(os.path.join(tmp, 't.tsv')).read())
+    finally:
+        shutil.rmtree(tmp)
+    save('metrics', **out)
+
+    # ---- checkpoint files written by the reference classes (data: pickled tensors + a text tag file)
+    def tiny(seed):
+        torch.manual_seed(seed)
+        model = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.BatchNorm1d(4), torch.nn.Linear(4, 2))
+        opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2, 4], gamma=0.1)
+        return model, opt, sched
+
+    def train_a_bit(model, opt, sched, steps):
+        for i in range(steps):
+            opt.zero_grad()
+            model(torch.full((5, 3), 0.1 * (i + 1)) + torch.arange(15.).view(5, 3) * 0.01).sum().backward()
+            opt.step()
+            sched.step()
+
+    os.chdir(HERE)  # relative save_dir: the tag file then holds bare file names (checkpoint.py:109-111), i.e. the fixture is relocatable
+    dst = 'checkpoint_ref'
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(dst)
+    model, opt, sched = tiny(5)
+    ck = CheckpointerV2(model, optimizer=opt, scheduler=sched, save_dir=dst, max_to_keep=2)
+    for it in (1, 2, 3):
+        train_a_bit(model, opt, sched, 1)
+        ck.save('model_{:06d}'.format(it), iteration=it, best_metric=0.1 * it)
+    ck.save('model_best', tag=False, iteration=3, best_metric=0.3)
+    expect = {k: v.numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(dst, 'expected_state.npz'), **expect)
+    assert sorted(os.listdir(dst)) == ['expected_state.npz', 'last_checkpoint', 'model_000002.pth', 'model_000003.pth', 'model_best.pth']
+    # cross-check in this container: the REFERENCE loads what this build writes, and this build loads what the reference wrote
+    tmp = os.path.relpath(tempfile.mkdtemp(dir=HERE), HERE)
+    try:
+        m2, o2, s2 = tiny(6)
+        mine = mine_ckpt.CheckpointerV2(m2, optimizer=o2, scheduler=s2, save_dir=tmp, max_to_keep=2)
+        extra = mine.load(os.path.join(dst, 'model_000003.pth'), resume=False)
+        assert extra == {'iteration': 3, 'best_metric': 0.1 * 3} and all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), model.state_dict().values()))
+        assert s2.state_dict() == sched.state_dict()
+        for it in (4, 5, 6):
+            train_a_bit(m2, o2, s2, 1)
+            mine.save('model_{:06d}'.format(it), iteration=it)
+        m3, o3, s3 = tiny(7)
+        ref = CheckpointerV2(m3, optimizer=o3, scheduler=s3, save_dir=tmp, max_to_keep=2, logger=logging.getLogger('golden'))
+        assert ref.load(None, resume=True) == {'iteration': 6}
+        assert all(torch.equal(a, b) for a, b in zip(m3.state_dict().values(), m2.state_dict().values()))
+        assert sorted(os.listdir(tmp)) == ['last_checkpoint', 'model_000005.pth', 'model_000006.pth']
+        assert open(os.path.join(tmp, 'last_checkpoint')).read() == 'model_000005.pth\nmodel_000006.pth'
+    finally:
+        shutil.rmtree(tmp)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'metrics':  # only the fixtures of SURVEY sec.8f rank 4
+        gen_metrics()
+        return
     gen_configs()
     T = install_reference()
     gen_fps(T)
@@ -579,6 +709,7 @@ def main():
     gen_vote_trainstep()
     gen_unet()
     gen_chunker()
+    gen_metrics()
     import sklearn
     manifest = dict(numpy=np.__version__, torch=torch.__version__, sklearn=sklearn.__version__,
                     reference='/root/reference (maxjaritz/mvpnet @ v0)', generator='tests/golden/make_golden.py')
