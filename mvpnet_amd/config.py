@@ -178,8 +178,11 @@ def build_optimizer(cfg, model):
     name = cfg.OPTIMIZER.TYPE
     if name == '':
         return None
-    return getattr(torch.optim, name)(model.parameters(), lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY,
-                                      **dict(cfg.OPTIMIZER.get(name, {})))
+    kwargs = dict(cfg.OPTIMIZER.get(name, {}))
+    params = [p for p in model.parameters()]
+    if name in ('Adam', 'AdamW') and 'fused' not in kwargs and params and all(p.is_cuda for p in params):
+        kwargs['fused'] = True  # same update rule in ONE kernel for all ~90 parameter tensors instead of ~10 multi-tensor launches
+    return getattr(torch.optim, name)(params, lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY, **kwargs)
 
 
 def build_scheduler(cfg, optimizer):

@@ -464,7 +464,11 @@ struct BwdSum {  // rows r = g*K + k; every row of group g receives dout[g] (gra
 // alone cost 180 us per call whatever the tensor size), so it is kept small and scales with the tensor.
 template <typename Src>
 __global__ __launch_bounds__(kRT) void colstats_kernel(Src src, int64_t R, int C, double* __restrict__ stat,
-                                                       double* __restrict__ partial) {
+                                                       double* __restrict__ partial, int zero_stat) {
+  // scratch variant: `stat` is only touched by the stats_reduce launch that follows, so workgroup 0 can clear it here
+  // instead of a memset launch in front of every BatchNorm pass
+  if (zero_stat && blockIdx.x == 0)
+    for (int j = threadIdx.x; j < 2 * C; j += kRT) stat[j] = 0.0;
   __shared__ double red[2][kRT][4];
   const int C4 = C >> 2;
   const int rpp = kRT / C4;
@@ -756,18 +760,20 @@ inline int64_t colstats_blocks_partial(int64_t R, int64_t C) {
   return std::min<int64_t>(2048, std::max<int64_t>(16, cdiv(R * C * 4, 32 * 1024)));
 }
 
+// zero_stat: `stat` is (re)initialised by this call (the BatchNorm passes) instead of accumulated into (mvp_colstats_f32)
 template <typename Src>
-int launch_colstats(Src src, int64_t R, int64_t C, double* stat, double* partial, hipStream_t s) {
+int launch_colstats(Src src, int64_t R, int64_t C, double* stat, double* partial, bool zero_stat, hipStream_t s) {
+  if (zero_stat && !(partial && R > 0) && hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
   if (R == 0) return MVP_OK;
   if (partial) {
     const int64_t blocks = colstats_blocks_partial(R, C);
-    hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)blocks), dim3(kRT), 0, s, src, R, (int)C, stat, partial);
+    hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)blocks), dim3(kRT), 0, s, src, R, (int)C, stat, partial, zero_stat ? 1 : 0);
     launch_stats_reduce(partial, blocks, (int)(2 * C), stat, s);
     return mvp_launch_status();
   }
   // fp64 atomics: one workgroup per ~512 KB of rows, between 16 and 256 of them (they queue per result address)
   const int64_t blocks = std::min<int64_t>(256, std::max<int64_t>(16, cdiv(R * C * 4, 512 * 1024)));
-  hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)blocks), dim3(kRT), 0, s, src, R, (int)C, stat, static_cast<double*>(nullptr));
+  hipLaunchKernelGGL(colstats_kernel<Src>, dim3((unsigned)blocks), dim3(kRT), 0, s, src, R, (int)C, stat, static_cast<double*>(nullptr), 0);
   return mvp_launch_status();
 }
 
@@ -903,8 +909,7 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
   const int64_t R = G * K;
   if (training) {
     MVP_NONNULL(stat);
-    if (hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
-    rc = launch_colstats(Plain{y}, R, C, stat, partial, s);
+    rc = launch_colstats(Plain{y}, R, C, stat, partial, true, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, stat, R, (int)C, eps, momentum,
                        mean, invstd, running_mean, running_var, static_cast<int64_t*>(nullptr));
@@ -945,13 +950,12 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t R = G * K;
-  if (hipMemsetAsync(stat, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return MVP_EINVAL;
   if (K == 1)
-    rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, partial, s);
+    rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, partial, true, s);
   else if (arg == nullptr)
-    rc = launch_colstats(BwdSum{dsrc, y, mean, invstd, gamma, beta, (int)K, relu}, R, C, stat, partial, s);
+    rc = launch_colstats(BwdSum{dsrc, y, mean, invstd, gamma, beta, (int)K, relu}, R, C, stat, partial, true, s);
   else
-    rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, gamma, beta, arg, (int)K, relu}, G, C, stat, partial, s);
+    rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, gamma, beta, arg, (int)K, relu}, G, C, stat, partial, true, s);
   if (rc || R == 0) return rc;
   if (K > 1) {  // through the max over K: one lane per group streams its K rows
     dim3 pgrid((unsigned)cdiv(G * (C / 4), kRT));
@@ -1038,7 +1042,7 @@ MVP_API int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat,
   MVP_NONNULL(stat);
   int rc = check_rows(R, C);
   if (rc) return rc;
-  return launch_colstats(Plain{y}, R, C, stat, partial, static_cast<hipStream_t>(stream));
+  return launch_colstats(Plain{y}, R, C, stat, partial, false, static_cast<hipStream_t>(stream));
 }
 
 // float64 elements of the optional `partial` scratch of the column-statistics passes over R rows of C columns
