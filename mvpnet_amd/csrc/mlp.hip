@@ -73,8 +73,11 @@ constexpr int kMaxActCin = 512;    // input-activation parameters staged in LDS 
 
 // VEC: X and W rows are 16-byte aligned with lengths that are multiples of 4 (decided by the host; a run-time test in the
 // kernel makes the compiler issue both the scalar and the vector loads).
+#ifndef MVP_MLP_WAVES128
+#define MVP_MLP_WAVES128 3
+#endif
 template <int BN, int BK, bool WT, bool VEC>
-__global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
+__global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 1) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
                                                       const float* __restrict__ W, int ldw, int Cout,
                                                       InAct act, const float* __restrict__ bias, EpiBwd epi,
                                                       float* __restrict__ Y /* (R, Cout) */, double* __restrict__ stat,
@@ -84,10 +87,15 @@ __global__ __launch_bounds__(kMT) void mlp_fwd_kernel(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLdB];
   __shared__ __attribute__((aligned(16))) float Ps[4][kMaxActCin];  // mean, invstd, gamma, beta of the input activation
   constexpr int kLdS = 36;
-  __shared__ __attribute__((aligned(16))) float Ss[4][32 * kLdS];   // per-wave output transposition tile (epilogue)
-  // statistics scratch of the epilogue: aliases the weight slabs (dead after the last barrier of the K loop)
+  // Epilogue scratch: the per-wave output transposition tiles (4 x 32 x 36 floats) and the statistics partials.  The weight
+  // slabs are dead after the last barrier of the K loop; with 128-column tiles both fit inside them (63 -> 45 KB of LDS per
+  // workgroup: three workgroups per CU instead of two), narrower tiles keep a separate transposition buffer.
+  constexpr int kSsFloats = 4 * 32 * kLdS;
+  constexpr bool kAliasS = sizeof(float) * kSsFloats + sizeof(double) * 2 * 4 * BN <= sizeof(float) * 2 * BN * kLdB;
+  __shared__ __attribute__((aligned(16))) float Ss_own[kAliasS ? 4 : kSsFloats];
+  float (*Ss)[32 * kLdS] = reinterpret_cast<float (*)[32 * kLdS]>(kAliasS ? &Bs[0][0] : &Ss_own[0]);
   static_assert(sizeof(double) * 2 * 4 * BN <= sizeof(float) * 2 * BN * kLdB, "sred must fit in Bs");
-  double (*sred)[4][BN] = reinterpret_cast<double (*)[4][BN]>(&Bs[0][0]);
+  double (*sred)[4][BN] = reinterpret_cast<double (*)[4][BN]>(&Bs[0][0] + (kAliasS ? kSsFloats : 0));
   constexpr int NB = BN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * kBM;
