@@ -95,7 +95,7 @@ class MVPNet3D(nn.Module):
         return self._geo_stream
 
     def forward(self, data_batch):
-        with R.zero_pool.step(data_batch['points'].device):  # one zero fill for all accumulators of this step (rows.ZeroPool)
+        with R.zero_pool.step(data_batch['points'].device), R.eval_invstd.scope(self):  # rows.ZeroPool / rows.EvalInvStd
             return self._forward(data_batch)
 
     def _forward(self, data_batch):

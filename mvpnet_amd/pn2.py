@@ -61,19 +61,26 @@ class SetAbstraction(nn.Module):
         self.mlp = SharedMLP(self.in_channels, mlp_channels, ndim=2, bn=True)
         self.grouper = None if num_centroids == 0 else QueryGrouper(radius, max_neighbors)
 
-    def geometry(self, xyz, with_csr=False):
-        """Everything of this layer that depends on coordinates only: centroids + neighbour index
-        [+ with_csr: the transposed index (offsets, slots) the backward of the grouping gathers through]."""
+    def centroids(self, xyz):
+        """Farthest point sampling -> centroid coordinates (the sequential part of the geometry)."""
         with torch.no_grad():
             if self.num_centroids == -1:
-                new_xyz = xyz
-            else:
-                index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False)
-                new_xyz = torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
+                return xyz
+            index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False)
+            return torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
+
+    def neighbours(self, new_xyz, xyz, with_csr=False):
+        """Ball query [+ with_csr: the transposed index (offsets, slots) the backward of the grouping gathers through]."""
+        with torch.no_grad():
             ball = ops.ball_query(new_xyz, xyz, self.radius, self.max_neighbors, transpose=False)
             if with_csr:
-                return (new_xyz, ball) + R.build_csr(ball, xyz.size(1))
-        return new_xyz, ball
+                return (ball,) + R.build_csr(ball, xyz.size(1))
+        return (ball,)
+
+    def geometry(self, xyz, with_csr=False):
+        """Everything of this layer that depends on coordinates only: centroids + neighbour index [+ transposed index]."""
+        new_xyz = self.centroids(xyz)
+        return (new_xyz,) + self.neighbours(new_xyz, xyz, with_csr)
 
     def forward_rows(self, xyz, feature=None, geometry=None):
         """xyz (B,N,3), feature (B,N,C) or None -> new_xyz (B,M,3), new_feature (B,M,C_out)."""
@@ -278,19 +285,42 @@ class PN2SSG(nn.Module):
         cur = torch.cuda.current_stream(xyz.device)
         if stream is not None:
             stream.wait_stream(cur)
+        # Only the FPS chain is sequential (level l + 1 samples level l's centroids).  Outside graph capture the ball queries, the
+        # 3-NN searches and the transposed indices go to a SECOND side stream, each as soon as its centroids exist, so the
+        # geometry's critical path is the FPS chain alone (2.8 of 3.7 ms at B = 32: it bounds the eval-mode forward).
+        # (Training keeps ONE side stream: its geometry hides under 11 ms of forward + backward anyway, and a third stream of
+        # small kernels takes issue slots from the MFMA kernels: 2790 -> 2750 chunks/s.)
+        two = stream is not None and not with_csr and not torch.cuda.is_current_stream_capturing()
+        s2 = self._second_stream(xyz.device) if two else None
+
+        def on_second(after, fn):
+            if not two:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(after)
+            with torch.cuda.stream(s2):
+                s2.wait_event(ev)
+                return fn()
+
         with torch.cuda.stream(stream if stream is not None else cur):
+            run = torch.cuda.current_stream(xyz.device)
             sa, xyzs = [], [xyz]
+            fp_by_level = {}
             for level, m in enumerate(self.sa_modules):
                 if m.num_centroids == 0:
                     sa.append(None)
                     xyzs.append(xyz.new_zeros([xyz.size(0), 1, 3]))
-                    continue
-                g = m.geometry(xyzs[-1], with_csr=with_csr and (level > 0 or self.in_channels > 0))
-                sa.append(g)
-                xyzs.append(g[0])
-            fp = []
-            for level, m in enumerate(self.fp_modules):
-                fp.append(None if m.interpolator is None else m.interpolator.geometry(xyzs[-2 - level], xyzs[-1 - level], with_csr=with_csr))
+                else:
+                    new_xyz = m.centroids(xyzs[-1])
+                    csr = with_csr and (level > 0 or self.in_channels > 0)
+                    sa.append((new_xyz,) + on_second(run, lambda m=m, a=new_xyz, b=xyzs[-1], c=csr: m.neighbours(a, b, c)))
+                    xyzs.append(new_xyz)
+                fpm = self.fp_modules[len(self.sa_modules) - 1 - level]  # propagates level + 1 -> level
+                if fpm.interpolator is not None:
+                    fp_by_level[level] = on_second(run, lambda i=fpm.interpolator, a=xyzs[-2], b=xyzs[-1]: i.geometry(a, b, with_csr=with_csr))
+            fp = [fp_by_level.get(len(self.sa_modules) - 1 - k) for k in range(len(self.fp_modules))]
+            if two:
+                run.wait_stream(s2)
             event = torch.cuda.Event()
             event.record()
         # `xyz` is read by the side stream long after this function returns (ball query / 3-NN of level 1 run after the 2.4 ms
@@ -305,10 +335,15 @@ class PN2SSG(nn.Module):
                         t.record_stream(cur)
         return plan
 
+    def _second_stream(self, device):
+        if getattr(self, '_geo_stream2', None) is None or self._geo_stream2.device != device:
+            self._geo_stream2 = torch.cuda.Stream(device=device)
+        return self._geo_stream2
+
     def forward(self, data_batch):
         """data_batch: 'points' (B,3,N) [+ 'feature' (B,C,N), or 'feature_rows' (B,N,C) channels-last]
         [+ 'geometry_plan' from plan_geometry()] -> {'seg_logit': (B,num_classes,N)}."""
-        with R.zero_pool.step(data_batch['points'].device):  # one zero fill for all accumulators of this step
+        with R.zero_pool.step(data_batch['points'].device), R.eval_invstd.scope(self):  # one zero fill per step / one invstd pass per eval forward
             return self._forward(data_batch)
 
     def _forward(self, data_batch):

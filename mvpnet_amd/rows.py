@@ -109,6 +109,51 @@ class ZeroPool:
 zero_pool = ZeroPool()
 
 
+class EvalInvStd:
+    """1/sqrt(running_var + eps) of ALL BatchNorm layers of a model in two multi-tensor launches per eval-mode forward,
+    instead of an add and an rsqrt launch per layer (50 launches of ~4 us each in PN2SSG, 5 % of the forward).  Filled by
+    the top-level model forward (`with eval_invstd.scope(model)`), looked up by running_var storage address; a miss falls
+    back to the per-layer computation.  Same arithmetic (fp32 add, fp32 rsqrt), so results are bit-identical."""
+
+    def __init__(self):
+        self.table = {}
+        self.depth = 0
+
+    class _Scope:
+        def __init__(self, owner, model):
+            self.owner, self.model = owner, model
+
+        def __enter__(self):
+            o = self.owner
+            if o.depth == 0 and not self.model.training:
+                by_eps = {}
+                for m in self.model.modules():
+                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.running_var is not None and m.running_var.is_cuda:
+                        by_eps.setdefault(float(m.eps), []).append(m.running_var)
+                for eps, rvs in by_eps.items():
+                    inv = torch._foreach_add(rvs, eps)
+                    torch._foreach_rsqrt_(inv)
+                    for rv, t in zip(rvs, inv):
+                        o.table[(rv.data_ptr(), eps)] = t
+            o.depth += 1
+
+        def __exit__(self, *exc):
+            o = self.owner
+            o.depth -= 1
+            if o.depth == 0:
+                o.table.clear()
+
+    def scope(self, model):
+        return EvalInvStd._Scope(self, model)
+
+    def get(self, running_var, eps):
+        t = self.table.get((running_var.data_ptr(), float(eps)))
+        return t if t is not None else torch.rsqrt(running_var + eps)
+
+
+eval_invstd = EvalInvStd()
+
+
 def build_csr(index, N):
     """index (B, ...) int64 positions into N points -> (offsets (B,N+1) int32, slots (B,E) int32): for every point the list of
     flattened positions that read it (mvp_csr_build_i64).  Turns the scatter-add backward of a gather into a gather."""
@@ -279,7 +324,7 @@ class BNActRows(torch.autograd.Function):
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
         else:
             mean = running_mean
-            invstd = torch.rsqrt(running_var + eps)
+            invstd = eval_invstd.get(running_var, eps)
         L.call('mvp_bn_rows_forward_f32', y, L.ptr(y), L.ptr(gamma), L.ptr(beta), G, K, C, int(training), float(eps),
                float(momentum), int(relu), L.ptr(running_mean) if training else None,
                L.ptr(running_var) if training else None, L.ptr(stat), L.ptr(mean), L.ptr(invstd), L.ptr(out), L.ptr(arg),
@@ -409,7 +454,7 @@ class MLPChainRows(torch.autograd.Function):
                 L.call('mvp_bn_finalize_f32', y, L.ptr(stat), R, cout, float(eps), float(mom), L.ptr(mean), L.ptr(invstd),
                        L.ptr(rm), L.ptr(rv), L.ptr(nbt))
             else:
-                mean, invstd = rm, torch.rsqrt(rv + eps)
+                mean, invstd = rm, eval_invstd.get(rv, eps)
             ys.append(y)
             means.append(mean)
             invstds.append(invstd)
