@@ -76,7 +76,9 @@ constexpr int kMaxActCin = 512;    // input-activation parameters staged in LDS 
 #ifndef MVP_MLP_WAVES128
 #define MVP_MLP_WAVES128 3
 #endif
-template <int BN, int BK, bool WT, bool VEC>
+// ACT: 0 = no input activation, 1 = its per-column parameters staged in LDS (Cin <= kMaxActCin), 2 = read from global memory.
+// A compile-time choice: as run-time branches they were replicated for each of the four k-groups behind the MFMA block.
+template <int BN, int BK, bool WT, bool VEC, int ACT>
 __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 1) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
                                                       const float* __restrict__ W, int ldw, int Cout,
                                                       InAct act, const float* __restrict__ bias, EpiBwd epi,
@@ -108,9 +110,9 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  const bool has_act = act.mean != nullptr;
-  const bool act_lds = has_act && Cin <= kMaxActCin;
-  if (act_lds) {
+  constexpr bool has_act = ACT != 0;
+  constexpr bool act_lds = ACT == 1;
+  if constexpr (act_lds) {
     for (int k = tid; k < min(kMaxActCin, (Cin + BK - 1) / BK * BK); k += kMT) {
       const int kc = min(k, Cin - 1);
       Ps[0][k] = act.mean[kc];
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
     for (int t = 0; t < NT; ++t) {
       const int k = k0 + 8 * t + 4 * lh;
       float v[4] = {an[t].x, an[t].y, an[t].z, an[t].w};
-      if (has_act) {
+      if constexpr (has_act) {
         float pm[4], pi[4], pg[4], pb[4];
-        if (act_lds) {
+        if constexpr (act_lds) {
           const float4 m4 = *reinterpret_cast<const float4*>(&Ps[0][k]), i4 = *reinterpret_cast<const float4*>(&Ps[1][k]);
           const float4 g4 = *reinterpret_cast<const float4*>(&Ps[2][k]), b4 = *reinterpret_cast<const float4*>(&Ps[3][k]);
           pm[0] = m4.x; pm[1] = m4.y; pm[2] = m4.z; pm[3] = m4.w;
@@ -172,8 +174,11 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
           v[e] = a > 0.f ? a : 0.f;
         }
       }
+      // No masking here: rows past R and k past Cin carry (finite) copies of valid data -- the loads are clamped --, the weight
+      // slab is ZERO for k >= Cin (store_b) and rows past R are neither stored nor counted in the epilogue.  Masking made the
+      // compiler wrap the activation of every k-group in an exec-mask branch with its own LDS waits.
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ac[t][e] = (arow_ok && k + e < Cin) ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) ac[t][e] = v[e];
     }
   };
 
@@ -556,8 +561,17 @@ void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int l
                    K >= 4 && N >= 4;
 #define MVP_MLP_LAUNCH(BN, VEC)                                                                                                   \
   /* K slab of 32: a 64-wide slab was measured slower (fewer slabs per tile expose the first load) */                                \
-  hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, ldw, N, act, \
-                     bias, epi, Y, stat, partial)
+  do {                                                                                                                             \
+    if (WT || act.mean == nullptr)                                                                                                 \
+      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, 0>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, ldw, N, \
+                         act, bias, epi, Y, stat, partial);                                                                        \
+    else if (K <= kMaxActCin)                                                                                                      \
+      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, WT ? 0 : 1>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, \
+                         ldw, N, act, bias, epi, Y, stat, partial);                                                                \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, WT ? 0 : 2>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, \
+                         ldw, N, act, bias, epi, Y, stat, partial);                                                                \
+  } while (0)
   // Few rows (the 128- and 512-point levels): narrower column tiles until the launch has a workgroup for each of the 256 CUs.
   int bn = N <= 32 ? 32 : N <= 64 ? 64 : 128;
   while (bn > 32 && (int64_t)gx * cdiv(N, bn) < 256) bn >>= 1;
