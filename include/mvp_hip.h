@@ -172,6 +172,10 @@ int mvp_group_rows_f32(const float* feature, const float* xyz, const float* cent
                        int64_t N, int64_t C, int64_t M, int64_t K, int64_t ld, float* out, mvp_stream_t stream);
 int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t N, int64_t C, int64_t M,
                                 int64_t K, int64_t ld, float* grad_feature, mvp_stream_t stream);
+/* FeatureAggregation input (mvpnet/models/mvpnet_3d.py:55-56: cat[feature, src - tgt, |src - tgt|^2]) on rows:
+ * feature (R*K, C) gathered rows, src_xyz (R*K, 3), tgt_xyz (R, 3) -> out (R*K, C+4), C % 4 == 0, in one pass. */
+int mvp_relation_rows_f32(const float* feature, const float* src_xyz, const float* tgt_xyz, int64_t R, int64_t K, int64_t C,
+                          float* out, mvp_stream_t stream);
 /* Set-abstraction grouping AFTER the feature part of the (linear) first shared-MLP layer (modules.py:20-37,107):
  *   out (B,M,K,C) = zf (B,N,C)[index] + wxyz (C,3) . (xyz (B,N,3)[index] - centre (B,M,3))
  * with zf = W1[:, :C_in] . feature evaluated once per point (8x fewer conv rows than grouping first) and the coordinate

@@ -47,9 +47,11 @@ class FeatureAggregation(nn.Module):
         if self.mlp is None:
             return gfeat.sum(2) if self.reduction_name == 'sum' else gfeat.max(2)[0]
         x = gfeat
-        if self.use_relation:
+        if self.use_relation and gfeat.is_cuda and gfeat.dtype == torch.float32 and C % 4 == 0:
+            x = R.relation_rows(gfeat, gxyz, points)  # feature, diff, dist (:55-56) written in one pass
+        elif self.use_relation:
             diff = gxyz - points.unsqueeze(2)
-            x = torch.cat([gfeat, diff, torch.sum(diff ** 2, dim=3, keepdim=True)], dim=3)  # feature, diff, dist (:55-56)
+            x = torch.cat([gfeat, diff, torch.sum(diff ** 2, dim=3, keepdim=True)], dim=3)
         if x.size(3) % 4:
             x = torch.nn.functional.pad(x, (0, 4 - x.size(3) % 4))
         # the reduction over the k neighbours (max or sum, :40-41,59) is folded into the last layer's BatchNorm + ReLU kernel

@@ -528,6 +528,29 @@ class MLPChainRows(torch.autograd.Function):
         return (dx0, None, None, None, None, None, None) + tuple(grads)
 
 
+class RelationRows(torch.autograd.Function):
+    """cat[feature (B,N,k,C), src_xyz (B,N,k,3) - tgt_xyz (B,N,3), squared length] -> (B,N,k,C+4) in one kernel
+    (mvp_relation_rows_f32).  Gradient reaches the feature columns only (coordinates carry none on this path)."""
+
+    @staticmethod
+    def forward(ctx, feature, src_xyz, tgt_xyz):
+        L.require_gpu(feature, src_xyz, tgt_xyz)
+        B, N, k, C = feature.shape
+        out = torch.empty((B, N, k, C + 4), dtype=torch.float32, device=feature.device)
+        L.call('mvp_relation_rows_f32', feature, L.ptr(feature), L.ptr(src_xyz), L.ptr(tgt_xyz), B * N, k, C, L.ptr(out))
+        ctx.C = C
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g[..., :ctx.C].contiguous(), None, None
+
+
+def relation_rows(feature, src_xyz, tgt_xyz):
+    return RelationRows.apply(feature.contiguous(), src_xyz.contiguous(), tgt_xyz.contiguous())
+
+
 class LinearRows(torch.autograd.Function):
     """y = x . W^T (+ bias) on rows with the fp32-MFMA kernels (forward, input gradient, weight gradient)."""
 

@@ -673,6 +673,23 @@ def test_column_statistics_scratch_variant(dev, G, K, C, pool):
     np.testing.assert_allclose(b[6].cpu().numpy(), a[6].cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('B,N,k,C', [(2, 1000, 3, 64), (1, 333, 5, 16), (3, 17, 1, 128)])
+def test_relation_rows(dev, B, N, k, C):
+    """mvp_relation_rows_f32 == cat[feature, src - tgt, pinned squared length]; gradient to the feature columns only."""
+    from mvpnet_amd import rows as R
+    torch.manual_seed(N)
+    feat = torch.randn(B, N, k, C, device=dev, requires_grad=True)
+    src, tgt = torch.randn(B, N, k, 3, device=dev), torch.randn(B, N, 3, device=dev)
+    out = R.relation_rows(feat, src, tgt)
+    d = src - tgt.unsqueeze(2)
+    dist = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    assert out.shape == (B, N, k, C + 4)
+    assert torch.equal(out[..., :C], feat.detach()) and torch.equal(out[..., C:C + 3], d) and torch.equal(out[..., C + 3], dist)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    assert torch.equal(feat.grad, w[..., :C])
+
+
 # ------------------------------------------------------------------ rows kernels added for the linear-first factorisations
 @pytest.mark.parametrize('B,N,M,K,C,with_zf', [(2, 300, 50, 16, 32, True), (3, 1000, 129, 32, 64, True), (1, 64, 8, 4, 128, False)])
 def test_group_lin_rows_vs_torch(dev, B, N, M, K, C, with_zf):
