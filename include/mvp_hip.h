@@ -259,10 +259,11 @@ int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, con
 int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ,
                            double* stat, double* partial, mvp_stream_t stream);
-/* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue. */
+/* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
+ * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                             const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
-                            float* dW, mvp_stream_t stream);
+                            float* dW, int64_t lddw, mvp_stream_t stream);
 
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.

@@ -58,7 +58,7 @@ _SIGNATURES = {
                                  _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_rows_backward_finish_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_finalize_f32': [_ptr, _i64, _i64, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
-    'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
     'mvp_mlp_input_grad_f32': [_ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_forward_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
@@ -106,6 +106,11 @@ def stream_of(t):
 
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_at(t, element_offset):
+    """Device pointer `element_offset` elements into contiguous tensor t."""
+    return ctypes.c_void_p(t.data_ptr() + int(element_offset) * t.element_size())
 
 
 def require_gpu(*tensors):

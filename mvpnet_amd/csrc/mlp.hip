@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
 template <int TM, int TN, bool VEC>
 __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
                                                      int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
-                                                     float* __restrict__ dW) {
+                                                     float* __restrict__ dW, int lddw) {
   constexpr int NBLK = (TM / 32) * (TN / 32);  // output blocks of 32 x 32
   constexpr int RS = 4 / NBLK;                 // waves per output block = row split of the slab
   constexpr int BR = 32 * RS;                  // slab rows
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = co0 + wco + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * Cin + ci, acc[i]);
+      if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * lddw + ci, acc[i]);
     }
   }
 }
@@ -613,14 +613,15 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
   return mvp_launch_status();
 }
 
-// dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin])  (accumulated into dW: gradient-accumulation semantics).  act as in mvp_mlp_forward_f32.
+// dW (Cout,Cin; row stride lddw) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin])  (accumulated into dW: gradient-accumulation semantics).
+// lddw > Cin: dW is a column slice of a wider weight gradient (the linear-first factorisations split a conv weight by columns).
 MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                                     const float* act_mean, const float* act_invstd, const float* act_gamma,
-                                    const float* act_beta, float* dW, mvp_stream_t stream) {
+                                    const float* act_beta, float* dW, int64_t lddw, mvp_stream_t stream) {
   MVP_NONNULL(dY);
   MVP_NONNULL(X);
   MVP_NONNULL(dW);
-  MVP_REQUIRE(R >= 0 && Cin > 0 && Cout > 0 && ldx >= Cin && Cin < (1 << 20) && Cout < (1 << 20));
+  MVP_REQUIRE(R >= 0 && Cin > 0 && Cout > 0 && ldx >= Cin && Cin < (1 << 20) && Cout < (1 << 20) && lddw >= Cin && lddw < (1 << 24));
   if (act_mean) {
     MVP_NONNULL(act_invstd);
     MVP_NONNULL(act_gamma);
@@ -643,10 +644,10 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
   do {                                                                                                                             \
     if (vec)                                                                                                                       \
       hipLaunchKernelGGL((mlp_dw_kernel<M_, N_, true>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
-                         rows_per_block, dW);                                                                                      \
+                         rows_per_block, dW, (int)lddw);                                                                           \
     else                                                                                                                           \
       hipLaunchKernelGGL((mlp_dw_kernel<M_, N_, false>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,        \
-                         rows_per_block, dW);                                                                                      \
+                         rows_per_block, dW, (int)lddw);                                                                           \
   } while (0)
   if (TM == 32 && TN == 32) MVP_DW_LAUNCH(32, 32);
   else if (TM == 32) MVP_DW_LAUNCH(32, 64);

@@ -111,10 +111,9 @@ class SetAbstraction(nn.Module):
                 cf = feature.size(2)
                 pad = (-cf) % 4
                 f = torch.nn.functional.pad(feature, (0, pad)) if pad else feature
-                w1f = torch.nn.functional.pad(w1[:, :cf], (0, pad)) if pad else w1[:, :cf]
-                zf = R.linear_rows(f.reshape(B * N, -1), w1f).view(B, N, c1)
+                zf = R.linear_rows(f.reshape(B * N, -1), l0.conv.weight, cols=(0, cf)).view(B, N, c1)
             bn_training = l0.bn.training
-            y1 = R.group_lin_rows(zf, xyz, new_xyz, w1[:, -3:], ball, want_stat=bn_training, csr=csr)  # (B,M,K,C_1): conv output of layer 1
+            y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=bn_training, csr=csr)  # (B,M,K,C_1): conv output of layer 1
             stat1 = None
             if bn_training:
                 y1, stat1 = y1
@@ -222,10 +221,10 @@ class FeaturePropagation(nn.Module):
                 index, weight = geometry[0], geometry[1]
                 csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
                 w1 = l0.conv.weight.reshape(c1, -1)                    # columns [interpolated (C2) | skip (C1)]
-                z = R.linear_rows(sparse_feature.reshape(B * M, c2), w1[:, :c2]).view(B, M, c1)
+                z = R.linear_rows(sparse_feature.reshape(B * M, c2), l0.conv.weight, cols=(0, c2)).view(B, M, c1)
                 zs = None
                 if dense_feature is not None:
-                    zs = R.linear_rows(dense_feature.reshape(B * N, -1), w1[:, c2:]).view(B, N, c1)
+                    zs = R.linear_rows(dense_feature.reshape(B * N, -1), l0.conv.weight, cols=(c2, w1.size(1))).view(B, N, c1)
                 bn_training = l0.bn.training
                 y1 = R.interp_add_rows(z, index, weight, zs, want_stat=bn_training, csr=csr)
                 stat1 = None

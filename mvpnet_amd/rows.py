@@ -176,11 +176,17 @@ class GroupLinRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, zf, xyz, centre, wxyz, index, want_stat, offsets=None, slots=None):
+        # wxyz: a weight whose LAST three columns multiply the coordinates -- a (C,3) matrix, or the layer's whole conv weight
+        # (C, C_in + 3 [,1,1]): the slice is taken here and its gradient written into the full-size gradient below, so autograd
+        # sees no slicing (which costs a zero fill and a strided copy per slice in backward).
+        w_full = wxyz
+        wxyz = w_full.detach().reshape(w_full.size(0), -1)[:, -3:].contiguous()
         L.require_gpu(xyz, centre, wxyz, index)
         B, N, _ = xyz.shape
         _, M, K = index.shape
         C = wxyz.size(0)
-        need_w = wxyz.requires_grad
+        need_w = w_full.requires_grad
+        ctx.w_shape = tuple(w_full.shape)
         dev = xyz.device
         out = torch.empty((B, M, K, C), dtype=torch.float32, device=dev)
         diff = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_w else None
@@ -212,17 +218,30 @@ class GroupLinRows(torch.autograd.Function):
             else:
                 L.call('mvp_group_rows_backward_f32', g, L.ptr(g), L.ptr(index), B, N, C, M, K, C, L.ptr(gz))
         if diff is not None and ctx.needs_input_grad[3]:
-            gw4 = zero_pool.zeros((C, 4), torch.float32, g.device)  # accumulated into
-            L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4))
-            gw = gw4[:, :3].contiguous()
+            # accumulated into; the other columns stay zero.  The diff rows are [dx,dy,dz,0]: as a 4-column operand (16-byte loads)
+            # the zero column adds 0.0 to the first element of the next row -- and, for the last row, to one slack element.
+            numel = 1
+            for d in ctx.w_shape:
+                numel *= d
+            ctot = numel // C
+            if ctot >= 4:
+                buf = zero_pool.zeros(numel + 4, torch.float32, g.device)
+                gw = buf[:numel].view(ctx.w_shape)
+                L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None,
+                       L.ptr_at(buf, ctot - 3), ctot)
+            else:  # the weight IS the (C,3) coordinate part (no input feature)
+                gw4 = zero_pool.zeros((C, 4), torch.float32, g.device)
+                L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4), 4)
+                gw = gw4[:, :3].contiguous().view(ctx.w_shape)
         return gz, None, None, gw, None, None, None, None
 
 
 def group_lin_rows(zf, xyz, centre, wxyz, index, want_stat=False, csr=None):
-    """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3), index (B,M,K) -> (B,M,K,C) [, stat (2C) float64].
+    """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3) -- or the whole conv weight (C, C_in+3[,1,1]) whose last
+    three columns are used --, index (B,M,K) -> (B,M,K,C) [, stat (2C) float64].
     csr: (offsets, slots) of build_csr(index, N) when the geometry plan already holds it."""
     offsets, slots = csr if csr is not None else (None, None)
-    return GroupLinRows.apply(None if zf is None else zf.contiguous(), xyz.contiguous(), centre.contiguous(), wxyz.contiguous(),
+    return GroupLinRows.apply(None if zf is None else zf.contiguous(), xyz.contiguous(), centre.contiguous(), wxyz,
                               index.contiguous(), bool(want_stat), offsets, slots)
 
 
@@ -506,7 +525,7 @@ class MLPChainRows(torch.autograd.Function):
             dw = dw_arena[dw_off:dw_off + cout * cin].view(cout, cin)
             dw_off += cout * cin
             L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
-                   L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw))
+                   L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin)
             grads[3 * i] = dw
             if i > 0 or ctx.needs_input_grad[0]:
                 dz = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
@@ -555,14 +574,25 @@ class LinearRows(torch.autograd.Function):
     """y = x . W^T (+ bias) on rows with the fp32-MFMA kernels (forward, input gradient, weight gradient)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w_full, bias, c0=0, c1=None):
+        # w_full (C_out, C_tot[,1[,1]]); columns [c0, c1) multiply x (R, >= c1 - c0 columns; extra columns are zero padding).
+        # The slice is copied here (one small kernel) and its gradient is written straight into a full-size zeroed gradient
+        # (lddw), so autograd sees no slicing: that costs a zero fill and a strided copy per slice in backward.
+        w2 = w_full.detach().reshape(w_full.size(0), -1)
+        c1 = w2.size(1) if c1 is None else c1
+        R, ldx = x.shape
+        cin = c1 - c0
+        w = w2[:, c0:c1]
+        if ldx != cin:
+            w = torch.nn.functional.pad(w, (0, ldx - cin))
+        w = w.contiguous()
         L.require_gpu(x, w, bias)
-        R, cin = x.shape
         cout = w.size(0)
         y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
-        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, cin, L.ptr(w), cin, cout, None, None, None, None, L.ptr(bias), L.ptr(y), None, None)
+        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, ldx, ldx, L.ptr(w), ldx, cout, None, None, None, None, L.ptr(bias), L.ptr(y), None, None)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.slice = (c0, cin, tuple(w_full.shape))
         return y
 
     @staticmethod
@@ -577,17 +607,20 @@ class LinearRows(torch.autograd.Function):
             gx = torch.empty_like(x)
             L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None)
         if ctx.needs_input_grad[1]:
-            gw = zero_pool.zeros(tuple(w.shape), torch.float32, w.device)  # accumulated into
-            L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, cin, cin, None, None, None, None, L.ptr(gw))
+            c0, ncol, shape = ctx.slice
+            gw = zero_pool.zeros(shape, torch.float32, w.device)  # accumulated into; columns outside the slice stay zero
+            L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None, L.ptr_at(gw, c0),
+                   gw.numel() // cout)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None, None
 
 
-def linear_rows(x, weight, bias=None):
-    """x (R, C_in) float32, weight (C_out, C_in[,1[,1]]), bias (C_out) or None -> (R, C_out)."""
-    w = weight.reshape(weight.size(0), -1).contiguous()
-    return LinearRows.apply(x.contiguous(), w, bias)
+def linear_rows(x, weight, bias=None, cols=None):
+    """x (R, C_in) float32, weight (C_out, C_in[,1[,1]]), bias (C_out) or None -> (R, C_out).
+    cols=(c0, c1): use only those columns of `weight` (x then has c1 - c0 columns, plus optional zero padding)."""
+    c0, c1 = (0, None) if cols is None else cols
+    return LinearRows.apply(x.contiguous(), weight, bias, c0, c1)
 
 
 def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max'):

@@ -614,7 +614,7 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout):
         # weight gradient with the same prologue
         dy = torch.randn(R, Cout, device=dev)
         dw = torch.zeros(Cout, Cin, device=dev)  # accumulated into
-        L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, ldx, *[L.ptr(t) for t in act], L.ptr(dw))
+        L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, ldx, *[L.ptr(t) for t in act], L.ptr(dw), Cin)
         refw = dy.to(hi).t() @ a
         np.testing.assert_allclose(dw.cpu().numpy(), refw.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(refw.abs().max())))
     # input gradient, plain and with the fused ReLU-mask / BN-backward sums epilogue

@@ -8,7 +8,7 @@ def bench(R, Cin, Cout, n=20):
     stat = torch.empty(2 * Cout, dtype=torch.float64, device=dev); part = torch.empty(((R + 127) // 128) * 2 * Cout, dtype=torch.float64, device=dev)
     dy = torch.randn(R, Cout, device=dev); dw = torch.empty(Cout, Cin, device=dev)
     def f(): L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, Cin, L.ptr(w), Cin, Cout, None, None, None, None, None, L.ptr(y), L.ptr(stat), L.ptr(part))
-    def g(): L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, None, None, None, None, L.ptr(dw))
+    def g(): L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, None, None, None, None, L.ptr(dw), Cin)
     def h(): torch.mm(x, w.t(), out=y)
     res = []
     for fn in (f, g, h):

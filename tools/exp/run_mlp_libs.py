@@ -22,7 +22,7 @@ for so in sorted(glob.glob(os.path.join(here, 'libmlp_*.so'))):
         out.append('%7.1f' % (s.elapsed_time(e) / 20 * 1e3))
         dy = torch.randn(R, Cout, device=dev); dw = torch.zeros(Cout, Cin, device=dev)
         def gdw():
-            assert lib.mvp_mlp_weight_grad_f32(L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, None, None, None, None, L.ptr(dw), None) == 0
+            assert lib.mvp_mlp_weight_grad_f32(L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, None, None, None, None, L.ptr(dw), Cin, None) == 0
         for _ in range(3): gdw()
         s2, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s2.record()
