@@ -201,6 +201,7 @@ class GroupLinRows(torch.autograd.Function):
         ctx.dims = (B, N, C, M, K)
         if want_stat:
             ctx.mark_non_differentiable(stat)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
             return out, stat
         return out
 
@@ -296,6 +297,7 @@ class InterpAddRows(torch.autograd.Function):
         ctx.has_add = add is not None
         if want_stat:
             ctx.mark_non_differentiable(stat)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
             return out, stat
         return out
 
