@@ -69,15 +69,17 @@ class LiftGatherFunction(torch.autograd.Function):
         ctx.save_for_backward(index)
         ctx.shape = tuple(feature.shape)
         gfeat = torch.empty((B, N, k, C), dtype=torch.float32, device=feature.device)
-        gxyz = torch.empty((B, N, k, 3), dtype=torch.float32, device=feature.device)
+        gxyz = torch.empty((B, N, k, 3), dtype=torch.float32, device=feature.device) if image_xyz is not None else None
         L.call('mvp_lift_gather_f32', feature, L.ptr(feature), L.ptr(image_xyz), L.ptr(index), B, P, C, N, k,
                L.ptr(gfeat), L.ptr(gxyz))
+        if gxyz is None:
+            return gfeat
         ctx.mark_non_differentiable(gxyz)
         return gfeat, gxyz
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_gfeat, _grad_gxyz):
+    def backward(ctx, grad_gfeat, _grad_gxyz=None):
         (index,) = ctx.saved_tensors
         B, N, k = index.shape
         C = ctx.shape[-1]
@@ -91,10 +93,12 @@ class LiftGatherFunction(torch.autograd.Function):
 
 
 def lift_gather(feature, image_xyz, knn_indices):
-    """feature (B,nv,h,w,C) or (B,P,C) float32 channels-last, image_xyz (B,nv,h,w,3) or (B,P,3),
-    knn_indices (B,N,k) -> gathered feature (B,N,k,C), gathered xyz (B,N,k,3)."""
-    if feature.dtype != torch.float32 or image_xyz.dtype != torch.float32 or knn_indices.dtype != torch.int64:
+    """feature (B,nv,h,w,C) or (B,P,C) float32 channels-last, image_xyz (B,nv,h,w,3) or (B,P,3) or None,
+    knn_indices (B,N,k) -> gathered feature (B,N,k,C), gathered xyz (B,N,k,3) (None without image_xyz)."""
+    if feature.dtype != torch.float32 or (image_xyz is not None and image_xyz.dtype != torch.float32) or knn_indices.dtype != torch.int64:
         raise RuntimeError('lift_gather: float32 feature/xyz and int64 indices expected')
+    if image_xyz is None:
+        return LiftGatherFunction.apply(feature.contiguous(), None, knn_indices.contiguous()), None
     return LiftGatherFunction.apply(feature.contiguous(), image_xyz.contiguous(), knn_indices.contiguous())
 
 

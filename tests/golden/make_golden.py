@@ -567,6 +567,27 @@ def gen_chunker():
     save('chunker', **out)
 
 
+def gen_mvpnet2d():
+    """MVPNet2D (mvpnet/models/mvpnet_2d.py:7-34, imported; group_points stubbed with the reference's test oracle) on a seeded
+    2D logit map and k-NN index: lifted logits and the gradient that reaches the 2D logits."""
+    from mvpnet.models.mvpnet_2d import MVPNet2D
+
+    class Net2D(torch.nn.Module):
+        def forward(self, data):
+            return {'seg_logit': self.logit}
+
+    rs = np.random.RandomState(77)
+    b, nv, h, w, nc, n, k = 2, 3, 12, 16, 20, 300, 3
+    net = Net2D()
+    net.logit = torch.from_numpy(rs.randn(b * nv, nc, h, w).astype(np.float32)).requires_grad_(True)
+    knn = torch.from_numpy(rs.randint(0, nv * h * w, (b, n, k)).astype(np.int64))
+    out = MVPNet2D(net)({'images': torch.zeros(b, nv, 3, h, w), 'knn_indices': knn})['seg_logit']
+    wgt = torch.from_numpy(rs.randn(*out.shape).astype(np.float32))
+    (out * wgt).sum().backward()
+    save('mvpnet2d', logit_2d=net.logit.detach().numpy(), knn_indices=knn.numpy(), seg_logit=out.detach().numpy(), weight=wgt.numpy(),
+         grad_logit_2d=net.logit.grad.numpy())
+
+
 def gen_metrics():
     """Meters, evaluator, loss and checkpoint files from the imported reference classes (mvpnet/models/metric.py,
     mvpnet/models/loss.py, mvpnet/evaluate_3d.py, common/utils/{metric_logger,checkpoint}.py) on seeded inputs."""
@@ -697,6 +718,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':  # only the fixtures of SURVEY sec.8f rank 4
         gen_metrics()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'mvpnet2d':
+        install_reference()
+        gen_mvpnet2d()
+        return
     gen_configs()
     T = install_reference()
     gen_fps(T)
@@ -710,6 +735,7 @@ def main():
     gen_unet()
     gen_chunker()
     gen_metrics()
+    gen_mvpnet2d()
     import sklearn
     manifest = dict(numpy=np.__version__, torch=torch.__version__, sklearn=sklearn.__version__,
                     reference='/root/reference (maxjaritz/mvpnet @ v0)', generator='tests/golden/make_golden.py')
