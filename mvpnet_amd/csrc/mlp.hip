@@ -28,8 +28,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMT = 256;   // threads
 constexpr int kBM = 128;   // rows per workgroup
-constexpr int kBK = 32;    // K slab
-constexpr int kLd = kBK + 1;
 
 struct InAct {  // previous layer's BatchNorm + ReLU, per input column (may be null = identity)
   const float* mean;
