@@ -134,6 +134,12 @@ def suffix(t):
 
 def call(name, tensor_for_device, *args):
     """Invoke `name(*args, stream)` on the current stream of tensor_for_device's device."""
-    with torch.cuda.device(tensor_for_device.device):
-        code = getattr(lib(), name)(*args, stream_of(tensor_for_device))
-    check(code, name)
+    dev = tensor_for_device.device
+    fn = getattr(_lib if _lib is not None else lib(), name)
+    if dev.index == torch.cuda.current_device():  # the usual case (one process per GPU): no device-guard context per launch
+        code = fn(*args, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    else:
+        with torch.cuda.device(dev):
+            code = fn(*args, stream_of(tensor_for_device))
+    if code != 0:
+        check(code, name)
