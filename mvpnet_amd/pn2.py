@@ -334,6 +334,15 @@ class PN2SSG(nn.Module):
                         t.record_stream(cur)
         return plan
 
+    @staticmethod
+    def slice_plan(plan, lo, hi):
+        """The geometry plan of clouds lo..hi-1 of a plan made for a larger batch (views, no copies).  FPS runs one workgroup
+        per cloud for ~2.8 ms whatever the batch size, so planning ALL chunks of a scene in one call and slicing per batch costs
+        one FPS chain per scene instead of one per batch (scene.infer_scene)."""
+        cut = lambda g: None if g is None else tuple(t[lo:hi] for t in g)
+        return {'sa': [cut(g) for g in plan['sa']], 'fp': [cut(g) for g in plan['fp']], 'event': plan['event'],
+                'stream': plan['stream'], 'xyz': plan['xyz']}
+
     def _second_stream(self, device):
         if getattr(self, '_geo_stream2', None) is None or self._geo_stream2.device != device:
             self._geo_stream2 = torch.cuda.Stream(device=device)
