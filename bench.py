@@ -208,7 +208,7 @@ def main():
     torch.manual_seed(0)
     net2d = SuppliedFeature2D()
     net2d.feature = feature
-    model = C.build_model_mvpnet_3d(cfg, net2d).to(dev).train()  # reference defaults incl. dropout 0.5
+    model = C.build_model_mvpnet_3d(cfg, net2d, load_2d_ckpt=False).to(dev).train()  # reference defaults incl. dropout 0.5
     D.broadcast_parameters(model)
     weights = torch.linspace(0.5, 1.5, 20, device=dev)  # stands in for the class log-weights file (TRAIN.LABEL_WEIGHTS_PATH)
     loss_fn = SegLoss(weight=weights)
@@ -336,7 +336,7 @@ def main():
     e2e = None
     if not args.train_only:
         torch.manual_seed(0)
-        model2 = C.build_model_mvpnet_3d(cfg).to(dev).train()
+        model2 = C.build_model_mvpnet_3d(cfg, load_2d_ckpt=False).to(dev).train()
         model2.net_2d.eval()
         opt2 = C.build_optimizer(cfg, model2)
         b2 = dict(batch, images=torch.randn(args.batch, 3, 3, 120, 160, device=dev))

@@ -6,8 +6,9 @@ The reference uses yacs (absent here): defaults in `common/config/base.py:10-137
 `common/config/__init__.py:4-17`, factories in `mvpnet/models/build.py:8-47` and
 `common/solver/build.py:7-41`.  This is a PyYAML + `ast.literal_eval` work-alike of exactly what those
 need: nested attribute access, defaults, `merge_from_file` / `merge_from_list`, tuples written as strings
-("(160, 120)") evaluated like yacs does, and TYPE-keyed purge.  Only the hot path's knobs are defaulted;
-unknown keys from a YAML are accepted and kept (dataset, logging... are out of scope but must not fail).
+("(160, 120)") evaluated like yacs does, and TYPE-keyed purge.  The default trees below are pinned key by key
+against the reference's own config modules (tests/golden/config_defaults.json, dumped by importing them with a
+dict stand-in for yacs: tests/golden/make_golden.py::gen_config_defaults).
 """
 import ast
 import copy
@@ -115,8 +116,12 @@ def get_cfg_mvpnet_3d():
 def get_cfg_sem_seg_3d():
     """mvpnet/config/sem_seg_3d.py (PN2SSG baseline: no input feature)"""
     cfg = _base()
-    cfg.merge(CfgNode._convert({'TASK': 'sem_seg_3d', 'VAL': {'METRIC': 'seg_iou'},
-                                'MODEL': {'TYPE': '', 'PN2SSG': dict(_PN2SSG, in_channels=0)}}))
+    cfg.merge(CfgNode._convert({
+        'TASK': 'sem_seg_3d', 'VAL': {'METRIC': 'seg_iou'},
+        'DATASET': {'ROOT_DIR': '', 'TRAIN': '', 'VAL': '',
+                    'ScanNet3DChunks': {'chunk_size': '(1.5, 1.5)', 'chunk_thresh': 0.3, 'chunk_margin': '(0.2, 0.2)', 'use_color': False},
+                    'ScanNet3DScene': {'use_color': False}},
+        'MODEL': {'TYPE': '', 'PN2SSG': dict(_PN2SSG, in_channels=0)}}))
     return cfg
 
 
@@ -152,11 +157,14 @@ def build_model_sem_seg_3d(cfg):
     return PN2SSG(**dict(cfg.MODEL.get('PN2SSG', {})))
 
 
-def build_model_mvpnet_3d(cfg, net_2d=None, load_2d_ckpt=False, freeze_2d=True):
+def build_model_mvpnet_3d(cfg, net_2d=None, load_2d_ckpt=True, freeze_2d=True):
     """mvpnet/models/build.py:23-47.  net_2d=None: built from cfg.MODEL_2D (TYPE UNetResNet34, mvpnet_amd/unet_resnet34.py);
-    with freeze_2d (the reference trains MVPNet with the 2D branch frozen, train_mvpnet_3d.py FROZEN_PATTERNS) it is put in
-    folded channels-last inference form AFTER an optional CKPT_PATH load.  A module instance can be supplied instead (e.g. a
-    feature provider); PN2SSG, FeatureAggregation and CKPT_PATH always come from cfg."""
+    with freeze_2d (the reference trains MVPNet with the 2D branch frozen, train_mvpnet_3d.py FROZEN_PATTERNS) it gets a folded
+    channels-last RUNTIME COPY (unet_resnet34.frozen_inference) while its own parameters keep the reference layout, so full
+    MVPNet3D checkpoints of either side load on the other.  MODEL_2D.CKPT_PATH is loaded like the reference does
+    (mvpnet_3d.py:78-81) whenever it is non-empty; load_2d_ckpt=False is for synthetic runs without the checkpoint file and
+    says so.  A module instance can be supplied instead (e.g. a feature provider); PN2SSG and FeatureAggregation always come
+    from cfg."""
     from .pn2 import PN2SSG
     from .mvpnet3d import MVPNet3D
     assert cfg.TASK == 'mvpnet_3d' and cfg.MODEL_3D.TYPE == 'PN2SSG', (cfg.TASK, cfg.MODEL_3D.TYPE)
@@ -166,9 +174,13 @@ def build_model_mvpnet_3d(cfg, net_2d=None, load_2d_ckpt=False, freeze_2d=True):
         assert cfg.MODEL_2D.TYPE == 'UNetResNet34', cfg.MODEL_2D.TYPE
         net_2d = UNetResNet34(**dict(cfg.MODEL_2D.get('UNetResNet34', {})))
     net_3d = PN2SSG(**dict(cfg.MODEL_3D.get('PN2SSG', {})))
-    model = MVPNet3D(net_2d, cfg.MODEL_2D.get('CKPT_PATH', '') if load_2d_ckpt else '', net_3d, **dict(cfg.FEAT_AGGR))
+    ckpt = cfg.MODEL_2D.get('CKPT_PATH', '')
+    if ckpt and not load_2d_ckpt:
+        import warnings
+        warnings.warn('MODEL_2D.CKPT_PATH ({}) is NOT loaded (load_2d_ckpt=False): the 2D network keeps its random initialisation'.format(ckpt))
+    model = MVPNet3D(net_2d, ckpt if load_2d_ckpt else '', net_3d, **dict(cfg.FEAT_AGGR))
     if built_here and freeze_2d:
-        model.net_2d = net_2d.frozen_inference()
+        net_2d.frozen_inference()
     return model
 
 

@@ -45,13 +45,19 @@ def shard_chunks(num_chunks, rank, world):
 class GradSync:
     """Flat-bucket gradient averaging: one all-reduce per step over all trainable parameters.
     At 3.9 MB the message is latency-bound on xGMI, so a single bucket (not per-layer buckets
-    sized for NVSwitch) is the right granularity."""
+    sized for NVSwitch) is the right granularity.
+
+    __call__(weight_sum=None).  The reference computes SegLoss ONCE on the gathered full batch (outside DataParallel):
+    weighted cross entropy with ignore_index normalises by the sum of w[y] over the valid points, so the full-batch gradient
+    is  sum_r (W_r / W_total) g_r  with g_r the gradient of rank r's mean loss and W_r its weight mass.  Pass the rank's
+    W_r (`SegLoss.last_weight_sum`, a 0-dim tensor) to get exactly that -- it travels in the same flat buffer, still ONE
+    collective.  Without it the plain mean over ranks is taken (equal to the above only for equal weight masses)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
 
-    def __call__(self):
+    def __call__(self, weight_sum=None):
         w = world_size()
         if w == 1 or not self.params:
             return
@@ -60,9 +66,17 @@ class GradSync:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             grads.append(p.grad)
-        flat = torch.cat([g.reshape(-1) for g in grads])           # one kernel in, ...
+        parts = [g.reshape(-1) for g in grads]
+        if weight_sum is not None:
+            parts.append(weight_sum.detach().to(device=grads[0].device, dtype=grads[0].dtype).reshape(1))
+        flat = torch.cat(parts)                                      # one kernel in, ...
+        if weight_sum is not None:
+            flat[:-1].mul_(flat[-1])                                 # g_r * W_r  (the last element stays W_r)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(w)
+        if weight_sum is not None:
+            flat = flat[:-1] / flat[-1].clamp_min(torch.finfo(flat.dtype).tiny)
+        else:
+            flat.div_(w)
         chunks = [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)]
         torch._foreach_copy_(grads, chunks)                          # ... one multi-tensor kernel out
 
@@ -76,13 +90,16 @@ def broadcast_parameters(module, src=0):
 
 
 def all_gather_logits(local_logits, num_chunks):
-    """local_logits: (n_local, C, N) for the chunks `shard_chunks(num_chunks, rank, W)` in that order.
-    Returns (num_chunks, C, N) in global chunk order on every rank.  Ranks with fewer chunks pad."""
+    """local_logits: (n_local, C, N) for the chunks `shard_chunks(num_chunks, rank, W)` in that order (n_local may be 0:
+    the tensor must still carry the common C and N).  Returns (num_chunks, C, N) in global chunk order on every rank.
+    Ranks with fewer chunks pad.  N must be the same on every rank: ragged chunks are cut / padded to the scene-wide
+    maximum of their VALID lengths by the caller (scene.infer_scene), which every rank knows from the chunk index lists."""
     w = world_size()
     if w == 1:
         return local_logits
-    rank = dist.get_rank()
     per = (num_chunks + w - 1) // w
+    if local_logits.size(0) > per:
+        raise RuntimeError('all_gather_logits: {} local chunks but at most {} per rank'.format(local_logits.size(0), per))
     pad = per - local_logits.size(0)
     if pad:
         local_logits = torch.cat([local_logits, local_logits.new_zeros((pad,) + tuple(local_logits.shape[1:]))])
@@ -90,7 +107,6 @@ def all_gather_logits(local_logits, num_chunks):
     dist.all_gather_into_tensor(out, local_logits.contiguous())
     # out is rank-major [r][j] -> chunk r + j*W
     out = out.view(w, per, *local_logits.shape[1:]).transpose(0, 1).reshape(w * per, *local_logits.shape[1:])
-    del rank
     return out[:num_chunks]
 
 

@@ -1,105 +1,22 @@
-"""Meters and evaluation: same names, constructor arguments, `update_dict` contract and
-string formats as the reference, so its training / test loops log the same lines:
+"""Segmentation meters and the whole-scene evaluator matrices.
 
-  AverageMeter, MetricLogger    common/utils/metric_logger.py:11-107
-  SegAccuracy, SegIoU           mvpnet/models/metric.py:5-73
-  Evaluator, CLASS_NAMES, ...   mvpnet/evaluate_3d.py:4-92
+  SegAccuracy, SegIoU           mvpnet/models/metric.py:5-73   (same names, `update_dict` contract, strings)
+  Evaluator, CLASS_NAMES, ...   mvpnet/evaluate_3d.py:4-92     (confusion matrix + accuracy / IoU numbers only)
 
-MI355X side: for fp32 logits on the GPU both segmentation meters get `argmax -> mask by ignore_index -> bincount`
-from ONE pass of `mvp_seg_confusion_f32` over the logits where the network left them ((B,C,N) or channels-last rows);
-the reference runs argmax, two boolean-mask compactions, `eq`, `bincount` and a reshape as separate ATen kernels, twice.
-The running confusion matrix of SegIoU stays on the device; nothing is synchronised until a value is read.
-Host tensors take the torch path (the reference's own arithmetic) -- these classes are host glue, not the hot path.
+MI355X side: for fp32 logits on the GPU both meters get `argmax -> mask by ignore_index -> bincount` from ONE pass of
+`mvp_seg_confusion_f32` over the logits where the network left them ((B,C,N) or channels-last rows); the reference runs
+argmax, two boolean-mask compactions, `eq`, `bincount` and a reshape as separate ATen kernels, twice.  The running
+confusion matrix of SegIoU stays on the device; nothing is synchronised until a value is read.  Host tensors take the
+torch path (the reference's own arithmetic).
+
+The generic host utilities of the reference (`common/utils/metric_logger.py`: AverageMeter, MetricLogger; the evaluator's
+table printing) are OUT OF SCOPE and not re-implemented: the reference's own `MetricLogger.add_meter(s)` accepts the two
+meters below as they are (they expose `name`, `update_dict`, `__str__`, `summary_str`, `reset`, `avg`, `global_avg`).
 Pinned against the imported reference classes by tests/golden/metrics.npz."""
-import collections
-
 import numpy as np
 import torch
 
 from . import _lib as L
-
-
-class AverageMeter(object):
-    """Windowed and global average of a stream of (value, count) pairs (metric_logger.py:11-50)."""
-    default_fmt = '{avg:.4f} ({global_avg:.4f})'
-    default_summary_fmt = '{global_avg:.4f}'
-
-    def __init__(self, window_size=20, fmt=None, summary_fmt=None):
-        self.values = collections.deque(maxlen=window_size)
-        self.counts = collections.deque(maxlen=window_size)
-        self.sum = 0.0
-        self.count = 0
-        self.fmt = fmt or self.default_fmt
-        self.summary_fmt = summary_fmt or self.default_summary_fmt
-
-    def update(self, value, count=1):
-        self.values.append(value)
-        self.counts.append(count)
-        self.sum += value
-        self.count += count
-
-    @property
-    def avg(self):
-        return np.sum(self.values) / np.sum(self.counts)
-
-    @property
-    def global_avg(self):
-        return self.sum / self.count if self.count != 0 else float('nan')
-
-    def reset(self):
-        self.values.clear()
-        self.counts.clear()
-        self.sum = 0.0
-        self.count = 0
-
-    def __str__(self):
-        return self.fmt.format(avg=self.avg, global_avg=self.global_avg)
-
-    @property
-    def summary_str(self):
-        return self.summary_fmt.format(global_avg=self.global_avg)
-
-
-class MetricLogger(object):
-    """name -> meter; every meter implements __str__, summary_str, reset (metric_logger.py:53-107)."""
-
-    def __init__(self, delimiter='\t'):
-        self.meters = collections.defaultdict(AverageMeter)
-        self.delimiter = delimiter
-
-    def update(self, **kwargs):
-        for name, v in kwargs.items():
-            if isinstance(v, (torch.Tensor, np.ndarray)):
-                count = v.numel() if isinstance(v, torch.Tensor) else v.size
-                value = v.item() if count == 1 else v.sum().item()
-            else:
-                assert isinstance(v, (float, int))
-                value, count = v, 1
-            self.meters[name].update(value, count)
-
-    def add_meter(self, name, meter):
-        self.meters[name] = meter
-
-    def add_meters(self, meters):
-        for meter in (meters if isinstance(meters, (list, tuple)) else [meters]):
-            self.add_meter(meter.name, meter)
-
-    def __getattr__(self, attr):
-        meters = self.__dict__.get('meters', {})
-        if attr in meters:
-            return meters[attr]
-        raise AttributeError(attr)
-
-    def __str__(self):
-        return self.delimiter.join('{}: {}'.format(name, str(meter)) for name, meter in self.meters.items())
-
-    @property
-    def summary_str(self):
-        return self.delimiter.join('{}: {}'.format(name, meter.summary_str) for name, meter in self.meters.items())
-
-    def reset(self):
-        for meter in self.meters.values():
-            meter.reset()
 
 
 def confusion_matrix(seg_logit, seg_label, num_classes=None, ignore_index=-100, out=None):
@@ -119,19 +36,44 @@ def confusion_matrix(seg_logit, seg_label, num_classes=None, ignore_index=-100, 
     return mat
 
 
-class SegAccuracy(AverageMeter):
-    """Fraction of non-ignored points whose argmax equals the label (metric.py:5-24)."""
+class SegAccuracy(object):
+    """Fraction of non-ignored points whose argmax equals the label (metric.py:5-24): printed as
+    `<mean over the last 20 updates> (<mean over all updates>)`, both weighted by the number of valid points."""
     name = 'seg_acc'
+    WINDOW = 20
 
     def __init__(self, ignore_index=-100):
-        super(SegAccuracy, self).__init__()
         self.ignore_index = ignore_index
+        self.reset()
+
+    def reset(self):
+        self.recent = []          # (correct, valid) of the last WINDOW updates
+        self.sum, self.count = 0.0, 0
 
     def update_dict(self, preds, labels):
         with torch.no_grad():
             mat = confusion_matrix(preds['seg_logit'], labels['seg_label'], ignore_index=self.ignore_index)
-            both = torch.stack([mat.diagonal().sum(), mat.sum()]).tolist()  # ONE device->host copy
-        self.update(both[0], both[1])
+            correct, valid = torch.stack([mat.diagonal().sum(), mat.sum()]).tolist()  # ONE device->host copy
+        self.recent = (self.recent + [(correct, valid)])[-self.WINDOW:]
+        self.sum += correct
+        self.count += valid
+
+    @property
+    def avg(self):
+        hit = sum(c for c, _ in self.recent)
+        tot = sum(v for _, v in self.recent)
+        return hit / tot if tot else float('nan')
+
+    @property
+    def global_avg(self):
+        return self.sum / self.count if self.count else float('nan')
+
+    def __str__(self):
+        return '{:.4f} ({:.4f})'.format(self.avg, self.global_avg)
+
+    @property
+    def summary_str(self):
+        return '{:.4f}'.format(self.global_avg)
 
 
 class SegIoU(object):
@@ -178,66 +120,62 @@ EVAL_CLASS_IDS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34,
 
 
 class Evaluator(object):
-    """Whole-scene evaluation on host label arrays (evaluate_3d.py:11-92).  The confusion matrix is what
-    sklearn.metrics.confusion_matrix(gt, pred, labels=self.labels) returns: pairs with either side outside
-    `labels` (ignored ground truth, the "unlabelled" prediction num_classes) are dropped.  Unlike the reference,
-    `update` does not overwrite the -100 entries of the caller's gt array."""
+    """Whole-scene confusion matrix on host label arrays and the numbers derived from it (evaluate_3d.py:11-92).
+    A (gt, pred) pair counts when BOTH sides are one of `labels` -- what sklearn's confusion_matrix(gt, pred, labels=...)
+    keeps: ignored ground truth and the "unlabelled" prediction (num_classes) drop out.  The caller's arrays are not
+    modified.  The reference's table printing (tabulate) is host formatting and is not part of this build."""
 
     def __init__(self, class_names, labels=None):
         self.class_names = tuple(class_names)
-        self.num_classes = len(class_names)
-        self.labels = np.arange(self.num_classes) if labels is None else np.array(labels)
-        assert self.labels.shape[0] == self.num_classes
-        self.confusion_matrix = np.zeros((self.num_classes, self.num_classes))
+        self.num_classes = n = len(self.class_names)
+        self.labels = np.arange(n) if labels is None else np.asarray(labels)
+        if self.labels.shape != (n,):
+            raise ValueError('one label id per class expected')
+        self._order = np.argsort(self.labels, kind='stable')
+        self._sorted = self.labels[self._order]
+        self.confusion_matrix = np.zeros((n, n))
+
+    def _position(self, values):
+        """index into `labels` of every value, -1 where the value is not a label"""
+        v = np.asarray(values).reshape(-1)
+        at = np.clip(np.searchsorted(self._sorted, v), 0, self.num_classes - 1)
+        return np.where(self._sorted[at] == v, self._order[at], -1)
 
     def update(self, pred_label, gt_label):
         gt = np.asarray(gt_label).reshape(-1)
-        pred = np.asarray(pred_label).reshape(-1)
-        if np.all(gt < 0):
+        if not (gt >= 0).any():
             print('Invalid label.')
             return
+        row, col = self._position(gt), self._position(pred_label)
+        both = (row >= 0) & (col >= 0)
         n = self.num_classes
-        lut = {int(v): i for i, v in enumerate(self.labels)}
-        to_pos = np.vectorize(lambda v: lut.get(int(v), -1), otypes=[np.int64])
-        gi, pi = to_pos(gt), to_pos(pred)
-        keep = (gi >= 0) & (pi >= 0)
-        self.confusion_matrix += np.bincount(gi[keep] * n + pi[keep], minlength=n * n).reshape(n, n)
+        self.confusion_matrix += np.bincount(row[both] * n + col[both], minlength=n * n).reshape(n, n)
 
     def batch_update(self, pred_labels, gt_labels):
-        assert len(pred_labels) == len(gt_labels)
-        for pred_label, gt_label in zip(pred_labels, gt_labels):
-            self.update(pred_label, gt_label)
+        if len(pred_labels) != len(gt_labels):
+            raise ValueError('one prediction array per ground-truth array expected')
+        for p, g in zip(pred_labels, gt_labels):
+            self.update(p, g)
 
     @property
     def overall_acc(self):
-        return np.sum(np.diag(self.confusion_matrix)) / np.sum(self.confusion_matrix)
-
-    @property
-    def overall_iou(self):
-        return np.nanmean(self.class_iou)
+        cm = self.confusion_matrix
+        return np.trace(cm) / cm.sum()
 
     @property
     def class_seg_acc(self):
-        return [self.confusion_matrix[i, i] / np.sum(self.confusion_matrix[i]) for i in range(self.num_classes)]
+        cm = self.confusion_matrix
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return list(np.diag(cm) / cm.sum(1))
 
     @property
     def class_iou(self):
         cm = self.confusion_matrix
-        out = []
-        for i in range(self.num_classes):
-            union = cm[:, i].sum() + cm[i, :].sum() - cm[i, i]
-            out.append(float('nan') if union == 0 else cm[i, i] / union)
-        return out
+        tp = np.diag(cm)
+        union = cm.sum(0) + cm.sum(1) - tp
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return list(np.where(union == 0, np.nan, tp / union))
 
-    def print_table(self):
-        from tabulate import tabulate
-        acc, iou = self.class_seg_acc, self.class_iou
-        rows = [[name, acc[i] * 100, iou[i] * 100, int(self.confusion_matrix[i].sum())] for i, name in enumerate(self.class_names)]
-        return tabulate(rows, headers=['Class', 'Accuracy', 'IOU', 'Total'], tablefmt='psql', floatfmt='.2f')
-
-    def save_table(self, filename):
-        from tabulate import tabulate
-        header = ('overall acc', 'overall iou') + self.class_names
-        with open(filename, 'w') as f:  # no alignment, to keep one format across runs
-            f.write(tabulate([[self.overall_acc, self.overall_iou] + self.class_iou], headers=header, tablefmt='tsv', floatfmt='.5f',
-                             numalign=None, stralign=None))
+    @property
+    def overall_iou(self):
+        return np.nanmean(self.class_iou)

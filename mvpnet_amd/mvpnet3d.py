@@ -129,6 +129,8 @@ class _SegLossFn(torch.autograd.Function):
     """F.cross_entropy(logit (B,C,N), label (B,N), weight, ignore_index) in one forward and one backward kernel
     (mvp_seg_loss_f32 / mvp_seg_loss_backward_f32): no (B,C,N) log-probability tensor, no nll_loss fill + scatter."""
 
+    last_acc = None
+
     @staticmethod
     def forward(ctx, logit, label, weight, ignore_index):
         L.require_gpu(label, weight)
@@ -140,6 +142,7 @@ class _SegLossFn(torch.autograd.Function):
                L.ptr(loss))
         ctx.save_for_backward(logit, label, weight, acc)
         ctx.ignore_index = int(ignore_index)
+        _SegLossFn.last_acc = acc  # [sum w*nll, sum w, ticket] of the latest call (SegLoss.last_weight_sum reads [1])
         return loss
 
     @staticmethod
@@ -162,14 +165,20 @@ class SegLoss(nn.Module):
     def __init__(self, weight=None, ignore_index=-100):
         super().__init__()
         self.weight, self.ignore_index = weight, ignore_index
+        self.last_weight_sum = None  # sum of w[label] over the valid points of the last call (0-dim tensor): dist.GradSync(weight_sum=)
 
     def forward(self, preds, labels):
         logit, label = preds['seg_logit'], labels['seg_label']
         if logit.is_cuda and logit.dtype == torch.float32 and logit.dim() == 3 and label.dtype == torch.int64:
             weight = None if self.weight is None else self.weight.to(device=logit.device, dtype=torch.float32).contiguous()
             loss = _SegLossFn.apply(logit, label.contiguous(), weight, self.ignore_index)
+            self.last_weight_sum = _SegLossFn.last_acc[1] if _SegLossFn.last_acc is not None else None
         else:
             loss = F.cross_entropy(logit, label, weight=self.weight, ignore_index=self.ignore_index)
+            with torch.no_grad():
+                valid = label != self.ignore_index
+                self.last_weight_sum = (valid.sum().to(logit.dtype) if self.weight is None
+                                        else self.weight.to(logit.device)[label[valid]].sum())
         return {'seg_loss': loss}
 
 
@@ -196,7 +205,7 @@ def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_n
     loss = loss_fn(preds, data_batch)['seg_loss']
     loss.backward()
     if grad_sync is not None:
-        grad_sync()
+        grad_sync(weight_sum=getattr(loss_fn, 'last_weight_sum', None))  # == the gradient of ONE loss over the gathered batch
     if max_grad_norm > 0:
         nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_grad_norm)
     optimizer.step()
@@ -267,7 +276,7 @@ class GraphedTrainStep:
             self.static_next['points'].copy_(next_batch['points'])
         self.graph.replay()
         if self.grad_sync is not None:
-            self.grad_sync()
+            self.grad_sync(weight_sum=getattr(self.loss_fn, 'last_weight_sum', None))
         if self.max_grad_norm > 0:
             nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_grad_norm)
         self.optimizer.step()

@@ -90,16 +90,20 @@ class SetAbstraction(nn.Module):
             assert use_feature
             new_xyz = xyz.new_zeros([B, 1, 3])
             x = torch.cat([feature, xyz], dim=2) if self.use_xyz else feature
-            return new_xyz, R.shared_mlp_rows(x.reshape(B * N, -1), self.mlp, K=N).view(B, 1, -1)
+            if x.size(2) % 4:
+                x = torch.nn.functional.pad(x, (0, 4 - x.size(2) % 4))
+            if N <= 255:  # the fused BN + ReLU + max kernel stores its arg-max in one byte
+                return new_xyz, R.shared_mlp_rows(x.reshape(B * N, -1), self.mlp, K=N).view(B, 1, -1)
+            return new_xyz, R.shared_mlp_rows(x.reshape(B * N, -1), self.mlp).view(B, N, -1).max(dim=1, keepdim=True)[0]
         geometry = self.geometry(xyz) if geometry is None else geometry
         new_xyz, ball = geometry[0], geometry[1]
         csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
         M, K = new_xyz.size(1), self.max_neighbors
-        if use_feature and not self.use_xyz:
-            raise NotImplementedError('use_xyz=False with features is not on the rows path')
         l0 = self.mlp[0]
         c1 = l0.conv.weight.size(0)
-        if l0.bn is not None and l0.relu is not None and l0.conv.bias is None and l0.bn.running_mean is not None and c1 % 4 == 0:
+        # the linear-first factorisation hands shared_mlp_rows a chain whose first layer is already applied: only its fused
+        # path (R.mlp_chain_is_fused) can take that
+        if (self.use_xyz or not use_feature) and R.mlp_chain_is_fused(self.mlp) and K <= 255:
             # The first shared-MLP layer is linear, so its feature columns commute with the grouping:
             #   W1.[f(idx) | xyz(idx) - c] = (W1f.f)(idx) + W1xyz.(xyz(idx) - c)
             # -> the 1x1 conv over the feature runs on the N points instead of the M*K = 8N grouped rows, and the
@@ -122,7 +126,9 @@ class SetAbstraction(nn.Module):
         if use_feature and feature.size(2) % 4:
             feature = torch.nn.functional.pad(feature, (0, 4 - feature.size(2) % 4))  # cannot happen with reference configs
         group = self.grouper.forward_rows(new_xyz, xyz, feature if use_feature else None, index=ball)  # (B,M,K,ld)
-        if use_feature and group.size(3) != self.in_channels:
+        if use_feature and not self.use_xyz:
+            group = group[..., :self.in_channels].contiguous()  # features only (modules.py:32-35 without the concat)
+        elif use_feature and group.size(3) != self.in_channels:
             # columns are [feature(C) | xyz(3) | pad]; the conv weight expects [feature(C_true) | xyz(3)]
             c_true = self.in_channels - 3
             if feature.size(2) != c_true:

@@ -625,6 +625,14 @@ def linear_rows(x, weight, bias=None, cols=None):
     return LinearRows.apply(x.contiguous(), weight, bias, c0, c1)
 
 
+def mlp_chain_is_fused(mlp, dropout_p=0.0):
+    """True when `mlp` (a SharedMLP) runs as ONE MLPChainRows node: conv without bias + BatchNorm with running statistics + ReLU
+    in every layer, widths the rows kernels tile (C % 4 == 0 and C / 4 divides 256), dropout only behind a single layer."""
+    return (dropout_p == 0 or len(mlp) == 1) and \
+        all(l.bn is not None and l.relu is not None and l.conv.bias is None and l.bn.running_mean is not None for l in mlp) and \
+        all(l.conv.weight.size(0) % 4 == 0 and 256 % (l.conv.weight.size(0) // 4) == 0 for l in mlp)
+
+
 def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max'):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
@@ -634,9 +642,7 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
     the grouping, see SetAbstraction.forward_rows); only its BatchNorm + ReLU and the remaining layers run here."""
     n = len(mlp)
     # dropout follows EVERY layer of a SharedMLPDO (mlp.py:86-92): a single-layer chain can still be fused, dropout on its output
-    fused = (dropout_p == 0 or n == 1) and all(l.bn is not None and l.relu is not None and l.conv.bias is None and
-                                   l.bn.running_mean is not None for l in mlp) and \
-        all(l.conv.weight.size(0) % 4 == 0 and 256 % (l.conv.weight.size(0) // 4) == 0 for l in mlp)
+    fused = mlp_chain_is_fused(mlp, dropout_p) and K <= 255
     if fused:
         bn_training = mlp[0].bn.training
         params, buffers, eps_mom = [], [], []
@@ -649,6 +655,10 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
                                  reduce == 'sum' and K > 1, *params)
         return F.dropout(out, p=dropout_p, training=training, inplace=False) if dropout_p > 0 else out
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
+    if K > 255:  # the pooled BatchNorm kernel keeps its arg-max in one byte: pool with torch after a K = 1 pass
+        x = shared_mlp_rows(x, mlp, 1, dropout_p, training)
+        x = x.view(-1, K, x.size(1))
+        return x.sum(dim=1) if reduce == 'sum' else x.max(dim=1)[0]
     for i, layer in enumerate(mlp):
         w = layer.conv.weight.reshape(layer.conv.weight.size(0), -1)  # (C_out, C_in)
         if x.size(1) != w.size(1):

@@ -97,6 +97,9 @@ class UNetResNet34(nn.Module):
         return nn.Sequential(nn.Conv2d(c_in, c_out, kernel_size=3, padding=1), nn.BatchNorm2d(c_out), nn.ReLU(inplace=True))
 
     def forward(self, data_dict):
+        fast = self.__dict__.get('_fast')
+        if fast is not None and not self.training:
+            return fast(data_dict)
         x = data_dict['image']
         h, w = x.shape[2], x.shape[3]
         pad_h, pad_w = (h + 15) // 16 * 16 - h, (w + 15) // 16 * 16 - w  # zero-pad to multiples of 16 (:66-73)
@@ -129,11 +132,40 @@ class UNetResNet34(nn.Module):
     # ------------------------------------------------------------------ frozen, folded, channels-last
     @torch.no_grad()
     def frozen_inference(self):
-        """Eval mode, requires_grad off, every BatchNorm folded into its convolution, channels_last memory format.
-        Irreversible (the BatchNorm modules become identities); use on the frozen 2D branch of MVPNet only."""
+        """Eval mode, requires_grad off, and a FOLDED RUNTIME COPY of the network (every BatchNorm folded into its convolution,
+        torch.channels_last) that eval-mode forward() dispatches to.  The module itself keeps the reference's parameter layout:
+        `state_dict()` still has the 426 reference keys, a full MVPNet3D checkpoint written by the reference loads, one saved
+        here loads there; the copy is rebuilt after every `load_state_dict` and follows `.to()` / `.cuda()`.  Use on the
+        frozen 2D branch of MVPNet (train_mvpnet_3d.py freezes net_2d)."""
         self.eval()
         for p in self.parameters():
             p.requires_grad_(False)
+        self._refold()
+        if not self.__dict__.get('_refold_hooked'):
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module._refold())
+            self.__dict__['_refold_hooked'] = True
+        return self
+
+    @torch.no_grad()
+    def _refold(self):
+        import copy
+        self.__dict__.pop('_fast', None)
+        fast = copy.deepcopy(self)
+        fast.__dict__.pop('_refold_hooked', None)
+        fast._load_state_dict_post_hooks.clear()
+        fast._fold_in_place()
+        self.__dict__['_fast'] = fast  # NOT a registered sub-module: invisible to state_dict() / parameters()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        fast = self.__dict__.get('_fast')
+        if fast is not None:
+            fast._apply(fn, *args, **kwargs)
+        return out
+
+    def _fold_in_place(self):
+        """Irreversible (the BatchNorm modules become identities): only ever applied to the runtime copy."""
+        self.eval()
         if not self._folded:
             _fold(self.encoder0, self.bn)
             self.bn = nn.Identity()

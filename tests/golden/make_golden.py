@@ -506,6 +506,59 @@ def gen_configs():
     print('configs.json')
 
 
+def gen_config_defaults():
+    """The full default trees of the reference's config modules (common/config/base.py:10-137 through
+    mvpnet/config/mvpnet_3d.py:6-80 and mvpnet/config/sem_seg_3d.py), dumped as data.  yacs is not installed: a dict
+    subclass with attribute access stands in for `yacs.config.CfgNode` (the config modules only assign attributes and
+    call `clone()`), the reference files themselves are imported unmodified."""
+    import copy
+
+    class CN(dict):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+
+        def __getattr__(self, name):
+            try:
+                return self[name]
+            except KeyError:
+                raise AttributeError(name)
+
+        def __setattr__(self, name, value):
+            self[name] = value
+
+        def clone(self):
+            return copy.deepcopy(self)
+
+    yacs = types.ModuleType('yacs')
+    yacs_config = types.ModuleType('yacs.config')
+    yacs_config.CfgNode = CN
+    yacs.config = yacs_config
+    sys.modules['yacs'], sys.modules['yacs.config'] = yacs, yacs_config
+
+    def load(rel, name):
+        # both task modules extend the ONE `_C` of common.config.base in place (a process imports only one of them):
+        # re-import the base for each so the trees do not leak into each other
+        for m in [m for m in sys.modules if m == 'common.config' or m.startswith('common.config.')]:
+            del sys.modules[m]
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    def plain(node):  # tuples -> lists (JSON); the test compares against tuples converted the same way
+        if isinstance(node, dict):
+            return {k: plain(v) for k, v in node.items()}
+        if isinstance(node, (tuple, list)):
+            return [plain(v) for v in node]
+        return node
+
+    out = {'mvpnet_3d': plain(load('mvpnet/config/mvpnet_3d.py', 'ref_cfg_mvpnet_3d')._C),
+           'sem_seg_3d': plain(load('mvpnet/config/sem_seg_3d.py', 'ref_cfg_sem_seg_3d')._C)}
+    with open(os.path.join(HERE, 'config_defaults.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('config_defaults.json')
+
+
 def gen_unet():
     """UNetResNet34 (mvpnet/models/unet_resnet34.py): the REFERENCE class run on CPU.  torchvision is not installed here, so
     `torchvision.models.resnet.resnet34` is provided by this repo's restatement of the standard ResNet-34 encoder
@@ -718,11 +771,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':  # only the fixtures of SURVEY sec.8f rank 4
         gen_metrics()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'config_defaults':
+        gen_config_defaults()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'mvpnet2d':
         install_reference()
         gen_mvpnet2d()
         return
     gen_configs()
+    gen_config_defaults()
     T = install_reference()
     gen_fps(T)
     gen_ball_query(T)

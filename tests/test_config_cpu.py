@@ -14,6 +14,22 @@ def yaml_text(name):
         return yaml.safe_dump(json.load(f)[name])
 
 
+def _plain(node):
+    if isinstance(node, dict):
+        return {k: _plain(v) for k, v in node.items()}
+    if isinstance(node, (tuple, list)):
+        return [_plain(v) for v in node]
+    return node
+
+
+def test_default_trees_equal_the_reference_config_modules():
+    """common/config/base.py:10-137 + mvpnet/config/{mvpnet_3d,sem_seg_3d}.py, dumped from the imported modules."""
+    with open(os.path.join(GOLDEN, 'config_defaults.json')) as f:
+        ref = json.load(f)
+    assert _plain(C.get_cfg_mvpnet_3d()) == ref['mvpnet_3d']
+    assert _plain(C.get_cfg_sem_seg_3d()) == ref['sem_seg_3d']
+
+
 def test_mvpnet_3d_yaml():
     cfg = C.load_cfg(text=yaml_text('mvpnet_3d_unet_resnet34_pn2ssg'), opts=['TRAIN.LOG_PERIOD', '10'])
     assert cfg.TASK == 'mvpnet_3d' and cfg.MODEL_3D.TYPE == 'PN2SSG' and cfg.MODEL_2D.TYPE == 'UNetResNet34'
@@ -22,7 +38,7 @@ def test_mvpnet_3d_yaml():
     assert cfg.TRAIN.BATCH_SIZE == 32 and cfg.TRAIN.LOG_PERIOD == 10
     assert cfg.SCHEDULER.MultiStepLR.milestones == (24000, 32000) and 'StepLR' not in cfg.SCHEDULER  # purged
     assert cfg.MODEL_3D.PN2SSG.in_channels == 64 and cfg.MODEL_3D.PN2SSG.num_classes == 20
-    model = C.build_model_mvpnet_3d(cfg, torch.nn.Identity())
+    model = C.build_model_mvpnet_3d(cfg, torch.nn.Identity(), load_2d_ckpt=False)
     n3d = sum(p.numel() for p in model.net_3d.parameters())
     nag = sum(p.numel() for p in model.feat_aggreg.parameters())
     assert (n3d, nag) == (967092, 12928)
@@ -31,11 +47,33 @@ def test_mvpnet_3d_yaml():
     assert isinstance(opt, torch.optim.Adam) and opt.defaults['lr'] == 0.002 and opt.defaults['betas'] == (0.9, 0.999)
     assert isinstance(sched, torch.optim.lr_scheduler.MultiStepLR) and sorted(sched.milestones) == [24000, 32000]
     # the whole model from the YAML alone: MODEL_2D.TYPE UNetResNet34, frozen (folded BatchNorm, channels-last)
-    full = C.build_model_mvpnet_3d(cfg)
+    import pytest
+    with pytest.raises(FileNotFoundError):       # MODEL_2D.CKPT_PATH is loaded like the reference does (mvpnet_3d.py:78-81)
+        C.build_model_mvpnet_3d(cfg)
+    with pytest.warns(UserWarning, match='NOT loaded'):
+        full = C.build_model_mvpnet_3d(cfg, load_2d_ckpt=False)
     assert type(full.net_2d).__name__ == 'UNetResNet34' and full.net_2d.num_classes == 20
     assert not any(p.requires_grad for p in full.net_2d.parameters())
     trainable = sum(p.numel() for p in full.parameters() if p.requires_grad)
     assert trainable == 967092 + 12928
+    # the frozen 2D branch runs from a folded runtime copy but KEEPS the reference's parameter layout: a full MVPNet3D
+    # checkpoint of the reference loads, and the copy follows the loaded weights
+    from mvpnet_amd.unet_resnet34 import UNetResNet34
+    plain = UNetResNet34(20, p=0.5)
+    assert list(full.net_2d.state_dict()) == list(plain.state_dict()) and len(full.state_dict()) == 426
+    x = {'image': torch.randn(1, 3, 24, 32)}
+    torch.manual_seed(1)
+    donor = UNetResNet34(20, p=0.5).eval()
+    for m in donor.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    sd = {'net_2d.' + k: v for k, v in donor.state_dict().items()}
+    sd.update({k: v for k, v in full.state_dict().items() if not k.startswith('net_2d.')})
+    full.load_state_dict(sd)
+    full.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(full.net_2d(x)['feature'], donor(x)['feature'], rtol=1e-4, atol=1e-4)
 
 
 def test_pn2ssg_chunk_yaml():

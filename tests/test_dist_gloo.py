@@ -43,11 +43,23 @@ def _worker(rank, world, port, num_chunks, tmp):
     loss.backward()
     D.GradSync(model.parameters())()
     grads = [p.grad.clone() for p in model.parameters()]
+    # ---- weighted cross entropy with ignored labels: the ranks' weight masses differ, so the plain mean of the per-rank
+    #      gradients is NOT the full-batch gradient; GradSync(weight_sum=W_r) is (the reference computes SegLoss once on the
+    #      gathered batch, train_mvpnet_3d.py:166-171) ----
+    from mvpnet_amd.mvpnet3d import SegLoss
+    cw = torch.linspace(0.5, 2.0, 3)
+    yw = y.clone()
+    yw[0, :7] = -100                      # rank 0 loses most of one sample
+    crit = SegLoss(weight=cw)
+    model.zero_grad()
+    crit({'seg_logit': model(x[sl])}, {'seg_label': yw[sl]})['seg_loss'].backward()
+    D.GradSync(model.parameters())(weight_sum=crit.last_weight_sum)
+    wgrads = [p.grad.clone() for p in model.parameters()]
     # ---- inference: shard, "run", all-gather ----
     mine = D.shard_chunks(num_chunks, rank, world)
     local = torch.stack([_logit_of_chunk(i) for i in mine]) if mine else torch.zeros(0, 20, 64)
     full = D.all_gather_logits(local, num_chunks)
-    torch.save({'grads': grads, 'full': full, 'mine': mine}, os.path.join(tmp, 'r{}.pt'.format(rank)))
+    torch.save({'grads': grads, 'wgrads': wgrads, 'full': full, 'mine': mine}, os.path.join(tmp, 'r{}.pt'.format(rank)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,6 +83,14 @@ def test_two_ranks_gloo(tmp_path):
     for r in range(2):
         for gsync, p in zip(out[r]['grads'], model.parameters()):
             np.testing.assert_allclose(gsync.numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-7)
+    cw = torch.linspace(0.5, 2.0, 3)
+    yw = y.clone()
+    yw[0, :7] = -100
+    model.zero_grad()
+    torch.nn.functional.cross_entropy(model(x), yw, weight=cw, ignore_index=-100).backward()
+    for r in range(2):
+        for gsync, p in zip(out[r]['wgrads'], model.parameters()):
+            np.testing.assert_allclose(gsync.numpy(), p.grad.numpy(), rtol=2e-5, atol=1e-7)
     # all-gather returns every chunk's logits in global order on both ranks
     expect = torch.stack([_logit_of_chunk(i) for i in range(num_chunks)])
     for r in range(2):
@@ -82,6 +102,15 @@ def test_two_ranks_gloo(tmp_path):
     mean_a, label_a, cnt_a = O.vote([(inds[i], out[0]['full'][i].numpy().T) for i in range(num_chunks)], 300, 20)
     mean_b, label_b, cnt_b = O.vote([(inds[i], expect[i].numpy().T) for i in range(num_chunks)], 300, 20)
     assert np.array_equal(label_a, label_b) and np.array_equal(cnt_a, cnt_b)
+
+
+def test_rank_without_chunks_takes_part_in_the_gather(tmp_path):
+    """fewer chunks than ranks: rank 1 owns nothing and contributes a (0, C, N) tensor of the common shape"""
+    out = _run(1, tmp_path)
+    assert out[0]['mine'] == [0] and out[1]['mine'] == []
+    expect = _logit_of_chunk(0).unsqueeze(0)
+    for r in range(2):
+        assert torch.equal(out[r]['full'], expect)
 
 
 def test_shard_chunks_cover_everything_once():

@@ -35,7 +35,10 @@ def test_unet_matches_reference():
 def test_unet_folded_channels_last():
     g = load_golden('unet_resnet34')
     model = _load(UNetResNet34(20), g).frozen_inference()
-    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in model.modules())
+    # the module keeps the reference's parameter layout; eval-mode forward runs the folded channels-last runtime copy
+    assert any(isinstance(m, torch.nn.BatchNorm2d) for m in model.modules())
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in model.__dict__['_fast'].modules())
+    assert list(model.state_dict()) == list(UNetResNet34(20).state_dict())
     assert not any(p.requires_grad for p in model.parameters())
     x = torch.from_numpy(g['b_image']).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():

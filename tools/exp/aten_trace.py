@@ -10,7 +10,7 @@ with open(os.path.join(bench.ROOT, 'tests', 'golden', 'configs.json')) as f:
     cfg = C.load_cfg(text=yaml.safe_dump(json.load(f)['mvpnet_3d_unet_resnet34_pn2ssg']))
 batch, feature, bt = bench.build_batch(0, 32, dev)
 net2d = bench.SuppliedFeature2D(); net2d.feature = feature
-model = C.build_model_mvpnet_3d(cfg, net2d).to(dev).train()
+model = C.build_model_mvpnet_3d(cfg, net2d, load_2d_ckpt=False).to(dev).train()
 loss_fn = SegLoss(weight=torch.linspace(0.5, 1.5, 20, device=dev))
 opt = C.build_optimizer(cfg, model)
 def fresh(b):

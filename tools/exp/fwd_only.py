@@ -11,7 +11,7 @@ with open(os.path.join(bench.ROOT, 'tests', 'golden', 'configs.json')) as f:
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 batch, feature, bt = bench.build_batch(0, B, dev)
 net2d = bench.SuppliedFeature2D(); net2d.feature = feature
-model = C.build_model_mvpnet_3d(cfg, net2d).to(dev).eval()
+model = C.build_model_mvpnet_3d(cfg, net2d, load_2d_ckpt=False).to(dev).eval()
 def fresh(b):
     nb = dict(b); nb.pop('geometry_plan', None); return nb
 with torch.no_grad():
