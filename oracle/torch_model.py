@@ -48,6 +48,9 @@ def _bnc(x):  # (B,3,N) -> (B,N,3) contiguous numpy, as the reference wrappers d
     return np.ascontiguousarray(x.detach().numpy().transpose(0, 2, 1))
 
 
+UPDATE_RUNNING = False  # set by mvpnet3d_forward(update_running=True): BatchNorm updates sd's running statistics in place
+
+
 def shared_mlp(x, sd, prefix, training, dropout_p=0.0):
     """Conv(k=1, no bias) -> BN -> ReLU per layer (conv.py:29-51); layers found by key."""
     i = 0
@@ -57,8 +60,10 @@ def shared_mlp(x, sd, prefix, training, dropout_p=0.0):
         conv = F.conv2d if w.dim() == 4 else F.conv1d
         x = conv(x, w, sd.get(p + 'conv.bias'))
         if p + 'bn.weight' in sd:
-            x = F.batch_norm(x, sd[p + 'bn.running_mean'].clone(), sd[p + 'bn.running_var'].clone(),
-                             sd[p + 'bn.weight'], sd[p + 'bn.bias'], training, 0.1, 1e-5)
+            rm, rv = sd[p + 'bn.running_mean'], sd[p + 'bn.running_var']
+            if not UPDATE_RUNNING:
+                rm, rv = rm.clone(), rv.clone()
+            x = F.batch_norm(x, rm, rv, sd[p + 'bn.weight'], sd[p + 'bn.bias'], training, 0.1, 1e-5)
         x = F.relu(x)
         if dropout_p > 0 and training:
             x = F.dropout(x, dropout_p, True)
@@ -121,8 +126,19 @@ def feature_aggregation(src_xyz, tgt_xyz, feature, sd, prefix, training):
     return shared_mlp(x, sd, prefix + '.mlp', training).sum(dim=3)
 
 
-def mvpnet3d_forward(sd, points, feature_nchw, image_xyz, knn_indices, training=False, return_stages=False, **pn2_kw):
-    """mvpnet_3d.py:88-118 with the 2D network replaced by a supplied (B*nv,C,h,w) feature map."""
+def mvpnet3d_forward(sd, points, feature_nchw, image_xyz, knn_indices, training=False, return_stages=False, update_running=False,
+                     **pn2_kw):
+    """mvpnet_3d.py:88-118 with the 2D network replaced by a supplied (B*nv,C,h,w) feature map.
+    update_running: training-mode BatchNorm also moves sd's running_mean / running_var (momentum 0.1), as the modules do."""
+    global UPDATE_RUNNING
+    UPDATE_RUNNING = bool(update_running)
+    try:
+        return _mvpnet3d_forward(sd, points, feature_nchw, image_xyz, knn_indices, training, return_stages, **pn2_kw)
+    finally:
+        UPDATE_RUNNING = False
+
+
+def _mvpnet3d_forward(sd, points, feature_nchw, image_xyz, knn_indices, training, return_stages, **pn2_kw):
     b = points.size(0)
     bn, c, h, w = feature_nchw.shape
     nv = bn // b

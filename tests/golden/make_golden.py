@@ -446,6 +446,60 @@ def gen_modules(lifting):
     save('mvpnet3d_full', **out)
 
 
+def gen_modules_b8():
+    """Train-mode parity at a batch where batch-statistics BatchNorm is well conditioned (B = 8; the B <= 2 fixtures above
+    leave <= 8 samples per channel at SA4): the REFERENCE MVPNet3D + SegLoss, forward + backward, on 8 synthetic chunks.
+    Stored: logits, loss, feature_2d3d, ALL gradient norms, six complete gradient tensors (element-wise checks), BN running
+    statistics of the first and the last BatchNorm after the step."""
+    from mvpnet.models.pn2.pn2ssg import PN2SSG
+    from mvpnet.models.mvpnet_3d import MVPNet3D
+    from mvpnet.models.loss import SegLoss
+    log_w = np.loadtxt(os.path.join(REF, 'mvpnet/data/meta_files/scannetv2_train_3d_log_weights_20_classes.txt'), dtype=np.float32)
+    out = {}
+    B = 8
+    cfg = dict(num_centroids=(256, 64, 16, 4), radius=(0.1, 0.2, 0.4, 0.8), max_neighbors=(32, 32, 32, 32))
+    kw = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
+    chunks = [make_chunk(40 + b, **kw) for b in range(B)]
+    lifts = [reference_lifting(c, 3) for c in chunks]
+    points = torch.from_numpy(np.stack([c['points'].T for c in chunks]))
+    image_xyz = torch.from_numpy(np.stack([l[0] for l in lifts]))
+    knn = torch.from_numpy(np.stack([l[2] for l in lifts]))
+    feat_cl = np.stack([c['feature_2d'] for c in chunks])
+    feat_nchw = torch.from_numpy(np.ascontiguousarray(np.moveaxis(feat_cl, -1, 2))).reshape(-1, 16, 30, 40)
+    label = torch.from_numpy(np.stack([c['seg_label'] for c in chunks]))
+    net2d = StubNet2D()
+    model = MVPNet3D(net2d, '', PN2SSG(64, 20, dropout_prob=0.0, **cfg), in_channels=16, mlp_channels=(64, 64, 64),
+                     reduction='sum', use_relation=True)
+    shapes = load_into(model, seed=808)
+    out['state_keys'] = np.asarray(json.dumps([[k, list(v)] for k, v in shapes.items()]))
+    fa = {}
+    model.feat_aggreg.register_forward_hook(lambda m, i, o: fa.__setitem__('o', o))
+    model.train()
+    net2d.feature = feat_nchw.clone().requires_grad_(True)
+    preds = model({'images': torch.zeros(B, 2, 3, 30, 40), 'image_xyz': image_xyz, 'knn_indices': knn, 'points': points})
+    loss = SegLoss(weight=torch.from_numpy(log_w))(preds, {'seg_label': label})['seg_loss']
+    loss.backward()
+    out['feature_2d3d'] = fa['o'].detach().numpy()
+    out['seg_logit'] = preds['seg_logit'].detach().numpy()
+    out['loss'] = loss.detach().numpy()
+    named = dict(model.named_parameters())
+    out['grad_names'] = np.asarray(json.dumps(list(named)))
+    out['grad_norms'] = np.asarray([p.grad.norm().item() for p in named.values()], np.float64)
+    out['grad_absmax'] = np.asarray([p.grad.abs().max().item() for p in named.values()], np.float64)
+    for pname in ('feat_aggreg.mlp.0.conv.weight', 'net_3d.sa_modules.0.mlp.0.conv.weight', 'net_3d.sa_modules.1.mlp.1.conv.weight',
+                  'net_3d.sa_modules.3.mlp.2.bn.weight', 'net_3d.fp_modules.3.mlp.0.conv.weight', 'net_3d.seg_logit.weight'):
+        out['grad_' + pname] = named[pname].grad.numpy().copy()
+    out['grad_feature_2d_sum'] = np.asarray([net2d.feature.grad.double().sum().item(), net2d.feature.grad.double().abs().sum().item()])
+    sd = model.state_dict()
+    for key in ('feat_aggreg.mlp.0.bn.running_mean', 'feat_aggreg.mlp.0.bn.running_var', 'net_3d.mlp_seg.0.bn.running_mean',
+                'net_3d.mlp_seg.0.bn.running_var', 'net_3d.sa_modules.3.mlp.2.bn.running_var'):
+        out['after_' + key] = sd[key].numpy().copy()
+    out['knn_indices'] = i32(knn.numpy())
+    out['image_xyz'] = image_xyz.numpy()
+    out['log_weights'] = log_w
+    save('mvpnet3d_b8', **out)
+
+
 # --------------------------------------------------------------------------- #
 # vote + train-step known answers (inline script code, re-typed: SURVEY.md sec.8c)
 # --------------------------------------------------------------------------- #
@@ -771,6 +825,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':  # only the fixtures of SURVEY sec.8f rank 4
         gen_metrics()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'b8':
+        install_reference()
+        gen_modules_b8()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'config_defaults':
         gen_config_defaults()
         return
@@ -788,6 +846,7 @@ def main():
     gen_interpolate(T)
     lifting = gen_lifting()
     gen_modules(lifting)
+    gen_modules_b8()
     gen_vote_trainstep()
     gen_unet()
     gen_chunker()

@@ -1,0 +1,106 @@
+"""Train-mode parity where it matters: (a) the B = 8 fixture of the imported reference (batch statistics over
+>= 32 samples per channel at every level) at the north star's 1e-4 on logits and element-wise on gradients; (b) ONE full
+bench-shaped training iteration (MVPNet3D(in=64), 8192 points, 3 x 120 x 160, B = 8; train_step with the prefetched geometry
+plan, ZeroPool arenas, lddw slices, CSR backward, fused loss, fused Adam) against the oracle graph on the host: logits, loss,
+EVERY weight gradient, the BatchNorm running statistics after the step, and the Adam update itself."""
+import collections
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mvpnet_amd.synthetic import make_chunk
+from tests.conftest import load_golden
+from tests.golden.weights import fill_state_dict
+
+pytestmark = pytest.mark.gpu
+CFG = dict(num_centroids=(256, 64, 16, 4), radius=(0.1, 0.2, 0.4, 0.8), max_neighbors=(32, 32, 32, 32))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    return torch.device('cuda:0')
+
+
+class StubNet2D(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.feature = None
+
+    def forward(self, data):
+        return {'feature': self.feature}
+
+
+def test_mvpnet3d_b8_train_mode_against_the_reference_fixture(dev):
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss
+    g = load_golden('mvpnet3d_b8')
+    B = 8
+    net2d = StubNet2D()
+    model = MVPNet3D(net2d, '', PN2SSG(64, 20, dropout_prob=0.0, **CFG), in_channels=16, mlp_channels=(64, 64, 64),
+                     reduction='sum', use_relation=True)
+    ref_keys = [(k, tuple(s)) for k, s in json.loads(str(g['state_keys']))]
+    assert [(k, tuple(v.shape)) for k, v in model.state_dict().items()] == ref_keys
+    sd = fill_state_dict(collections.OrderedDict(ref_keys), 808)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = model.to(dev).train()
+    kw = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
+    chunks = [make_chunk(40 + b, **kw) for b in range(B)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    points = t(np.stack([c['points'].T for c in chunks]))
+    net2d.feature = t(np.moveaxis(np.stack([c['feature_2d'] for c in chunks]), -1, 2)).reshape(-1, 16, 30, 40).requires_grad_(True)
+    label = t(np.stack([c['seg_label'] for c in chunks]))
+    fa = {}
+    model.feat_aggreg.register_forward_hook(lambda m, i, o: fa.__setitem__('o', o))
+    batch = {'images': torch.zeros(B, 2, 3, 30, 40, device=dev), 'image_xyz': t(g['image_xyz']),
+             'knn_indices': t(g['knn_indices'].astype(np.int64)), 'points': points}
+    preds = model(batch)
+    err_f = np.abs(fa['o'].detach().transpose(1, 2).cpu().numpy() - g['feature_2d3d']).max()
+    err_l = np.abs(preds['seg_logit'].detach().cpu().numpy() - g['seg_logit']).max()
+    print('b8 fixture: feature_2d3d max err {:.3e}, logits max err {:.3e}'.format(err_f, err_l))
+    assert err_f <= 1e-4 and err_l <= 1e-4          # north star: fp32 logits within 1e-4 -- in TRAIN mode, at a real batch size
+    loss = SegLoss(weight=t(g['log_weights']))(preds, {'seg_label': label})['seg_loss']
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-5)
+    loss.backward()
+    named = dict(model.named_parameters())
+    names = json.loads(str(g['grad_names']))
+    worst = 0.0
+    for name, norm in zip(names, g['grad_norms']):
+        rel = abs(named[name].grad.norm().item() - norm) / max(norm, 1e-12)
+        worst = max(worst, rel)
+    print('b8 fixture: worst relative gradient-norm error {:.3e}'.format(worst))
+    assert worst < 2e-3
+    for key in g.files:
+        if key.startswith('grad_') and key[5:] in named:
+            exp = g[key]
+            got = named[key[5:]].grad.cpu().numpy().reshape(exp.shape)
+            e = np.abs(got - exp).max() / np.abs(exp).max()
+            print('b8 fixture: {} element-wise max err / max |g| = {:.3e}'.format(key, e))
+            assert e < 2e-3, key                      # element-wise, relative to the tensor's largest entry
+        if key.startswith('after_'):
+            np.testing.assert_allclose(model.state_dict()[key[6:]].cpu().numpy(), g[key], rtol=1e-4, atol=1e-6)
+    gs = net2d.feature.grad.double()
+    np.testing.assert_allclose([gs.sum().item(), gs.abs().sum().item()], g['grad_feature_2d_sum'], rtol=1e-3)
+
+
+def test_full_train_step_at_the_bench_shape(dev):
+    from tests import operating_point as OP
+    rep = OP.run(8, dev, write=os.path.join(ROOT, 'gpurun_out', 'operating_point_B8.json'))
+    lg, gw, rs = rep['logit'], rep['grads_worst'], rep['running_stats']
+    print(json.dumps({k: rep[k] for k in ('feature_2d3d', 'logit', 'loss', 'grads_worst', 'running_stats', 'adam_update_max_err')}, indent=1))
+    # logits: within 1e-4 of the reference arithmetic (CPU fp32), and as close to the float64 value of the graph as the CPU is
+    assert lg['gpu_vs_cpu32_max'] <= 1e-4 or lg['gpu_vs_f64_max'] <= 1.5 * lg['cpu32_vs_f64_max'], lg
+    assert lg['gpu_vs_f64_mean'] <= 2.0 * lg['cpu32_vs_f64_mean'] + 1e-7
+    assert abs(rep['loss']['gpu'] - rep['loss']['cpu32']) <= 2e-5 * abs(rep['loss']['cpu32'])
+    # every weight gradient: relative L2 against float64 no worse than 2x the CPU reference's own (floor 1e-4)
+    for name, row in rep['grads'].items():
+        assert row['gpu_vs_f64_relL2'] <= max(2.0 * row['cpu32_vs_f64_relL2'], 1e-4), (name, row)
+    assert rs['gpu_vs_cpu32_max'] <= 1e-5
+    assert rep['adam_update_max_err'] <= 1e-6
+    assert rep['num_batches_tracked'] == [1]

@@ -111,3 +111,34 @@ def test_train_step_known_answer():
     np.testing.assert_allclose(losses, g['losses'], rtol=1e-6)
     np.testing.assert_allclose(lin.weight.detach().numpy(), g['w4'], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(lin.bias.detach().numpy(), g['b4'], rtol=1e-5, atol=1e-7)
+
+
+def test_mvpnet3d_b8_train_mode():
+    """B = 8 train-mode fixture of the imported reference (batch-statistics BatchNorm with >= 32 samples per channel): the oracle
+    graph reproduces logits, loss, every gradient norm, six complete gradient tensors and the BatchNorm running statistics."""
+    g = load_golden('mvpnet3d_b8')
+    sd = weights(g, 808, grad=True)
+    kw = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
+    chunks = [make_chunk(40 + b, **kw) for b in range(8)]
+    batch = {k: np.stack([c[k] for c in chunks]) for k in ('depth_mm', 'kinv', 'pose', 'pixel_box', 'points')}
+    xyz, mask, knn = OM.lifting(batch, 3)
+    np.testing.assert_array_equal(knn, g['knn_indices'])
+    points = torch.from_numpy(np.stack([c['points'].T for c in chunks]))
+    feat_nchw = torch.from_numpy(np.ascontiguousarray(np.moveaxis(np.stack([c['feature_2d'] for c in chunks]), -1, 2))).reshape(-1, 16, 30, 40)
+    label = torch.from_numpy(np.stack([c['seg_label'] for c in chunks]))
+    logit, st = OM.mvpnet3d_forward(sd, points, feat_nchw, torch.from_numpy(xyz), torch.from_numpy(knn), training=True,
+                                    return_stages=True, update_running=True, **CFG)
+    np.testing.assert_allclose(st['feature_2d3d'].detach().numpy(), g['feature_2d3d'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(logit.detach().numpy(), g['seg_logit'], rtol=0, atol=1e-4)
+    loss = OM.seg_loss(logit, label, torch.from_numpy(g['log_weights']))
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-6)
+    loss.backward()
+    names = json.loads(str(g['grad_names']))
+    for name, norm, amax in zip(names, g['grad_norms'], g['grad_absmax']):
+        np.testing.assert_allclose(sd[name].grad.norm().item(), norm, rtol=2e-3, atol=1e-7)
+    for key in g.files:
+        if key.startswith('grad_') and key[5:] in sd:
+            exp = g[key]
+            np.testing.assert_allclose(sd[key[5:]].grad.numpy().reshape(exp.shape), exp, rtol=0, atol=2e-3 * np.abs(exp).max())
+        if key.startswith('after_'):
+            np.testing.assert_allclose(sd[key[6:]].numpy(), g[key], rtol=1e-5, atol=1e-6)
