@@ -158,6 +158,22 @@ int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv, const f
                  const float* box, const float* points, const float* feature, int64_t B, int64_t nv, int64_t h,
                  int64_t w, int64_t N, int64_t C, int64_t k, void* workspace, int64_t* knn_index, float* gfeature,
                  float* gxyz, float* image_xyz, uint8_t* mask, mvp_stream_t stream);
+/* mvp_lift_f32 + the loader's augmentation applied where the reference applies it (mvpnet/data/scannet_2d3d.py):
+ *   flip (B,nv) uint8 or NULL: views mirrored horizontally AFTER the un-projection (:293-296: image, image_xyz, image_mask are
+ *        `np.fliplr`ed) -> knn_index holds the mirrored flat ids `view*h*w + row*w + (w-1-col)`, `feature` is indexed in mirrored
+ *        order (the 2D network saw the mirrored image), image_xyz / mask are written mirrored; equal distances are ordered by
+ *        the sensor-order id (the ball tree's tie order is unspecified upstream);
+ *   rot (B,3,3) float64 row-major or NULL: rotation applied AFTER the k-NN search (:400-409, `Rotation.apply` = float64 product,
+ *        one rounding to float32) to the gathered xyz and to the points -> points_out (B,N,3) or NULL.  The public image_xyz
+ *        tensor is not rotated by this call (the model never reads it; mvp_rotate_rows_f32 does it on request). */
+int mvp_lift_aug_f32(const void* depth, int depth_is_u16, const float* kinv, const float* cam, const float* pose,
+                     const float* box, const float* points, const float* feature, int64_t B, int64_t nv, int64_t h,
+                     int64_t w, int64_t N, int64_t C, int64_t k, void* workspace, int64_t* knn_index, float* gfeature,
+                     float* gxyz, float* image_xyz, uint8_t* mask, const uint8_t* flip, const double* rot, float* points_out,
+                     mvp_stream_t stream);
+/* out[b,r,:] = float32( rot[b] (float64 3x3) . xyz[b,r,:] ), rows R per batch element: the z-rotation augmentation of `points`
+ * / `image_xyz` (scannet_2d3d.py:400-409) for tensors that did not go through mvp_lift_aug_f32.  In place allowed. */
+int mvp_rotate_rows_f32(const float* xyz, const double* rot, int64_t B, int64_t R, float* out, mvp_stream_t stream);
 
 /* ---- channels-last ("rows") PointNet++ kernels ---------------------------------------------
  * Same mathematics as the channel-major ops above with a point's C features stored as one

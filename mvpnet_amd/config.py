@@ -184,6 +184,17 @@ def build_model_mvpnet_3d(cfg, net_2d=None, load_2d_ckpt=True, freeze_2d=True):
     return model
 
 
+def build_augmentation(cfg, rng=None):
+    """DATASET.ScanNet2D3DChunks.augmentation.{flip, z_rot} of the YAML (mvpnet/data/build.py -> ScanNet2D3DChunks(flip=, z_rot=))
+    as the device-side augmentation of mvpnet_amd.augment (None when both are off).  color_jitter stays a loader transform."""
+    from .augment import DeviceAugmentation
+    aug = cfg.DATASET.get('ScanNet2D3DChunks', {}).get('augmentation', {})
+    flip, z_rot = aug.get('flip', 0.0), aug.get('z_rot', ())
+    if not flip and not z_rot:
+        return None
+    return DeviceAugmentation(flip=flip, z_rot=z_rot, rng=rng)
+
+
 def build_optimizer(cfg, model):
     """common/solver/build.py:7-22"""
     import torch

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kPrepThreads) void lift_prepare_kernel(const DepthT
                                                            const float* __restrict__ box, int B, int nv, int h, int w,
                                                            int pitch, float4* __restrict__ rec,
                                                            uint16_t* __restrict__ plane, float* __restrict__ image_xyz,
-                                                           uint8_t* __restrict__ mask) {
+                                                           uint8_t* __restrict__ mask, const uint8_t* __restrict__ flip) {
   const int bv = blockIdx.y;  // b * nv + view
   const int pp = blockIdx.x * kPrepThreads + threadIdx.x;
   const int prow = plane_rows(h);
@@ -81,12 +81,15 @@ __global__ __launch_bounds__(kPrepThreads) void lift_prepare_kernel(const DepthT
   }
   rec[p] = make_float4((float)xw, (float)yw, (float)zw, ok ? 0.0f : INFINITY);
   *pl = (uint16_t)(ok ? (unsigned)fminf(floorf((float)zc * (1.0f / kPlaneUnit)), (float)kPlaneSat) : kPlaneInvalid);
+  // Horizontal flip of a view (scannet_2d3d.py:293-296: image, image_xyz and image_mask are flipped AFTER the un-projection):
+  // the search structures stay in the sensor's pixel order, only the public per-pixel tensors are written mirrored.
+  const size_t po = (flip && flip[bv]) ? (size_t)bv * h * w + (size_t)v * w + (w - 1 - u) : p;
   if (image_xyz) {
-    image_xyz[p * 3 + 0] = (float)xw;
-    image_xyz[p * 3 + 1] = (float)yw;
-    image_xyz[p * 3 + 2] = (float)zw;
+    image_xyz[po * 3 + 0] = (float)xw;
+    image_xyz[po * 3 + 1] = (float)yw;
+    image_xyz[po * 3 + 2] = (float)zw;
   }
-  if (mask) mask[p] = ok ? 1 : 0;
+  if (mask) mask[po] = ok ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -261,7 +264,10 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
                                                                      int h, int w, int N, int C, int bpc,
                                                                      int64_t* __restrict__ knn_index,
                                                                      float* __restrict__ gfeat,
-                                                                     float* __restrict__ gxyz) {
+                                                                     float* __restrict__ gxyz,
+                                                                     const uint8_t* __restrict__ flip,
+                                                                     const double* __restrict__ rot,
+                                                                     float* __restrict__ points_out) {
   __shared__ ViewParam vp[kMaxViews];
   __shared__ int sidx[kLFThreads * K];
   __shared__ int slist[kLFThreads * kSurvCap];
@@ -292,12 +298,39 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
     PackedSource src{crec};
     filtered_probe<K>(crec, plane + (size_t)b * nv * plane_rows(h) * pitch, vp, nv, h, w, pitch, qx, qy, qz, bd, bi, slist, tid);
     projective_rings<K, 2>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
+    // Augmentation of the loader, applied where the reference applies it: the flip changes which flat pixel id (and feature
+    // row) a neighbour has (scannet_2d3d.py:293-307), the rotation about z acts on `points` and `image_xyz` AFTER the search
+    // (:400-409; float64 product, one rounding to float32 -- scipy's Rotation.apply on float32 input).
+    double r0 = 1, r1 = 0, r2 = 0, r3 = 0, r4 = 1, r5 = 0, r6 = 0, r7 = 0, r8 = 1;
+    if (rot) {
+      const double* Rm = rot + (size_t)b * 9;
+      r0 = Rm[0]; r1 = Rm[1]; r2 = Rm[2]; r3 = Rm[3]; r4 = Rm[4]; r5 = Rm[5]; r6 = Rm[6]; r7 = Rm[7]; r8 = Rm[8];
+    }
+    auto rotate = [&](float x, float y, float z, float* o) {
+      if (rot) {
+        const double dx = x, dy = y, dz = z;
+        o[0] = (float)((r0 * dx + r1 * dy) + r2 * dz);
+        o[1] = (float)((r3 * dx + r4 * dy) + r5 * dz);
+        o[2] = (float)((r6 * dx + r7 * dy) + r8 * dz);
+      } else {
+        o[0] = x; o[1] = y; o[2] = z;
+      }
+    };
+    if (points_out) rotate(qx, qy, qz, points_out + ((size_t)b * N + n) * 3);
 #pragma unroll
     for (int s = 0; s < K; ++s) {
       const bool found = bd[s] < INFINITY;
       const int id = found ? bi[s] : -1;
-      sidx[tid * K + s] = id;
-      knn_index[((size_t)b * N + n) * K + s] = (int64_t)id;
+      int oid = id;  // id in the (possibly mirrored) public pixel order: what knn_indices holds and the feature map is indexed by
+      if (flip && found) {
+        const int vi = id / hw, rem = id - vi * hw;
+        if (flip[(size_t)b * nv + vi]) {
+          const int vv = rem / w, uu = rem - vv * w;
+          oid = vi * hw + vv * w + (w - 1 - uu);
+        }
+      }
+      sidx[tid * K + s] = oid;
+      knn_index[((size_t)b * N + n) * K + s] = (int64_t)oid;
       if (gxyz) {
         float x = 0.f, y = 0.f, z = 0.f;
         if (found) {
@@ -307,9 +340,7 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
           z = r.z;
         }
         float* o = gxyz + (((size_t)b * N + n) * K + s) * 3;
-        o[0] = x;
-        o[1] = y;
-        o[2] = z;
+        if (found) rotate(x, y, z, o); else { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
       }
     }
   }
@@ -357,12 +388,12 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
 template <int K>
 int launch_lift(const float4* rec, const uint16_t* plane, int pitch, const float* points, const float* cam, const float* pose, const float* feature,
                 int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N, int64_t C, int64_t* knn_index, float* gfeat,
-                float* gxyz, hipStream_t s) {
+                float* gxyz, const uint8_t* flip, const double* rot, float* points_out, hipStream_t s) {
   const int bpc = (int)cdiv(N, kLFThreads);
   const int64_t groups = cdiv(B, kXcds);  // chunks per XCD (rounded up; surplus workgroups exit at once)
   dim3 grid((unsigned)(kXcds * groups * bpc));
   hipLaunchKernelGGL((lift_knn_gather_kernel<K>), grid, dim3(kLFThreads), 0, s, rec, plane, pitch, points, cam, pose, feature,
-                     (int)B, (int)nv, (int)h, (int)w, (int)N, (int)C, bpc, knn_index, gfeat, gxyz);
+                     (int)B, (int)nv, (int)h, (int)w, (int)N, (int)C, bpc, knn_index, gfeat, gxyz, flip, rot, points_out);
   return mvp_launch_status();
 }
 
@@ -374,10 +405,15 @@ MVP_API int64_t mvp_lift_workspace_bytes(int64_t B, int64_t nv, int64_t h, int64
   return B * nv * h * w * (int64_t)sizeof(float4) + ((B * nv * plane_rows((int)h) * plane_pitch((int)w) * 2 + 15) & ~(int64_t)15);
 }
 
-MVP_API int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv, const float* cam, const float* pose,
-                         const float* box, const float* points, const float* feature, int64_t B, int64_t nv,
-                         int64_t h, int64_t w, int64_t N, int64_t C, int64_t k, void* workspace, int64_t* knn_index,
-                         float* gfeature, float* gxyz, float* image_xyz, uint8_t* mask, mvp_stream_t stream) {
+// flip (B*nv uint8, may be NULL): views whose image / image_xyz / image_mask the loader mirrored horizontally; knn_index then holds
+//   mirrored flat ids and `feature` is indexed in the mirrored order (it was computed from the mirrored image).  Distance ties
+//   are broken by the sensor-order id.   rot (B*9 float64 row-major, may be NULL): per-chunk rotation applied AFTER the search
+//   to the gathered xyz and to the points (-> points_out (B,N,3), may be NULL); image_xyz (public tensor) is NOT rotated here.
+MVP_API int mvp_lift_aug_f32(const void* depth, int depth_is_u16, const float* kinv, const float* cam, const float* pose,
+                             const float* box, const float* points, const float* feature, int64_t B, int64_t nv,
+                             int64_t h, int64_t w, int64_t N, int64_t C, int64_t k, void* workspace, int64_t* knn_index,
+                             float* gfeature, float* gxyz, float* image_xyz, uint8_t* mask, const uint8_t* flip,
+                             const double* rot, float* points_out, mvp_stream_t stream) {
   MVP_NONNULL(depth);
   MVP_NONNULL(kinv);
   MVP_NONNULL(cam);
@@ -399,18 +435,27 @@ MVP_API int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv,
   dim3 grid((unsigned)cdiv((int64_t)plane_rows((int)h) * pitch, kPrepThreads), (unsigned)(B * nv));
   if (depth_is_u16)
     hipLaunchKernelGGL((lift_prepare_kernel<uint16_t>), grid, dim3(kPrepThreads), 0, s, static_cast<const uint16_t*>(depth), kinv,
-                       pose, box, (int)B, (int)nv, (int)h, (int)w, pitch, rec, plane, image_xyz, mask);
+                       pose, box, (int)B, (int)nv, (int)h, (int)w, pitch, rec, plane, image_xyz, mask, flip);
   else
     hipLaunchKernelGGL((lift_prepare_kernel<float>), grid, dim3(kPrepThreads), 0, s, static_cast<const float*>(depth), kinv, pose,
-                       box, (int)B, (int)nv, (int)h, (int)w, pitch, rec, plane, image_xyz, mask);
+                       box, (int)B, (int)nv, (int)h, (int)w, pitch, rec, plane, image_xyz, mask, flip);
   int rc = mvp_launch_status();
   if (rc != MVP_OK || N == 0) return rc;
   switch (k) {
 #define MVP_CASE(KK) \
   case KK:           \
-    return launch_lift<KK>(rec, plane, pitch, points, cam, pose, feature, B, nv, h, w, N, C, knn_index, gfeature, gxyz, s);
+    return launch_lift<KK>(rec, plane, pitch, points, cam, pose, feature, B, nv, h, w, N, C, knn_index, gfeature, gxyz, flip, rot, \
+                           points_out, s);
     MVP_CASE(1) MVP_CASE(2) MVP_CASE(3) MVP_CASE(4) MVP_CASE(5) MVP_CASE(6) MVP_CASE(7) MVP_CASE(8)
 #undef MVP_CASE
   }
   return MVP_EUNSUPPORTED;
+}
+
+MVP_API int mvp_lift_f32(const void* depth, int depth_is_u16, const float* kinv, const float* cam, const float* pose,
+                         const float* box, const float* points, const float* feature, int64_t B, int64_t nv,
+                         int64_t h, int64_t w, int64_t N, int64_t C, int64_t k, void* workspace, int64_t* knn_index,
+                         float* gfeature, float* gxyz, float* image_xyz, uint8_t* mask, mvp_stream_t stream) {
+  return mvp_lift_aug_f32(depth, depth_is_u16, kinv, cam, pose, box, points, feature, B, nv, h, w, N, C, k, workspace, knn_index,
+                          gfeature, gxyz, image_xyz, mask, nullptr, nullptr, nullptr, stream);
 }

@@ -235,3 +235,30 @@ MVP_API int mvp_vote_finish_f32(const float* sum, const int32_t* count, int64_t 
                      static_cast<hipStream_t>(stream), sum, count, n_pts, (int)C, mean, label);
   return mvp_launch_status();
 }
+
+namespace {
+__global__ __launch_bounds__(256) void rotate_rows_kernel(const float* __restrict__ xyz, const double* __restrict__ rot, int64_t R,
+                                                          float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const double* M = rot + (size_t)b * 9;
+  const float* p = xyz + ((size_t)b * R + r) * 3;
+  const double x = p[0], y = p[1], z = p[2];
+  float* o = out + ((size_t)b * R + r) * 3;
+  o[0] = (float)((M[0] * x + M[1] * y) + M[2] * z);
+  o[1] = (float)((M[3] * x + M[4] * y) + M[5] * z);
+  o[2] = (float)((M[6] * x + M[7] * y) + M[8] * z);
+}
+}  // namespace
+
+MVP_API int mvp_rotate_rows_f32(const float* xyz, const double* rot, int64_t B, int64_t R, float* out, mvp_stream_t stream) {
+  MVP_NONNULL(xyz);
+  MVP_NONNULL(rot);
+  MVP_NONNULL(out);
+  MVP_REQUIRE(B >= 0 && R >= 0 && B < 65536);
+  if (B == 0 || R == 0) return MVP_OK;
+  hipLaunchKernelGGL(rotate_rows_kernel, dim3((unsigned)cdiv(R, 256), (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), xyz, rot,
+                     R, out);
+  return mvp_launch_status();
+}

@@ -71,6 +71,18 @@ class FeatureAggregation(nn.Module):
         return self.reduction(self.mlp(x), 3)
 
 
+def net3d_points(data_batch):
+    """(B,3,N) points as the 3D network sees them: the loader's points, or -- when the batch carries a device-side z rotation
+    ('z_rot' (B,3,3) float64 from mvpnet_amd.augment, lifting still to be done on the device) -- those points rotated
+    (scannet_2d3d.py:400-409; the pixel k-NN runs on the UN-rotated points, everything after it on the rotated ones)."""
+    points = data_batch['points']
+    if 'z_rot' not in data_batch or 'knn_indices' in data_batch:
+        return points
+    if '_points_rot' not in data_batch:
+        data_batch['_points_rot'] = ops.rotate_rows(points.transpose(1, 2).contiguous(), data_batch['z_rot']).transpose(1, 2).contiguous()
+    return data_batch['_points_rot']
+
+
 class MVPNet3D(nn.Module):
     def __init__(self, net_2d, net_2d_ckpt_path, net_3d, **feat_aggr_kwargs):
         super().__init__()
@@ -87,9 +99,10 @@ class MVPNet3D(nn.Module):
         (h,w)), pose (B,nv,4,4) [, kinv, pixel_box (B,4), k]: gathered feature, gathered xyz, knn_indices."""
         cam = data_batch['cam_matrix']
         kinv = data_batch['kinv'] if 'kinv' in data_batch else torch.linalg.inv(cam)
-        points_nc = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
+        points_nc = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3), un-rotated: the search precedes the rotation
         return ops.lift(feature_cl, data_batch['depth'], kinv, cam, data_batch['pose'], points_nc,
-                        k=int(data_batch.get('k', 3)), box=data_batch.get('pixel_box'))
+                        k=int(data_batch.get('k', 3)), box=data_batch.get('pixel_box'), flip=data_batch.get('flip'),
+                        rot=data_batch.get('z_rot'))
 
     def _side_stream(self, device):
         if getattr(self, '_geo_stream', None) is None or self._geo_stream.device != device:
@@ -104,8 +117,9 @@ class MVPNet3D(nn.Module):
         # coordinate-only work of the 3D network (FPS chain, ball queries, 3-NN) starts on a side stream
         # now and overlaps the 2D network, the lifting and the aggregation MLP below.
         plan = data_batch.get('geometry_plan')
-        if plan is None and hasattr(self.net_3d, 'plan_geometry') and data_batch['points'].is_cuda:
-            pts_rows = data_batch['points'].transpose(1, 2).contiguous()
+        points = net3d_points(data_batch)  # what the 3D network sees (rotated when the batch carries a device-side z rotation)
+        if plan is None and hasattr(self.net_3d, 'plan_geometry') and points.is_cuda:
+            pts_rows = points.transpose(1, 2).contiguous()
             plan = self.net_3d.plan_geometry(pts_rows, stream=self._side_stream(pts_rows.device))
         images = data_batch['images']  # (B,nv,3,h,w)
         b, nv, _, h, w = images.shape
@@ -113,7 +127,6 @@ class MVPNet3D(nn.Module):
         c = feature_2d.size(1)
         # channels-last view (B,nv,h,w,C); free when the 2D net already runs in torch.channels_last
         feature_cl = feature_2d.permute(0, 2, 3, 1).contiguous().view(b, nv, h, w, c)
-        points = data_batch['points']
         if 'knn_indices' in data_batch and 'image_xyz' in data_batch:  # loader-supplied, as in the reference
             gfeat, gxyz = ops.lift_gather(feature_cl, data_batch['image_xyz'], data_batch['knn_indices'])
         else:  # device lifting: un-project + pixel k-NN + gather fused (mvp_lift_f32)
@@ -189,7 +202,7 @@ def prefetch_geometry(model, data_batch):
     the device-side counterpart of the reference's dataloader workers running ahead of the training loop."""
     net = model.module if hasattr(model, 'module') else model
     if 'geometry_plan' not in data_batch and hasattr(net, 'net_3d') and data_batch['points'].is_cuda:
-        pts_rows = data_batch['points'].transpose(1, 2).contiguous()
+        pts_rows = net3d_points(data_batch).transpose(1, 2).contiguous()
         data_batch['geometry_plan'] = net.net_3d.plan_geometry(pts_rows, stream=net._side_stream(pts_rows.device))
     return data_batch
 
@@ -233,15 +246,15 @@ class GraphedTrainStep:
     feature map is produced inside the graph by model.net_2d) and replays.  Batches must arrive in sequence: `batch` of call
     i is `next_batch` of call i-1, as with train_step(..., next_batch=...)."""
 
-    COPY_KEYS = ('images', 'points', 'seg_label', 'depth', 'cam_matrix', 'kinv', 'pose', 'pixel_box', 'image_xyz', 'knn_indices')
+    COPY_KEYS = ('images', 'points', 'seg_label', 'depth', 'cam_matrix', 'kinv', 'pose', 'pixel_box', 'image_xyz', 'knn_indices', 'flip', 'z_rot')
 
     def __init__(self, model, loss_fn, optimizer, batch, next_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, warmup=3):
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.scheduler, self.max_grad_norm, self.grad_sync = scheduler, max_grad_norm, grad_sync
         net = model.module if hasattr(model, 'module') else model
         self.static = {k: (v.clone() if torch.is_tensor(v) and k in self.COPY_KEYS else v) for k, v in batch.items()
-                       if k not in ('geometry_plan', 'prefetch_next')}
-        self.static_next = {'points': next_batch['points'].clone()}
+                       if k not in ('geometry_plan', 'prefetch_next') and not k.startswith('_')}
+        self.static_next = {k: next_batch[k].clone() for k in ('points', 'z_rot') if k in next_batch}  # what the geometry reads
         dev = self.static['points'].device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -272,8 +285,10 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 if k in self.COPY_KEYS and torch.is_tensor(v) and v.data_ptr() != self.static[k].data_ptr():
                     self.static[k].copy_(v)
-        if next_batch is not None and next_batch['points'].data_ptr() != self.static_next['points'].data_ptr():
-            self.static_next['points'].copy_(next_batch['points'])
+        if next_batch is not None:
+            for k, dst in self.static_next.items():
+                if next_batch[k].data_ptr() != dst.data_ptr():
+                    dst.copy_(next_batch[k])
         self.graph.replay()
         if self.grad_sync is not None:
             self.grad_sync(weight_sum=getattr(self.loss_fn, 'last_weight_sum', None))

@@ -6,10 +6,10 @@ from .ball_query import ball_query, ball_query_distance
 from .group_points import group_points
 from .knn_distance import knn_distance
 from .interpolate import feature_interpolate
-from .lifting import unproject, pixel_knn, lift_gather, lift
+from .lifting import unproject, pixel_knn, lift_gather, lift, rotate_rows
 
 __all__ = ['farthest_point_sample', 'ball_query', 'ball_query_distance', 'group_points', 'knn_distance',
-           'feature_interpolate', 'unproject', 'pixel_knn', 'lift_gather', 'lift']
+           'feature_interpolate', 'unproject', 'pixel_knn', 'lift_gather', 'lift', 'rotate_rows']
 
 
 def as_point_major(x, transpose):

@@ -107,8 +107,8 @@ class LiftFunction(torch.autograd.Function):
     the feature map only (scatter-add by the k-NN index)."""
 
     @staticmethod
-    def forward(ctx, feature, depth, kinv, cam, pose, box, points, k, want_image_xyz):
-        L.require_gpu(feature, depth, kinv, cam, pose, box, points)
+    def forward(ctx, feature, depth, kinv, cam, pose, box, points, k, want_image_xyz, flip=None, rot=None):
+        L.require_gpu(feature, depth, kinv, cam, pose, box, points, flip, rot)
         B, nv, h, w = depth.shape
         N, C = points.size(1), feature.size(-1)
         if depth.dtype == torch.float32:
@@ -123,15 +123,23 @@ class LiftFunction(torch.autograd.Function):
         gxyz = torch.empty((B, N, k, 3), dtype=torch.float32, device=depth.device)
         xyz = torch.empty((B, nv, h, w, 3), dtype=torch.float32, device=depth.device) if want_image_xyz else None
         mask = torch.empty((B, nv, h, w), dtype=torch.uint8, device=depth.device) if want_image_xyz else None
-        L.call('mvp_lift_f32', depth, L.ptr(depth), is_u16, L.ptr(kinv), L.ptr(cam), L.ptr(pose), L.ptr(box), L.ptr(points),
-               L.ptr(feature), B, nv, h, w, N, C, k, L.ptr(ws), L.ptr(knn), L.ptr(gfeat), L.ptr(gxyz), L.ptr(xyz), L.ptr(mask))
+        points_rot = torch.empty_like(points) if rot is not None else None
+        if flip is None and rot is None:
+            L.call('mvp_lift_f32', depth, L.ptr(depth), is_u16, L.ptr(kinv), L.ptr(cam), L.ptr(pose), L.ptr(box), L.ptr(points),
+                   L.ptr(feature), B, nv, h, w, N, C, k, L.ptr(ws), L.ptr(knn), L.ptr(gfeat), L.ptr(gxyz), L.ptr(xyz), L.ptr(mask))
+        else:
+            L.call('mvp_lift_aug_f32', depth, L.ptr(depth), is_u16, L.ptr(kinv), L.ptr(cam), L.ptr(pose), L.ptr(box), L.ptr(points),
+                   L.ptr(feature), B, nv, h, w, N, C, k, L.ptr(ws), L.ptr(knn), L.ptr(gfeat), L.ptr(gxyz), L.ptr(xyz), L.ptr(mask),
+                   L.ptr(flip), L.ptr(rot), L.ptr(points_rot))
         ctx.save_for_backward(knn)
         ctx.shape = tuple(feature.shape)
+        outs = (gfeat, gxyz, knn)
         if want_image_xyz:
-            ctx.mark_non_differentiable(gxyz, knn, xyz, mask)
-            return gfeat, gxyz, knn, xyz, mask
-        ctx.mark_non_differentiable(gxyz, knn)
-        return gfeat, gxyz, knn
+            outs += (xyz, mask)
+        if rot is not None:
+            outs += (points_rot,)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
 
     @staticmethod
     @once_differentiable
@@ -145,15 +153,39 @@ class LiftFunction(torch.autograd.Function):
         grad = torch.empty(ctx.shape, dtype=torch.float32, device=grad_gfeat.device)
         g = grad_gfeat.contiguous()
         L.call('mvp_lift_gather_backward_f32', g, L.ptr(g), L.ptr(knn), B, P, C, N, k, L.ptr(grad))
-        return (grad,) + (None,) * 8
+        return (grad,) + (None,) * 10
 
 
-def lift(feature, depth, kinv, cam, pose, points, k=3, box=None, return_image_xyz=False):
+def lift(feature, depth, kinv, cam, pose, points, k=3, box=None, return_image_xyz=False, flip=None, rot=None):
     """feature (B,nv,h,w,C) f32 channels-last; depth (B,nv,h,w) f32 m / int16 mm; kinv, cam (B,nv,3,3);
     pose (B,nv,4,4); points (B,N,3) -> gathered feature (B,N,k,C), gathered xyz (B,N,k,3), knn_indices (B,N,k)
-    [, image_xyz (B,nv,h,w,3), image_mask (B,nv,h,w) uint8]."""
+    [, image_xyz (B,nv,h,w,3), image_mask (B,nv,h,w) uint8] [, rotated points (B,N,3) when `rot` is given].
+    flip (B,nv) bool / uint8: views the loader mirrored (scannet_2d3d.py:293-296) -- `feature` comes from the mirrored image, the
+        returned indices / image_xyz / mask are in mirrored pixel order;
+    rot (B,3,3) float64: rotation applied after the search to the gathered xyz and the points (:400-409); image_xyz is returned
+        un-rotated (rotate_rows does it on request)."""
     if feature.dtype != torch.float32 or points.dtype != torch.float32 or feature.size(-1) % 4:
         raise RuntimeError('lift: float32 channels-last feature with C % 4 == 0 expected')
+    if flip is not None:
+        if tuple(flip.shape) != tuple(depth.shape[:2]):
+            raise RuntimeError('lift: flip must be (B, nv)')
+        flip = flip.to(torch.uint8).contiguous()
+    if rot is not None:
+        if rot.dtype != torch.float64 or tuple(rot.shape) != (depth.size(0), 3, 3):
+            raise RuntimeError('lift: rot must be (B, 3, 3) float64')
+        rot = rot.contiguous()
     return LiftFunction.apply(feature.contiguous(), depth.contiguous(), kinv.contiguous(), cam.contiguous(),
                               pose.contiguous(), None if box is None else box.contiguous(), points.contiguous(), int(k),
-                              bool(return_image_xyz))
+                              bool(return_image_xyz), flip, rot)
+
+
+def rotate_rows(xyz, rot):
+    """xyz (B, ..., 3) float32, rot (B,3,3) float64 -> float32( rot[b] . xyz ) per row (scannet_2d3d.py:400-409)."""
+    if xyz.dtype != torch.float32 or rot.dtype != torch.float64 or xyz.size(-1) != 3 or tuple(rot.shape) != (xyz.size(0), 3, 3):
+        raise RuntimeError('rotate_rows: (B,...,3) float32 rows and (B,3,3) float64 matrices expected')
+    L.require_gpu(xyz, rot)
+    x = xyz.contiguous()
+    out = torch.empty_like(x)
+    B = x.size(0)
+    L.call('mvp_rotate_rows_f32', x, L.ptr(x), L.ptr(rot.contiguous()), B, x.numel() // (3 * B) if B else 0, L.ptr(out))
+    return out

@@ -178,3 +178,30 @@ def vote(chunks, n_pts, num_classes):
     label = np.empty((n_pts,), np.int64)
     lib().mvpo_vote_finish(_p(s), _p(cnt), _i(n_pts), _i(num_classes), _p(mean), _p(label))
     return mean, label, cnt
+
+
+def augment_lifting(image_xyz, image_mask, points, flip=None, rot=None):
+    """The loader's augmentation of the lifting tensors, re-stated from mvpnet/data/scannet_2d3d.py (TEST INFRASTRUCTURE):
+      :293-296  per-view horizontal flip of image_xyz / image_mask (np.fliplr) BEFORE the k-NN fit (so indices are in mirrored order);
+      :400-409  z-rotation of `points` and `image_xyz` AFTER the k-NN: float64 matrix product, cast to float32.
+    image_xyz (B,nv,h,w,3) f32, image_mask (B,nv,h,w) bool, points (B,N,3) f32, flip (B,nv) bool, rot (B,3,3) float64.
+    Returns flipped image_xyz, flipped mask (inputs of pixel_knn) -- call BEFORE the search -- and a function that rotates."""
+    xyz, mask = np.array(image_xyz, copy=True), np.array(image_mask, copy=True)
+    if flip is not None:
+        for b in range(xyz.shape[0]):
+            for v in range(xyz.shape[1]):
+                if flip[b, v]:
+                    xyz[b, v] = xyz[b, v][:, ::-1]      # np.fliplr on (h, w, 3)
+                    mask[b, v] = mask[b, v][:, ::-1]
+
+    def rotate(x):  # x (B, ..., 3) float32
+        if rot is None:
+            return x
+        out = np.empty_like(x)
+        for b in range(x.shape[0]):
+            v = x[b].reshape(-1, 3).astype(np.float64)
+            M = np.asarray(rot[b], np.float64)
+            r = np.stack([(M[i, 0] * v[:, 0] + M[i, 1] * v[:, 1]) + M[i, 2] * v[:, 2] for i in range(3)], 1)
+            out[b] = r.astype(np.float32).reshape(x[b].shape)
+        return out
+    return xyz, mask, rotate

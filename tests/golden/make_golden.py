@@ -297,6 +297,48 @@ def gen_lifting():
     return out
 
 
+def gen_lifting_aug():
+    """The loader's augmentation around the lifting (mvpnet/data/scannet_2d3d.py:293-313,400-409; that module cannot be imported
+    -- open3d / torchvision -- so its lines are re-typed here as the vector generator, with the random draws replaced by fixed
+    flags / angles): per-view `np.fliplr` of image_xyz and image_mask BEFORE the ball-tree fit, flat pixel ids taken in the
+    mirrored order, then `scipy.spatial.transform.Rotation.from_euler('z', angle, degrees=True).apply` on `points` and `image_xyz`."""
+    from sklearn.neighbors import NearestNeighbors
+    from scipy.spatial.transform import Rotation
+    out = {}
+    kw = dict(nb_pts=1024, nv=3, h=30, w=40, channels=8)
+    cases = [(5, (True, False, True), 73.25), (6, (False, True, True), -141.5)]
+    out['kwargs'] = np.asarray(json.dumps(kw))
+    out['chunk_ids'] = np.asarray([c[0] for c in cases])
+    out['flip'] = np.asarray([c[1] for c in cases])
+    out['angle_deg'] = np.asarray([c[2] for c in cases], np.float64)
+    for ci, (chunk_id, flips, angle) in enumerate(cases):
+        chunk = make_chunk(chunk_id, with_feature=False, **kw)
+        image_xyz, image_mask, _ = reference_lifting(chunk, 3)                  # (nv,h,w,3), (nv,h,w): the un-mirrored tensors
+        nv, h, w = image_mask.shape
+        image_xyz_list, image_mask_list, image_ind_list = [x for x in image_xyz], [m for m in image_mask], []
+        for i in range(nv):                                                     # :288-302
+            if flips[i]:
+                image_xyz_list[i] = np.fliplr(image_xyz_list[i])
+                image_mask_list[i] = np.fliplr(image_mask_list[i])
+            image_ind = np.nonzero(image_mask_list[i].ravel())[0]
+            image_ind_list.append(image_ind + i * h * w)
+        image_xyz_valid = np.concatenate([x[m] for x, m in zip(image_xyz_list, image_mask_list)], axis=0)
+        image_ind_all = np.hstack(image_ind_list)
+        nbrs = NearestNeighbors(n_neighbors=3, algorithm='ball_tree').fit(image_xyz_valid)   # :310-313
+        _, knn_indices = nbrs.kneighbors(chunk['points'])
+        knn_indices = image_ind_all[knn_indices]
+        Rot = Rotation.from_euler('z', angle, degrees=True)                      # :400-409
+        points = Rot.apply(chunk['points']).astype(dtype=np.float32, copy=False)
+        xyz = np.stack(image_xyz_list, axis=0).astype(np.float32, copy=False)
+        xyz = Rot.apply(xyz.reshape([-1, 3])).reshape(xyz.shape).astype(dtype=np.float32, copy=False)
+        out['c%d_knn_indices' % ci] = i32(knn_indices)
+        out['c%d_image_xyz' % ci] = xyz
+        out['c%d_image_mask' % ci] = np.packbits(np.stack(image_mask_list, 0))
+        out['c%d_points' % ci] = points
+        out['c%d_rot' % ci] = Rot.as_matrix().astype(np.float64)
+    save('lifting_aug', **out)
+
+
 # --------------------------------------------------------------------------- #
 # module-level vectors (reference nn.Modules, seeded weights from weights.py)
 # --------------------------------------------------------------------------- #
@@ -497,6 +539,31 @@ def gen_modules_b8():
     out['knn_indices'] = i32(knn.numpy())
     out['image_xyz'] = image_xyz.numpy()
     out['log_weights'] = log_w
+    # The float64 value of the same graph (what BOTH fp32 implementations approximate): the oracle's restatement of the modules
+    # (oracle/torch_model.py, held to the reference's fp32 outputs above by tests/test_oracle_model_golden.py) evaluated in double
+    # with the index sets decided in fp32.  Lets a test state how far the reference's own fp32 path is from the exact value.
+    from oracle import torch_model as OM
+    from oracle import c_oracle as O
+    real = dict(fps=O.fps, ball=O.ball_query, knn3=O.knn3)
+    O.fps = lambda p, m: real['fps'](p.astype(np.float32), m)
+    O.ball_query = lambda q, k, r, K, with_distance=False: real['ball'](q.astype(np.float32), k.astype(np.float32), r, K, with_distance)
+
+    def knn3_64(q, k):
+        i, _ = real['knn3'](q.astype(np.float32), k.astype(np.float32))
+        qq, kk = q.astype(np.float64), k.astype(np.float64)
+        return i, np.stack([((qq - np.take_along_axis(kk, i[:, :, j:j + 1].repeat(3, 2), 1)) ** 2).sum(-1) for j in range(3)], -1)
+    O.knn3 = knn3_64
+    try:
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in model.state_dict().items()}
+        sd64 = {k: torch.from_numpy(v).double() if v.dtype == np.float32 else torch.from_numpy(v)
+                for k, v in __import__('tests.golden.weights', fromlist=['fill_state_dict']).fill_state_dict(shapes, 808).items()}
+        with torch.no_grad():
+            l64 = OM.mvpnet3d_forward(sd64, points.double(), feat_nchw.double(), image_xyz.double(), knn, training=True, **cfg)
+    finally:
+        O.fps, O.ball_query, O.knn3 = real['fps'], real['ball'], real['knn3']
+    out['seg_logit_f64'] = l64.numpy()
+    print('  b8: reference fp32 vs float64 logits: max {:.3e} mean {:.3e}'.format(
+        np.abs(out['seg_logit'] - out['seg_logit_f64']).max(), np.abs(out['seg_logit'] - out['seg_logit_f64']).mean()))
     save('mvpnet3d_b8', **out)
 
 
@@ -825,6 +892,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':  # only the fixtures of SURVEY sec.8f rank 4
         gen_metrics()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'lifting_aug':
+        gen_lifting_aug()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'b8':
         install_reference()
         gen_modules_b8()
@@ -845,6 +915,7 @@ def main():
     gen_group_points(T)
     gen_interpolate(T)
     lifting = gen_lifting()
+    gen_lifting_aug()
     gen_modules(lifting)
     gen_modules_b8()
     gen_vote_trainstep()

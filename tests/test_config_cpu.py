@@ -82,3 +82,24 @@ def test_pn2ssg_chunk_yaml():
     assert cfg.TRAIN.AUGMENTATION == (('CropPad', 8192), 'RandomRotateZ')
     model = C.build_model_sem_seg_3d(cfg)
     assert sum(p.numel() for p in model.parameters()) == 965044 and model.in_channels == 0
+
+
+def test_yaml_augmentation_is_honoured():
+    """DATASET.ScanNet2D3DChunks.augmentation of mvpnet_3d_unet_resnet34_pn2ssg.yaml (flip 0.5, z_rot (-180, 180)) becomes the
+    device-side augmentation; its random draws are the reference's (one rand() per view, one uniform angle per chunk)."""
+    import numpy as np
+    cfg = C.load_cfg(text=yaml_text('mvpnet_3d_unet_resnet34_pn2ssg'))
+    aug = C.build_augmentation(cfg, rng=np.random.RandomState(11))
+    assert aug.flip == 0.5 and aug.z_rot == (-180, 180)
+    images = torch.arange(2 * 3 * 3 * 2 * 4, dtype=torch.float32).view(2, 3, 3, 2, 4)
+    batch = aug({'images': images.clone(), 'depth': torch.zeros(2, 3, 2, 4)})
+    rs = np.random.RandomState(11)
+    flags = np.array([[rs.rand() < 0.5 for _ in range(3)] for _ in range(2)])
+    assert np.array_equal(batch['flip'].numpy().astype(bool), flags)
+    for b in range(2):
+        for v in range(3):
+            assert torch.equal(batch['images'][b, v], images[b, v].flip(-1) if flags[b, v] else images[b, v])
+    from scipy.spatial.transform import Rotation
+    for b in range(2):
+        np.testing.assert_array_equal(batch['z_rot'][b].numpy(), Rotation.from_euler('z', rs.uniform(low=-180, high=180), degrees=True).as_matrix())
+    assert C.build_augmentation(C.load_cfg(text='TASK: mvpnet_3d')) is None

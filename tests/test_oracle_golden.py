@@ -122,3 +122,26 @@ def test_vote():
     np.testing.assert_allclose(mean, g['mean'], rtol=1e-6, atol=1e-7)
     np.testing.assert_array_equal(label, g['label'])
     assert (label[cnt == 0] == 20).all() and (cnt == 0).sum() >= 300
+
+
+def test_lifting_augmentation_golden():
+    """Flip + z-rotation around the lifting (scannet_2d3d.py:293-313,400-409; tests/golden/lifting_aug.npz from the re-typed loader
+    lines with sklearn's ball tree and scipy's Rotation): the oracle restatement gives the same mirrored pixel ids, the same
+    rotated points and the same mirrored + rotated image_xyz, bit for bit."""
+    import json
+    from mvpnet_amd.synthetic import make_chunk
+    g = load_golden('lifting_aug')
+    kw = json.loads(str(g['kwargs']))
+    for ci, chunk_id in enumerate(g['chunk_ids']):
+        c = make_chunk(int(chunk_id), with_feature=False, **kw)
+        depth = O.depth_mm_to_m(c['depth_mm'][None])
+        xyz, mask = O.unproject(depth, c['kinv'][None], c['pose'][None], c['pixel_box'][None])
+        flip = g['flip'][ci][None]
+        rot = g['c%d_rot' % ci][None]
+        fxyz, fmask, rotate = O.augment_lifting(xyz, mask, c['points'][None], flip=flip, rot=rot)
+        nv, h, w = fmask.shape[1:]
+        np.testing.assert_array_equal(np.packbits(fmask[0]), g['c%d_image_mask' % ci])
+        knn = O.pixel_knn(fxyz, fmask, c['points'][None], 3)
+        np.testing.assert_array_equal(knn[0], g['c%d_knn_indices' % ci])
+        np.testing.assert_array_equal(rotate(c['points'][None])[0], g['c%d_points' % ci])
+        np.testing.assert_array_equal(rotate(fxyz)[0], g['c%d_image_xyz' % ci])
