@@ -258,6 +258,15 @@ int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float
  * stat = [sum y | sum y^2] over R rows */
 int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
+/* Contraction precision of the three shared-MLP entry points below (process-wide):
+ *   terms = 0  fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain; the default);
+ *   terms = 6  split-bf16: every fp32 operand as 3 bf16 pieces, the 6 products of order <= 2 on v_mfma_f32_32x32x16_bf16 with fp32
+ *              accumulation -- fp32-level accuracy at 2.67x the fp32-MFMA rate;
+ *   terms = 3  2 pieces, 3 products: ~2^-17 relative error per product, 5.3x the rate.
+ * Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Returns MVP_EINVAL for other values. */
+int mvp_set_mlp_precision(int terms, int min_width);
+int mvp_get_mlp_precision(void);
+
 /* Shared-MLP layer on rows with fp32 MFMA (mlp.hip): Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias).
  * act = identity when act_mean == NULL, else relu(((x-mean)*invstd)*gamma+beta) per input column: the previous
  * layer's BatchNorm + ReLU fused into the load (common/nn/modules/conv.py:41-51), so that activation is never stored.

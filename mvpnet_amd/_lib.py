@@ -70,7 +70,8 @@ _SIGNATURES = {
     'mvp_seg_loss_backward_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
-EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count'] + sorted(_SIGNATURES)
+EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -90,12 +91,36 @@ def lib():
         handle.mvp_group_lin_partial_count.argtypes = [_i64, _i64, _i64, _i64]
         handle.mvp_colstats_partial_count.restype = ctypes.c_int64
         handle.mvp_colstats_partial_count.argtypes = [_i64, _i64]
+        handle.mvp_set_mlp_precision.restype = ctypes.c_int
+        handle.mvp_set_mlp_precision.argtypes = [ctypes.c_int, ctypes.c_int]
+        handle.mvp_get_mlp_precision.restype = ctypes.c_int
+        handle.mvp_get_mlp_precision.argtypes = []
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         _lib = handle
+        env = os.environ.get('MVP_MLP_PRECISION')
+        if env:
+            set_mlp_precision(env, int(os.environ.get('MVP_MLP_MIN_WIDTH', '0')))
     return _lib
+
+
+MLP_PRECISIONS = {'fp32': 0, 'bf16x3': 3, 'bf16x6': 6}
+
+
+def set_mlp_precision(name, min_width=0):
+    """Contraction precision of the shared-MLP kernels (mvp_set_mlp_precision): 'fp32' (fp32 MFMA), 'bf16x6' (split-bf16,
+    3 pieces / 6 products, fp32-level accuracy), 'bf16x3' (2 pieces / 3 products, ~2^-17 per product).  Layers narrower than
+    `min_width` channels stay on the fp32 MFMA.  Also settable through MVP_MLP_PRECISION / MVP_MLP_MIN_WIDTH."""
+    if name not in MLP_PRECISIONS:
+        raise ValueError('mlp precision must be one of {}'.format(sorted(MLP_PRECISIONS)))
+    check(lib().mvp_set_mlp_precision(MLP_PRECISIONS[name], int(min_width)), 'mvp_set_mlp_precision')
+
+
+def get_mlp_precision():
+    terms = lib().mvp_get_mlp_precision()
+    return {v: k for k, v in MLP_PRECISIONS.items()}[terms]
 
 
 def check(code, what):

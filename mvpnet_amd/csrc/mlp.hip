@@ -110,26 +110,36 @@ constexpr int kMaxActCin = 512;    // input-activation parameters staged in LDS 
 #endif
 // ACT: 0 = no input activation, 1 = its per-column parameters staged in LDS (Cin <= kMaxActCin), 2 = read from global memory.
 // A compile-time choice: as run-time branches they were replicated for each of the four k-groups behind the MFMA block.
-template <int BN, int BK, bool WT, bool VEC, int ACT>
-__global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 1) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
+// NS: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 / 3 = split-bf16 with 2 / 3 pieces per operand on v_mfma_f32_32x32x16_bf16 (VEC only).
+//   The k <-> (lane half, position) assignment of the fp32 path is kept: lane half h owns k = 8 t + 4 h + e of the slab; bf16 MFMA
+//   s (= 0, 1) of a slab takes t = 2 s, 2 s + 1, i.e. its 8 operand positions are p = 4 (t & 1) + e.  The weight slab lies in
+//   LDS already split and in that order: piece-major, 80 bytes per column (4 units of 16 bytes = the 8 positions of (s, h); stride
+//   5 units: b128 fragment reads are conflict-free), so a B fragment is ONE ds_read_b128 per piece.
+template <int BN, int BK, bool WT, bool VEC, int ACT, int NS>
+__global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_WAVES128 : (NS != 0 && BN == 128) ? 2 : 1) void mlp_fwd_kernel(const float* __restrict__ X, int64_t R, int Cin, int ldx,
                                                       const float* __restrict__ W, int ldw, int Cout,
                                                       InAct act, const float* __restrict__ bias, EpiBwd epi,
                                                       float* __restrict__ Y /* (R, Cout) */, double* __restrict__ stat,
                                                       double* __restrict__ partial) {
-  constexpr int kLdB = BK + 4;  // LDS row stride of the weight slab (words): 16-byte aligned rows, conflict-free b128 access
+  static_assert(NS == 0 || (VEC && BK == 32), "split-bf16 needs the vector path and 32-wide slabs");
+  constexpr int kLdB = BK + 4;  // LDS row stride of the fp32 weight slab (words): 16-byte aligned rows, conflict-free b128 access
   constexpr int NT = BK / 8;    // MFMA k-groups per slab (k = 8 t + 4 h + e)
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLdB];
+  constexpr int kColB = 80;                    // split path: bytes per column and piece
+  constexpr int kPieceB = BN * kColB;          // bytes per piece
+  constexpr int kBufB = NS == 0 ? BN * kLdB * 4 : NS * kPieceB;   // bytes per slab buffer
+  __shared__ __attribute__((aligned(16))) unsigned char BsRaw[2 * kBufB];
+  float* const Bs0 = reinterpret_cast<float*>(BsRaw);
   __shared__ __attribute__((aligned(16))) float Ps[4][kMaxActCin];  // mean, invstd, gamma, beta of the input activation
   constexpr int kLdS = 36;
   // Epilogue scratch: the per-wave output transposition tiles (4 x 32 x 36 floats) and the statistics partials.  The weight
   // slabs are dead after the last barrier of the K loop; with 128-column tiles both fit inside them (63 -> 45 KB of LDS per
   // workgroup: three workgroups per CU instead of two), narrower tiles keep a separate transposition buffer.
   constexpr int kSsFloats = 4 * 32 * kLdS;
-  constexpr bool kAliasS = sizeof(float) * kSsFloats + sizeof(double) * 2 * 4 * BN <= sizeof(float) * 2 * BN * kLdB;
+  constexpr bool kAliasS = sizeof(float) * kSsFloats + sizeof(double) * 2 * 4 * BN <= (size_t)2 * kBufB;
   __shared__ __attribute__((aligned(16))) float Ss_own[kAliasS ? 4 : kSsFloats];
-  float (*Ss)[32 * kLdS] = reinterpret_cast<float (*)[32 * kLdS]>(kAliasS ? &Bs[0][0] : &Ss_own[0]);
-  static_assert(sizeof(double) * 2 * 4 * BN <= sizeof(float) * 2 * BN * kLdB, "sred must fit in Bs");
-  double (*sred)[4][BN] = reinterpret_cast<double (*)[4][BN]>(&Bs[0][0] + (kAliasS ? kSsFloats : 0));
+  float (*Ss)[32 * kLdS] = reinterpret_cast<float (*)[32 * kLdS]>(kAliasS ? Bs0 : &Ss_own[0]);
+  static_assert(sizeof(double) * 2 * 4 * BN <= (size_t)2 * kBufB, "sred must fit in Bs");
+  double (*sred)[4][BN] = reinterpret_cast<double (*)[4][BN]>(Bs0 + (kAliasS ? kSsFloats : 0));
   constexpr int NB = BN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * kBM;
@@ -221,7 +231,20 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
   constexpr int KH = BK / 32;         // WT: 32-wide k groups per slab
   float4 bn[WT ? NB * KH : NV];
   auto load_b = [&](int k0) {
-    if constexpr (!WT) {
+    if constexpr (WT && NS != 0) {
+      // split path, weight read across: thread (column c = tid % 32 of every 32-column block, k quad kq = 4 (tid / 32)) takes the
+      // four k of ONE output column -- the same (column, 4 consecutive k) ownership as the forward mapping, so both share the
+      // split + ds_write_b64 below; the loads are 4-byte (two full 128-byte rows of W per wave instruction)
+      const int c = tid & 31, kq = (tid >> 5) * 4;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int co = min(col0 + u * 32 + c, Cout - 1);
+        bn[u].x = W[(size_t)min(k0 + kq + 0, Cin - 1) * ldw + co];
+        bn[u].y = W[(size_t)min(k0 + kq + 1, Cin - 1) * ldw + co];
+        bn[u].z = W[(size_t)min(k0 + kq + 2, Cin - 1) * ldw + co];
+        bn[u].w = W[(size_t)min(k0 + kq + 3, Cin - 1) * ldw + co];
+      }
+    } else if constexpr (!WT) {
       const int c = tid / LPC, k = k0 + (tid % LPC) * 4;
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
@@ -255,7 +278,33 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
     }
   };
   auto store_b = [&](int buf, int k0) {  // registers -> LDS; entries outside (Cout, Cin) become zeros here
-    float* dst = Bs[buf];
+    if constexpr (NS != 0) {
+      // (column, 4 consecutive k) per thread and pass -> NS x ds_write_b64: the 4 values are positions 4 (t & 1) .. + 3 of
+      // unit (2 s + h), t = kq / 8, h = (kq / 4) & 1, s = t / 2
+      const int c = WT ? (tid & 31) : (tid / LPC), kq = WT ? (tid >> 5) * 4 : (tid % LPC) * 4;
+      const int t = kq >> 3, unit = 2 * (t >> 1) + ((kq >> 2) & 1);
+      unsigned char* base = BsRaw + (size_t)buf * kBufB + unit * 16 + (t & 1) * 8;
+      const int k = k0 + kq;
+      constexpr int PASSES = WT ? NB : NV;   // both are BN / 32: 32 columns per pass
+#pragma unroll
+      for (int u = 0; u < PASSES; ++u) {
+        const int cl = u * 32 + c;
+        const bool cok = col0 + cl < Cout;
+        float4 v = bn[u];
+        v.x = (cok && k + 0 < Cin) ? v.x : 0.f;
+        v.y = (cok && k + 1 < Cin) ? v.y : 0.f;
+        v.z = (cok && k + 2 < Cin) ? v.z : 0.f;
+        v.w = (cok && k + 3 < Cin) ? v.w : 0.f;
+        unsigned lo[NS], hi[NS];
+        split_pair<NS>(v.x, v.y, lo);
+        split_pair<NS>(v.z, v.w, hi);
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc)
+          *reinterpret_cast<uint2*>(base + (size_t)pc * kPieceB + (size_t)cl * kColB) = make_uint2(lo[pc], hi[pc]);
+      }
+      return;
+    }
+    float* dst = Bs0 + (size_t)buf * (kBufB / 4);
     if constexpr (!WT) {
       const int c = tid / LPC, kq = (tid % LPC) * 4, k = k0 + kq;
 #pragma unroll
@@ -286,11 +335,32 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
     }
   };
 
+  // split path: the activated slab as bf16 fragments, af[s][piece] = positions p = 0..7 <-> (t = 2 s + (p >> 2), e = p & 3)
+  u32x4 af[NS == 0 ? 1 : 2][NS == 0 ? 1 : NS];
+  auto split_a = [&]() {
+    if constexpr (NS != 0) {
+#pragma unroll
+      for (int sI = 0; sI < 2; ++sI) {
+        unsigned q0[NS], q1[NS], q2[NS], q3[NS];
+        split_pair<NS>(ac[2 * sI][0], ac[2 * sI][1], q0);
+        split_pair<NS>(ac[2 * sI][2], ac[2 * sI][3], q1);
+        split_pair<NS>(ac[2 * sI + 1][0], ac[2 * sI + 1][1], q2);
+        split_pair<NS>(ac[2 * sI + 1][2], ac[2 * sI + 1][3], q3);
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) af[sI][pc] = u32x4{q0[pc], q1[pc], q2[pc], q3[pc]};
+      }
+    }
+  };
+  f32x16 acc1;  // split path, 32-column tiles: the two bf16 MFMAs of a slab alternate between two accumulators (no dependent chain)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+
   load_a(0);
   load_b(0);
   __syncthreads();  // Ps visible
   store_b(0, 0);
   activate(0);
+  split_a();
   __syncthreads();
   int buf = 0;
   for (int k0 = 0; k0 < Cin; k0 += BK) {
@@ -301,29 +371,64 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT) ? MVP_MLP_WAVES128 : 
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the consumers of those loads BELOW the MFMAs
     __builtin_amdgcn_s_setprio(MVP_MFMA_PRIO);  // waves inside their MFMA block win the issue arbitration over waves that stage / store
-    const float* bp = Bs[buf] + li * kLdB + 4 * lh;
+    if constexpr (NS == 0) {
+      const float* bp = Bs0 + (size_t)buf * (kBufB / 4) + li * kLdB + 4 * lh;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float4 bf[NB];
+      for (int t = 0; t < NT; ++t) {
+        float4 bf[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const float4*>(bp + j * 32 * kLdB + 8 * t);
+        for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const float4*>(bp + j * 32 * kLdB + 8 * t);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][0], bf[j].x, acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][0], bf[j].x, acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][1], bf[j].y, acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][1], bf[j].y, acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][2], bf[j].z, acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][2], bf[j].z, acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][3], bf[j].w, acc[j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][3], bf[j].w, acc[j], 0, 0, 0);
+      }
+    } else {
+      using SP = SplitPairs<NS == 0 ? 2 : NS>;
+      // lane (column li of a 32-column block, half lh): unit (2 s + lh) of its column, one b128 per piece
+      const unsigned char* bp = BsRaw + (size_t)buf * kBufB + (size_t)li * kColB + lh * 16;
+      constexpr int JG = NB >= 2 ? 2 : 1;  // column blocks in flight: consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int sI = 0; sI < 2; ++sI) {
+#pragma unroll
+        for (int j0 = 0; j0 < NB; j0 += JG) {
+          u32x4 bfr[JG][NS == 0 ? 1 : NS];
+#pragma unroll
+          for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+            for (int pc = 0; pc < NS; ++pc)
+              bfr[jj][pc] = *reinterpret_cast<const u32x4*>(bp + (size_t)pc * kPieceB + (size_t)(j0 + jj) * 32 * kColB + sI * 32);
+#pragma unroll
+          for (int q = 0; q < SP::N; ++q)
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+              const bf16x8 a8 = __builtin_bit_cast(bf16x8, af[sI][SP::A[q]]);
+              const bf16x8 b8 = __builtin_bit_cast(bf16x8, bfr[jj][SP::B[q]]);
+              if (NB == 1 && sI == 1)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc1, 0, 0, 0);
+              else
+                acc[j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[j0 + jj], 0, 0, 0);
+            }
+        }
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (more) {
       store_b(buf ^ 1, k0 + BK);  // last read in the previous iteration, which ended with a barrier
       activate(k0 + BK);
+      split_a();
     }
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (NS != 0 && NB == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] += acc1[i];
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
@@ -584,6 +689,162 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix pipe (split-bf16, see the top of the file): dW (Cout, Cin) += dY^T . act(X).
+// The reduction runs over ROWS, so an MFMA operand fragment of v_mfma_f32_32x32x16_bf16 is "8 consecutive rows of ONE column":
+// lane (c = lane & 31, g = lane >> 5) reads rows r0 + 8 g .. + 7 of column c with eight 4-byte loads -- every wave instruction
+// is two full 128-byte row segments, no LDS, no transposition (a transposing LDS stage would write and read every element once
+// with nothing shared between waves: its traffic alone costs as much LDS time as the six-term contraction costs MFMA time).
+// A wave owns all TMB x TNB 32 x 32 blocks of the tile and every fourth 16-row step of the workgroup's row range; the loads of
+// its next step are in flight under the MFMAs of the current one.  The four partial tiles meet in LDS (two rounds), one fp32
+// atomic per element and workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int TMB, int TNB, int NS>
+__global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
+                                                        int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
+                                                        float* __restrict__ dW, int lddw) {
+  using SP = SplitPairs<NS>;
+  __shared__ float red[2][TMB * TNB * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, g = lane >> 5;
+  const int co0 = blockIdx.x * (32 * TMB), ci0 = blockIdx.y * (32 * TNB);
+  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_block;
+  const int64_t r_end = min(R, r_begin + rows_per_block);
+  f32x16 acc[TMB][TNB];
+#pragma unroll
+  for (int a = 0; a < TMB; ++a)
+#pragma unroll
+    for (int b = 0; b < TNB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  // this lane's columns: fixed for the whole kernel, so the activation parameters live in registers
+  int dcol[TMB], xcol[TNB];
+  bool dok[TMB], xok[TNB];
+  float pm[TNB], pi[TNB], pg[TNB], pb[TNB];
+  const bool has_act = act.mean != nullptr;
+#pragma unroll
+  for (int a = 0; a < TMB; ++a) {
+    dok[a] = co0 + 32 * a + c < Cout;
+    dcol[a] = min(co0 + 32 * a + c, Cout - 1);
+  }
+#pragma unroll
+  for (int b = 0; b < TNB; ++b) {
+    xok[b] = ci0 + 32 * b + c < Cin;
+    xcol[b] = min(ci0 + 32 * b + c, Cin - 1);
+    pm[b] = pi[b] = pg[b] = pb[b] = 0.f;
+    if (has_act) {
+      pm[b] = act.mean[xcol[b]];
+      pi[b] = act.invstd[xcol[b]];
+      pg[b] = act.gamma[xcol[b]];
+      pb[b] = act.beta[xcol[b]];
+    }
+  }
+  float dn[TMB][8], xn[TNB][8];  // raw values of the NEXT step
+  auto load = [&](int64_t r0) {  // unconditional, rows clamped into the tensor (masked when consumed)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int64_t r = min(r0 + 8 * g + p, R - 1);
+#pragma unroll
+      for (int a = 0; a < TMB; ++a) dn[a][p] = dY[(size_t)r * Cout + dcol[a]];
+#pragma unroll
+      for (int b = 0; b < TNB; ++b) xn[b][p] = X[(size_t)r * ldx + xcol[b]];
+    }
+  };
+  u32x4 fa[TMB][NS], fb[TNB][NS];
+  auto prepare = [&](int64_t r0) {  // mask, activate, split -> fragments of the CURRENT step
+    bool rok[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) rok[p] = r0 + 8 * g + p < r_end;
+#pragma unroll
+    for (int a = 0; a < TMB; ++a) {
+      float v[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) v[p] = (rok[p] && dok[a]) ? dn[a][p] : 0.f;
+      unsigned q[4][NS];
+#pragma unroll
+      for (int h2 = 0; h2 < 4; ++h2) split_pair<NS>(v[2 * h2], v[2 * h2 + 1], q[h2]);
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) fa[a][pc] = u32x4{q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
+    }
+#pragma unroll
+    for (int b = 0; b < TNB; ++b) {
+      float v[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        float x = xn[b][p];
+        if (has_act) {
+          const float z = ((x - pm[b]) * pi[b]) * pg[b] + pb[b];
+          x = z > 0.f ? z : 0.f;
+        }
+        v[p] = (rok[p] && xok[b]) ? x : 0.f;
+      }
+      unsigned q[4][NS];
+#pragma unroll
+      for (int h2 = 0; h2 < 4; ++h2) split_pair<NS>(v[2 * h2], v[2 * h2 + 1], q[h2]);
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) fb[b][pc] = u32x4{q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
+    }
+  };
+  // steps of 16 rows; wave w takes steps w, w + 4, ...
+  int64_t r0 = r_begin + (int64_t)wave * 16;
+  if (r0 < r_end) load(r0);
+  for (; r0 < r_end; r0 += 64) {
+    prepare(r0);
+    if (r0 + 64 < r_end) load(r0 + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(MVP_DW_PRIO);
+#pragma unroll
+    for (int q = 0; q < SP::N; ++q)
+#pragma unroll
+      for (int a = 0; a < TMB; ++a)
+#pragma unroll
+        for (int b = 0; b < TNB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a][SP::A[q]]),
+                                                             __builtin_bit_cast(bf16x8, fb[b][SP::B[q]]), acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // 4 partial tiles -> 1 through LDS: waves 2, 3 publish; waves 0, 1 add; wave 1 publishes; wave 0 adds and flushes
+  constexpr int NBLK = TMB * TNB;
+  auto publish = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < TMB; ++a)
+#pragma unroll
+      for (int b = 0; b < TNB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[slot][((a * TNB + b) * 16 + i) * 64 + lane] = acc[a][b][i];
+  };
+  auto absorb = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < TMB; ++a)
+#pragma unroll
+      for (int b = 0; b < TNB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] += red[slot][((a * TNB + b) * 16 + i) * 64 + lane];
+  };
+  static_assert(NBLK <= 4, "tile");
+  if (wave >= 2) publish(wave - 2);
+  __syncthreads();
+  if (wave < 2) absorb(wave);
+  __syncthreads();
+  if (wave == 1) publish(0);
+  __syncthreads();
+  if (wave == 0) {
+    absorb(0);
+#pragma unroll
+    for (int a = 0; a < TMB; ++a)
+#pragma unroll
+      for (int b = 0; b < TNB; ++b) {
+        const int ci = ci0 + 32 * b + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = co0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * g;
+          if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * lddw + ci, acc[a][b][i]);
+        }
+      }
+  }
+}
+
 // Tile width by output columns, vector / scalar loads by alignment.
 template <bool WT>
 void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int ldw, int N, InAct act, const float* bias, EpiBwd epi,
@@ -591,29 +852,35 @@ void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int l
   const unsigned gx = (unsigned)cdiv(R, kBM);
   const bool vec = ldx % 4 == 0 && ldw % 4 == 0 && K % 4 == 0 && N % 4 == 0 && ((uintptr_t)X) % 16 == 0 && ((uintptr_t)W) % 16 == 0 &&
                    K >= 4 && N >= 4;
-#define MVP_MLP_LAUNCH(BN, VEC)                                                                                                   \
+#define MVP_MLP_LAUNCH(BN, VEC, NS_)                                                                                              \
   /* K slab of 32: a 64-wide slab was measured slower (fewer slabs per tile expose the first load) */                                \
   do {                                                                                                                             \
     if (WT || act.mean == nullptr)                                                                                                 \
-      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, 0>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, ldw, N, \
+      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, 0, NS_>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, ldw, N, \
                          act, bias, epi, Y, stat, partial);                                                                        \
     else if (K <= kMaxActCin)                                                                                                      \
-      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, WT ? 0 : 1>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, \
+      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, WT ? 0 : 1, NS_>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, \
                          ldw, N, act, bias, epi, Y, stat, partial);                                                                \
     else                                                                                                                           \
-      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, WT ? 0 : 2>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, \
+      hipLaunchKernelGGL((mlp_fwd_kernel<BN, 32, WT, VEC, WT ? 0 : 2, NS_>), dim3(gx, (unsigned)cdiv(N, BN)), dim3(kMT), 0, s, X, R, K, ldx, W, \
                          ldw, N, act, bias, epi, Y, stat, partial);                                                                \
   } while (0)
   // Few rows (the 128- and 512-point levels): narrower column tiles until the launch has a workgroup for each of the 256 CUs.
   int bn = N <= 32 ? 32 : N <= 64 ? 64 : 128;
   while (bn > 32 && (int64_t)gx * cdiv(N, bn) < 256) bn >>= 1;
-  if (bn == 32) {
-    if (vec) MVP_MLP_LAUNCH(32, true); else MVP_MLP_LAUNCH(32, false);
-  } else if (bn == 64) {
-    if (vec) MVP_MLP_LAUNCH(64, true); else MVP_MLP_LAUNCH(64, false);
-  } else {
-    if (vec) MVP_MLP_LAUNCH(128, true); else MVP_MLP_LAUNCH(128, false);
-  }
+  // split-bf16 contraction (mvp_set_mlp_precision): vector path only, and only for layers at least g_mlp_min_width wide
+  const int ns = (vec && std::max(K, N) >= g_mlp_min_width) ? (g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0) : 0;
+#define MVP_MLP_BY_NS(BN)                                                                                                          \
+  do {                                                                                                                             \
+    if (!vec) MVP_MLP_LAUNCH(BN, false, 0);                                                                                        \
+    else if (ns == 2) MVP_MLP_LAUNCH(BN, true, 2);                                                                                 \
+    else if (ns == 3) MVP_MLP_LAUNCH(BN, true, 3);                                                                                 \
+    else MVP_MLP_LAUNCH(BN, true, 0);                                                                                              \
+  } while (0)
+  if (bn == 32) MVP_MLP_BY_NS(32);
+  else if (bn == 64) MVP_MLP_BY_NS(64);
+  else MVP_MLP_BY_NS(128);
+#undef MVP_MLP_BY_NS
 #undef MVP_MLP_LAUNCH
 }
 
@@ -663,6 +930,34 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
   if (R == 0) return MVP_OK;
   const int TM = Cout <= 32 ? 32 : 64, TN = Cin <= 32 ? 32 : 64;
   const int64_t tiles = cdiv(Cout, TM) * cdiv(Cin, TN);
+  {
+    // split-bf16 contraction (mvp_set_mlp_precision): any alignment (the operand loads are 4-byte), layers at least
+    // g_mlp_min_width wide; Cin >= 8 (the 4-column coordinate operand of the first set-abstraction layer stays on fp32)
+    const int ns = (std::max(Cin, Cout) >= g_mlp_min_width && Cin >= 8) ? (g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0) : 0;
+    if (ns != 0) {
+      int64_t splits = std::min<int64_t>(cdiv(1024, tiles), 512);
+      int64_t rows_per_block = cdiv(cdiv(R, splits), 64) * 64;
+      if (rows_per_block < 256) rows_per_block = 256;
+      splits = cdiv(R, rows_per_block);
+      InAct act{act_mean, act_invstd, act_gamma, act_beta};
+      dim3 grid((unsigned)cdiv(Cout, TM), (unsigned)cdiv(Cin, TN), (unsigned)splits);
+#define MVP_DWBF(A_, B_)                                                                                                           \
+  do {                                                                                                                             \
+    if (ns == 2)                                                                                                                   \
+      hipLaunchKernelGGL((mlp_dw_bf_kernel<A_, B_, 2>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
+                         rows_per_block, dW, (int)lddw);                                                                           \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((mlp_dw_bf_kernel<A_, B_, 3>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
+                         rows_per_block, dW, (int)lddw);                                                                           \
+  } while (0)
+      if (TM == 32 && TN == 32) MVP_DWBF(1, 1);
+      else if (TM == 32) MVP_DWBF(1, 2);
+      else if (TN == 32) MVP_DWBF(2, 1);
+      else MVP_DWBF(2, 2);
+#undef MVP_DWBF
+      return mvp_launch_status();
+    }
+  }
   // ~4 workgroups per CU in total, but at most 512 row splits: each split queues one atomic on every dW element
   int64_t splits = std::min<int64_t>(cdiv(1024, tiles), 512);
   const int64_t slab = 32 * (4 / ((TM / 32) * (TN / 32)));
@@ -719,3 +1014,17 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
     launch_stats_reduce(partial, (int64_t)gx, (int)(2 * Cin), stat, s);
   return mvp_launch_status();
 }
+
+// Contraction precision of the shared-MLP kernels (forward, input gradient, weight gradient):
+//   terms = 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain);
+//   terms = 6: split-bf16 with 3 pieces per operand and 6 products on v_mfma_f32_32x32x16_bf16 (fp32-level accuracy, 2.67x the rate);
+//   terms = 3: 2 pieces, 3 products (~2^-17 relative per product, 5.3x the rate).
+// Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Process-wide, not thread-safe against concurrent launches.
+MVP_API int mvp_set_mlp_precision(int terms, int min_width) {
+  MVP_REQUIRE(terms == 0 || terms == 3 || terms == 6);
+  MVP_REQUIRE(min_width >= 0);
+  g_mlp_terms = terms;
+  g_mlp_min_width = min_width;
+  return MVP_OK;
+}
+MVP_API int mvp_get_mlp_precision(void) { return g_mlp_terms; }
