@@ -90,6 +90,11 @@ int mvp_knn_distance_f32(const float* query, const float* key, int64_t B, int64_
                          int64_t* index, float* distance, mvp_stream_t stream);
 int mvp_knn_distance_f64(const double* query, const double* key, int64_t B, int64_t N1, int64_t N2, int64_t k,
                          int64_t* index, double* distance, mvp_stream_t stream);
+/* 3-NN + FeatureInterpolator's weights (mvpnet/models/pn2/modules.py:135-140) in one launch:
+ *   weight[b,n,k] = (1 / max(d2_k, eps)) / sum_j (1 / max(d2_j, eps)), every operation rounded once (float32);
+ *   distance may be NULL.  N2 >= 3. */
+int mvp_knn3_weights_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float eps, int64_t* index,
+                         float* weight, float* distance, mvp_stream_t stream);
 
 /* ---- feature interpolation (K = 3) ----------------------------------------------------
  * replaces interpolate_cuda.interpolate_forward / _backward

@@ -30,6 +30,7 @@ _SIGNATURES = {
     'mvp_group_points_backward_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_knn_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_knn_distance_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_knn3_weights_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr, _ptr, _ptr],
     'mvp_interpolate_forward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_forward_f64': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],

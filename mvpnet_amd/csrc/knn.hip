@@ -45,10 +45,13 @@ __device__ __forceinline__ void topk_insert(T (&bd)[K], int (&bi)[K], T d, int j
 }
 
 // query (B,N1,3), key (B,N2,3), optional mask (B,N2) -> index (B,N1,K), dist (B,N1,K) (may be null)
+// weight (B,N1,K) (may be null): the inverse-squared-distance interpolation weights of FeatureInterpolator
+// (mvpnet/models/pn2/modules.py:135-140): inv = 1 / max(d, eps); w = inv / sum_k inv, each operation rounded once.
 template <typename T, int K, bool MASKED>
 __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const T* __restrict__ query, const T* __restrict__ key,
                                                           const uint8_t* __restrict__ mask, int N1, int N2,
-                                                          int64_t* __restrict__ index, T* __restrict__ dist) {
+                                                          int64_t* __restrict__ index, T* __restrict__ dist,
+                                                          T* __restrict__ weight, T eps) {
   __shared__ Rec4<T> skey[kKnnTile];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
@@ -99,15 +102,26 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const T* __restrict__ 
       index[((size_t)b * N1 + qi) * K + s] = bi[s];
       if (dist) dist[((size_t)b * N1 + qi) * K + s] = bd[s];
     }
+    if (weight) {
+      T inv[K];
+      T sum = T(0);
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        inv[s] = T(1) / (bd[s] < eps ? eps : bd[s]);  // IEEE division (no fast-math in this library)
+        sum = s == 0 ? inv[0] : sum + inv[s];
+      }
+#pragma unroll
+      for (int s = 0; s < K; ++s) weight[((size_t)b * N1 + qi) * K + s] = inv[s] / sum;
+    }
   }
 }
 
 template <typename T, int K, bool MASKED>
 int knn_launch(const T* query, const T* key, const uint8_t* mask, int64_t B, int64_t N1, int64_t N2, int64_t* index,
-               T* dist, hipStream_t s) {
+               T* dist, hipStream_t s, T* weight = nullptr, T eps = T(0)) {
   dim3 grid((unsigned)cdiv(N1, kKnnThreads), (unsigned)B);
   hipLaunchKernelGGL((knn_kernel<T, K, MASKED>), grid, dim3(kKnnThreads), 0, s, query, key, mask, (int)N1, (int)N2,
-                     index, dist);
+                     index, dist, weight, eps);
   return mvp_launch_status();
 }
 
@@ -134,6 +148,21 @@ MVP_API int mvp_knn_distance_f32(const float* query, const float* key, int64_t B
 MVP_API int mvp_knn_distance_f64(const double* query, const double* key, int64_t B, int64_t N1, int64_t N2, int64_t k,
                                  int64_t* index, double* distance, mvp_stream_t stream) {
   return knn_distance_entry<double>(query, key, B, N1, N2, k, index, distance, stream);
+}
+
+// 3-NN + the interpolation weights of FeatureInterpolator.forward (modules.py:135-140) from ONE kernel: index (B,N1,3),
+// weight (B,N1,3) = (1 / max(d2, eps)) / sum_k (1 / max(d2_k, eps)); distance (B,N1,3) optional.  Replaces knn_distance + the
+// clamp / reciprocal / sum / div launches of the reference module.
+MVP_API int mvp_knn3_weights_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float eps,
+                                 int64_t* index, float* weight, float* distance, mvp_stream_t stream) {
+  MVP_NONNULL(query);
+  MVP_NONNULL(key);
+  MVP_NONNULL(index);
+  MVP_NONNULL(weight);
+  MVP_REQUIRE(B >= 0 && N1 >= 0 && N2 >= 3 && eps > 0.f);
+  MVP_REQUIRE(N1 < (1ll << 31) && N2 < (1ll << 31) && B < 65536);
+  if (B == 0 || N1 == 0) return MVP_OK;
+  return knn_launch<float, 3, false>(query, key, nullptr, B, N1, N2, index, distance, static_cast<hipStream_t>(stream), weight, eps);
 }
 
 MVP_API int mvp_pixel_knn_bruteforce_f32(const float* image_xyz, const uint8_t* mask, const float* points, int64_t B,

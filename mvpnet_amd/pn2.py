@@ -170,9 +170,12 @@ class FeatureInterpolator(nn.Module):
     def geometry(self, query_xyz, key_xyz, with_csr=False):
         """3-NN index and inverse-squared-distance weights (coordinates only) [+ with_csr: the transposed index]."""
         with torch.no_grad():
-            index, distance = ops.knn_distance(query_xyz, key_xyz, self.num_neighbors, transpose=False)
-            inv = 1.0 / torch.clamp(distance, min=self._eps)
-            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            if query_xyz.is_cuda and query_xyz.dtype == torch.float32 and self.num_neighbors == 3:
+                index, weight = R.knn3_weights(query_xyz, key_xyz, self._eps)  # index + weights from ONE kernel (no clamp / 1/x / sum / div)
+            else:
+                index, distance = ops.knn_distance(query_xyz, key_xyz, self.num_neighbors, transpose=False)
+                inv = 1.0 / torch.clamp(distance, min=self._eps)
+                weight = inv / torch.sum(inv, dim=2, keepdim=True)
             if with_csr:
                 return (index, weight) + R.build_csr(index, key_xyz.size(1))
         return index, weight

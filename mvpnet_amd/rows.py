@@ -168,6 +168,20 @@ def build_csr(index, N):
     return offsets, slots
 
 
+def knn3_weights(query, key, eps=1e-10):
+    """query (B,N1,3), key (B,N2,3) float32 -> index (B,N1,3) int64, weight (B,N1,3): the 3 nearest keys and FeatureInterpolator's
+    inverse-squared-distance weights (modules.py:135-140) from one launch (mvp_knn3_weights_f32)."""
+    L.require_gpu(query, key)
+    q, k = query.contiguous(), key.contiguous()
+    B, N1, _ = q.shape
+    if k.size(1) < 3:
+        raise RuntimeError('knn3_weights: at least 3 keys expected')
+    index = torch.empty((B, N1, 3), dtype=torch.int64, device=q.device)
+    weight = torch.empty((B, N1, 3), dtype=torch.float32, device=q.device)
+    L.call('mvp_knn3_weights_f32', q, L.ptr(q), L.ptr(k), B, N1, k.size(1), float(eps), L.ptr(index), L.ptr(weight), None)
+    return index, weight
+
+
 class GroupLinRows(torch.autograd.Function):
     """out[b,m,k,:] = zf[b,j,:] + wxyz . (xyz[b,j] - centre[b,m]),  j = index[b,m,k]   (zf may be None).
     want_stat: also return the float64 column sums [sum out | sum out^2] (the BatchNorm batch statistics of this layer,

@@ -774,3 +774,22 @@ def test_csr_build(dev):
         assert sorted(used.tolist()) == np.nonzero(valid)[0].tolist()
         owner = np.repeat(np.arange(N), np.diff(offsets[b]))
         np.testing.assert_array_equal(idx[b][used], owner)
+
+
+@pytest.mark.parametrize('B,N1,N2', [(2, 512, 128), (3, 8192, 2048), (1, 31, 3)])
+def test_knn3_weights_epilogue(dev, B, N1, N2):
+    """mvp_knn3_weights_f32: the 3-NN index of knn_distance and FeatureInterpolator's weights (modules.py:135-140) from one kernel,
+    against the module's own torch chain (clamp -> reciprocal -> sum -> div); coincident query/key pairs exercise the eps clamp."""
+    from mvpnet_amd import ops
+    from mvpnet_amd import rows as R
+    torch.manual_seed(B * N1)
+    key = torch.rand(B, N2, 3, device=dev)
+    query = torch.rand(B, N1, 3, device=dev)
+    query[:, :min(N1, N2) // 2] = key[:, :min(N1, N2) // 2]  # exact hits: d2 = 0 -> clamped to eps
+    idx, w = R.knn3_weights(query, key, 1e-10)
+    ridx, dist = ops.knn_distance(query, key, 3, transpose=False)
+    assert torch.equal(idx, ridx)
+    inv = 1.0 / torch.clamp(dist, min=1e-10)
+    ref = inv / torch.sum(inv, dim=2, keepdim=True)
+    np.testing.assert_allclose(w.cpu().numpy(), ref.cpu().numpy(), rtol=3e-7, atol=0)
+    np.testing.assert_allclose(w.sum(2).cpu().numpy(), 1.0, rtol=1e-6)
