@@ -289,6 +289,24 @@ int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, con
 int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ,
                            double* stat, double* partial, mvp_stream_t stream);
+
+/* The WHOLE backward of shared-MLP layer i in one kernel (csrc/mlp_bwd.hip): BatchNorm-backward "finish" + weight gradient + input
+ * gradient with the previous layer's ReLU mask and BatchNorm-backward column sums, from ONE read of dz_i, y_i and y_{i-1}
+ * (2 C + 2 Cp floats of HBM traffic per row instead of the 5 C + 3 Cp of the three entry points above; no dy_i tensor).
+ *   G (R,C): dz_i when Yi != NULL -- then dy_i = gamma_i*invstd_i * (dz_i - stat_i[c]/R - xhat_i * stat_i[C+c]/R), xhat_i from Yi,
+ *            (training = 0 drops the two batch terms) and dgamma_i / dbeta_i (C, may be NULL) receive stat_i[C+c] / stat_i[c] --
+ *            or dy_i itself when Yi == NULL;
+ *   X (R,ldx): the layer's input; act_* != NULL: X is y_{i-1} and the input is relu(bn_{i-1}(y_{i-1})), re-created on the fly;
+ *   dW (C,lddw) += dy_i^T . input;  dZ (R,Cp) or NULL = (dy_i . W) [* relu'(bn_{i-1}(y_{i-1}))];
+ *   stat_prev (2 Cp, accumulated into): column sums of dZ and dZ * xhat_{i-1} (needs act_* and dZ; partial = float64 scratch of
+ *   mvp_mlp_layer_backward_partial_count(R, Cp) values).
+ * Contraction: split-bf16 only (mvp_set_mlp_precision 3 or 6); C <= 64, Cp <= 96, Cp % 4 == 0 -- otherwise MVP_EUNSUPPORTED. */
+int64_t mvp_mlp_layer_backward_partial_count(int64_t R, int64_t Cp);
+int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                               const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx,
+                               const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                               const float* W, int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
+                               double* stat_prev, double* partial, mvp_stream_t stream);
 /* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
  * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,

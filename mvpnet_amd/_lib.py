@@ -64,6 +64,8 @@ _SIGNATURES = {
     'mvp_bn_finalize_f32': [_ptr, _i64, _i64, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
     'mvp_mlp_input_grad_f32': [_ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_mlp_layer_backward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
+                                   _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr],
     'mvp_mlp_forward_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
@@ -72,7 +74,7 @@ _SIGNATURES = {
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
-           'mvp_set_mlp_precision', 'mvp_get_mlp_precision'] + sorted(_SIGNATURES)
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -96,6 +98,8 @@ def lib():
         handle.mvp_set_mlp_precision.argtypes = [ctypes.c_int, ctypes.c_int]
         handle.mvp_get_mlp_precision.restype = ctypes.c_int
         handle.mvp_get_mlp_precision.argtypes = []
+        handle.mvp_mlp_layer_backward_partial_count.restype = ctypes.c_int64
+        handle.mvp_mlp_layer_backward_partial_count.argtypes = [_i64, _i64]
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes

@@ -1,0 +1,426 @@
+// mlp_bwd.hip -- the whole backward of ONE shared-MLP layer (pointwise conv + BatchNorm + ReLU on rows) in one kernel for gfx950.
+//
+// The unfused backward of layer i (mlp.hip + rows.hip; reference: autograd through common/nn/modules/conv.py:41-51) makes three
+// passes over HBM:
+//     dy_i   = gamma*invstd * (dz_i - dbeta/R - xhat_i * dgamma/R)            bn_rows_bwd_kernel   reads dz_i, y_i      writes dy_i
+//     dW_i  += dy_i^T . a_{i-1}                                                mlp_dw_*             reads dy_i, y_{i-1}
+//     dz_{i-1} = (dy_i . W_i) * relu'(bn(y_{i-1})) (+ its two column sums)      mlp_fwd_kernel<WT>   reads dy_i, y_{i-1}  writes dz_{i-1}
+// = 5 C_i + 3 C_{i-1} floats of traffic per row.  Here a wave loads its 32 rows of dz_i, y_i and y_{i-1} ONCE, forms dy_i and a_{i-1} in
+// registers, and feeds both contractions from them: 2 C_i + 2 C_{i-1} floats per row, no dy_i tensor at all.
+//
+// Layout: everything lives in the accumulator layout of the 32x32 MFMAs -- lane = channel (c = lane & 31 of a 32-channel block), the
+// 16 values of a lane = rows 8 m + 4 h + e (h = lane >> 5, register q = 4 m + e) of the wave's 32-row tile:
+//   * global loads are 4 bytes per lane, two full 128-byte row segments per wave instruction;
+//   * dW (reduction over ROWS): v_mfma_f32_32x32x16_bf16 wants "8 rows of one channel" per lane -- registers q = 8 s .. 8 s + 7 ARE the
+//     operand of row step s, for dy_i (A, i = c_out) and a_{i-1} (B, j = c_in) alike: no data movement;
+//   * dz_{i-1} (reduction over c_out): dy_i goes once through a wave-private 32 x 32 LDS tile per channel block to become "8 channels of
+//     one row" per lane; W_i sits in LDS for the whole kernel, already split in bf16 pieces and in fragment order (64 bytes per
+//     (c_in, 32-c_out slab, piece), 16-byte units XOR-swizzled: conflict-free b128 reads, no padding);
+//   * the result tile comes out as lane = c_in, registers = the SAME rows: the ReLU mask, xhat_{i-1} and the two BatchNorm-backward column
+//     sums are formed against the y_{i-1} values still in registers; stores go through the LDS tile as 16 bytes per lane.
+// Contraction: split-bf16 (mlp_common.h), 3 or 2 pieces.  Per-workgroup dW tiles meet in LDS, one fp32 atomic per element and
+// workgroup; the column sums leave through per-workgroup slots + stats_reduce (no atomics).
+#include "mlp_common.h"
+#include "stats_reduce.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int kBT = 256;        // threads
+constexpr int kTileLd = 36;     // row stride (floats) of the wave-private transposition tile
+
+struct BwdArgs {
+  const float* G;       // (R, C): dz_i (finish != 0) or dy_i itself
+  const float* Yi;      // (R, C) pre-BN output of layer i (finish only)
+  const float* mean_i;  // finish: BatchNorm of layer i
+  const float* invstd_i;
+  const float* gamma_i;
+  const double* stat_i;  // (2 C): column sums of dz_i and dz_i * xhat_i
+  float* dgamma_i;       // (C) <- stat_i[C + c], (C) <- stat_i[c]: BatchNorm parameter gradients of layer i (finish only, may be null)
+  float* dbeta_i;
+  float inv_rows;        // 1 / R in training mode, 0 with running statistics
+  const float* X;        // (R, ldx): y_{i-1} (pre-BN) or the layer input itself
+  int ldx;
+  InAct act;             // BatchNorm + ReLU of layer i-1 (mean == nullptr: X is the plain input)
+  const float* W;        // (C, ldw) weight of layer i
+  int ldw;
+  float* dW;             // (C, lddw) accumulated into
+  int lddw;
+  float* dZ;             // (R, Cp) or nullptr
+  double* partial;       // (workgroups, 2 Cp) column sums of dz_{i-1} and dz_{i-1} * xhat_{i-1}; nullptr without act
+  int64_t R;
+  int C, Cp;
+  int64_t tiles_per_wg;
+};
+
+template <int CB, int CPB, int NS>
+__global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
+  using SP = SplitPairs<NS>;
+  constexpr int kWBytes = NS * CB * CPB * 32 * 64;                 // split weight: 64 bytes per (c_in, slab, piece)
+  constexpr int kTileBytes = 4 * 32 * kTileLd * 4;
+  constexpr int kRedBytes = 2 * CB * CPB * 16 * 64 * 4;
+  constexpr int kLds = (kWBytes + kTileBytes) > kRedBytes ? (kWBytes + kTileBytes) : kRedBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+  __shared__ double sred[2][4][CPB * 32];
+  unsigned char* Wl = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  float* tile = reinterpret_cast<float*>(lds + kWBytes) + wave * 32 * kTileLd;
+  const int C = p.C, Cp = p.Cp;
+  const bool finish = p.Yi != nullptr;
+  const bool has_act = p.act.mean != nullptr;
+  const bool want_dz = p.dZ != nullptr;
+
+  // ---- W_i -> LDS, split, fragment order.  Thread: (c_in, quad of 4 consecutive c_out)
+  if (want_dz) {
+    const int quads = CB * 8;  // c_out quads
+    for (int t = tid; t < quads * CPB * 32; t += kBT) {
+      const int ci = t % (CPB * 32), cq = t / (CPB * 32);
+      const int co = 4 * cq;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (co + e < C && ci < Cp) ? p.W[(size_t)(co + e) * p.ldw + ci] : 0.f;
+      unsigned lo[NS], hi[NS];
+      split_pair<NS>(v[0], v[1], lo);
+      split_pair<NS>(v[2], v[3], hi);
+      const int a = cq >> 3, coq = cq & 7;          // 32-channel slab, quad inside it: c_out = 32 a + 8 t + 4 h' + e
+      const int tt = coq >> 1, hh = coq & 1;
+      const int unit = 2 * (tt >> 1) + hh, half = tt & 1;
+      const int sw = (ci >> 2) & 3;
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc)
+        *reinterpret_cast<uint2*>(Wl + ((size_t)(pc * CB + a) * (CPB * 32) + ci) * 64 + ((unit ^ sw) * 16) + half * 8) = make_uint2(lo[pc], hi[pc]);
+    }
+  }
+  if (finish && p.dgamma_i && blockIdx.x == 0)
+    for (int col = tid; col < C; col += kBT) {
+      p.dbeta_i[col] = (float)p.stat_i[col];
+      p.dgamma_i[col] = (float)p.stat_i[C + col];
+    }
+  // ---- per-lane column constants
+  float sc[CB], mu[CB], is[CB], db[CB], dg[CB];
+  bool cok[CB];
+#pragma unroll
+  for (int a = 0; a < CB; ++a) {
+    const int col = 32 * a + c;
+    cok[a] = col < C;
+    sc[a] = mu[a] = is[a] = db[a] = dg[a] = 0.f;
+    if (finish && cok[a]) {
+      mu[a] = p.mean_i[col];
+      is[a] = p.invstd_i[col];
+      sc[a] = p.gamma_i[col] * is[a];
+      db[a] = (float)p.stat_i[col] * p.inv_rows;
+      dg[a] = (float)p.stat_i[C + col] * p.inv_rows;
+    }
+  }
+  float pm[CPB], pi[CPB], pg[CPB], pb[CPB];
+  bool xok[CPB];
+#pragma unroll
+  for (int b = 0; b < CPB; ++b) {
+    const int col = 32 * b + c;
+    xok[b] = col < Cp;
+    pm[b] = pi[b] = pg[b] = pb[b] = 0.f;
+    if (has_act && xok[b]) {
+      pm[b] = p.act.mean[col];
+      pi[b] = p.act.invstd[col];
+      pg[b] = p.act.gamma[col];
+      pb[b] = p.act.beta[col];
+    }
+  }
+  f32x16 accw[CB][CPB];
+#pragma unroll
+  for (int a = 0; a < CB; ++a)
+#pragma unroll
+    for (int b = 0; b < CPB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accw[a][b][i] = 0.f;
+  float ssum[CPB], tsum[CPB];
+#pragma unroll
+  for (int b = 0; b < CPB; ++b) ssum[b] = tsum[b] = 0.f;
+  __syncthreads();  // weight image complete
+
+  const int64_t ntiles = (p.R + 31) / 32;
+  const int64_t t_begin = (int64_t)blockIdx.x * p.tiles_per_wg;
+  const int64_t t_end = min(ntiles, t_begin + p.tiles_per_wg);
+  for (int64_t t = t_begin + wave; t < t_end; t += 4) {
+    const int64_t r0 = t * 32;
+    // ---- loads: 16 rows per lane (8 m + 4 h + e), 4 bytes each; rows / columns past the tensor are clamped and masked below
+    float x[CPB][16], g[CB][16], yv[CB][16];
+    bool rok[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t r = r0 + 8 * (q >> 2) + 4 * h + (q & 3);
+      rok[q] = r < p.R;
+      const int64_t rc = rok[q] ? r : p.R - 1;
+#pragma unroll
+      for (int a = 0; a < CB; ++a) {
+        const int col = cok[a] ? 32 * a + c : C - 1;
+        g[a][q] = p.G[(size_t)rc * C + col];
+        yv[a][q] = finish ? p.Yi[(size_t)rc * C + col] : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < CPB; ++b) x[b][q] = p.X[(size_t)rc * p.ldx + (xok[b] ? 32 * b + c : Cp - 1)];
+    }
+    // ---- dy_i and a_{i-1} in registers
+    float av[CPB][16];
+#pragma unroll
+    for (int b = 0; b < CPB; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = x[b][q];
+        if (has_act) {
+          const float z = ((v - pm[b]) * pi[b]) * pg[b] + pb[b];
+          v = z > 0.f ? z : 0.f;
+        }
+        av[b][q] = (rok[q] && xok[b]) ? v : 0.f;
+      }
+#pragma unroll
+    for (int a = 0; a < CB; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float d = g[a][q];
+        if (finish) {
+          const float xh = (yv[a][q] - mu[a]) * is[a];
+          d = sc[a] * ((d - db[a]) - xh * dg[a]);
+        }
+        g[a][q] = (rok[q] && cok[a]) ? d : 0.f;
+      }
+    // ---- dW += dy^T . a : two row steps, operands straight from the registers
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fa[CB][NS], fb[CPB][NS];
+#pragma unroll
+      for (int a = 0; a < CB; ++a) {
+        unsigned qq[4][NS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair<NS>(g[a][8 * s + 2 * j], g[a][8 * s + 2 * j + 1], qq[j]);
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) fa[a][pc] = u32x4{qq[0][pc], qq[1][pc], qq[2][pc], qq[3][pc]};
+      }
+#pragma unroll
+      for (int b = 0; b < CPB; ++b) {
+        unsigned qq[4][NS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair<NS>(av[b][8 * s + 2 * j], av[b][8 * s + 2 * j + 1], qq[j]);
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) fb[b][pc] = u32x4{qq[0][pc], qq[1][pc], qq[2][pc], qq[3][pc]};
+      }
+#pragma unroll
+      for (int qd = 0; qd < SP::N; ++qd)
+#pragma unroll
+        for (int a = 0; a < CB; ++a)
+#pragma unroll
+          for (int b = 0; b < CPB; ++b)
+            accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a][SP::A[qd]]),
+                                                                __builtin_bit_cast(bf16x8, fb[b][SP::B[qd]]), accw[a][b], 0, 0, 0);
+    }
+    if (!want_dz) continue;
+    // ---- dz_{i-1} = dy . W : dy block a through the LDS tile -> "8 channels of one row" per lane
+    f32x16 accz[CPB];
+#pragma unroll
+    for (int b = 0; b < CPB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accz[b][i] = 0.f;
+#pragma unroll
+    for (int a = 0; a < CB; ++a) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tile[(8 * (q >> 2) + 4 * h + (q & 3)) * kTileLd + c] = g[a][q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {  // c_out step: channels 32 a + 16 s + {4 h + e, 8 + 4 h + e}
+        const float4 v0 = *reinterpret_cast<const float4*>(tile + c * kTileLd + 16 * s + 4 * h);
+        const float4 v1 = *reinterpret_cast<const float4*>(tile + c * kTileLd + 16 * s + 8 + 4 * h);
+        unsigned q0[NS], q1[NS], q2[NS], q3[NS];
+        split_pair<NS>(v0.x, v0.y, q0);
+        split_pair<NS>(v0.z, v0.w, q1);
+        split_pair<NS>(v1.x, v1.y, q2);
+        split_pair<NS>(v1.z, v1.w, q3);
+        u32x4 fr[NS];
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) fr[pc] = u32x4{q0[pc], q1[pc], q2[pc], q3[pc]};
+#pragma unroll
+        for (int b = 0; b < CPB; ++b) {
+          const int ci = 32 * b + c;
+          u32x4 wf[NS];
+#pragma unroll
+          for (int pc = 0; pc < NS; ++pc)
+            wf[pc] = *reinterpret_cast<const u32x4*>(Wl + ((size_t)(pc * CB + a) * (CPB * 32) + ci) * 64 + (((2 * s + h) ^ ((ci >> 2) & 3)) * 16));
+#pragma unroll
+          for (int qd = 0; qd < SP::N; ++qd)
+            accz[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[SP::A[qd]]),
+                                                             __builtin_bit_cast(bf16x8, wf[SP::B[qd]]), accz[b], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next block
+    }
+    // ---- epilogue: ReLU mask + column sums against the y_{i-1} values in registers, 16-byte stores through the tile
+#pragma unroll
+    for (int b = 0; b < CPB; ++b) {
+      float s = 0.f, tq = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float d = accz[b][q];
+        if (has_act) {
+          const float xh = (x[b][q] - pm[b]) * pi[b];
+          d = (xh * pg[b] + pb[b] > 0.f) ? d : 0.f;
+          d = (rok[q] && xok[b]) ? d : 0.f;
+          s += d;
+          tq += d * xh;
+        }
+        tile[(8 * (q >> 2) + 4 * h + (q & 3)) * kTileLd + c] = d;
+      }
+      ssum[b] += s;
+      tsum[b] += tq;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const int row = pp * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * kTileLd + c4);
+        const int64_t r = r0 + row;
+        const int cc = 32 * b + c4;
+        if (r < p.R && cc < Cp) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.dZ + (size_t)r * Cp + cc));  // Cp % 4 == 0
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // ---- column sums: lane halves -> waves -> this workgroup's slot
+  if (p.partial) {
+#pragma unroll
+    for (int b = 0; b < CPB; ++b) {
+      const float s = ssum[b] + __shfl_xor(ssum[b], 32, kWave), tq = tsum[b] + __shfl_xor(tsum[b], 32, kWave);
+      if (lane < 32) {
+        sred[0][wave][32 * b + c] = (double)s;
+        sred[1][wave][32 * b + c] = (double)tq;
+      }
+    }
+  }
+  __syncthreads();  // also: every wave is done with the weight image / tiles -> the dW reduction may reuse the LDS
+  if (p.partial) {
+    for (int col = tid; col < CPB * 32; col += kBT)
+      if (col < Cp) {
+        p.partial[((size_t)blockIdx.x * 2 + 0) * Cp + col] = sred[0][0][col] + sred[0][1][col] + sred[0][2][col] + sred[0][3][col];
+        p.partial[((size_t)blockIdx.x * 2 + 1) * Cp + col] = sred[1][0][col] + sred[1][1][col] + sred[1][2][col] + sred[1][3][col];
+      }
+  }
+  // ---- dW: 4 partial tiles -> 1 (two rounds through LDS), one atomic per element and workgroup
+  float* red = reinterpret_cast<float*>(lds);
+  constexpr int kSlot = CB * CPB * 16 * 64;
+  auto publish = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < CB; ++a)
+#pragma unroll
+      for (int b = 0; b < CPB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[slot * kSlot + ((a * CPB + b) * 16 + i) * 64 + lane] = accw[a][b][i];
+  };
+  auto absorb = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < CB; ++a)
+#pragma unroll
+      for (int b = 0; b < CPB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accw[a][b][i] += red[slot * kSlot + ((a * CPB + b) * 16 + i) * 64 + lane];
+  };
+  if (wave >= 2) publish(wave - 2);
+  __syncthreads();
+  if (wave < 2) absorb(wave);
+  __syncthreads();
+  if (wave == 1) publish(0);
+  __syncthreads();
+  if (wave == 0) {
+    absorb(0);
+#pragma unroll
+    for (int a = 0; a < CB; ++a)
+#pragma unroll
+      for (int b = 0; b < CPB; ++b) {
+        const int ci = 32 * b + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (co < C && ci < Cp) atomicAdd(p.dW + (size_t)co * p.lddw + ci, accw[a][b][i]);
+        }
+      }
+  }
+}
+
+}  // namespace
+
+// Number of float64 scratch values mvp_mlp_layer_backward_f32 needs for its column sums (workgroups x 2 x Cp).
+MVP_API int64_t mvp_mlp_layer_backward_partial_count(int64_t R, int64_t Cp) {
+  if (R < 0 || Cp <= 0) return 0;
+  const int64_t ntiles = cdiv(R, 32);
+  const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(ntiles, 8)));
+  return wgs * 2 * Cp;
+}
+
+// Whole backward of shared-MLP layer i on rows (see the top of the file):
+//   G (R,C): dz_i when Yi != NULL (then dy_i = gamma_i*invstd_i * (dz_i - stat_i[c]/R - xhat_i*stat_i[C+c]/R), xhat_i from Yi; training = 0
+//            drops the two batch terms) -- or dy_i itself when Yi == NULL;
+//   X (R,ldx): layer input, act_* != NULL: it is y_{i-1} and the input is relu(bn_{i-1}(y_{i-1})) re-created on the fly;
+//   dW (C, lddw) += dy_i^T . input;   dZ (R,Cp) = (dy_i . W) [* relu'(bn_{i-1}(y_{i-1}))], dZ == NULL: not wanted;
+//   stat_prev (2 Cp, accumulated into) += column sums of dZ and dZ * xhat_{i-1} (with act_* and dZ only; `partial` = scratch of
+//   mvp_mlp_layer_backward_partial_count doubles).
+//   dgamma_i / dbeta_i (C, may be NULL): with Yi, the BatchNorm parameter gradients of layer i = stat_i[C + c] / stat_i[c] as float32.
+// Needs a split-bf16 precision (mvp_set_mlp_precision 3 or 6), C <= 64, Cp <= 96 and Cp % 4 == 0: MVP_EUNSUPPORTED otherwise
+// (callers then use the three separate entry points).
+MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                       const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float* act_mean,
+                                       const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W,
+                                       int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
+                                       double* stat_prev, double* partial, mvp_stream_t stream) {
+  MVP_NONNULL(G);
+  MVP_NONNULL(X);
+  MVP_NONNULL(W);
+  MVP_NONNULL(dW);
+  if (Yi) {
+    MVP_NONNULL(mean_i);
+    MVP_NONNULL(invstd_i);
+    MVP_NONNULL(gamma_i);
+    MVP_NONNULL(stat_i);
+  }
+  if (act_mean) {
+    MVP_NONNULL(act_invstd);
+    MVP_NONNULL(act_gamma);
+    MVP_NONNULL(act_beta);
+  }
+  if (dZ && act_mean) {
+    MVP_NONNULL(stat_prev);
+    MVP_NONNULL(partial);
+  }
+  MVP_REQUIRE(R >= 0 && C > 0 && Cp > 0 && ldx >= Cp && ldw >= Cp && lddw >= Cp && lddw < (1 << 24) && ldx < (1 << 24));
+  const int ns = g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0;
+  if (ns == 0 || C > 64 || Cp > 96 || (dZ && Cp % 4 != 0) || (dZ && ((uintptr_t)dZ % 16) != 0)) return MVP_EUNSUPPORTED;
+  if (R == 0) return MVP_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  BwdArgs a;
+  a.G = G; a.Yi = Yi; a.mean_i = mean_i; a.invstd_i = invstd_i; a.gamma_i = gamma_i; a.stat_i = stat_i;
+  a.dgamma_i = dbeta_i ? dgamma_i : nullptr; a.dbeta_i = dbeta_i;
+  a.inv_rows = training ? 1.0f / (float)R : 0.f;
+  a.X = X; a.ldx = (int)ldx;
+  a.act = InAct{act_mean, act_invstd, act_gamma, act_beta};
+  a.W = W; a.ldw = (int)ldw; a.dW = dW; a.lddw = (int)lddw; a.dZ = dZ;
+  a.partial = (dZ && act_mean) ? partial : nullptr;
+  a.R = R; a.C = (int)C; a.Cp = (int)Cp;
+  const int64_t ntiles = cdiv(R, 32);
+  const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(ntiles, 8)));
+  a.tiles_per_wg = cdiv(cdiv(ntiles, wgs), 4) * 4;
+  const int64_t grid = cdiv(ntiles, a.tiles_per_wg);
+  const int cb = C <= 32 ? 1 : 2, cpb = Cp <= 32 ? 1 : Cp <= 64 ? 2 : 3;
+#define MVP_BWD(A_, B_)                                                                                        \
+  do {                                                                                                         \
+    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2>), dim3((unsigned)grid), dim3(kBT), 0, s, a); \
+    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3>), dim3((unsigned)grid), dim3(kBT), 0, s, a);        \
+  } while (0)
+  if (cb == 1 && cpb == 1) MVP_BWD(1, 1);
+  else if (cb == 1 && cpb == 2) MVP_BWD(1, 2);
+  else if (cb == 1) MVP_BWD(1, 3);
+  else if (cpb == 1) MVP_BWD(2, 1);
+  else if (cpb == 2) MVP_BWD(2, 2);
+  else MVP_BWD(2, 3);
+#undef MVP_BWD
+  int rc = mvp_launch_status();
+  if (rc != MVP_OK) return rc;
+  if (a.partial) launch_stats_reduce(partial, grid, (int)(2 * Cp), stat_prev, s);
+  return mvp_launch_status();
+}

@@ -1,0 +1,52 @@
+// mlp_common.h -- shared by mlp.hip and mlp_bwd.hip: MFMA vector types, the split-bf16 helpers, the precision switch.
+#pragma once
+#include "common.h"
+
+extern int g_mlp_terms;      // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (mvp_set_mlp_precision, defined in mlp.hip)
+extern int g_mlp_min_width;  // layers with max(Cin, Cout) below this stay on the fp32 MFMA
+
+namespace {
+
+struct InAct {  // previous layer's BatchNorm + ReLU, per input column (may be null = identity)
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------
+// Split-bf16 contraction: fp32 operands on the bf16 matrix pipe (16x the fp32-MFMA rate) without giving up fp32 accuracy.
+//   x = x0 + x1 (+ x2),  x0 = bf16_rn(x), x1 = bf16_rn(x - x0), x2 = bf16_rn(x - x0 - x1)   (the residuals are exact in fp32)
+//   NS = 3 pieces (24 significant bits: x is represented EXACTLY up to ~2^-26) and the six products of total order <= 2
+//        a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 -> dropped terms <= 2^-25 |ab|: the error of one fp32 rounding ("bf16x6", 2.67x);
+//   NS = 2 pieces and the three products a0b0 + a0b1 + a1b0 -> relative error ~2^-17 per product, unbiased ("bf16x3", 5.3x).
+// Products of bf16 pairs are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; small terms are accumulated first.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16(float x, float y) {  // v_cvt_pk_bf16_f32: low half = rn(x), high half = rn(y)
+  bf16x2 p = {(__bf16)x, (__bf16)y};
+  return __builtin_bit_cast(unsigned, p);
+}
+template <int NS>
+__device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NS]) {
+  pc[0] = pack_bf16(x, y);
+  float rx = x - __uint_as_float(pc[0] << 16), ry = y - __uint_as_float(pc[0] & 0xffff0000u);
+  pc[1] = pack_bf16(rx, ry);
+  if constexpr (NS == 3) {
+    rx -= __uint_as_float(pc[1] << 16);
+    ry -= __uint_as_float(pc[1] & 0xffff0000u);
+    pc[2] = pack_bf16(rx, ry);
+  }
+}
+// the products to accumulate, smallest first: (piece of A, piece of B)
+template <int NS> struct SplitPairs;
+template <> struct SplitPairs<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
+template <> struct SplitPairs<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
+
+
+}  // namespace

@@ -528,38 +528,66 @@ class MLPChainRows(torch.autograd.Function):
         dw_arena = zero_pool.zeros(sum(w_numel), torch.float32, g.device)
         st_arena = zero_pool.zeros(2 * sum(params[3 * i].size(1) for i in range(1, nl)), torch.float64, g.device)
         dw_off, st_off = 0, 0
+        dev = dy.device
+        split = L.get_mlp_precision() != 'fp32'   # the one-kernel layer backward (mvp_mlp_layer_backward_f32) contracts in split-bf16 only
+        # State while walking the layers backwards: `gcur` is either dy_i itself (pending is None) or dz_i = the gradient w.r.t.
+        # layer i's ACTIVATION already masked by its ReLU, with `pending` = its two BatchNorm-backward column sums: the "finish"
+        # step (dz_i -> dy_i) then happens INSIDE the fused layer kernel, or as its own pass when the layer cannot be fused.
+        gcur, pending = dy, None
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
-            grads[3 * i + 1], grads[3 * i + 2] = dgam, dbet
+            cout = ys[i].size(1)
+            need_dz = (i > 0 or ctx.needs_input_grad[0]) and w is not None
+            cin = 0 if w is None else w.size(1)
+            src = None if w is None else (x0 if i == 0 else ys[i - 1])
+            fuse = split and w is not None and cout <= 64 and cin <= 96 and (not need_dz or cin % 4 == 0) and \
+                (i > 0 or src.size(1) == cin or not need_dz)
+            if pending is not None and not fuse:
+                # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)
+                dyi = torch.empty((R, cout), dtype=torch.float32, device=dev)
+                dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
+                L.call('mvp_bn_rows_backward_finish_f32', gcur, L.ptr(gcur), L.ptr(ys[i]), L.ptr(means[i]), L.ptr(invstds[i]), L.ptr(params[3 * i + 1]),
+                       L.ptr(params[3 * i + 2]), R, cout, int(training), L.ptr(pending), L.ptr(dyi), L.ptr(dgb[0]), L.ptr(dgb[1]))
+                gcur, pending = dyi, None
+                dgam, dbet = dgb[0], dgb[1]
+            if pending is None:
+                grads[3 * i + 1], grads[3 * i + 2] = dgam, dbet
             if w is None:  # i == 0: x0 was this layer's pre-BN output, its gradient is dy itself
-                dx0 = dy
+                dx0 = gcur
                 break
-            cout, cin = w.size(0), w.size(1)
-            # layer input = x0 (first layer) or relu(bn(y_{i-1})) re-created inside the kernels from y_{i-1}
-            src = x0 if i == 0 else ys[i - 1]
             act = none4 if i == 0 else (means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1])
             dw = dw_arena[dw_off:dw_off + cout * cin].view(cout, cin)
             dw_off += cout * cin
-            L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
-                   L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin)
             grads[3 * i] = dw
-            if i > 0 or ctx.needs_input_grad[0]:
-                dz = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
-                if i > 0:
+            stat = None
+            if i > 0:
+                stat = st_arena[st_off:st_off + 2 * cin]
+                st_off += 2 * cin
+            dz = torch.empty((R, cin), dtype=torch.float32, device=dev) if need_dz else None
+            if fuse:
+                dgb = torch.empty((2, cout), dtype=torch.float32, device=dev) if pending is not None else None
+                part = torch.empty(L.lib().mvp_mlp_layer_backward_partial_count(R, cin), dtype=torch.float64, device=dev) if (i > 0 and need_dz) else None
+                L.call('mvp_mlp_layer_backward_f32', gcur, L.ptr(gcur), L.ptr(ys[i]) if pending is not None else None,
+                       L.ptr(means[i]) if pending is not None else None, L.ptr(invstds[i]) if pending is not None else None,
+                       L.ptr(params[3 * i + 1]) if pending is not None else None, L.ptr(pending), L.ptr(None if dgb is None else dgb[0]),
+                       L.ptr(None if dgb is None else dgb[1]), int(training), L.ptr(src), src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]),
+                       L.ptr(act[3]), L.ptr(w), cin, R, cout, cin, L.ptr(dw), cin, L.ptr(dz), L.ptr(stat), L.ptr(part))
+                if pending is not None:
+                    grads[3 * i + 1], grads[3 * i + 2] = dgb[0], dgb[1]
+            else:
+                L.call('mvp_mlp_weight_grad_f32', gcur, L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
+                       L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin)
+                if need_dz and i > 0:
                     # d(input) = dy . W with the previous layer's ReLU mask and BN-backward column sums in the epilogue
-                    stat = st_arena[st_off:st_off + 2 * cin]
-                    st_off += 2 * cin
-                    pm, pi, pg, pb = means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1]
-                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(w), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
-                           L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat), L.ptr(_partial(R, cin, dy.device)))
-                    dy_prev = torch.empty((R, cin), dtype=torch.float32, device=dy.device)
-                    dgb = torch.empty((2, cin), dtype=torch.float32, device=dy.device)
-                    L.call('mvp_bn_rows_backward_finish_f32', dz, L.ptr(dz), L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb),
-                           R, cin, int(training), L.ptr(stat), L.ptr(dy_prev), L.ptr(dgb[0]), L.ptr(dgb[1]))
-                    dy, dgam, dbet = dy_prev, dgb[0], dgb[1]
-                else:
-                    L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(dz), None, None)
-                    dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
+                    pm, pi, pg, pb = act
+                    L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(w), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
+                           L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat), L.ptr(_partial(R, cin, dev)))
+                elif need_dz:
+                    L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(dz), None, None)
+            if i > 0:
+                gcur, pending = dz, stat
+            elif need_dz:
+                dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
         return (dx0, None, None, None, None, None, None) + tuple(grads)
 
 

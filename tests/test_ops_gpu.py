@@ -793,3 +793,69 @@ def test_knn3_weights_epilogue(dev, B, N1, N2):
     ref = inv / torch.sum(inv, dim=2, keepdim=True)
     np.testing.assert_allclose(w.cpu().numpy(), ref.cpu().numpy(), rtol=3e-7, atol=0)
     np.testing.assert_allclose(w.sum(2).cpu().numpy(), 1.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize('R,C,Cp,ldx', [(5000, 32, 32, 32), (3333, 64, 32, 32), (4097, 64, 64, 64), (1000, 64, 68, 68), (70000, 32, 32, 32),
+                                        (33, 20, 12, 12), (262144, 64, 64, 64)])
+@pytest.mark.parametrize('precision', ['bf16x6', 'bf16x3'])
+def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
+    """mvp_mlp_layer_backward_f32 (BatchNorm finish + weight gradient + input gradient with the previous layer's ReLU mask and column
+    sums in ONE kernel) against a float64 evaluation of the three steps; all four combinations of {dz_i given / dy_i given} x
+    {previous activation / plain input}; rows not a multiple of 32, channels not a multiple of 32, no-dZ mode."""
+    from mvpnet_amd import _lib as L
+    before = L.get_mlp_precision()
+    L.set_mlp_precision(precision)
+    loose = 16.0 if precision == 'bf16x3' else 1.0
+    hi = torch.float64
+    torch.manual_seed(R + C)
+    try:
+        w = torch.randn(C, Cp, device=dev) * 0.2
+        x = torch.randn(R, ldx, device=dev)
+        gsrc = torch.randn(R, C, device=dev)
+        yi = torch.randn(R, C, device=dev) * 1.5 + 0.2
+        mean_i, invstd_i, gamma_i = torch.randn(C, device=dev) * 0.3, torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5
+        stat_i = torch.randn(2 * C, device=dev, dtype=hi) * R * 0.01
+        pm, pi = torch.randn(Cp, device=dev) * 0.3, torch.rand(Cp, device=dev) + 0.5
+        pg, pb = torch.rand(Cp, device=dev) + 0.5, torch.randn(Cp, device=dev) * 0.2
+        for finish in (False, True):
+            for use_act in (False, True):
+                for want_dz in ((True, False) if Cp % 4 == 0 else (False,)):
+                    if finish:
+                        xh_i = (yi.to(hi) - mean_i.to(hi)) * invstd_i.to(hi)
+                        dy = (gamma_i.to(hi) * invstd_i.to(hi)) * ((gsrc.to(hi) - stat_i[:C] / R) - xh_i * (stat_i[C:] / R))
+                    else:
+                        dy = gsrc.to(hi)
+                    a = x[:, :Cp].to(hi)
+                    xh = (a - pm.to(hi)) * pi.to(hi)
+                    if use_act:
+                        a = torch.relu(xh * pg.to(hi) + pb.to(hi))
+                    ref_dw = dy.t() @ a
+                    ref_dz = dy @ w.to(hi)
+                    if use_act:
+                        ref_dz = torch.where(xh * pg.to(hi) + pb.to(hi) > 0, ref_dz, torch.zeros_like(ref_dz))
+                    dw = torch.zeros(C, Cp + 3, device=dev)  # a column slice of a wider gradient (lddw > Cp)
+                    dz = torch.full((R, Cp), float('nan'), device=dev) if want_dz else None
+                    stat = torch.zeros(2 * Cp, dtype=hi, device=dev)
+                    part = torch.empty(L.lib().mvp_mlp_layer_backward_partial_count(R, Cp), dtype=hi, device=dev)
+                    dgb = torch.empty(2, C, device=dev)
+                    act = (pm, pi, pg, pb) if use_act else (None,) * 4
+                    L.call('mvp_mlp_layer_backward_f32', gsrc, L.ptr(gsrc), L.ptr(yi) if finish else None, L.ptr(mean_i) if finish else None,
+                           L.ptr(invstd_i) if finish else None, L.ptr(gamma_i) if finish else None, L.ptr(stat_i) if finish else None,
+                           L.ptr(dgb[0]) if finish else None, L.ptr(dgb[1]) if finish else None, 1, L.ptr(x), ldx, *[L.ptr(t) for t in act],
+                           L.ptr(w), Cp, R, C, Cp, L.ptr(dw), Cp + 3, L.ptr(dz), L.ptr(stat), L.ptr(part))
+                    tag = 'finish={} act={} dz={}'.format(finish, use_act, want_dz)
+                    sw = max(1.0, float(ref_dw.abs().max()))
+                    np.testing.assert_allclose(dw[:, :Cp].cpu().numpy(), ref_dw.cpu().numpy(), rtol=1e-4 * loose, atol=3e-5 * sw * loose, err_msg=tag)
+                    assert float(dw[:, Cp:].abs().max()) == 0.0, tag
+                    if finish:
+                        np.testing.assert_array_equal(dgb[0].cpu().numpy(), stat_i[C:].float().cpu().numpy())
+                        np.testing.assert_array_equal(dgb[1].cpu().numpy(), stat_i[:C].float().cpu().numpy())
+                    if want_dz:
+                        sz = max(1.0, float(ref_dz.abs().max()))
+                        np.testing.assert_allclose(dz.cpu().numpy(), ref_dz.cpu().numpy(), rtol=1e-5 * loose, atol=2e-5 * sz * loose, err_msg=tag)
+                        if use_act:
+                            big = max(1.0, R / 5000.0)
+                            np.testing.assert_allclose(stat[:Cp].cpu().numpy(), ref_dz.sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
+                            np.testing.assert_allclose(stat[Cp:].cpu().numpy(), (ref_dz * xh).sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
+    finally:
+        L.set_mlp_precision(before)
