@@ -301,6 +301,21 @@ def main():
             cur = nxt
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / 10 * 1e3 if not args.train_only else float('nan')
+        # configs[1] at B = 1: the LATENCY of one chunk -- nothing to prefetch behind, the forward waits for its own
+        # geometry (the FPS chain is a serial dependency of ~2700 steps), synchronised after every chunk
+        b1_ms = float('nan')
+        if not args.train_only:
+            one = {k: (v[:1] if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == args.batch else v) for k, v in batch.items()}
+            net2d.feature = feature[:one['depth'].size(1)]
+            for _ in range(3):
+                model(fresh(one))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                model(fresh(one))
+                torch.cuda.synchronize()
+            b1_ms = (time.perf_counter() - t1) / 20 * 1e3
+            net2d.feature = feature
     # configs[3]: whole-scene inference -- 64 chunks of one synthetic scene sharded over the ranks, ONE all-gather of the per-chunk
     # logits, vote on the device (mvpnet_amd/scene.py).  Extra field; the chunk inputs are the resident batch, tiled.
     scene = None
@@ -382,7 +397,9 @@ def main():
             'with_2d_network': e2e,
             'scene_inference': scene,
             'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),
-                         'note': 'configs[1]: lifting + aggregation + PN2SSG forward, eval mode, same batch, next batch geometry prefetched'},
+                         'latency_ms_B1': round(b1_ms, 3),
+                         'note': 'configs[1]: lifting + aggregation + PN2SSG forward, eval mode, same batch, next batch geometry prefetched; '
+                                 'latency_ms_B1 = one chunk alone, synchronised per chunk (bounded by the serial FPS chain)'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': lift_traffic(args.batch), 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},

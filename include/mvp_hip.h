@@ -264,8 +264,8 @@ int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float
 int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
 /* Contraction precision of the three shared-MLP entry points below (process-wide):
- *   terms = 0  fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain; the default);
- *   terms = 6  split-bf16: every fp32 operand as 3 bf16 pieces, the 6 products of order <= 2 on v_mfma_f32_32x32x16_bf16 with fp32
+ *   terms = 0  fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain);
+ *   terms = 6  (the default) split-bf16: every fp32 operand as 3 bf16 pieces, the 6 products of order <= 2 on v_mfma_f32_32x32x16_bf16 with fp32
  *              accumulation -- fp32-level accuracy at 2.67x the fp32-MFMA rate;
  *   terms = 3  2 pieces, 3 products: ~2^-17 relative error per product, 5.3x the rate.
  * Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Returns MVP_EINVAL for other values. */
@@ -300,7 +300,8 @@ int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float
  *   dW (C,lddw) += dy_i^T . input;  dZ (R,Cp) or NULL = (dy_i . W) [* relu'(bn_{i-1}(y_{i-1}))];
  *   stat_prev (2 Cp, accumulated into): column sums of dZ and dZ * xhat_{i-1} (needs act_* and dZ; partial = float64 scratch of
  *   mvp_mlp_layer_backward_partial_count(R, Cp) values).
- * Contraction: split-bf16 only (mvp_set_mlp_precision 3 or 6); C <= 64, Cp <= 96, Cp % 4 == 0 -- otherwise MVP_EUNSUPPORTED. */
+ * Contraction: split-bf16 only (mvp_set_mlp_precision 3 or 6); C <= 128, Cp <= 128, Cp % 4 == 0 -- otherwise MVP_EUNSUPPORTED.
+ * Layers wider than 64 input channels are cut into c_in slices (one workgroup row each) that re-read dy_i. */
 int64_t mvp_mlp_layer_backward_partial_count(int64_t R, int64_t Cp);
 int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
                                const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx,

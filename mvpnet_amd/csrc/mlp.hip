@@ -22,7 +22,7 @@
 #include "mlp_common.h"
 #include <algorithm>
 
-int g_mlp_terms = 0;       // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6   (mvp_set_mlp_precision); shared with mlp_bwd.hip
+int g_mlp_terms = 6;       // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (default: fp32-level accuracy, measured) -- mvp_set_mlp_precision; shared with mlp_bwd.hip
 int g_mlp_min_width = 0;   // layers with max(Cin, Cout) below this stay on the fp32 MFMA
 
 namespace {

@@ -66,7 +66,11 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   float* tile = reinterpret_cast<float*>(lds + kWBytes) + wave * 32 * kTileLd;
-  const int C = p.C, Cp = p.Cp;
+  const int C = p.C;
+  // blockIdx.y: this workgroup's slice of the INPUT channels (c_in = ci0 .. ci0 + 32 CPB - 1).  Wide layers are cut along c_in:
+  // every slice needs all of dy_i (re-read: 2 C per slice) but owns its columns of dW and dZ outright -- no cross-workgroup sums.
+  const int ci0 = blockIdx.y * (CPB * 32);
+  const int Cp = min(CPB * 32, p.Cp - ci0);          // columns of this slice
   const bool finish = p.Yi != nullptr;
   const bool has_act = p.act.mean != nullptr;
   const bool want_dz = p.dZ != nullptr;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
       const int co = 4 * cq;
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (co + e < C && ci < Cp) ? p.W[(size_t)(co + e) * p.ldw + ci] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = (co + e < C && ci < Cp) ? p.W[(size_t)(co + e) * p.ldw + ci0 + ci] : 0.f;
       unsigned lo[NS], hi[NS];
       split_pair<NS>(v[0], v[1], lo);
       split_pair<NS>(v[2], v[3], hi);
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
         *reinterpret_cast<uint2*>(Wl + ((size_t)(pc * CB + a) * (CPB * 32) + ci) * 64 + ((unit ^ sw) * 16) + half * 8) = make_uint2(lo[pc], hi[pc]);
     }
   }
-  if (finish && p.dgamma_i && blockIdx.x == 0)
+  if (finish && p.dgamma_i && blockIdx.x == 0 && blockIdx.y == 0)
     for (int col = tid; col < C; col += kBT) {
       p.dbeta_i[col] = (float)p.stat_i[col];
       p.dgamma_i[col] = (float)p.stat_i[C + col];
@@ -121,10 +125,10 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
     xok[b] = col < Cp;
     pm[b] = pi[b] = pg[b] = pb[b] = 0.f;
     if (has_act && xok[b]) {
-      pm[b] = p.act.mean[col];
-      pi[b] = p.act.invstd[col];
-      pg[b] = p.act.gamma[col];
-      pb[b] = p.act.beta[col];
+      pm[b] = p.act.mean[ci0 + col];
+      pi[b] = p.act.invstd[ci0 + col];
+      pg[b] = p.act.gamma[ci0 + col];
+      pb[b] = p.act.beta[ci0 + col];
     }
   }
   f32x16 accw[CB][CPB];
@@ -145,26 +149,36 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
   for (int64_t t = t_begin + wave; t < t_end; t += 4) {
     const int64_t r0 = t * 32;
     // ---- loads: 16 rows per lane (8 m + 4 h + e), 4 bytes each; rows / columns past the tensor are clamped and masked below
-    float x[CPB][16], g[CB][16], yv[CB][16];
+    float x[CPB][16], gn[16], yn[16];
     bool rok[16];
+    // 32-bit offsets from per-tile (wave-uniform) base pointers: 64-bit per-element addresses cost two registers each
+    const int lim = (int)min((int64_t)31, p.R - 1 - r0);      // last valid local row of this tile
+    const float* Gt = p.G + (size_t)r0 * C;
+    const float* Yt = finish ? p.Yi + (size_t)r0 * C : p.G;
+    const float* Xt = p.X + (size_t)r0 * p.ldx + ci0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int64_t r = r0 + 8 * (q >> 2) + 4 * h + (q & 3);
-      rok[q] = r < p.R;
-      const int64_t rc = rok[q] ? r : p.R - 1;
+    for (int q = 0; q < 16; ++q) rok[q] = 8 * (q >> 2) + 4 * h + (q & 3) <= lim;
+    auto load_g = [&](int a) {  // channel block a of dz_i / dy_i (and y_i): issued one block ahead of its use
+      const int col = min(32 * a + c, C - 1);
 #pragma unroll
-      for (int a = 0; a < CB; ++a) {
-        const int col = cok[a] ? 32 * a + c : C - 1;
-        g[a][q] = p.G[(size_t)rc * C + col];
-        yv[a][q] = finish ? p.Yi[(size_t)rc * C + col] : 0.f;
+      for (int q = 0; q < 16; ++q) {
+        const int off = min(8 * (q >> 2) + 4 * h + (q & 3), lim) * C + col;
+        gn[q] = Gt[off];
+        yn[q] = finish ? Yt[off] : 0.f;
       }
+    };
 #pragma unroll
-      for (int b = 0; b < CPB; ++b) x[b][q] = p.X[(size_t)rc * p.ldx + (xok[b] ? 32 * b + c : Cp - 1)];
+    for (int b = 0; b < CPB; ++b) {
+      const int col = xok[b] ? 32 * b + c : Cp - 1;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x[b][q] = Xt[min(8 * (q >> 2) + 4 * h + (q & 3), lim) * p.ldx + col];
     }
-    // ---- dy_i and a_{i-1} in registers
-    float av[CPB][16];
+    load_g(0);
+    // ---- a_{i-1}: activation + split, both row steps (operand B of dW for every channel block of dy)
+    u32x4 fb[CPB][2][NS];
 #pragma unroll
-    for (int b = 0; b < CPB; ++b)
+    for (int b = 0; b < CPB; ++b) {
+      float av[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float v = x[b][q];
@@ -172,50 +186,17 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
           const float z = ((v - pm[b]) * pi[b]) * pg[b] + pb[b];
           v = z > 0.f ? z : 0.f;
         }
-        av[b][q] = (rok[q] && xok[b]) ? v : 0.f;
+        av[q] = (rok[q] && xok[b]) ? v : 0.f;
       }
 #pragma unroll
-    for (int a = 0; a < CB; ++a)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float d = g[a][q];
-        if (finish) {
-          const float xh = (yv[a][q] - mu[a]) * is[a];
-          d = sc[a] * ((d - db[a]) - xh * dg[a]);
-        }
-        g[a][q] = (rok[q] && cok[a]) ? d : 0.f;
-      }
-    // ---- dW += dy^T . a : two row steps, operands straight from the registers
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 fa[CB][NS], fb[CPB][NS];
-#pragma unroll
-      for (int a = 0; a < CB; ++a) {
+      for (int s = 0; s < 2; ++s) {
         unsigned qq[4][NS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair<NS>(g[a][8 * s + 2 * j], g[a][8 * s + 2 * j + 1], qq[j]);
+        for (int j = 0; j < 4; ++j) split_pair<NS>(av[8 * s + 2 * j], av[8 * s + 2 * j + 1], qq[j]);
 #pragma unroll
-        for (int pc = 0; pc < NS; ++pc) fa[a][pc] = u32x4{qq[0][pc], qq[1][pc], qq[2][pc], qq[3][pc]};
+        for (int pc = 0; pc < NS; ++pc) fb[b][s][pc] = u32x4{qq[0][pc], qq[1][pc], qq[2][pc], qq[3][pc]};
       }
-#pragma unroll
-      for (int b = 0; b < CPB; ++b) {
-        unsigned qq[4][NS];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair<NS>(av[b][8 * s + 2 * j], av[b][8 * s + 2 * j + 1], qq[j]);
-#pragma unroll
-        for (int pc = 0; pc < NS; ++pc) fb[b][pc] = u32x4{qq[0][pc], qq[1][pc], qq[2][pc], qq[3][pc]};
-      }
-#pragma unroll
-      for (int qd = 0; qd < SP::N; ++qd)
-#pragma unroll
-        for (int a = 0; a < CB; ++a)
-#pragma unroll
-          for (int b = 0; b < CPB; ++b)
-            accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a][SP::A[qd]]),
-                                                                __builtin_bit_cast(bf16x8, fb[b][SP::B[qd]]), accw[a][b], 0, 0, 0);
     }
-    if (!want_dz) continue;
-    // ---- dz_{i-1} = dy . W : dy block a through the LDS tile -> "8 channels of one row" per lane
     f32x16 accz[CPB];
 #pragma unroll
     for (int b = 0; b < CPB; ++b)
@@ -223,8 +204,39 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
       for (int i = 0; i < 16; ++i) accz[b][i] = 0.f;
 #pragma unroll
     for (int a = 0; a < CB; ++a) {
+      __builtin_amdgcn_sched_barrier(0);  // keep the blocks sequential: the scheduler otherwise hoists every block's loads and splits
+      // ---- dy_i, channel block a
+      float dyv[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) tile[(8 * (q >> 2) + 4 * h + (q & 3)) * kTileLd + c] = g[a][q];
+      for (int q = 0; q < 16; ++q) {
+        float d = gn[q];
+        if (finish) {
+          const float xh = (yn[q] - mu[a]) * is[a];
+          d = sc[a] * ((d - db[a]) - xh * dg[a]);
+        }
+        dyv[q] = (rok[q] && cok[a]) ? d : 0.f;
+      }
+      if (a + 1 < CB) load_g(a + 1);  // in flight under this block's MFMAs
+      // ---- dW[a][:] += dy^T . a : two row steps, operands straight from the registers
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        unsigned qq[4][NS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair<NS>(dyv[8 * s + 2 * j], dyv[8 * s + 2 * j + 1], qq[j]);
+        u32x4 fa[NS];
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) fa[pc] = u32x4{qq[0][pc], qq[1][pc], qq[2][pc], qq[3][pc]};
+#pragma unroll
+        for (int qd = 0; qd < SP::N; ++qd)
+#pragma unroll
+          for (int b = 0; b < CPB; ++b)
+            accw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[SP::A[qd]]),
+                                                                __builtin_bit_cast(bf16x8, fb[b][s][SP::B[qd]]), accw[a][b], 0, 0, 0);
+      }
+      if (!want_dz) continue;
+      // ---- dz_{i-1} += dy[:, block a] . W[block a, :] : the block through the LDS tile -> "8 channels of one row" per lane
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tile[(8 * (q >> 2) + 4 * h + (q & 3)) * kTileLd + c] = dyv[q];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int s = 0; s < 2; ++s) {  // c_out step: channels 32 a + 16 s + {4 h + e, 8 + 4 h + e}
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
       }
       __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next block
     }
+    if (!want_dz) continue;
     // ---- epilogue: ReLU mask + column sums against the y_{i-1} values in registers, 16-byte stores through the tile
 #pragma unroll
     for (int b = 0; b < CPB; ++b) {
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * kTileLd + c4);
         const int64_t r = r0 + row;
         const int cc = 32 * b + c4;
-        if (r < p.R && cc < Cp) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.dZ + (size_t)r * Cp + cc));  // Cp % 4 == 0
+        if (r < p.R && cc < Cp) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.dZ + (size_t)r * p.Cp + ci0 + cc));  // Cp % 4 == 0
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
   if (p.partial) {
     for (int col = tid; col < CPB * 32; col += kBT)
       if (col < Cp) {
-        p.partial[((size_t)blockIdx.x * 2 + 0) * Cp + col] = sred[0][0][col] + sred[0][1][col] + sred[0][2][col] + sred[0][3][col];
-        p.partial[((size_t)blockIdx.x * 2 + 1) * Cp + col] = sred[1][0][col] + sred[1][1][col] + sred[1][2][col] + sred[1][3][col];
+        p.partial[((size_t)blockIdx.x * 2 + 0) * p.Cp + ci0 + col] = sred[0][0][col] + sred[0][1][col] + sred[0][2][col] + sred[0][3][col];
+        p.partial[((size_t)blockIdx.x * 2 + 1) * p.Cp + ci0 + col] = sred[1][0][col] + sred[1][1][col] + sred[1][2][col] + sred[1][3][col];
       }
   }
   // ---- dW: 4 partial tiles -> 1 (two rounds through LDS), one atomic per element and workgroup
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int co = 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (co < C && ci < Cp) atomicAdd(p.dW + (size_t)co * p.lddw + ci, accw[a][b][i]);
+          if (co < C && ci < Cp) atomicAdd(p.dW + (size_t)co * p.lddw + ci0 + ci, accw[a][b][i]);
         }
       }
   }
@@ -362,7 +375,7 @@ MVP_API int64_t mvp_mlp_layer_backward_partial_count(int64_t R, int64_t Cp) {
 //   stat_prev (2 Cp, accumulated into) += column sums of dZ and dZ * xhat_{i-1} (with act_* and dZ only; `partial` = scratch of
 //   mvp_mlp_layer_backward_partial_count doubles).
 //   dgamma_i / dbeta_i (C, may be NULL): with Yi, the BatchNorm parameter gradients of layer i = stat_i[C + c] / stat_i[c] as float32.
-// Needs a split-bf16 precision (mvp_set_mlp_precision 3 or 6), C <= 64, Cp <= 96 and Cp % 4 == 0: MVP_EUNSUPPORTED otherwise
+// Needs a split-bf16 precision (mvp_set_mlp_precision 3 or 6), C <= 128, Cp <= 128 and Cp % 4 == 0: MVP_EUNSUPPORTED otherwise
 // (callers then use the three separate entry points).
 MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
                                        const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float* act_mean,
@@ -390,7 +403,7 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   }
   MVP_REQUIRE(R >= 0 && C > 0 && Cp > 0 && ldx >= Cp && ldw >= Cp && lddw >= Cp && lddw < (1 << 24) && ldx < (1 << 24));
   const int ns = g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0;
-  if (ns == 0 || C > 64 || Cp > 96 || (dZ && Cp % 4 != 0) || (dZ && ((uintptr_t)dZ % 16) != 0)) return MVP_EUNSUPPORTED;
+  if (ns == 0 || C > 128 || Cp > 128 || (dZ && Cp % 4 != 0) || (dZ && ((uintptr_t)dZ % 16) != 0)) return MVP_EUNSUPPORTED;
   if (R == 0) return MVP_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   BwdArgs a;
@@ -406,18 +419,24 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(ntiles, 8)));
   a.tiles_per_wg = cdiv(cdiv(ntiles, wgs), 4) * 4;
   const int64_t grid = cdiv(ntiles, a.tiles_per_wg);
-  const int cb = C <= 32 ? 1 : 2, cpb = Cp <= 32 ? 1 : Cp <= 64 ? 2 : 3;
-#define MVP_BWD(A_, B_)                                                                                        \
-  do {                                                                                                         \
-    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2>), dim3((unsigned)grid), dim3(kBT), 0, s, a); \
-    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3>), dim3((unsigned)grid), dim3(kBT), 0, s, a);        \
+  // c_in slices of at most 64 (96 for one odd-width slice: the 68-column input of the aggregation MLP) per workgroup row
+  const int cb = C <= 32 ? 1 : C <= 64 ? 2 : 4;
+  const int cpb = Cp <= 32 ? 1 : (Cp <= 64 || Cp > 96 || cb == 4) ? 2 : 3;
+  const unsigned gy = (unsigned)cdiv(Cp, 32 * cpb);
+#define MVP_BWD(A_, B_)                                                                                           \
+  do {                                                                                                            \
+    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
+    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a);        \
   } while (0)
   if (cb == 1 && cpb == 1) MVP_BWD(1, 1);
   else if (cb == 1 && cpb == 2) MVP_BWD(1, 2);
   else if (cb == 1) MVP_BWD(1, 3);
-  else if (cpb == 1) MVP_BWD(2, 1);
-  else if (cpb == 2) MVP_BWD(2, 2);
-  else MVP_BWD(2, 3);
+  else if (cb == 2 && cpb == 1) MVP_BWD(2, 1);
+  else if (cb == 2 && cpb == 2) MVP_BWD(2, 2);
+  else if (cb == 2) MVP_BWD(2, 3);
+  else if (cpb == 1) MVP_BWD(4, 1);
+  else if (cpb == 2) MVP_BWD(4, 2);
+  else return MVP_EUNSUPPORTED;
 #undef MVP_BWD
   int rc = mvp_launch_status();
   if (rc != MVP_OK) return rc;

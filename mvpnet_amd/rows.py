@@ -540,7 +540,7 @@ class MLPChainRows(torch.autograd.Function):
             need_dz = (i > 0 or ctx.needs_input_grad[0]) and w is not None
             cin = 0 if w is None else w.size(1)
             src = None if w is None else (x0 if i == 0 else ys[i - 1])
-            fuse = split and w is not None and cout <= 64 and cin <= 96 and (not need_dz or cin % 4 == 0) and \
+            fuse = split and w is not None and cout <= 128 and cin <= 128 and (not need_dz or cin % 4 == 0) and \
                 (i > 0 or src.size(1) == cin or not need_dz)
             if pending is not None and not fuse:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)

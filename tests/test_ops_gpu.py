@@ -796,7 +796,8 @@ def test_knn3_weights_epilogue(dev, B, N1, N2):
 
 
 @pytest.mark.parametrize('R,C,Cp,ldx', [(5000, 32, 32, 32), (3333, 64, 32, 32), (4097, 64, 64, 64), (1000, 64, 68, 68), (70000, 32, 32, 32),
-                                        (33, 20, 12, 12), (262144, 64, 64, 64)])
+                                        (33, 20, 12, 12), (262144, 64, 64, 64), (9000, 128, 64, 64), (6001, 128, 128, 128), (777, 100, 96, 100),
+                                        (2500, 32, 128, 128), (1200, 64, 72, 72)])
 @pytest.mark.parametrize('precision', ['bf16x6', 'bf16x3'])
 def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
     """mvp_mlp_layer_backward_f32 (BatchNorm finish + weight gradient + input gradient with the previous layer's ReLU mask and column
