@@ -271,6 +271,9 @@ int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, flo
  * Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Returns MVP_EINVAL for other values. */
 int mvp_set_mlp_precision(int terms, int min_width);
 int mvp_get_mlp_precision(void);
+/* Ablation switch (returns the previous value): 1 (default) = long narrow forward layers (>= 32768 rows, C_in, C_out <= 128) run on the
+ * persistent streaming kernel with the weight matrix resident in LDS; 0 = the per-tile kernel everywhere. */
+int mvp_set_mlp_stream(int on);
 
 /* Shared-MLP layer on rows with fp32 MFMA (mlp.hip): Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias).
  * act = identity when act_mean == NULL, else relu(((x-mean)*invstd)*gamma+beta) per input column: the previous

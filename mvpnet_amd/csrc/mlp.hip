@@ -22,8 +22,14 @@
 #include "mlp_common.h"
 #include <algorithm>
 
+// mlp_stream.hip: persistent streaming forward for long narrow layers (MVP_EUNSUPPORTED when the layer does not qualify)
+int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const float* W, int ldw, int Cout, const float* act_mean,
+                           const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y,
+                           double* stat, double* partial, int ns, hipStream_t s);
+
 int g_mlp_terms = 6;       // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (default: fp32-level accuracy, measured) -- mvp_set_mlp_precision; shared with mlp_bwd.hip
 int g_mlp_min_width = 0;   // layers with max(Cin, Cout) below this stay on the fp32 MFMA
+int g_mlp_stream = 1;      // 1: long narrow forward layers take mlp_stream.hip (MVP_MLP_STREAM=0 / mvp_set_mlp_stream(0): tile kernel everywhere)
 
 namespace {
 
@@ -867,6 +873,11 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
   if (R == 0) return MVP_OK;  // stat / dW style outputs are ACCUMULATED into: the caller provides zeros
   InAct act{act_mean, act_invstd, act_gamma, act_beta};
   const unsigned gx = (unsigned)cdiv(R, kBM);
+  if (g_mlp_stream && std::max(Cin, Cout) >= g_mlp_min_width) {  // long narrow layers: resident weights, persistent row streaming
+    const int rc = mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, bias, Y,
+                                          stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, s);
+    if (rc != MVP_EUNSUPPORTED) return rc;
+  }
   launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat,
                     stat ? partial : nullptr, s);
   if (stat && partial)
@@ -990,3 +1001,10 @@ MVP_API int mvp_set_mlp_precision(int terms, int min_width) {
   return MVP_OK;
 }
 MVP_API int mvp_get_mlp_precision(void) { return g_mlp_terms; }
+// Ablation switch: 0 routes every forward layer through the per-tile kernel (mlp_fwd_kernel), 1 (default) lets long narrow layers
+// (>= 32768 rows, C_in and C_out <= 128, split-bf16) take the persistent streaming kernel (mlp_stream.hip).  Returns the old value.
+MVP_API int mvp_set_mlp_stream(int on) {
+  const int old = g_mlp_stream;
+  g_mlp_stream = on ? 1 : 0;
+  return old;
+}

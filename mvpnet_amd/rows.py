@@ -6,11 +6,20 @@ torch.max over neighbours: mvpnet/models/pn2/modules.py:20-37,107-108,135-145;
 common/nn/modules/conv.py:41-51) but on (rows, C) matrices, so gathers / scatters are
 coalesced row accesses and a shared-MLP layer is one row-major GEMM.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd.function import once_differentiable
 
 from . import _lib as L
+
+
+# Widest layer (output channels; input channels up to 2x... see below) whose backward runs as ONE kernel (mvp_mlp_layer_backward_f32).
+# Measured on MI355X (profiles/r02_*): up to 64 x 96 the one-kernel backward halves the layer's HBM traffic and time; the 128-wide
+# variants run at one wave per SIMD and re-read dy_i per c_in slice -- tuning knob, default from the measurements.
+FUSE_BWD_MAX_COUT = int(os.environ.get('MVP_BWD_FUSE_MAXC', '64'))
+FUSE_BWD_MAX_CIN = int(os.environ.get('MVP_BWD_FUSE_MAXCIN', '96'))
 
 
 def _round4(c):
@@ -540,7 +549,7 @@ class MLPChainRows(torch.autograd.Function):
             need_dz = (i > 0 or ctx.needs_input_grad[0]) and w is not None
             cin = 0 if w is None else w.size(1)
             src = None if w is None else (x0 if i == 0 else ys[i - 1])
-            fuse = split and w is not None and cout <= 128 and cin <= 128 and (not need_dz or cin % 4 == 0) and \
+            fuse = split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and (not need_dz or cin % 4 == 0) and \
                 (i > 0 or src.size(1) == cin or not need_dz)
             if pending is not None and not fuse:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)
