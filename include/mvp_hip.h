@@ -284,6 +284,14 @@ int mvp_set_mlp_stream(int on);
 int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
                         const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                         const float* bias, float* Y, double* stat, double* partial, mvp_stream_t stream);
+/* mvp_mlp_forward_f32 (no bias) + the layer's training-mode BatchNorm finalize (what mvp_bn_finalize_f32 computes from `stat`: mean,
+ * invstd with the biased variance; running_mean / running_var with momentum and the unbiased variance, may be NULL;
+ * num_batches_tracked += 1, may be NULL) carried by the last workgroup of the statistics reduction: one launch fewer per layer.
+ * stat (2*Cout float64) must be zero on entry (it receives the column sums). */
+int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+                           const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* Y,
+                           double* stat, double* partial, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
 /* `partial` (both entry points below and above): optional scratch of ceil(R/128) * 2 * (output columns) float64; when
  * given, the statistics are reduced without atomics (recommended for R >~ 1e5), otherwise with fp64 atomics. */
 /* d(input) with the previous layer's ReLU mask and BatchNorm-backward column sums fused into the epilogue:

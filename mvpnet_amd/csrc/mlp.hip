@@ -25,7 +25,8 @@
 // mlp_stream.hip: persistent streaming forward for long narrow layers (MVP_EUNSUPPORTED when the layer does not qualify)
 int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const float* W, int ldw, int Cout, const float* act_mean,
                            const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y,
-                           double* stat, double* partial, int ns, hipStream_t s);
+                           double* stat, double* partial, int ns, float bn_eps, float bn_momentum, float* bn_mean, float* bn_invstd,
+                           float* bn_running_mean, float* bn_running_var, int64_t* bn_num_batches, hipStream_t s);
 
 int g_mlp_terms = 6;       // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (default: fp32-level accuracy, measured) -- mvp_set_mlp_precision; shared with mlp_bwd.hip
 int g_mlp_min_width = 0;   // layers with max(Cin, Cout) below this stay on the fp32 MFMA
@@ -856,6 +857,33 @@ void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int l
 
 // Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias); stat (2*Cout float64, accumulated into) +=
 // column sums of y and y^2 when non-NULL.  act_* all NULL = identity, else the previous BatchNorm + ReLU.
+namespace {
+// forward + statistics (+ optional BatchNorm finalize inside the statistics reduction: fin_mean != nullptr)
+int mlp_forward_impl(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout, const float* act_mean,
+                     const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y, double* stat,
+                     double* partial, float bn_eps, float bn_momentum, float* bn_mean, float* bn_invstd, float* bn_running_mean,
+                     float* bn_running_var, int64_t* bn_num_batches, hipStream_t s) {
+  InAct act{act_mean, act_invstd, act_gamma, act_beta};
+  const unsigned gx = (unsigned)cdiv(R, kBM);
+  const BnFinalize fin{R, bn_eps, bn_momentum, bn_mean, bn_invstd, bn_running_mean, bn_running_var, bn_num_batches};
+  if (g_mlp_stream && std::max(Cin, Cout) >= g_mlp_min_width) {  // long narrow layers: resident weights, persistent row streaming
+    const int rc = mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, bias, Y,
+                                          stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, bn_eps, bn_momentum, bn_mean,
+                                          bn_invstd, bn_running_mean, bn_running_var, bn_num_batches, s);
+    if (rc != MVP_EUNSUPPORTED) return rc;
+  }
+  launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat,
+                    stat ? partial : nullptr, s);
+  if (stat && bn_mean)  // with scratch slots: reduce + finalize; without (fp64 atomics in the main kernel): finalize only (no slots to add)
+    launch_stats_reduce_finalize(partial, partial ? (int64_t)gx : 0, (int)(2 * Cout), stat, fin, s);
+  else if (stat && partial)
+    launch_stats_reduce(partial, (int64_t)gx, (int)(2 * Cout), stat, s);
+  return mvp_launch_status();
+}
+}  // namespace
+
+// Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias); stat (2*Cout float64, accumulated into) +=
+// column sums of y and y^2 when non-NULL.  act_* all NULL = identity, else the previous BatchNorm + ReLU.
 MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw,
                                 int64_t Cout, const float* act_mean, const float* act_invstd, const float* act_gamma,
                                 const float* act_beta, const float* bias, float* Y, double* stat, double* partial,
@@ -869,20 +897,33 @@ MVP_API int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t 
     MVP_NONNULL(act_gamma);
     MVP_NONNULL(act_beta);
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (R == 0) return MVP_OK;  // stat / dW style outputs are ACCUMULATED into: the caller provides zeros
-  InAct act{act_mean, act_invstd, act_gamma, act_beta};
-  const unsigned gx = (unsigned)cdiv(R, kBM);
-  if (g_mlp_stream && std::max(Cin, Cout) >= g_mlp_min_width) {  // long narrow layers: resident weights, persistent row streaming
-    const int rc = mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, bias, Y,
-                                          stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, s);
-    if (rc != MVP_EUNSUPPORTED) return rc;
+  return mlp_forward_impl(X, R, Cin, ldx, W, ldw, Cout, act_mean, act_invstd, act_gamma, act_beta, bias, Y, stat, partial, 0.f, 0.f, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+// One shared-MLP layer in training mode: mvp_mlp_forward_f32 (no bias) + this layer's BatchNorm finalize -- mean, invstd (biased
+// variance, eps) and the running statistics (momentum, unbiased variance), num_batches_tracked += 1 -- done by the last workgroup of
+// the statistics reduction instead of a separate mvp_bn_finalize_f32 launch.  stat (2*Cout) must be zero on entry.
+MVP_API int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+                                   const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* Y,
+                                   double* stat, double* partial, float eps, float momentum, float* mean, float* invstd,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream) {
+  MVP_NONNULL(X);
+  MVP_NONNULL(W);
+  MVP_NONNULL(Y);
+  MVP_NONNULL(stat);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_REQUIRE(R > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldw >= Cin && Cin < (1 << 20) && Cout < (1 << 20));
+  if (act_mean) {
+    MVP_NONNULL(act_invstd);
+    MVP_NONNULL(act_gamma);
+    MVP_NONNULL(act_beta);
   }
-  launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat,
-                    stat ? partial : nullptr, s);
-  if (stat && partial)
-    launch_stats_reduce(partial, (int64_t)gx, (int)(2 * Cout), stat, s);
-  return mvp_launch_status();
+  if (running_mean) MVP_NONNULL(running_var);
+  return mlp_forward_impl(X, R, Cin, ldx, W, ldw, Cout, act_mean, act_invstd, act_gamma, act_beta, nullptr, Y, stat, partial, eps, momentum,
+                          mean, invstd, running_mean, running_var, num_batches_tracked, static_cast<hipStream_t>(stream));
 }
 
 // dW (Cout,Cin; row stride lddw) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin])  (accumulated into dW: gradient-accumulation semantics).

@@ -87,24 +87,32 @@ __global__ __launch_bounds__(kST) void mlp_stream_fwd_kernel(StreamArgs p) {
   const int64_t t_begin = (int64_t)blockIdx.x * p.tiles_per_wg;
   const int64_t t_end = min(ntiles, t_begin + p.tiles_per_wg);
   float* st = tiles[wave];
-  float4 an[KS][4];  // raw values of the NEXT tile: this lane's row, k = 32 slab + 8 t + 4 lh .. + 3
-  auto load_a = [&](int64_t t) {
+  // Prefetch ring: the raw rows of the wave's next PF tiles are in flight while it works on the current one (a wave holds only
+  // 16 KS registers per tile, and bytes in flight -- not arithmetic -- are what bound these layers).
+  constexpr int PF = KS == 1 ? 3 : KS == 2 ? 2 : 1;
+  float4 an[PF][KS][4];  // raw values: this lane's row, k = 32 slab + 8 t + 4 lh .. + 3
+  auto load_a = [&](float4 (&dst)[KS][4], int64_t t) {
     const int64_t row = min(t * 32 + li, p.R - 1);
     const float* xrow = p.X + (size_t)row * p.ldx;
 #pragma unroll
     for (int sl = 0; sl < KS; ++sl)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) an[sl][tt] = *reinterpret_cast<const float4*>(xrow + min(32 * sl + 8 * tt + 4 * lh, Cin - 4));
+      for (int tt = 0; tt < 4; ++tt) dst[sl][tt] = *reinterpret_cast<const float4*>(xrow + min(32 * sl + 8 * tt + 4 * lh, Cin - 4));
   };
-  int64_t t = t_begin + wave;
-  if (t < t_end) load_a(t);
-  for (; t < t_end; t += 4) {
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (t_begin + wave + 4 * u < t_end) load_a(an[u], t_begin + wave + 4 * u);
+  for (int64_t tb = t_begin + wave; tb < t_end; tb += 4 * PF) {
+#pragma unroll
+   for (int u = 0; u < PF; ++u) {
+    const int64_t t = tb + 4 * u;
+    if (t >= t_end) break;
     float4 ac[KS][4];
 #pragma unroll
     for (int sl = 0; sl < KS; ++sl)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) ac[sl][tt] = an[sl][tt];
-    if (t + 4 < t_end) load_a(t + 4);  // in flight under this tile's MFMAs
+      for (int tt = 0; tt < 4; ++tt) ac[sl][tt] = an[u][sl][tt];
+    if (t + 4 * PF < t_end) load_a(an[u], t + 4 * PF);  // refill this ring slot: in flight under the next PF tiles' work
     f32x16 acc[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(kST) void mlp_stream_fwd_kernel(StreamArgs p) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+   }
   }
   if (p.partial) {
 #pragma unroll
@@ -216,11 +225,13 @@ void launch_stream(const StreamArgs& a, unsigned grid, bool has_act, hipStream_t
 }  // namespace
 
 // Internal (not exported): the streaming forward for long narrow layers.  Returns MVP_EUNSUPPORTED when the layer does not qualify
-// (the caller then takes mlp_fwd_kernel); on success the statistics partial slots have been reduced into `stat`.
+// (the caller then takes mlp_fwd_kernel); on success the statistics partial slots have been reduced into `stat` (and, with bn_mean,
+// the BatchNorm finalize has run in the reduction's last workgroup).
 // `partial` must hold at least ceil(R / 128) * 2 * Cout doubles (what mvp_mlp_forward_f32's callers provide).
 int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const float* W, int ldw, int Cout, const float* act_mean,
                            const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y,
-                           double* stat, double* partial, int ns, hipStream_t s) {
+                           double* stat, double* partial, int ns, float bn_eps, float bn_momentum, float* bn_mean, float* bn_invstd,
+                           float* bn_running_mean, float* bn_running_var, int64_t* bn_num_batches, hipStream_t s) {
   const InAct act{act_mean, act_invstd, act_gamma, act_beta};
   if (ns == 0 || Cin > 128 || Cout > 128 || Cin < 4 || Cout % 4 != 0 || R < 32768 || (stat && !partial)) return MVP_EUNSUPPORTED;
   if (ldx % 4 != 0 || Cin % 4 != 0 || ((uintptr_t)X % 16) != 0 || ((uintptr_t)Y % 16) != 0) return MVP_EUNSUPPORTED;
@@ -256,6 +267,12 @@ int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const fl
 #undef MVP_STREAM
   int rc = mvp_launch_status();
   if (rc != MVP_OK) return rc;
-  if (a.partial) launch_stats_reduce(partial, (int64_t)grid, 2 * Cout, stat, s);
+  if (a.partial) {
+    if (bn_mean)  // BatchNorm finalize (mean / invstd / running statistics) carried by the reduction's last workgroup
+      launch_stats_reduce_finalize(partial, (int64_t)grid, 2 * Cout, stat,
+                                   BnFinalize{R, bn_eps, bn_momentum, bn_mean, bn_invstd, bn_running_mean, bn_running_var, bn_num_batches}, s);
+    else
+      launch_stats_reduce(partial, (int64_t)grid, 2 * Cout, stat, s);
+  }
   return mvp_launch_status();
 }

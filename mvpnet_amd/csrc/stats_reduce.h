@@ -40,6 +40,86 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double* __restr
 }
 
 
+// BatchNorm "finalize" carried by the reduction itself: the LAST workgroup of stats_reduce_finalize_kernel (ticket counter) turns the
+// completed sums into mean / invstd and moves the running statistics -- the separate bn_finalize launch (25 per training step, ~5 us
+// each plus the launch gap) disappears.  Same arithmetic as bn_finalize_kernel (rows.hip).
+struct BnFinalize {
+  int64_t rows;        // R: statistics are over this many rows
+  float eps, momentum;
+  float* mean;         // (C) out
+  float* invstd;       // (C) out
+  float* running_mean; // (C) in/out or nullptr
+  float* running_var;
+  int64_t* num_batches_tracked;  // or nullptr
+};
+
+__device__ unsigned g_stats_ticket[64];  // one counter per in-flight launch (host rotates), self-resetting
+
+__global__ __launch_bounds__(256) void stats_reduce_finalize_kernel(const double* __restrict__ partial, int64_t nblk, int C2,
+                                                                    double* __restrict__ stat, BnFinalize fin, int slot) {
+  __shared__ double red[256];
+  __shared__ unsigned last;
+  const int64_t per = (nblk + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * per, t1 = min(nblk, t0 + per);
+  const int cpp = min(C2, 256);
+  const int phases = 256 / cpp;
+  const int col = threadIdx.x % cpp, ph = threadIdx.x / cpp;
+  for (int cb = 0; cb < C2; cb += cpp) {
+    const int c = cb + col;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (ph < phases && c < C2) {
+      int64_t t = t0 + ph;
+      for (; t + 3 * phases < t1; t += 4 * phases) {
+        a0 += partial[(size_t)t * C2 + c];
+        a1 += partial[(size_t)(t + phases) * C2 + c];
+        a2 += partial[(size_t)(t + 2 * phases) * C2 + c];
+        a3 += partial[(size_t)(t + 3 * phases) * C2 + c];
+      }
+      for (; t < t1; t += phases) a0 += partial[(size_t)t * C2 + c];
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ph == 0 && c < C2 && t1 > t0) {
+      double acc = 0.0;
+      for (int g = 0; g < phases; ++g) acc += red[g * cpp + col];
+      atomicAdd(stat + c, acc);
+    }
+    __syncthreads();
+  }
+  // ---- last workgroup: finalize
+  __threadfence();
+  if (threadIdx.x == 0) last = atomicAdd(&g_stats_ticket[slot], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int C = C2 / 2;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double s1 = __hip_atomic_load(stat + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double s2 = __hip_atomic_load(stat + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double m = s1 / (double)fin.rows;
+    double var = s2 / (double)fin.rows - m * m;
+    if (var < 0.0) var = 0.0;
+    fin.mean[c] = (float)m;
+    fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
+    if (fin.running_mean) {
+      const double unbiased = fin.rows > 1 ? var * ((double)fin.rows / (double)(fin.rows - 1)) : var;
+      fin.running_mean[c] = (float)((1.0 - fin.momentum) * (double)fin.running_mean[c] + fin.momentum * m);
+      fin.running_var[c] = (float)((1.0 - fin.momentum) * (double)fin.running_var[c] + fin.momentum * unbiased);
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (fin.num_batches_tracked) *fin.num_batches_tracked += 1;
+    g_stats_ticket[slot] = 0u;  // ready for the next launch that draws this slot
+  }
+}
+
+static inline void launch_stats_reduce_finalize(const double* partial, int64_t nblk, int C2, double* stat, const BnFinalize& fin, hipStream_t s) {
+  static unsigned next_slot = 0;  // host side, one process per GPU: consecutive launches never share a counter
+  const int slot = (int)(next_slot++ & 63u);
+  const int64_t blocks = nblk < 16 ? 1 : (nblk / 16 > 128 ? 128 : nblk / 16);
+  hipLaunchKernelGGL(stats_reduce_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, nblk, C2, stat, fin, slot);
+}
+
 static inline void launch_stats_reduce(const double* partial, int64_t nblk, int C2, double* stat, hipStream_t s) {
   const int64_t blocks = nblk < 16 ? 1 : (nblk / 16 > 128 ? 128 : nblk / 16);
   hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, nblk, C2, stat);

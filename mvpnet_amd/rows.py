@@ -489,6 +489,21 @@ class MLPChainRows(torch.autograd.Function):
             else:
                 cout, cin = w.size(0), w.size(1)
                 y = torch.empty((R, cout), dtype=torch.float32, device=dev)
+                if training and R > 0:
+                    # forward + batch statistics + BatchNorm finalize (mean / invstd / running statistics) in one call: the finalize
+                    # rides on the last workgroup of the statistics reduction
+                    rm, rv, nbt = bn_buffers[i]
+                    mean = torch.empty(cout, dtype=torch.float32, device=dev)
+                    invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+                    L.call('mvp_mlp_forward_bn_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
+                           L.ptr(act[2]), L.ptr(act[3]), L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev)), float(eps), float(mom),
+                           L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.ptr(nbt))
+                    ys.append(y)
+                    means.append(mean)
+                    invstds.append(invstd)
+                    act = (mean, invstd, gamma, beta)
+                    x = y
+                    continue
                 L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
                        L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None))
             rm, rv, nbt = bn_buffers[i]

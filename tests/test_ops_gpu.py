@@ -860,3 +860,40 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
                             np.testing.assert_allclose(stat[Cp:].cpu().numpy(), (ref_dz * xh).sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
     finally:
         L.set_mlp_precision(before)
+
+
+@pytest.mark.parametrize('R,Cin,Cout', [(3000, 64, 64), (70000, 32, 64), (140000, 64, 128), (40000, 320, 256)])
+@pytest.mark.parametrize('stream', [0, 1])
+def test_mlp_forward_with_bn_finalize(dev, R, Cin, Cout, stream):
+    """mvp_mlp_forward_bn_f32 (BatchNorm finalize in the last workgroup of the statistics reduction) == mvp_mlp_forward_f32 followed by
+    mvp_bn_finalize_f32: outputs, mean, invstd, running statistics, num_batches_tracked -- on the atomics path (few rows), the
+    scratch-slot path and the persistent streaming kernel; repeated calls (the ticket counters reset themselves)."""
+    from mvpnet_amd import _lib as L
+    old = L.lib().mvp_set_mlp_stream(stream)
+    try:
+        torch.manual_seed(R)
+        x = torch.randn(R, Cin, device=dev)
+        w = torch.randn(Cout, Cin, device=dev) * 0.2
+        part = lambda: torch.empty(((R + 127) // 128) * 2 * Cout, dtype=torch.float64, device=dev) if R >= 65536 else None
+        for rep in range(3):
+            rm0, rv0 = torch.randn(Cout, device=dev), torch.rand(Cout, device=dev) + 0.5
+            # reference: two calls
+            y1 = torch.empty(R, Cout, device=dev)
+            st1 = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+            L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, Cin, L.ptr(w), Cin, Cout, None, None, None, None, None, L.ptr(y1), L.ptr(st1), L.ptr(part()))
+            m1, i1, rm1, rv1 = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev), rm0.clone(), rv0.clone()
+            n1 = torch.zeros((), dtype=torch.int64, device=dev)
+            L.call('mvp_bn_finalize_f32', y1, L.ptr(st1), R, Cout, 1e-5, 0.1, L.ptr(m1), L.ptr(i1), L.ptr(rm1), L.ptr(rv1), L.ptr(n1))
+            # one call
+            y2 = torch.empty(R, Cout, device=dev)
+            st2 = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+            m2, i2, rm2, rv2 = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev), rm0.clone(), rv0.clone()
+            n2 = torch.zeros((), dtype=torch.int64, device=dev)
+            L.call('mvp_mlp_forward_bn_f32', x, L.ptr(x), R, Cin, Cin, L.ptr(w), Cin, Cout, None, None, None, None, L.ptr(y2), L.ptr(st2), L.ptr(part()),
+                   1e-5, 0.1, L.ptr(m2), L.ptr(i2), L.ptr(rm2), L.ptr(rv2), L.ptr(n2))
+            assert torch.equal(y1, y2) and int(n2) == 1
+            np.testing.assert_allclose(st2.cpu().numpy(), st1.cpu().numpy(), rtol=1e-12, atol=1e-9 * R)
+            for a, b in ((m1, m2), (i1, i2), (rm1, rm2), (rv1, rv2)):
+                np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    finally:
+        L.lib().mvp_set_mlp_stream(old)
