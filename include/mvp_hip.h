@@ -271,8 +271,8 @@ int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, flo
  * Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Returns MVP_EINVAL for other values. */
 int mvp_set_mlp_precision(int terms, int min_width);
 int mvp_get_mlp_precision(void);
-/* Ablation switch (returns the previous value): 1 (default) = long narrow forward layers (>= 32768 rows, C_in, C_out <= 128) run on the
- * persistent streaming kernel with the weight matrix resident in LDS; 0 = the per-tile kernel everywhere. */
+/* Switch (returns the previous value): 1 = long narrow forward layers (>= 32768 rows, C_in, C_out <= 128) run on the persistent
+ * streaming kernel with the weight matrix resident in LDS; 0 (default: measured 1.2 % faster on the bench step) = the per-tile kernel. */
 int mvp_set_mlp_stream(int on);
 
 /* Shared-MLP layer on rows with fp32 MFMA (mlp.hip): Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias).
@@ -292,6 +292,25 @@ int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, 
                            const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* Y,
                            double* stat, double* partial, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                            float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
+/* Last layer of a set-abstraction shared MLP, training mode, WITHOUT materialising its (R,Cout) output (reference shape being replaced:
+ * the (B,C,M,32) tensor of mvpnet/models/pn2/modules.py:100-108 + torch.max over dim 3).  Rows are groups of K = 32 consecutive
+ * neighbours (R = 32 G).  Leaves per group and column the largest / smallest PRE-BatchNorm value (ymax, ymin (G,Cout) float32) and the
+ * first row attaining each (amax, amin (G,Cout) uint8), the layer's batch statistics (stat, zero on entry; partial = scratch of
+ * ceil(R/128)*2*Cout doubles) and its BatchNorm finalize as mvp_mlp_forward_bn_f32.  mvp_pool_finalize_f32 then gives
+ * out = max_k relu(bn(y_k)) (exact: bn o relu is monotone in y), arg, and ysel (the pre-BN value behind out: the backward's xhat).
+ * MVP_EUNSUPPORTED unless split-bf16 precision, Cin, Cout <= 128, Cin % 4 == 0, Cout % 4 == 0, R % 32 == 0, R >= 32768. */
+int mvp_mlp_forward_pool_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+                             const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* ymax,
+                             float* ymin, uint8_t* amax, uint8_t* amin, double* stat, double* partial, float eps, float momentum,
+                             float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                             mvp_stream_t stream);
+int mvp_pool_finalize_f32(const float* ymax, const float* ymin, const uint8_t* amax, const uint8_t* amin, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t C, int relu, float* out,
+                          uint8_t* arg, float* ysel, mvp_stream_t stream);
+/* BatchNorm-backward column sums of such a layer from the (G,C) tensors: stat[0:C] = sum dz, stat[C:2C] = sum dz * xhat, dz = dout where
+ * out > 0 (relu), xhat = (ysel - mean) * invstd; stat is (re)initialised; partial = mvp_colstats_partial_count(G, C) doubles. */
+int mvp_pool_backward_stats_f32(const float* dout, const float* out, const float* ysel, const float* mean, const float* invstd,
+                                int64_t G, int64_t C, int relu, double* stat, double* partial, mvp_stream_t stream);
 /* `partial` (both entry points below and above): optional scratch of ceil(R/128) * 2 * (output columns) float64; when
  * given, the statistics are reduced without atomics (recommended for R >~ 1e5), otherwise with fp64 atomics. */
 /* d(input) with the previous layer's ReLU mask and BatchNorm-backward column sums fused into the epilogue:
@@ -312,13 +331,18 @@ int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float
  *   stat_prev (2 Cp, accumulated into): column sums of dZ and dZ * xhat_{i-1} (needs act_* and dZ; partial = float64 scratch of
  *   mvp_mlp_layer_backward_partial_count(R, Cp) values).
  * Contraction: split-bf16 only (mvp_set_mlp_precision 3 or 6); C <= 128, Cp <= 128, Cp % 4 == 0 -- otherwise MVP_EUNSUPPORTED.
- * Layers wider than 64 input channels are cut into c_in slices (one workgroup row each) that re-read dy_i. */
+ * Layers wider than 64 input channels are cut into c_in slices (one workgroup row each) that re-read dy_i.
+ *   pool_dout / pool_out (R/32, C) float32, pool_arg (R/32, C) uint8, all NULL or all set: layer i is the last layer of a
+ *            set-abstraction MLP that ran through mvp_mlp_forward_pool_f32 (its (R,C) output was never stored; rows = groups of 32
+ *            neighbours).  G and Yi are then ignored (pass NULL): y_i is re-computed from X, dz_i = pool_dout at the arg-max row where
+ *            pool_out > 0, stat_i from mvp_pool_backward_stats_f32.  Needs C, Cp <= 64, R % 32 == 0, act_* set. */
 int64_t mvp_mlp_layer_backward_partial_count(int64_t R, int64_t Cp);
 int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
                                const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx,
                                const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                                const float* W, int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
-                               double* stat_prev, double* partial, mvp_stream_t stream);
+                               double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
+                               const uint8_t* pool_arg, mvp_stream_t stream);
 /* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
  * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,

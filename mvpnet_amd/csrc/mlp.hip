@@ -26,11 +26,12 @@
 int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const float* W, int ldw, int Cout, const float* act_mean,
                            const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y,
                            double* stat, double* partial, int ns, float bn_eps, float bn_momentum, float* bn_mean, float* bn_invstd,
-                           float* bn_running_mean, float* bn_running_var, int64_t* bn_num_batches, hipStream_t s);
+                           float* bn_running_mean, float* bn_running_var, int64_t* bn_num_batches, float* ymax, float* ymin,
+                           uint8_t* amax, uint8_t* amin, hipStream_t s);
 
 int g_mlp_terms = 6;       // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (default: fp32-level accuracy, measured) -- mvp_set_mlp_precision; shared with mlp_bwd.hip
 int g_mlp_min_width = 0;   // layers with max(Cin, Cout) below this stay on the fp32 MFMA
-int g_mlp_stream = 1;      // 1: long narrow forward layers take mlp_stream.hip (MVP_MLP_STREAM=0 / mvp_set_mlp_stream(0): tile kernel everywhere)
+int g_mlp_stream = 0;      // 1: long narrow forward layers take mlp_stream.hip (MVP_MLP_STREAM=0 / mvp_set_mlp_stream(0): tile kernel everywhere)
 
 namespace {
 
@@ -869,7 +870,7 @@ int mlp_forward_impl(const float* X, int64_t R, int64_t Cin, int64_t ldx, const 
   if (g_mlp_stream && std::max(Cin, Cout) >= g_mlp_min_width) {  // long narrow layers: resident weights, persistent row streaming
     const int rc = mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, bias, Y,
                                           stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, bn_eps, bn_momentum, bn_mean,
-                                          bn_invstd, bn_running_mean, bn_running_var, bn_num_batches, s);
+                                          bn_invstd, bn_running_mean, bn_running_var, bn_num_batches, nullptr, nullptr, nullptr, nullptr, s);
     if (rc != MVP_EUNSUPPORTED) return rc;
   }
   launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat,
@@ -924,6 +925,37 @@ MVP_API int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64
   if (running_mean) MVP_NONNULL(running_var);
   return mlp_forward_impl(X, R, Cin, ldx, W, ldw, Cout, act_mean, act_invstd, act_gamma, act_beta, nullptr, Y, stat, partial, eps, momentum,
                           mean, invstd, running_mean, running_var, num_batches_tracked, static_cast<hipStream_t>(stream));
+}
+
+// Last layer of a set-abstraction shared MLP in training mode WITHOUT its (rows, Cout) output tensor: the rows are groups of K = 32
+// consecutive neighbours (R = 32 G); per group and column the kernel leaves the largest and the smallest pre-BatchNorm value and the
+// first row attaining each (ymax, ymin (G,Cout) float32; amax, amin (G,Cout) uint8), plus the layer's batch statistics and
+// BatchNorm finalize as mvp_mlp_forward_bn_f32.  mvp_pool_finalize_f32 then produces max_k relu(bn(y_k)) from them.
+// MVP_EUNSUPPORTED unless: split-bf16 precision, Cin, Cout <= 128, Cin % 4 == 0, Cout % 4 == 0, R % 32 == 0, R >= 32768.
+MVP_API int mvp_mlp_forward_pool_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+                                     const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                                     float* ymax, float* ymin, uint8_t* amax, uint8_t* amin, double* stat, double* partial, float eps,
+                                     float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                     int64_t* num_batches_tracked, mvp_stream_t stream) {
+  MVP_NONNULL(X);
+  MVP_NONNULL(W);
+  MVP_NONNULL(ymax);
+  MVP_NONNULL(ymin);
+  MVP_NONNULL(amax);
+  MVP_NONNULL(amin);
+  MVP_NONNULL(stat);
+  MVP_NONNULL(partial);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_REQUIRE(R > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ldw >= Cin);
+  if (act_mean) {
+    MVP_NONNULL(act_invstd);
+    MVP_NONNULL(act_gamma);
+    MVP_NONNULL(act_beta);
+  }
+  return mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, nullptr, nullptr,
+                                stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, eps, momentum, mean, invstd, running_mean,
+                                running_var, num_batches_tracked, ymax, ymin, amax, amin, static_cast<hipStream_t>(stream));
 }
 
 // dW (Cout,Cin; row stride lddw) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin])  (accumulated into dW: gradient-accumulation semantics).
@@ -1042,7 +1074,7 @@ MVP_API int mvp_set_mlp_precision(int terms, int min_width) {
   return MVP_OK;
 }
 MVP_API int mvp_get_mlp_precision(void) { return g_mlp_terms; }
-// Ablation switch: 0 routes every forward layer through the per-tile kernel (mlp_fwd_kernel), 1 (default) lets long narrow layers
+// Switch: 0 (default; measured 1.2 % faster on the bench step) routes every forward layer through the per-tile kernel (mlp_fwd_kernel), 1 lets long narrow layers
 // (>= 32768 rows, C_in and C_out <= 128, split-bf16) take the persistent streaming kernel (mlp_stream.hip).  Returns the old value.
 MVP_API int mvp_set_mlp_stream(int on) {
   const int old = g_mlp_stream;

@@ -51,21 +51,28 @@ struct BwdArgs {
   int64_t R;
   int C, Cp;
   int64_t tiles_per_wg;
+  // POOL front end (layer i is the LAST layer of a set-abstraction MLP whose (rows, C) output was never stored: rows = groups of 32):
+  // y_i is re-computed from y_{i-1} and dz_i comes from the pooled gradient -- G / Yi are unused.
+  const float* pool_dout;    // (R / 32, C) gradient of the pooled output
+  const float* pool_out;     // (R / 32, C) pooled output (ReLU mask: > 0)
+  const uint8_t* pool_arg;   // (R / 32, C) row of the group that attained the maximum
 };
 
-template <int CB, int CPB, int NS>
+template <int CB, int CPB, int NS, bool POOL>
 __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
   using SP = SplitPairs<NS>;
   constexpr int kWBytes = NS * CB * CPB * 32 * 64;                 // split weight: 64 bytes per (c_in, slab, piece)
+  constexpr int kImages = POOL ? 2 : 1;                            // POOL: + the forward-orientation image (k = c_in) for re-computing y_i
   constexpr int kTileBytes = 4 * 32 * kTileLd * 4;
   constexpr int kRedBytes = 2 * CB * CPB * 16 * 64 * 4;
-  constexpr int kLds = (kWBytes + kTileBytes) > kRedBytes ? (kWBytes + kTileBytes) : kRedBytes;
+  constexpr int kLds = (kImages * kWBytes + kTileBytes) > kRedBytes ? (kImages * kWBytes + kTileBytes) : kRedBytes;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
   __shared__ double sred[2][4][CPB * 32];
   unsigned char* Wl = lds;
+  unsigned char* Wf = lds + kWBytes;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
-  float* tile = reinterpret_cast<float*>(lds + kWBytes) + wave * 32 * kTileLd;
+  float* tile = reinterpret_cast<float*>(lds + kImages * kWBytes) + wave * 32 * kTileLd;
   const int C = p.C;
   // blockIdx.y: this workgroup's slice of the INPUT channels (c_in = ci0 .. ci0 + 32 CPB - 1).  Wide layers are cut along c_in:
   // every slice needs all of dy_i (re-read: 2 C per slice) but owns its columns of dW and dZ outright -- no cross-workgroup sums.
@@ -96,7 +103,25 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
         *reinterpret_cast<uint2*>(Wl + ((size_t)(pc * CB + a) * (CPB * 32) + ci) * 64 + ((unit ^ sw) * 16) + half * 8) = make_uint2(lo[pc], hi[pc]);
     }
   }
-  if (finish && p.dgamma_i && blockIdx.x == 0 && blockIdx.y == 0)
+  if constexpr (POOL) {  // forward orientation: thread (c_out, quad of 4 consecutive c_in); B operand of y_i = a_{i-1} . W_i^T (k = c_in)
+    for (int t = tid; t < CB * 32 * CPB * 8; t += kBT) {
+      const int co = t % (CB * 32), cq = t / (CB * 32);
+      const int ci = 4 * cq;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (co < C && ci + e < Cp) ? p.W[(size_t)co * p.ldw + ci0 + ci + e] : 0.f;
+      unsigned lo[NS], hi[NS];
+      split_pair<NS>(v[0], v[1], lo);
+      split_pair<NS>(v[2], v[3], hi);
+      const int b = cq >> 3, ciq = cq & 7;
+      const int tt = ciq >> 1, hh = ciq & 1;
+      const int unit = 2 * (tt >> 1) + hh, half = tt & 1;
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc)
+        *reinterpret_cast<uint2*>(Wf + ((size_t)(pc * CPB + b) * (CB * 32) + co) * 64 + ((unit ^ ((co >> 2) & 3)) * 16) + half * 8) = make_uint2(lo[pc], hi[pc]);
+    }
+  }
+  if ((finish || POOL) && p.dgamma_i && blockIdx.x == 0 && blockIdx.y == 0)
     for (int col = tid; col < C; col += kBT) {
       p.dbeta_i[col] = (float)p.stat_i[col];
       p.dgamma_i[col] = (float)p.stat_i[C + col];
@@ -109,7 +134,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
     const int col = 32 * a + c;
     cok[a] = col < C;
     sc[a] = mu[a] = is[a] = db[a] = dg[a] = 0.f;
-    if (finish && cok[a]) {
+    if ((finish || POOL) && cok[a]) {
       mu[a] = p.mean_i[col];
       is[a] = p.invstd_i[col];
       sc[a] = p.gamma_i[col] * is[a];
@@ -173,9 +198,10 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) x[b][q] = Xt[min(8 * (q >> 2) + 4 * h + (q & 3), lim) * p.ldx + col];
     }
-    load_g(0);
+    if constexpr (!POOL) load_g(0);
     // ---- a_{i-1}: activation + split, both row steps (operand B of dW for every channel block of dy)
     u32x4 fb[CPB][2][NS];
+    u32x4 far[POOL ? CPB : 1][2][NS];
 #pragma unroll
     for (int b = 0; b < CPB; ++b) {
       float av[16];
@@ -196,6 +222,24 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
 #pragma unroll
         for (int pc = 0; pc < NS; ++pc) fb[b][s][pc] = u32x4{qq[0][pc], qq[1][pc], qq[2][pc], qq[3][pc]};
       }
+      if constexpr (POOL) {  // the same activations as "8 channels of one row" per lane (operand A of the y_i re-computation)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[(8 * (q >> 2) + 4 * h + (q & 3)) * kTileLd + c] = av[q];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const float4 v0 = *reinterpret_cast<const float4*>(tile + c * kTileLd + 16 * s + 4 * h);
+          const float4 v1 = *reinterpret_cast<const float4*>(tile + c * kTileLd + 16 * s + 8 + 4 * h);
+          unsigned q0[NS], q1[NS], q2[NS], q3[NS];
+          split_pair<NS>(v0.x, v0.y, q0);
+          split_pair<NS>(v0.z, v0.w, q1);
+          split_pair<NS>(v1.x, v1.y, q2);
+          split_pair<NS>(v1.z, v1.w, q3);
+#pragma unroll
+          for (int pc = 0; pc < NS; ++pc) far[b][s][pc] = u32x4{q0[pc], q1[pc], q2[pc], q3[pc]};
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     f32x16 accz[CPB];
 #pragma unroll
@@ -207,16 +251,48 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
       __builtin_amdgcn_sched_barrier(0);  // keep the blocks sequential: the scheduler otherwise hoists every block's loads and splits
       // ---- dy_i, channel block a
       float dyv[16];
+      if constexpr (POOL) {
+        // y_i[:, block a] = a_{i-1} . W_i[block a, :]^T again (it was never stored), then dz_i from the pooled gradient: the row of the
+        // group (= this tile) that attained the maximum gets dout where the pooled output is positive
+        f32x16 yl;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float d = gn[q];
-        if (finish) {
-          const float xh = (yn[q] - mu[a]) * is[a];
-          d = sc[a] * ((d - db[a]) - xh * dg[a]);
+        for (int i = 0; i < 16; ++i) yl[i] = 0.f;
+        const int co = 32 * a + c;
+#pragma unroll
+        for (int b = 0; b < CPB; ++b)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            u32x4 wf[NS];
+#pragma unroll
+            for (int pc = 0; pc < NS; ++pc)
+              wf[pc] = *reinterpret_cast<const u32x4*>(Wf + ((size_t)(pc * CPB + b) * (CB * 32) + co) * 64 + (((2 * s + h) ^ ((co >> 2) & 3)) * 16));
+#pragma unroll
+            for (int qd = 0; qd < SP::N; ++qd)
+              yl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, far[b][s][SP::A[qd]]),
+                                                          __builtin_bit_cast(bf16x8, wf[SP::B[qd]]), yl, 0, 0, 0);
+          }
+        const size_t go = (size_t)t * C + min(co, C - 1);
+        const float dd = (p.pool_out[go] > 0.f) ? p.pool_dout[go] : 0.f;
+        const int ar = (int)p.pool_arg[go];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = 8 * (q >> 2) + 4 * h + (q & 3);
+          const float xh = (yl[q] - mu[a]) * is[a];
+          const float d = sc[a] * (((ar == row ? dd : 0.f) - db[a]) - xh * dg[a]);
+          dyv[q] = cok[a] ? d : 0.f;
         }
-        dyv[q] = (rok[q] && cok[a]) ? d : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float d = gn[q];
+          if (finish) {
+            const float xh = (yn[q] - mu[a]) * is[a];
+            d = sc[a] * ((d - db[a]) - xh * dg[a]);
+          }
+          dyv[q] = (rok[q] && cok[a]) ? d : 0.f;
+        }
+        if (a + 1 < CB) load_g(a + 1);  // in flight under this block's MFMAs
       }
-      if (a + 1 < CB) load_g(a + 1);  // in flight under this block's MFMAs
       // ---- dW[a][:] += dy^T . a : two row steps, operands straight from the registers
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -381,8 +457,20 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
                                        const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float* act_mean,
                                        const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W,
                                        int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
-                                       double* stat_prev, double* partial, mvp_stream_t stream) {
-  MVP_NONNULL(G);
+                                       double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
+                                       const uint8_t* pool_arg, mvp_stream_t stream) {
+  if (pool_dout) {  // POOL front end: y_i re-computed, dz_i from the pooled gradient (rows = groups of 32)
+    MVP_NONNULL(pool_out);
+    MVP_NONNULL(pool_arg);
+    MVP_NONNULL(mean_i);
+    MVP_NONNULL(invstd_i);
+    MVP_NONNULL(gamma_i);
+    MVP_NONNULL(stat_i);
+    MVP_NONNULL(act_mean);
+    if (Yi != nullptr || R % 32 != 0 || C > 64 || Cp > 64) return MVP_EUNSUPPORTED;
+  } else {
+    MVP_NONNULL(G);
+  }
   MVP_NONNULL(X);
   MVP_NONNULL(W);
   MVP_NONNULL(dW);
@@ -415,6 +503,7 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   a.W = W; a.ldw = (int)ldw; a.dW = dW; a.lddw = (int)lddw; a.dZ = dZ;
   a.partial = (dZ && act_mean) ? partial : nullptr;
   a.R = R; a.C = (int)C; a.Cp = (int)Cp;
+  a.pool_dout = pool_dout; a.pool_out = pool_out; a.pool_arg = pool_arg;
   const int64_t ntiles = cdiv(R, 32);
   const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(ntiles, 8)));
   a.tiles_per_wg = cdiv(cdiv(ntiles, wgs), 4) * 4;
@@ -423,12 +512,23 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   const int cb = C <= 32 ? 1 : C <= 64 ? 2 : 4;
   const int cpb = Cp <= 32 ? 1 : (Cp <= 64 || Cp > 96 || cb == 4) ? 2 : 3;
   const unsigned gy = (unsigned)cdiv(Cp, 32 * cpb);
-#define MVP_BWD(A_, B_)                                                                                           \
-  do {                                                                                                            \
-    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
-    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a);        \
+#define MVP_BWD(A_, B_)                                                                                                  \
+  do {                                                                                                                   \
+    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, false>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
+    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, false>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a);        \
   } while (0)
-  if (cb == 1 && cpb == 1) MVP_BWD(1, 1);
+#define MVP_BWD_POOL(A_, B_)                                                                                            \
+  do {                                                                                                                  \
+    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, true>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a); \
+    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, true>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a);        \
+  } while (0)
+  if (pool_dout) {
+    if (cb == 1 && cpb == 1) MVP_BWD_POOL(1, 1);
+    else if (cb == 1 && cpb == 2) MVP_BWD_POOL(1, 2);
+    else if (cb == 2 && cpb == 1) MVP_BWD_POOL(2, 1);
+    else if (cb == 2 && cpb == 2) MVP_BWD_POOL(2, 2);
+    else return MVP_EUNSUPPORTED;
+  } else if (cb == 1 && cpb == 1) MVP_BWD(1, 1);
   else if (cb == 1 && cpb == 2) MVP_BWD(1, 2);
   else if (cb == 1) MVP_BWD(1, 3);
   else if (cb == 2 && cpb == 1) MVP_BWD(2, 1);
@@ -437,6 +537,7 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   else if (cpb == 1) MVP_BWD(4, 1);
   else if (cpb == 2) MVP_BWD(4, 2);
   else return MVP_EUNSUPPORTED;
+#undef MVP_BWD_POOL
 #undef MVP_BWD
   int rc = mvp_launch_status();
   if (rc != MVP_OK) return rc;

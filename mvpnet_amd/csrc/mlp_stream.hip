@@ -34,9 +34,15 @@ struct StreamArgs {
   float* Y;
   double* partial;  // (workgroups, 2, Cout) or nullptr
   int64_t tiles_per_wg;
+  // POOL: every 32-row tile is one group (ball) of K = 32 neighbours; instead of Y the kernel leaves, per group and column, the
+  // largest and the smallest PRE-BatchNorm value and the (first) row that attains each
+  float* ymax;
+  float* ymin;
+  uint8_t* amax;
+  uint8_t* amin;
 };
 
-template <int KS, int NB, bool ACT, int NS>
+template <int KS, int NB, bool ACT, int NS, bool POOL>
 __global__ __launch_bounds__(kST) void mlp_stream_fwd_kernel(StreamArgs p) {
   using SP = SplitPairs<NS>;
   constexpr int kCols = NB * 32;
@@ -174,6 +180,37 @@ __global__ __launch_bounds__(kST) void mlp_stream_fwd_kernel(StreamArgs p) {
     for (int j = 0; j < NB; ++j) {
       const bool cok = 32 * j + li < Cout;
       float s = 0.f, q = 0.f;
+      if constexpr (POOL) {
+        // max / min over the tile's 32 rows per column: 16 rows in this lane's registers (ascending with i), 16 in the partner
+        // lane (lane ^ 32); ties keep the LOWER row.  BatchNorm + ReLU are monotone in y for either sign of gamma * invstd, so
+        // max_k relu(bn(y_k)) = relu(bn(max_k y_k)) (or of min_k for a negative scale) exactly, in floating point too.
+        float vmax = -INFINITY, vmin = INFINITY;
+        int rmax = 0, rmin = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = (i & 3) + 8 * (i >> 2) + 4 * lh;
+          const float y = acc[j][i] + bv[j];
+          s += y;
+          q += y * y;
+          if (y > vmax) { vmax = y; rmax = m; }
+          if (y < vmin) { vmin = y; rmin = m; }
+        }
+        const float omax = __shfl_xor(vmax, 32, kWave), omin = __shfl_xor(vmin, 32, kWave);
+        const int ormax = __shfl_xor(rmax, 32, kWave), ormin = __shfl_xor(rmin, 32, kWave);
+        if (omax > vmax || (omax == vmax && ormax < rmax)) { vmax = omax; rmax = ormax; }
+        if (omin < vmin || (omin == vmin && ormin < rmin)) { vmin = omin; rmin = ormin; }
+        if (lh == 0 && cok) {
+          const size_t o = (size_t)t * Cout + 32 * j + li;
+          p.ymax[o] = vmax;
+          p.ymin[o] = vmin;
+          p.amax[o] = (uint8_t)rmax;
+          p.amin[o] = (uint8_t)rmin;
+        }
+        if (!cok) s = q = 0.f;
+        ssum[j] += s;
+        qsum[j] += q;
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = (i & 3) + 8 * (i >> 2) + 4 * lh;
@@ -218,8 +255,13 @@ __global__ __launch_bounds__(kST) void mlp_stream_fwd_kernel(StreamArgs p) {
 
 template <int KS, int NB, int NS>
 void launch_stream(const StreamArgs& a, unsigned grid, bool has_act, hipStream_t s) {
-  if (has_act) hipLaunchKernelGGL((mlp_stream_fwd_kernel<KS, NB, true, NS>), dim3(grid), dim3(kST), 0, s, a);
-  else hipLaunchKernelGGL((mlp_stream_fwd_kernel<KS, NB, false, NS>), dim3(grid), dim3(kST), 0, s, a);
+  if (a.ymax) {  // pooled: always behind a BatchNorm + ReLU'd input in this code base
+    if (has_act) hipLaunchKernelGGL((mlp_stream_fwd_kernel<KS, NB, true, NS, true>), dim3(grid), dim3(kST), 0, s, a);
+    else hipLaunchKernelGGL((mlp_stream_fwd_kernel<KS, NB, false, NS, true>), dim3(grid), dim3(kST), 0, s, a);
+    return;
+  }
+  if (has_act) hipLaunchKernelGGL((mlp_stream_fwd_kernel<KS, NB, true, NS, false>), dim3(grid), dim3(kST), 0, s, a);
+  else hipLaunchKernelGGL((mlp_stream_fwd_kernel<KS, NB, false, NS, false>), dim3(grid), dim3(kST), 0, s, a);
 }
 
 }  // namespace
@@ -228,14 +270,17 @@ void launch_stream(const StreamArgs& a, unsigned grid, bool has_act, hipStream_t
 // (the caller then takes mlp_fwd_kernel); on success the statistics partial slots have been reduced into `stat` (and, with bn_mean,
 // the BatchNorm finalize has run in the reduction's last workgroup).
 // `partial` must hold at least ceil(R / 128) * 2 * Cout doubles (what mvp_mlp_forward_f32's callers provide).
+// ymax != nullptr: pooled mode (K = 32 rows per group, R % 32 == 0): no Y; per group and column the max / min pre-BN value + row.
 int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const float* W, int ldw, int Cout, const float* act_mean,
                            const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y,
                            double* stat, double* partial, int ns, float bn_eps, float bn_momentum, float* bn_mean, float* bn_invstd,
-                           float* bn_running_mean, float* bn_running_var, int64_t* bn_num_batches, hipStream_t s) {
+                           float* bn_running_mean, float* bn_running_var, int64_t* bn_num_batches, float* ymax, float* ymin,
+                           uint8_t* amax, uint8_t* amin, hipStream_t s) {
   const InAct act{act_mean, act_invstd, act_gamma, act_beta};
   if (ns == 0 || Cin > 128 || Cout > 128 || Cin < 4 || Cout % 4 != 0 || R < 32768 || (stat && !partial)) return MVP_EUNSUPPORTED;
-  if (ldx % 4 != 0 || Cin % 4 != 0 || ((uintptr_t)X % 16) != 0 || ((uintptr_t)Y % 16) != 0) return MVP_EUNSUPPORTED;
-  StreamArgs a{X, R, Cin, ldx, W, ldw, Cout, act, bias, Y, stat ? partial : nullptr, 0};
+  if (ldx % 4 != 0 || Cin % 4 != 0 || ((uintptr_t)X % 16) != 0 || (!ymax && ((uintptr_t)Y % 16) != 0)) return MVP_EUNSUPPORTED;
+  if (ymax && R % 32 != 0) return MVP_EUNSUPPORTED;
+  StreamArgs a{X, R, Cin, ldx, W, ldw, Cout, act, bias, Y, stat ? partial : nullptr, 0, ymax, ymin, amax, amin};
   const int64_t ntiles = cdiv(R, 32);
   const int ks = (int)cdiv(Cin, 32), nb = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
   // persistent workgroups: enough to fill the chip at the occupancy the weight image allows, at least 16 tiles each

@@ -460,6 +460,68 @@ struct BwdMax {  // rows are groups g; only the arg-max row of each (g, c) carri
   }
 };
 
+struct BwdMaxSel {  // as BwdMax for the layers that never stored y: xhat of the arg-max row from the pooled PRE-BN value ysel (G,C)
+  const float *dout, *out, *ysel, *mean, *invstd;
+  int relu;
+  struct Params { float mm[4], ii[4]; };
+  __device__ __forceinline__ Params params(int c) const {
+    const float4 mu = ld4(mean + c), is = ld4(invstd + c);
+    Params p;
+    p.mm[0] = mu.x; p.mm[1] = mu.y; p.mm[2] = mu.z; p.mm[3] = mu.w;
+    p.ii[0] = is.x; p.ii[1] = is.y; p.ii[2] = is.z; p.ii[3] = is.w;
+    return p;
+  }
+  __device__ __forceinline__ void at(const Params& p, int64_t g, int c, int C, float4& f, float4& gg) const {
+    const float4 d = ld4(dout + (size_t)g * C + c), o = ld4(out + (size_t)g * C + c), ys = ld4(ysel + (size_t)g * C + c);
+    const float dd[4] = {d.x, d.y, d.z, d.w}, oo[4] = {o.x, o.y, o.z, o.w}, yy[4] = {ys.x, ys.y, ys.z, ys.w};
+    float fo[4], go[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dz = (!relu || oo[i] > 0.f) ? dd[i] : 0.f;
+      fo[i] = dz;
+      go[i] = dz * ((yy[i] - p.mm[i]) * p.ii[i]);
+    }
+    f = make_float4(fo[0], fo[1], fo[2], fo[3]);
+    gg = make_float4(go[0], go[1], go[2], go[3]);
+  }
+};
+
+// out = act(bn(ysel)), ysel = ymax where gamma * invstd >= 0 else ymin (the extremum the monotone map bn o relu turns into the max
+// over the group), arg = the row that attained it.  One lane per (group, 4 channels).
+__global__ __launch_bounds__(kRT) void pool_finalize_kernel(const float* __restrict__ ymax, const float* __restrict__ ymin,
+                                                            const uint8_t* __restrict__ amax, const uint8_t* __restrict__ amin,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int64_t G,
+                                                            int C, int relu, float* __restrict__ out, uint8_t* __restrict__ arg,
+                                                            float* __restrict__ ysel) {
+  const int C4 = C >> 2;
+  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  const int64_t g = t / C4;
+  const int c = (int)(t - g * C4) * 4;
+  if (g >= G) return;
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+  const float4 hi = ld4(ymax + (size_t)g * C + c), lo = ld4(ymin + (size_t)g * C + c);
+  const uchar4 ah = *reinterpret_cast<const uchar4*>(amax + (size_t)g * C + c), al = *reinterpret_cast<const uchar4*>(amin + (size_t)g * C + c);
+  const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, ii[4] = {is.x, is.y, is.z, is.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w};
+  const float bb[4] = {be.x, be.y, be.z, be.w}, hv[4] = {hi.x, hi.y, hi.z, hi.w}, lv[4] = {lo.x, lo.y, lo.z, lo.w};
+  const uint8_t ha[4] = {ah.x, ah.y, ah.z, ah.w}, la[4] = {al.x, al.y, al.z, al.w};
+  float o[4], ys[4];
+  uint8_t ar[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool up = gg[i] * ii[i] >= 0.f;
+    ys[i] = up ? hv[i] : lv[i];
+    ar[i] = up ? ha[i] : la[i];
+    const float a = ((ys[i] - mm[i]) * ii[i]) * gg[i] + bb[i];
+    o[i] = (relu && !(a > 0.f)) ? 0.f : a;
+  }
+  st4(out + (size_t)g * C + c, make_float4(o[0], o[1], o[2], o[3]));
+  st4(ysel + (size_t)g * C + c, make_float4(ys[0], ys[1], ys[2], ys[3]));
+  uchar4 u;
+  u.x = ar[0]; u.y = ar[1]; u.z = ar[2]; u.w = ar[3];
+  *reinterpret_cast<uchar4*>(arg + (size_t)g * C + c) = u;
+}
+
 struct BwdSum {  // rows r = g*K + k; every row of group g receives dout[g] (gradient of a SUM over K), masked by its own ReLU
   const float *dout, *y, *mean, *invstd, *gamma, *beta;
   int K, relu;
@@ -1012,6 +1074,45 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
     hipLaunchKernelGGL(bn_rows_bwd_kernel<false>, grid, dim3(kRT), 0, s, dsrc, y, mean, invstd, gamma, beta, stat, R, (int)C, training,
                        dy, dgamma, dbeta);
   return mvp_launch_status();
+}
+
+// Pooled output of a layer that ran through mvp_mlp_forward_pool_f32: out (G,C) = max_k act(bn(y_k)), arg (G,C) = its row, ysel (G,C) =
+// the pre-BN value it came from (kept for the backward's xhat).
+MVP_API int mvp_pool_finalize_f32(const float* ymax, const float* ymin, const uint8_t* amax, const uint8_t* amin, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t C, int relu, float* out,
+                                  uint8_t* arg, float* ysel, mvp_stream_t stream) {
+  MVP_NONNULL(ymax);
+  MVP_NONNULL(ymin);
+  MVP_NONNULL(amax);
+  MVP_NONNULL(amin);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(beta);
+  MVP_NONNULL(out);
+  MVP_NONNULL(arg);
+  MVP_NONNULL(ysel);
+  int rc = check_rows(G, C);
+  if (rc || G == 0) return rc;
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)cdiv(G * (C / 4), kRT)), dim3(kRT), 0, static_cast<hipStream_t>(stream), ymax, ymin, amax,
+                     amin, mean, invstd, gamma, beta, G, (int)C, relu, out, arg, ysel);
+  return mvp_launch_status();
+}
+
+// The two BatchNorm-backward column sums of a max-pooled layer from the (G,C) tensors alone: stat[0:C] = sum dz, stat[C:2C] = sum dz * xhat
+// with dz = dout where the pooled output is positive (ReLU) and xhat = (ysel - mean) * invstd of the arg-max row.  stat is
+// (re)initialised by this call; partial = scratch of mvp_colstats_partial_count(G, C) doubles.
+MVP_API int mvp_pool_backward_stats_f32(const float* dout, const float* out, const float* ysel, const float* mean, const float* invstd,
+                                        int64_t G, int64_t C, int relu, double* stat, double* partial, mvp_stream_t stream) {
+  MVP_NONNULL(dout);
+  MVP_NONNULL(out);
+  MVP_NONNULL(ysel);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(stat);
+  int rc = check_rows(G, C);
+  if (rc) return rc;
+  return launch_colstats(BwdMaxSel{dout, out, ysel, mean, invstd, relu}, G, C, stat, partial, true, static_cast<hipStream_t>(stream));
 }
 
 MVP_API int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean,

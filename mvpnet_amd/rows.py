@@ -20,6 +20,10 @@ from . import _lib as L
 # variants run at one wave per SIMD and re-read dy_i per c_in slice -- tuning knob, default from the measurements.
 FUSE_BWD_MAX_COUT = int(os.environ.get('MVP_BWD_FUSE_MAXC', '64'))
 FUSE_BWD_MAX_CIN = int(os.environ.get('MVP_BWD_FUSE_MAXCIN', '96'))
+# Set-abstraction levels (K = 32 neighbours, max pooling): run the LAST shared-MLP layer without ever storing its (B*M*32, C) output --
+# forward leaves per-ball max / min of the pre-BN values (mvp_mlp_forward_pool_f32), backward re-computes the layer from its input inside
+# the one-kernel layer backward (POOL front end).  Needs C_out, C_in <= 64 and >= 32768 rows (levels 1 and, with 64-wide MLPs, 2).
+POOL_WITHOUT_Y = os.environ.get('MVP_POOL_NO_Y', '1') != '0'
 
 
 def _round4(c):
@@ -472,6 +476,10 @@ class MLPChainRows(torch.autograd.Function):
         couts = [x0.size(1) if params[3 * i] is None else params[3 * i].size(0) for i in range(nl)]
         # the kernels ADD their column sums to `stat`: one zeroed arena for the whole chain instead of a memset per layer
         arena = zero_pool.zeros(2 * sum(couts), torch.float64, dev) if training else None
+        wl = params[3 * (nl - 1)]
+        pooled = bool(POOL_WITHOUT_Y and training and K == 32 and not pool_sum and nl >= 2 and wl is not None and R % 32 == 0 and R >= 32768 and
+                      L.get_mlp_precision() != 'fp32' and wl.size(0) <= min(64, FUSE_BWD_MAX_COUT) and wl.size(1) <= 64 and
+                      wl.size(0) % 4 == 0 and wl.size(1) % 4 == 0)
         off = 0
         for i in range(nl):
             w, gamma, beta = params[3 * i], params[3 * i + 1], params[3 * i + 2]
@@ -488,6 +496,29 @@ class MLPChainRows(torch.autograd.Function):
                     L.call('mvp_colstats_f32', y, L.ptr(y), R, cout, L.ptr(stat), L.ptr(_cs_partial(R, cout, dev)))
             else:
                 cout, cin = w.size(0), w.size(1)
+                if pooled and i == nl - 1:
+                    # last layer of a set-abstraction MLP: batch statistics + per-ball max / min of the pre-BN output, no (R, cout) tensor
+                    G = R // K
+                    rm, rv, nbt = bn_buffers[i]
+                    mean = torch.empty(cout, dtype=torch.float32, device=dev)
+                    invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+                    ymax = torch.empty((G, cout), dtype=torch.float32, device=dev)
+                    ymin = torch.empty((G, cout), dtype=torch.float32, device=dev)
+                    amax = torch.empty((G, cout), dtype=torch.uint8, device=dev)
+                    amin = torch.empty((G, cout), dtype=torch.uint8, device=dev)
+                    L.call('mvp_mlp_forward_pool_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
+                           L.ptr(act[2]), L.ptr(act[3]), L.ptr(ymax), L.ptr(ymin), L.ptr(amax), L.ptr(amin), L.ptr(stat),
+                           L.ptr(torch.empty(((R + 127) // 128) * 2 * cout, dtype=torch.float64, device=dev)), float(eps), float(mom),
+                           L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.ptr(nbt))
+                    out = torch.empty((G, cout), dtype=torch.float32, device=dev)
+                    arg = torch.empty((G, cout), dtype=torch.uint8, device=dev)
+                    ysel = torch.empty((G, cout), dtype=torch.float32, device=dev)
+                    L.call('mvp_pool_finalize_f32', ymax, L.ptr(ymax), L.ptr(ymin), L.ptr(amax), L.ptr(amin), L.ptr(mean), L.ptr(invstd),
+                           L.ptr(gamma), L.ptr(beta), G, cout, 1, L.ptr(out), L.ptr(arg), L.ptr(ysel))
+                    ys.append(ysel)  # stands in for y_L in the saved list: (G, cout), the pre-BN value behind each pooled output
+                    means.append(mean)
+                    invstds.append(invstd)
+                    break
                 y = torch.empty((R, cout), dtype=torch.float32, device=dev)
                 if training and R > 0:
                     # forward + batch statistics + BatchNorm finalize (mean / invstd / running statistics) in one call: the finalize
@@ -521,8 +552,10 @@ class MLPChainRows(torch.autograd.Function):
             x = y
         cl = ys[-1].size(1)
         G = R // K
-        out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, pool_sum)
+        if not pooled:
+            out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, pool_sum)
         ctx.first_linear = params[0] is not None
+        ctx.pooled = pooled
         ctx.save_for_backward(x0, out, arg, *ys, *means, *invstds, *[p for p in params if p is not None])
         ctx.cfg = (nl, training, K, R)
         return out
@@ -544,7 +577,18 @@ class MLPChainRows(torch.autograd.Function):
         G = R // K
         # last layer: through max-over-K + ReLU + BN
         cl = ys[-1].size(1)
-        dy, dgam, dbet = _bn_backward(g, out, arg, ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, training)
+        pool = None
+        if ctx.pooled:
+            # the last layer's (R, cl) output does not exist: its BatchNorm-backward column sums come from the (G, cl) tensors, dy_L is
+            # formed inside the one-kernel layer backward from the re-computed y_L
+            ysel = ys[-1]
+            stat_l = torch.empty(2 * cl, dtype=torch.float64, device=g.device)
+            L.call('mvp_pool_backward_stats_f32', g, L.ptr(g), L.ptr(out), L.ptr(ysel), L.ptr(means[-1]), L.ptr(invstds[-1]), G, cl, 1,
+                   L.ptr(stat_l), L.ptr(_cs_partial(G, cl, g.device)))
+            pool = (g, out, arg)
+            dy, dgam, dbet = None, None, None
+        else:
+            dy, dgam, dbet = _bn_backward(g, out, arg, ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, training)
         dx0 = None
         none4 = (None, None, None, None)
         # `dW` and `stat` are accumulated into by the kernels: two zeroed arenas for the whole chain
@@ -552,20 +596,23 @@ class MLPChainRows(torch.autograd.Function):
         dw_arena = zero_pool.zeros(sum(w_numel), torch.float32, g.device)
         st_arena = zero_pool.zeros(2 * sum(params[3 * i].size(1) for i in range(1, nl)), torch.float64, g.device)
         dw_off, st_off = 0, 0
-        dev = dy.device
+        dev = g.device
         split = L.get_mlp_precision() != 'fp32'   # the one-kernel layer backward (mvp_mlp_layer_backward_f32) contracts in split-bf16 only
         # State while walking the layers backwards: `gcur` is either dy_i itself (pending is None) or dz_i = the gradient w.r.t.
         # layer i's ACTIVATION already masked by its ReLU, with `pending` = its two BatchNorm-backward column sums: the "finish"
         # step (dz_i -> dy_i) then happens INSIDE the fused layer kernel, or as its own pass when the layer cannot be fused.
         gcur, pending = dy, None
+        if pool is not None:
+            gcur, pending = None, stat_l
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
             cout = ys[i].size(1)
             need_dz = (i > 0 or ctx.needs_input_grad[0]) and w is not None
             cin = 0 if w is None else w.size(1)
             src = None if w is None else (x0 if i == 0 else ys[i - 1])
-            fuse = split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and (not need_dz or cin % 4 == 0) and \
-                (i > 0 or src.size(1) == cin or not need_dz)
+            pool_here = pool is not None and i == nl - 1
+            fuse = pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and
+                                 (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
             if pending is not None and not fuse:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)
                 dyi = torch.empty((R, cout), dtype=torch.float32, device=dev)
@@ -591,11 +638,12 @@ class MLPChainRows(torch.autograd.Function):
             if fuse:
                 dgb = torch.empty((2, cout), dtype=torch.float32, device=dev) if pending is not None else None
                 part = torch.empty(L.lib().mvp_mlp_layer_backward_partial_count(R, cin), dtype=torch.float64, device=dev) if (i > 0 and need_dz) else None
-                L.call('mvp_mlp_layer_backward_f32', gcur, L.ptr(gcur), L.ptr(ys[i]) if pending is not None else None,
+                L.call('mvp_mlp_layer_backward_f32', src, L.ptr(gcur), L.ptr(ys[i]) if (pending is not None and not pool_here) else None,
                        L.ptr(means[i]) if pending is not None else None, L.ptr(invstds[i]) if pending is not None else None,
                        L.ptr(params[3 * i + 1]) if pending is not None else None, L.ptr(pending), L.ptr(None if dgb is None else dgb[0]),
                        L.ptr(None if dgb is None else dgb[1]), int(training), L.ptr(src), src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]),
-                       L.ptr(act[3]), L.ptr(w), cin, R, cout, cin, L.ptr(dw), cin, L.ptr(dz), L.ptr(stat), L.ptr(part))
+                       L.ptr(act[3]), L.ptr(w), cin, R, cout, cin, L.ptr(dw), cin, L.ptr(dz), L.ptr(stat), L.ptr(part),
+                       L.ptr(pool[0]) if pool_here else None, L.ptr(pool[1]) if pool_here else None, L.ptr(pool[2]) if pool_here else None)
                 if pending is not None:
                     grads[3 * i + 1], grads[3 * i + 2] = dgb[0], dgb[1]
             else:

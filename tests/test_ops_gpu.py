@@ -843,7 +843,7 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
                     L.call('mvp_mlp_layer_backward_f32', gsrc, L.ptr(gsrc), L.ptr(yi) if finish else None, L.ptr(mean_i) if finish else None,
                            L.ptr(invstd_i) if finish else None, L.ptr(gamma_i) if finish else None, L.ptr(stat_i) if finish else None,
                            L.ptr(dgb[0]) if finish else None, L.ptr(dgb[1]) if finish else None, 1, L.ptr(x), ldx, *[L.ptr(t) for t in act],
-                           L.ptr(w), Cp, R, C, Cp, L.ptr(dw), Cp + 3, L.ptr(dz), L.ptr(stat), L.ptr(part))
+                           L.ptr(w), Cp, R, C, Cp, L.ptr(dw), Cp + 3, L.ptr(dz), L.ptr(stat), L.ptr(part), None, None, None)
                     tag = 'finish={} act={} dz={}'.format(finish, use_act, want_dz)
                     sw = max(1.0, float(ref_dw.abs().max()))
                     np.testing.assert_allclose(dw[:, :Cp].cpu().numpy(), ref_dw.cpu().numpy(), rtol=1e-4 * loose, atol=3e-5 * sw * loose, err_msg=tag)
@@ -897,3 +897,45 @@ def test_mlp_forward_with_bn_finalize(dev, R, Cin, Cout, stream):
                 np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-7)
     finally:
         L.lib().mvp_set_mlp_stream(old)
+
+
+@pytest.mark.parametrize('chain', [(32, (32, 64)), (64, (64, 64, 64)), (16, (32, 32))])
+def test_pooled_last_layer_without_its_output_tensor(dev, chain):
+    """Set-abstraction MLP chains (K = 32, max pooling) with the last layer run WITHOUT its (rows, C) output (mvp_mlp_forward_pool_f32 +
+    mvp_pool_finalize_f32 forward; pooled statistics + the POOL front end of mvp_mlp_layer_backward_f32 backward) against the same
+    chain with the tensor materialised: pooled output, BatchNorm running statistics, input gradient and every parameter gradient."""
+    import copy
+    from mvpnet_amd.nn import SharedMLP
+    from mvpnet_amd import rows as R
+    cin, widths = chain
+    torch.manual_seed(cin)
+    base = SharedMLP(cin, widths, ndim=2, bn=True).to(dev).train()
+    for m in base.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    base[len(widths) - 1].bn.weight.data[::5] *= -1.0  # negative scales: the pooled value is then the group MINIMUM
+    G, K = 2048, 32
+    x0 = torch.randn(G * K, cin, device=dev)
+    x0[: 5 * K] = x0[:K].repeat(5, 1)  # duplicated rows inside / across groups: arg-max ties
+    wgt = torch.randn(G, widths[-1], device=dev)
+    res = []
+    old = R.POOL_WITHOUT_Y
+    try:
+        for flag in (False, True):
+            R.POOL_WITHOUT_Y = flag
+            mlp = copy.deepcopy(base)
+            x = x0.clone().requires_grad_(True)
+            out = R.shared_mlp_rows(x, mlp, K=K)
+            (out * wgt).sum().backward()
+            res.append((out.detach(), x.grad, [p.grad for p in mlp.parameters()], [b.clone() for b in mlp.buffers()]))
+    finally:
+        R.POOL_WITHOUT_Y = old
+    (o0, gx0, gp0, b0), (o1, gx1, gp1, b1) = res
+    np.testing.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    sx = float(gx0.abs().max())
+    np.testing.assert_allclose(gx1.cpu().numpy(), gx0.cpu().numpy(), rtol=1e-3, atol=2e-4 * sx)
+    for a, b in zip(gp0, gp1):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=2e-4 * float(a.abs().max()))
+    for a, b in zip(b0, b1):
+        np.testing.assert_allclose(b.float().cpu().numpy(), a.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
