@@ -126,3 +126,70 @@ def test_two_ranks_one_gpu(tmp_path):
     mean2, label2, cnt2 = infer_scene(model, batches, chunk_inds, 3000)
     np.testing.assert_allclose(mean2.cpu().numpy(), mean.cpu().numpy(), rtol=0, atol=1e-5)
     assert torch.equal(cnt2, cnt)
+
+
+RAGGED = [1024, 640, 300]   # points per chunk; the last is below min_nb_pts = 512 and gets padded by duplication (test_mvpnet_3d.py:146-154)
+
+
+def _ragged_batch(i, dev, model):
+    """one chunk with ITS OWN number of points (the reference feeds every chunk whole, nb_pts = -1), padded like the reference pads"""
+    from mvpnet_amd.synthetic import make_chunk
+    from mvpnet_amd.scene import pad_sparse_chunk
+    c = make_chunk(700 + i, **dict(KW, nb_pts=RAGGED[i]))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    nv = KW['nv']
+    one = pad_sparse_chunk({'points': t(c['points'].T)}, min_nb_pts=512, generator=torch.Generator().manual_seed(i))
+    batch = {'images': torch.zeros(1, nv, 3, KW['h'], KW['w'], device=dev), 'points': one['points'].unsqueeze(0).contiguous(),
+             'depth': t(c['depth_mm'].astype(np.int16)[None]), 'cam_matrix': t(np.repeat(c['cam_matrix'][None, :3, :3], nv, 0)[None]),
+             'kinv': t(c['kinv'][None]), 'pose': t(c['pose'][None]), 'pixel_box': t(c['pixel_box'][None]), 'k': 3}
+    model.net_2d.table[batch['images'].data_ptr()] = t(c['feature_2d']).view(nv, KW['h'], KW['w'], KW['channels']).permute(0, 3, 1, 2)
+    return batch
+
+
+def _ragged_inds(dev):
+    rs = np.random.RandomState(21)
+    return [torch.from_numpy(rs.choice(2500, n, replace=False)).to(dev) for n in RAGGED]  # len = the chunk's TRUE point count
+
+
+def _worker_ragged(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      MVP_DIST_BACKEND='gloo')
+    from mvpnet_amd import dist as D
+    from mvpnet_amd.scene import infer_scene
+    dev = torch.device('cuda:0')
+    D.init_from_env()
+    model = _model(dev).eval()
+    mine = D.shard_chunks(len(RAGGED), rank, world)
+    batches = [_ragged_batch(i, dev, model) for i in mine]
+    mean, label, cnt = infer_scene(model, batches, _ragged_inds(dev), 2500)
+    # a scene with ONE chunk: rank 1 owns nothing and still takes part in the collective
+    m1, l1, c1 = infer_scene(model, [_ragged_batch(0, dev, model)] if rank == 0 else [], _ragged_inds(dev)[:1], 2500)
+    torch.save({'mean': mean.cpu(), 'label': label.cpu(), 'cnt': cnt.cpu(), 'm1': m1.cpu(), 'c1': c1.cpu()}, os.path.join(tmp, 'g{}.pt'.format(rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_chunks_and_empty_rank(tmp_path):
+    """Whole-scene inference with chunks of DIFFERENT sizes (1024 / 640 / 300 -> padded to 512 points) over two ranks, and a scene with
+    fewer chunks than ranks: every rank's vote equals the reference's sequential loop (one chunk at a time, logits cut to the chunk's
+    true length, test_mvpnet_3d.py:142-174)."""
+    assert torch.cuda.is_available()
+    mp.spawn(_worker_ragged, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [torch.load(os.path.join(str(tmp_path), 'g{}.pt'.format(r))) for r in range(2)]
+    for k in ('mean', 'label', 'cnt', 'm1', 'c1'):
+        assert torch.equal(r0[k], r1[k]), k
+    from oracle import c_oracle as O
+    dev = torch.device('cuda:0')
+    model = _model(dev).eval()
+    inds = _ragged_inds(dev)
+    chunks = []
+    with torch.no_grad():
+        for i in range(len(RAGGED)):
+            logit = model(_ragged_batch(i, dev, model))['seg_logit'][0]            # (C, N_i padded)
+            chunks.append((inds[i].cpu().numpy(), logit[:, :RAGGED[i]].t().contiguous().cpu().numpy()))
+    mean, label, cnt = O.vote(chunks, 2500, 20)
+    np.testing.assert_allclose(r0['mean'].numpy(), mean, rtol=0, atol=1e-5)
+    assert np.array_equal(r0['cnt'].numpy(), cnt) and (r0['label'].numpy() == label).mean() > 0.999
+    m1, l1, c1 = O.vote(chunks[:1], 2500, 20)
+    np.testing.assert_allclose(r0['m1'].numpy(), m1, rtol=0, atol=1e-5)
+    assert np.array_equal(r0['c1'].numpy(), c1)
