@@ -263,6 +263,23 @@ int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float
  * stat = [sum y | sum y^2] over R rows */
 int mvp_bn_finalize_f32(const double* stat, int64_t R, int64_t C, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
+/* ---- fused set-abstraction level, inference (csrc/sa_fused.hip) --------------------------------------------------------------
+ * gather of the ball's K = 32 neighbours -> first layer (zf = its feature columns applied per point, + coordinate columns on the
+ * centred xyz) -> BN + ReLU -> layer 2 -> BN + ReLU -> layer 3 -> BN + ReLU -> max over the neighbours, in ONE kernel: nothing between
+ * the gathered rows and the (B,M,C3) output touches HBM (reference: QueryGrouper + SharedMLP(ndim=2) + torch.max,
+ * mvpnet/models/pn2/modules.py:20-37,100-108).  One wave per ball, activations between layers staged through a wave-private LDS tile,
+ * both weight matrices resident in LDS, split-bf16 MFMA.
+ *   zf (B,N,C1) or NULL, xyz (B,N,3), centre (B,M,3), index (B,M,32) int64 (-1 = empty slot), wxyz (C1,3);
+ *   bnL_* = mean, invstd (= 1/sqrt(running_var + eps)), gamma, beta of layer L; W2 (C2,C1), W3 (C3,C2) row-major;
+ *   out (B,M,C3), arg (B,M,C3) uint8 or NULL (first neighbour attaining the maximum).
+ * MVP_EUNSUPPORTED unless K == 32, C1, C2 <= 64, C3 <= 128, all % 4 == 0 and a split-bf16 precision is set. */
+int mvp_sa_fused_forward_f32(const float* zf, const float* xyz, const float* centre, const int64_t* index, const float* wxyz, int64_t B,
+                             int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd,
+                             const float* bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean,
+                             const float* bn2_invstd, const float* bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3,
+                             const float* bn3_mean, const float* bn3_invstd, const float* bn3_gamma, const float* bn3_beta, float* out,
+                             uint8_t* arg, mvp_stream_t stream);
+
 /* Contraction precision of the three shared-MLP entry points below (process-wide):
  *   terms = 0  fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain);
  *   terms = 6  (the default) split-bf16: every fp32 operand as 3 bf16 pieces, the 6 products of order <= 2 on v_mfma_f32_32x32x16_bf16 with fp32

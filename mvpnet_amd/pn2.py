@@ -117,6 +117,11 @@ class SetAbstraction(nn.Module):
                 f = torch.nn.functional.pad(feature, (0, pad)) if pad else feature
                 zf = R.linear_rows(f.reshape(B * N, -1), l0.conv.weight, cols=(0, cf)).view(B, N, c1)
             bn_training = l0.bn.training
+            if not bn_training and not torch.is_grad_enabled():
+                # inference: gather -> 3 layers -> max in ONE kernel, nothing between the gathered rows and (B,M,C_3) touches HBM
+                fused = R.sa_fused_eval(zf, xyz, new_xyz, ball, self.mlp)
+                if fused is not None:
+                    return new_xyz, fused
             y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=bn_training, csr=csr)  # (B,M,K,C_1): conv output of layer 1
             stat1 = None
             if bn_training:

@@ -739,6 +739,36 @@ def linear_rows(x, weight, bias=None, cols=None):
     return LinearRows.apply(x.contiguous(), weight, bias, c0, c1)
 
 
+SA_FUSED_EVAL = os.environ.get('MVP_SA_FUSED', '1') != '0'
+
+
+def sa_fused_eval(zf, xyz, centre, index, mlp):
+    """A whole set-abstraction level in ONE kernel, inference mode (mvp_sa_fused_forward_f32, csrc/sa_fused.hip): zf (B,N,C1) = the first
+    layer's feature columns applied per point (or None), xyz (B,N,3), centre (B,M,3), index (B,M,32), mlp = the level's 3-layer
+    SharedMLP in eval mode -> (B,M,C3), or None when the level does not qualify (the caller then runs the per-layer kernels)."""
+    if not (SA_FUSED_EVAL and len(mlp) == 3 and mlp_chain_is_fused(mlp) and index.size(2) == 32 and L.get_mlp_precision() != 'fp32'):
+        return None
+    c1, c2, c3 = (l.conv.weight.size(0) for l in mlp)
+    if c1 > 64 or c2 > 64 or c3 > 128 or c1 % 4 or c2 % 4 or c3 % 4 or any(l.bn.training for l in mlp):
+        return None
+    L.require_gpu(xyz, centre, index)
+    B, N, _ = xyz.shape
+    M = centre.size(1)
+    bn = []
+    for l in mlp:
+        bn += [l.bn.running_mean, eval_invstd.get(l.bn.running_var, l.bn.eps), l.bn.weight, l.bn.bias]
+    w1 = mlp[0].conv.weight.detach().reshape(c1, -1)
+    wxyz = w1[:, -3:].contiguous()
+    w2 = mlp[1].conv.weight.detach().reshape(c2, c1).contiguous()
+    w3 = mlp[2].conv.weight.detach().reshape(c3, c2).contiguous()
+    out = torch.empty((B, M, c3), dtype=torch.float32, device=xyz.device)
+    zfc = None if zf is None else zf.contiguous()
+    L.call('mvp_sa_fused_forward_f32', xyz, L.ptr(zfc), L.ptr(xyz.contiguous()), L.ptr(centre.contiguous()), L.ptr(index.contiguous()), L.ptr(wxyz),
+           B, N, M, 32, c1, *[L.ptr(t.detach().contiguous()) for t in bn[0:4]], L.ptr(w2), c2, *[L.ptr(t.detach().contiguous()) for t in bn[4:8]],
+           L.ptr(w3), c3, *[L.ptr(t.detach().contiguous()) for t in bn[8:12]], L.ptr(out), None)
+    return out
+
+
 def mlp_chain_is_fused(mlp, dropout_p=0.0):
     """True when `mlp` (a SharedMLP) runs as ONE MLPChainRows node: conv without bias + BatchNorm with running statistics + ReLU
     in every layer, widths the rows kernels tile (C % 4 == 0 and C / 4 divides 256), dropout only behind a single layer."""

@@ -939,3 +939,47 @@ def test_pooled_last_layer_without_its_output_tensor(dev, chain):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=2e-4 * float(a.abs().max()))
     for a, b in zip(b0, b1):
         np.testing.assert_allclose(b.float().cpu().numpy(), a.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('cin,widths,N,M', [(64, (32, 32, 64), 2048, 512), (64, (64, 64, 128), 1024, 256), (0, (32, 32, 64), 1500, 300),
+                                            (16, (16, 48, 20), 700, 129)])
+def test_sa_fused_inference_kernel(dev, cin, widths, N, M):
+    """mvp_sa_fused_forward_f32 (gather -> 3 layers -> max in ONE kernel, LDS-staged per-ball neighbourhoods) against the per-layer
+    kernels of the same SetAbstraction module in eval mode: same centroids (bit-exact), pooled features to fp32 rounding; with and
+    without input features, channel counts that are not multiples of 32, ball queries with padded (duplicated) and empty slots."""
+    from mvpnet_amd.pn2 import SetAbstraction
+    from mvpnet_amd import rows as R
+    torch.manual_seed(N + cin)
+    sa = SetAbstraction(cin, widths, M, 0.12, 32, use_xyz=True).to(dev).eval()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    sa.mlp[2].bn.weight.data[::3] *= -1.0
+    B = 3
+    xyz = torch.rand(B, N, 3, device=dev)
+    feat = torch.randn(B, N, cin, device=dev) if cin else None
+    res = []
+    old = R.SA_FUSED_EVAL
+    try:
+        for flag in (False, True):
+            R.SA_FUSED_EVAL = flag
+            with torch.no_grad():
+                res.append(sa(xyz, feat, rows=True))
+    finally:
+        R.SA_FUSED_EVAL = old
+    (x0, f0), (x1, f1) = res
+    assert torch.equal(x0, x1) and f0.shape == f1.shape == (B, M, widths[-1])
+    np.testing.assert_allclose(f1.cpu().numpy(), f0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # a ball query with empty slots (index -1): zero rows, exactly like the unfused gather
+    geo = list(sa.geometry(xyz))
+    geo[1] = geo[1].clone()
+    geo[1][:, ::7, 20:] = -1
+    for flag in (False, True):
+        R.SA_FUSED_EVAL = flag
+        with torch.no_grad():
+            res.append(sa(xyz, feat, rows=True, geometry=tuple(geo))[1])
+    R.SA_FUSED_EVAL = old
+    np.testing.assert_allclose(res[3].cpu().numpy(), res[2].cpu().numpy(), rtol=1e-5, atol=1e-5)

@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/ctr_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --train-only"
+cmd="python $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --train-only"
 env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- $cmd > $out/trace.log 2>&1
 env "$@" rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- $cmd > $out/fetch.log 2>&1
 env "$@" rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- $cmd > $out/write.log 2>&1
