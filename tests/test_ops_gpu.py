@@ -942,7 +942,7 @@ def test_pooled_last_layer_without_its_output_tensor(dev, chain):
 
 
 @pytest.mark.parametrize('cin,widths,N,M', [(64, (32, 32, 64), 2048, 512), (64, (64, 64, 128), 1024, 256), (0, (32, 32, 64), 1500, 300),
-                                            (16, (16, 48, 20), 700, 129)])
+                                            (16, (16, 64, 32), 700, 129)])
 def test_sa_fused_inference_kernel(dev, cin, widths, N, M):
     """mvp_sa_fused_forward_f32 (gather -> 3 layers -> max in ONE kernel, LDS-staged per-ball neighbourhoods) against the per-layer
     kernels of the same SetAbstraction module in eval mode: same centroids (bit-exact), pooled features to fp32 rounding; with and
