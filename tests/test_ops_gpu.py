@@ -983,3 +983,32 @@ def test_sa_fused_inference_kernel(dev, cin, widths, N, M):
             res.append(sa(xyz, feat, rows=True, geometry=tuple(geo))[1])
     R.SA_FUSED_EVAL = old
     np.testing.assert_allclose(res[3].cpu().numpy(), res[2].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'clusters', 'lattice', 'duplicates', 'coincident', 'plane'])
+@pytest.mark.parametrize('N,M', [(8192, 2048), (5000, 1300), (4096, 4096), (3000, 700)])
+def test_fps_bucketed_exact(dev, kind, N, M):
+    """The bucketed FPS (Morton-ordered sub-buckets skipped by a distance lower bound, csrc/fps.hip) is EXACT: indices equal the
+    oracle's (first maximum = lowest index) on uniform, clustered, 2 cm-lattice (many exact ties), duplicated (padding), all-coincident
+    and planar clouds; M = N exercises the all-zero tail."""
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(N + M + len(kind))
+    if kind == 'uniform':
+        pts = rs.rand(2, N, 3)
+    elif kind == 'clusters':
+        c = rs.rand(2, 7, 3) * 2.0
+        pts = c[:, rs.randint(0, 7, N)] + 0.03 * rs.randn(2, N, 3)
+    elif kind == 'lattice':
+        pts = np.round(rs.rand(2, N, 3) * 1.9 / 0.02) * 0.02
+    elif kind == 'duplicates':
+        base = rs.rand(2, N * 3 // 4, 3)
+        pts = np.concatenate([base, base[:, rs.randint(0, base.shape[1], N - base.shape[1])]], 1)
+    elif kind == 'coincident':
+        pts = np.tile(rs.rand(2, 1, 3), (1, N, 1))
+    else:
+        pts = rs.rand(2, N, 3) * np.array([1.9, 1.9, 0.0]) + np.array([0.0, 0.0, 0.7])
+    pts = pts.astype(np.float32)
+    if M == N and kind not in ('uniform', 'duplicates'):
+        M = N // 2  # keep the oracle's O(N M) run short
+    idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
+    np.testing.assert_array_equal(idx, O().fps(pts, M))
