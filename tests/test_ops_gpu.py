@@ -987,10 +987,9 @@ def test_sa_fused_inference_kernel(dev, cin, widths, N, M):
 
 @pytest.mark.parametrize('kind', ['uniform', 'clusters', 'lattice', 'duplicates', 'coincident', 'plane'])
 @pytest.mark.parametrize('N,M', [(8192, 2048), (5000, 1300), (4096, 4096), (3000, 700)])
-def test_fps_bucketed_exact(dev, kind, N, M):
-    """The bucketed FPS (Morton-ordered sub-buckets skipped by a distance lower bound, csrc/fps.hip) is EXACT: indices equal the
-    oracle's (first maximum = lowest index) on uniform, clustered, 2 cm-lattice (many exact ties), duplicated (padding), all-coincident
-    and planar clouds; M = N exercises the all-zero tail."""
+def test_fps_exact_on_structured_clouds(dev, kind, N, M):
+    """FPS at the 3000 - 8192-point sizes is EXACT: indices equal the oracle's (first maximum = lowest index) on uniform, clustered,
+    2 cm-lattice (many exact ties), duplicated (padding), all-coincident and planar clouds; M = N exercises the all-zero tail."""
     from mvpnet_amd.ops import farthest_point_sample
     rs = np.random.RandomState(N + M + len(kind))
     if kind == 'uniform':
