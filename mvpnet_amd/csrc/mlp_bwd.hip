@@ -171,34 +171,50 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
   const int64_t ntiles = (p.R + 31) / 32;
   const int64_t t_begin = (int64_t)blockIdx.x * p.tiles_per_wg;
   const int64_t t_end = min(ntiles, t_begin + p.tiles_per_wg);
-  for (int64_t t = t_begin + wave; t < t_end; t += 4) {
-    const int64_t r0 = t * 32;
-    // ---- loads: 16 rows per lane (8 m + 4 h + e), 4 bytes each; rows / columns past the tensor are clamped and masked below
-    float x[CPB][16], gn[16], yn[16];
-    bool rok[16];
-    // 32-bit offsets from per-tile (wave-uniform) base pointers: 64-bit per-element addresses cost two registers each
-    const int lim = (int)min((int64_t)31, p.R - 1 - r0);      // last valid local row of this tile
-    const float* Gt = p.G + (size_t)r0 * C;
-    const float* Yt = finish ? p.Yi + (size_t)r0 * C : p.G;
-    const float* Xt = p.X + (size_t)r0 * p.ldx + ci0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) rok[q] = 8 * (q >> 2) + 4 * h + (q & 3) <= lim;
-    auto load_g = [&](int a) {  // channel block a of dz_i / dy_i (and y_i): issued one block ahead of its use
-      const int col = min(32 * a + c, C - 1);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int off = min(8 * (q >> 2) + 4 * h + (q & 3), lim) * C + col;
-        gn[q] = Gt[off];
-        yn[q] = finish ? Yt[off] : 0.f;
-      }
-    };
+  // Cross-tile prefetch: y_{i-1} of the wave's NEXT tile (xn) and channel block 0 of its dz_i / y_i (gn, yn) are requested while
+  // the current tile is being worked on -- a wave has no other way to hide the ~2 us of an HBM round trip (1 - 2 waves per SIMD).
+  float xn[CPB][16], gn[16], yn[16];
+  auto tile_lim = [&](int64_t tt) { return (int)min((int64_t)31, p.R - 1 - tt * 32); };
+  auto load_x = [&](int64_t tt) {
+    const int lim = tile_lim(tt);
+    const float* Xt = p.X + (size_t)tt * 32 * p.ldx + ci0;
 #pragma unroll
     for (int b = 0; b < CPB; ++b) {
       const int col = xok[b] ? 32 * b + c : Cp - 1;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) x[b][q] = Xt[min(8 * (q >> 2) + 4 * h + (q & 3), lim) * p.ldx + col];
+      for (int q = 0; q < 16; ++q) xn[b][q] = Xt[min(8 * (q >> 2) + 4 * h + (q & 3), lim) * p.ldx + col];
     }
-    if constexpr (!POOL) load_g(0);
+  };
+  auto load_g = [&](int64_t tt, int a) {  // channel block a of dz_i / dy_i (and y_i) of tile tt: issued one block ahead of its use
+    const int lim = tile_lim(tt);
+    const float* Gt = p.G + (size_t)tt * 32 * C;
+    const float* Yt = finish ? p.Yi + (size_t)tt * 32 * C : p.G;
+    const int col = min(32 * a + c, C - 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int off = min(8 * (q >> 2) + 4 * h + (q & 3), lim) * C + col;
+      gn[q] = Gt[off];
+      yn[q] = finish ? Yt[off] : 0.f;
+    }
+  };
+  if (t_begin + wave < t_end) {
+    load_x(t_begin + wave);
+    if constexpr (!POOL) load_g(t_begin + wave, 0);
+  }
+  for (int64_t t = t_begin + wave; t < t_end; t += 4) {
+    const int64_t r0 = t * 32;
+    // ---- this tile's y_{i-1}: 16 rows per lane (8 m + 4 h + e); rows / columns past the tensor were clamped and are masked below
+    float x[CPB][16];
+    bool rok[16];
+    const int lim = tile_lim(t);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rok[q] = 8 * (q >> 2) + 4 * h + (q & 3) <= lim;
+#pragma unroll
+    for (int b = 0; b < CPB; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x[b][q] = xn[b][q];
+    const bool more = t + 4 < t_end;
+    if (more) load_x(t + 4);
     // ---- a_{i-1}: activation + split, both row steps (operand B of dW for every channel block of dy)
     u32x4 fb[CPB][2][NS];
     u32x4 far[POOL ? CPB : 1][2][NS];
@@ -291,7 +307,8 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
           }
           dyv[q] = (rok[q] && cok[a]) ? d : 0.f;
         }
-        if (a + 1 < CB) load_g(a + 1);  // in flight under this block's MFMAs
+        if (a + 1 < CB) load_g(t, a + 1);      // in flight under this block's MFMAs
+        else if (more) load_g(t + 4, 0);       // ... and the next tile's first block under the last one's
       }
       // ---- dW[a][:] += dy^T . a : two row steps, operands straight from the registers
 #pragma unroll
