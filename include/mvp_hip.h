@@ -288,6 +288,9 @@ int mvp_sa_fused_forward_f32(const float* zf, const float* xyz, const float* cen
  * Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Returns MVP_EINVAL for other values. */
 int mvp_set_mlp_precision(int terms, int min_width);
 int mvp_get_mlp_precision(void);
+/* Split of the gradient contractions (dW, input gradient, mvp_mlp_layer_backward_f32) while the forward precision is a split one:
+ * terms = 3 (default) or 6. */
+int mvp_set_mlp_precision_backward(int terms);
 /* Switch (returns the previous value): 1 = long narrow forward layers (>= 32768 rows, C_in, C_out <= 128) run on the persistent
  * streaming kernel with the weight matrix resident in LDS; 0 (default: measured 1.2 % faster on the bench step) = the per-tile kernel. */
 int mvp_set_mlp_stream(int on);

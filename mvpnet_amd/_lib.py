@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmvp_hip.so')
 _lib = None
+MLP_PRECISIONS = {'fp32': 0, 'bf16x3': 3, 'bf16x6': 6}
 
 _i64 = ctypes.c_int64
 _ptr = ctypes.c_void_p
@@ -82,7 +83,7 @@ _SIGNATURES = {
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
-           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream'] + sorted(_SIGNATURES)
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -117,13 +118,16 @@ def lib():
         handle.mvp_set_mlp_stream.argtypes = [ctypes.c_int]
         if os.environ.get('MVP_MLP_STREAM') is not None:
             handle.mvp_set_mlp_stream(int(os.environ['MVP_MLP_STREAM']))
+        handle.mvp_set_mlp_precision_backward.restype = ctypes.c_int
+        handle.mvp_set_mlp_precision_backward.argtypes = [ctypes.c_int]
+        if os.environ.get('MVP_MLP_PRECISION_BWD'):
+            check(handle.mvp_set_mlp_precision_backward(MLP_PRECISIONS[os.environ['MVP_MLP_PRECISION_BWD']]), 'mvp_set_mlp_precision_backward')
         env = os.environ.get('MVP_MLP_PRECISION')
         if env:
             set_mlp_precision(env, int(os.environ.get('MVP_MLP_MIN_WIDTH', '0')))
     return _lib
 
 
-MLP_PRECISIONS = {'fp32': 0, 'bf16x3': 3, 'bf16x6': 6}
 
 
 def set_mlp_precision(name, min_width=0):
@@ -133,6 +137,14 @@ def set_mlp_precision(name, min_width=0):
     if name not in MLP_PRECISIONS:
         raise ValueError('mlp precision must be one of {}'.format(sorted(MLP_PRECISIONS)))
     check(lib().mvp_set_mlp_precision(MLP_PRECISIONS[name], int(min_width)), 'mvp_set_mlp_precision')
+
+
+def set_mlp_precision_backward(name):
+    """Split of the gradient contractions (weight / input gradient, one-kernel layer backward) while the forward runs a split
+    precision: 'bf16x3' (default: 2^-17 per product, invisible next to the ~1 % fp32 noise of these gradients) or 'bf16x6'."""
+    if name not in ('bf16x3', 'bf16x6'):
+        raise ValueError("backward mlp precision must be 'bf16x3' or 'bf16x6'")
+    check(lib().mvp_set_mlp_precision_backward(MLP_PRECISIONS[name]), 'mvp_set_mlp_precision_backward')
 
 
 def get_mlp_precision():

@@ -30,6 +30,7 @@ int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const fl
                            uint8_t* amax, uint8_t* amin, hipStream_t s);
 
 int g_mlp_terms = 6;       // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (default: fp32-level accuracy, measured) -- mvp_set_mlp_precision; shared with mlp_bwd.hip
+int g_mlp_terms_bwd = 3;   // gradient contractions: 3 products (2^-17 per product, far below the 1 % fp32 noise of the gradients themselves; measured)
 int g_mlp_min_width = 0;   // layers with max(Cin, Cout) below this stay on the fp32 MFMA
 int g_mlp_stream = 0;      // 1: long narrow forward layers take mlp_stream.hip (MVP_MLP_STREAM=0 / mvp_set_mlp_stream(0): tile kernel everywhere)
 
@@ -839,7 +840,8 @@ void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int l
   int bn = N <= 32 ? 32 : N <= 64 ? 64 : 128;
   while (bn > 32 && (int64_t)gx * cdiv(N, bn) < 256) bn >>= 1;
   // split-bf16 contraction (mvp_set_mlp_precision): vector path only, and only for layers at least g_mlp_min_width wide
-  const int ns = (vec && std::max(K, N) >= g_mlp_min_width) ? (g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0) : 0;
+  const int fwd_pieces = g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0;
+  const int ns = (vec && std::max(K, N) >= g_mlp_min_width) ? (WT ? mlp_bwd_pieces() : fwd_pieces) : 0;
 #define MVP_MLP_BY_NS(BN)                                                                                                          \
   do {                                                                                                                             \
     if (!vec) MVP_MLP_LAUNCH(BN, false, 0);                                                                                        \
@@ -979,7 +981,7 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
   {
     // split-bf16 contraction (mvp_set_mlp_precision): any alignment (the operand loads are 4-byte), layers at least
     // g_mlp_min_width wide; Cin >= 8 (the 4-column coordinate operand of the first set-abstraction layer stays on fp32)
-    const int ns = (std::max(Cin, Cout) >= g_mlp_min_width && Cin >= 8) ? (g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0) : 0;
+    const int ns = (std::max(Cin, Cout) >= g_mlp_min_width && Cin >= 8) ? mlp_bwd_pieces() : 0;
     if (ns != 0) {
       int64_t splits = std::min<int64_t>(cdiv(1024, tiles), 512);
       int64_t rows_per_block = cdiv(cdiv(R, splits), 64) * 64;
@@ -1074,6 +1076,14 @@ MVP_API int mvp_set_mlp_precision(int terms, int min_width) {
   return MVP_OK;
 }
 MVP_API int mvp_get_mlp_precision(void) { return g_mlp_terms; }
+// Split of the GRADIENT contractions (weight gradient, input gradient, one-kernel layer backward) when the forward precision is a
+// split one: terms = 3 (default) or 6.  Gradients through batch-statistics BatchNorm + max pooling carry ~1 % fp32 noise whatever the
+// contraction (profiles/r02_numerics_operating_point.txt); 2^-17 per product is invisible next to it and halves their MFMA + split work.
+MVP_API int mvp_set_mlp_precision_backward(int terms) {
+  MVP_REQUIRE(terms == 3 || terms == 6);
+  g_mlp_terms_bwd = terms;
+  return MVP_OK;
+}
 // Switch: 0 (default; measured 1.2 % faster on the bench step) routes every forward layer through the per-tile kernel (mlp_fwd_kernel), 1 lets long narrow layers
 // (>= 32768 rows, C_in and C_out <= 128, split-bf16) take the persistent streaming kernel (mlp_stream.hip).  Returns the old value.
 MVP_API int mvp_set_mlp_stream(int on) {

@@ -23,6 +23,7 @@
 #include "mlp_common.h"
 #include "stats_reduce.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -58,7 +59,7 @@ struct BwdArgs {
   const uint8_t* pool_arg;   // (R / 32, C) row of the group that attained the maximum
 };
 
-template <int CB, int CPB, int NS, bool POOL>
+template <int CB, int CPB, int NS, bool POOL, bool PF>
 __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
   using SP = SplitPairs<NS>;
   constexpr int kWBytes = NS * CB * CPB * 32 * 64;                 // split weight: 64 bytes per (c_in, slab, piece)
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
       yn[q] = finish ? Yt[off] : 0.f;
     }
   };
-  if (t_begin + wave < t_end) {
+  if (PF && t_begin + wave < t_end) {
     load_x(t_begin + wave);
     if constexpr (!POOL) load_g(t_begin + wave, 0);
   }
@@ -209,11 +210,15 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
     const int lim = tile_lim(t);
 #pragma unroll
     for (int q = 0; q < 16; ++q) rok[q] = 8 * (q >> 2) + 4 * h + (q & 3) <= lim;
+    if constexpr (!PF) {  // no cross-tile prefetch (fewer registers: more waves per SIMD on the narrow variants)
+      load_x(t);
+      if constexpr (!POOL) load_g(t, 0);
+    }
 #pragma unroll
     for (int b = 0; b < CPB; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) x[b][q] = xn[b][q];
-    const bool more = t + 4 < t_end;
+    const bool more = PF && t + 4 < t_end;
     if (more) load_x(t + 4);
     // ---- a_{i-1}: activation + split, both row steps (operand B of dW for every channel block of dy)
     u32x4 fb[CPB][2][NS];
@@ -507,7 +512,7 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
     MVP_NONNULL(partial);
   }
   MVP_REQUIRE(R >= 0 && C > 0 && Cp > 0 && ldx >= Cp && ldw >= Cp && lddw >= Cp && lddw < (1 << 24) && ldx < (1 << 24));
-  const int ns = g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0;
+  const int ns = mlp_bwd_pieces();
   if (ns == 0 || C > 128 || Cp > 128 || (dZ && Cp % 4 != 0) || (dZ && ((uintptr_t)dZ % 16) != 0)) return MVP_EUNSUPPORTED;
   if (R == 0) return MVP_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -529,15 +534,27 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   const int cb = C <= 32 ? 1 : C <= 64 ? 2 : 4;
   const int cpb = Cp <= 32 ? 1 : (Cp <= 64 || Cp > 96 || cb == 4) ? 2 : 3;
   const unsigned gy = (unsigned)cdiv(Cp, 32 * cpb);
-#define MVP_BWD(A_, B_)                                                                                                  \
+#define MVP_BWD1(A_, B_, PF_)                                                                                                  \
   do {                                                                                                                   \
-    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, false>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
-    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, false>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a);        \
+    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, false, PF_>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
+    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, false, PF_>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a);        \
   } while (0)
-#define MVP_BWD_POOL(A_, B_)                                                                                            \
+#define MVP_BWD_POOL1(A_, B_, PF_)                                                                                            \
   do {                                                                                                                  \
-    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, true>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a); \
-    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, true>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a);        \
+    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a); \
+    else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a);        \
+  } while (0)
+  // cross-tile prefetch costs registers: it pays where the kernel runs at one wave per SIMD anyway (measured per variant, profiles/)
+  static const int pf_mode = []() { const char* e = getenv("MVP_BWD_PREFETCH"); return e ? atoi(e) : -1; }();  // -1 auto, 0 off, 1 on
+#define MVP_BWD(A_, B_)                                                       \
+  do {                                                                        \
+    const bool pf = pf_mode < 0 ? ((A_) * (B_) >= 4) : pf_mode != 0;           \
+    if (pf) MVP_BWD1(A_, B_, true); else MVP_BWD1(A_, B_, false);              \
+  } while (0)
+#define MVP_BWD_POOL(A_, B_)                                                  \
+  do {                                                                        \
+    const bool pf = pf_mode < 0 ? true : pf_mode != 0;                         \
+    if (pf) MVP_BWD_POOL1(A_, B_, true); else MVP_BWD_POOL1(A_, B_, false);    \
   } while (0)
   if (pool_dout) {
     if (cb == 1 && cpb == 1) MVP_BWD_POOL(1, 1);
@@ -555,6 +572,8 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   else if (cpb == 2) MVP_BWD(4, 2);
   else return MVP_EUNSUPPORTED;
 #undef MVP_BWD_POOL
+#undef MVP_BWD_POOL1
+#undef MVP_BWD1
 #undef MVP_BWD
   int rc = mvp_launch_status();
   if (rc != MVP_OK) return rc;

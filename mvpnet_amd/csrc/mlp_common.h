@@ -3,7 +3,11 @@
 #include "common.h"
 
 extern int g_mlp_terms;      // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (mvp_set_mlp_precision, defined in mlp.hip)
+extern int g_mlp_terms_bwd;  // split used by the GRADIENT contractions (dW, input gradient, layer backward) when g_mlp_terms != 0: 3 or 6
 extern int g_mlp_min_width;  // layers with max(Cin, Cout) below this stay on the fp32 MFMA
+
+// pieces per operand of the backward contractions: 0 (fp32 MFMA) when the forward runs fp32, else from g_mlp_terms_bwd
+static inline int mlp_bwd_pieces() { return g_mlp_terms == 0 ? 0 : (g_mlp_terms_bwd == 6 ? 3 : 2); }
 
 namespace {
 

@@ -589,8 +589,11 @@ def mlp_precision(request):
     from mvpnet_amd import _lib as L
     before = L.get_mlp_precision()
     L.set_mlp_precision(request.param)
+    if request.param != 'fp32':
+        L.set_mlp_precision_backward(request.param)  # the gradient entry points in the SAME split as the forward for these checks
     yield request.param
     L.set_mlp_precision(before)
+    L.set_mlp_precision_backward('bf16x3')
 
 
 @pytest.mark.parametrize('R,Cin,ldx,Cout', [(1000, 68, 68, 32), (4096, 64, 64, 64), (777, 131, 132, 128), (300, 259, 260, 256),
@@ -806,6 +809,7 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
     from mvpnet_amd import _lib as L
     before = L.get_mlp_precision()
     L.set_mlp_precision(precision)
+    L.set_mlp_precision_backward(precision)
     loose = 16.0 if precision == 'bf16x3' else 1.0
     hi = torch.float64
     torch.manual_seed(R + C)
@@ -860,6 +864,7 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
                             np.testing.assert_allclose(stat[Cp:].cpu().numpy(), (ref_dz * xh).sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
     finally:
         L.set_mlp_precision(before)
+        L.set_mlp_precision_backward('bf16x3')
 
 
 @pytest.mark.parametrize('R,Cin,Cout', [(3000, 64, 64), (70000, 32, 64), (140000, 64, 128), (40000, 320, 256)])
