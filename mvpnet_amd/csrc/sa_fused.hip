@@ -284,9 +284,12 @@ MVP_API int mvp_sa_fused_forward_f32(const float* zf, const float* xyz, const fl
   switch (key) {
     case 111: MVP_SA(1, 1, 1); break;
     case 112: MVP_SA(1, 1, 2); break;
+    case 121: MVP_SA(1, 2, 1); break;
     case 122: MVP_SA(1, 2, 2); break;
     case 124: MVP_SA(1, 2, 4); break;
+    case 211: MVP_SA(2, 1, 1); break;
     case 212: MVP_SA(2, 1, 2); break;
+    case 221: MVP_SA(2, 2, 1); break;
     case 222: MVP_SA(2, 2, 2); break;
     case 224: MVP_SA(2, 2, 4); break;
     default: return MVP_EUNSUPPORTED;

@@ -751,6 +751,10 @@ def sa_fused_eval(zf, xyz, centre, index, mlp):
     c1, c2, c3 = (l.conv.weight.size(0) for l in mlp)
     if c1 > 64 or c2 > 64 or c3 > 128 or c1 % 4 or c2 % 4 or c3 % 4 or any(l.bn.training for l in mlp):
         return None
+    blocks = lambda c: 1 if c <= 32 else 2 if c <= 64 else 4
+    if (blocks(c1), blocks(c2), blocks(c3)) not in {(1, 1, 1), (1, 1, 2), (1, 2, 1), (1, 2, 2), (1, 2, 4), (2, 1, 1), (2, 1, 2), (2, 2, 1), (2, 2, 2),
+                                                     (2, 2, 4)}:
+        return None  # not an instantiated (C1, C2, C3) block shape of csrc/sa_fused.hip
     L.require_gpu(xyz, centre, index)
     B, N, _ = xyz.shape
     M = centre.size(1)
