@@ -13,7 +13,7 @@ The frozen 2D CNN (UNetResNet34, out of scope; torchvision is absent) is replace
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the lifting kernels (un-project + pixel k-NN + gather): algorithmic bytes
-                  (13 403 136 B/chunk) / their device time measured with HIP
+                  (13 287 936 B/chunk = SURVEY.md sec.8d with the uint16 depth fed here) / their device time measured with HIP
                   events on the launch stream, against the 8 TB/s HBM3E peak;
   cpu_baseline -- the same fwd+bwd step on the host cores with the CPU oracle (rank 0, N=1 only).
 """
@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-LIFT_BYTES_PER_CHUNK = 13403136  # 4P + 12N + 2*(4*C*N*k) + 8Nk + 12Nk, P=57600 N=8192 C=64 k=3
+LIFT_BYTES_PER_CHUNK = 13403136 - 2 * 57600  # 2P (uint16 depth, as fed here; 4P for float) + 12N + 2*(4*C*N*k) + 8Nk + 12Nk, P=57600 N=8192 C=64 k=3
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -101,14 +101,16 @@ class TimedLifting:
 
 
 def lift_traffic(batch):
-    """HBM bytes per mvp_lift_f32 launch from the PMC passes committed under profiles/ (measured at B = 32;
-    FETCH_SIZE doubled per the gfx950 calibration note); None for any other batch size."""
-    path = os.path.join(ROOT, 'profiles', 'r01_lift_traffic.json')
-    if not os.path.exists(path):
+    """HBM bytes per mvp_lift_f32 launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE of the two lifting
+    kernels INSIDE the train step at B = 32, tools/step_counters.sh; FETCH_SIZE doubled per the gfx950 calibration note).  A committed
+    measurement, not a live counter read: None for any other batch size."""
+    path = os.path.join(ROOT, 'profiles', 'r02_step_traffic.json')
+    if batch != 32 or not os.path.exists(path):
         return None
     with open(path) as f:
-        rec = json.load(f)
-    return rec['hbm_bytes_per_launch'] if rec.get('batch') == batch else None
+        rows = json.load(f)['kernels']
+    mb = sum(r.get('fetch_MB', 0.0) + r.get('write_MB', 0.0) for r in rows if r['kernel'].startswith('lift_'))
+    return int(round(mb * 1e6)) if mb else None
 
 
 def cpu_baseline(bt, batch_chunks=2):
@@ -402,7 +404,7 @@ def main():
                                  'latency_ms_B1 = one chunk alone, synchronised per chunk (bounded by the serial FPS chain)'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': lift_traffic(args.batch), 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
+                         'traffic': lift_traffic(args.batch), 'traffic_source': 'profiles/r02_step_traffic.json (committed rocprofv3 PMC passes of this step at B=32, not read live)', 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(bt)
