@@ -171,6 +171,8 @@ def main():
     ap.add_argument('--train-only', action='store_true', help='skip the extra forward-only (configs[1]) measurement (profiling runs)')
     ap.add_argument('--graph', action='store_true', help='replay forward + backward from ONE captured HIP graph (mvpnet3d.GraphedTrainStep) instead '
                                                          'of ~400 eager launches; same GPU time on an idle host, immune to a busy one')
+    ap.add_argument('--graph-geometry', default='eager', choices=['eager', 'captured'], help='with --graph: next batch geometry issued eagerly on the side '
+                    'stream next to the replay (default) or forked inside the captured graph')
     ap.add_argument('--host-profile', action='store_true', help='cProfile the timed loop (host/launch cost), top entries to stderr')
     ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
                                               'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml kept in tests/golden/configs.json')
@@ -247,7 +249,8 @@ def main():
         # lifting -> fork: next batch's geometry -> aggregation + PointNet++ -> loss -> backward -> join;
         # gradient all-reduce, Adam and the scheduler run eagerly after each replay.
         from mvpnet_amd.mvpnet3d import GraphedTrainStep
-        graphed = GraphedTrainStep(model, loss_fn, optimizer, fresh(batch), fresh(batch), scheduler=scheduler, grad_sync=grad_sync)
+        graphed = GraphedTrainStep(model, loss_fn, optimizer, fresh(batch), fresh(batch), scheduler=scheduler, grad_sync=grad_sync,
+                                   geometry=args.graph_geometry)
 
         def step():
             return graphed.step(batch, batch)
@@ -394,7 +397,7 @@ def main():
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
                        'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world),
-                       'launch': 'hip graph (forward + backward), optimizer eager' if args.graph else 'eager'},
+                       'launch': 'hip graph (forward + backward; next-batch geometry {}), optimizer eager'.format(args.graph_geometry) if args.graph else 'eager'},
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
             'with_2d_network': e2e,
             'scene_inference': scene,

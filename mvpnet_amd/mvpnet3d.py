@@ -248,7 +248,15 @@ class GraphedTrainStep:
 
     COPY_KEYS = ('images', 'points', 'seg_label', 'depth', 'cam_matrix', 'kinv', 'pose', 'pixel_box', 'image_xyz', 'knn_indices', 'flip', 'z_rot')
 
-    def __init__(self, model, loss_fn, optimizer, batch, next_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, warmup=3):
+    def __init__(self, model, loss_fn, optimizer, batch, next_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, warmup=3,
+                 geometry='eager'):
+        """geometry='eager' (default): only the training stream is captured; the coordinate-only work of the NEXT batch (FPS chain,
+        ball queries, 3-NN, transposed indices: ~40 launches) is issued eagerly on the side stream next to the replay and copied into
+        the static plan afterwards -- a real second stream overlaps with the replay kernel by kernel, which the graph executor does
+        not do for a captured fork (measured: 9.95 ms captured fork vs 9.56 ms eager step).  geometry='captured': the fork / join
+        lives inside the graph (no per-step host work besides the replay)."""
+        assert geometry in ('eager', 'captured')
+        self.geometry = geometry
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.scheduler, self.max_grad_norm, self.grad_sync = scheduler, max_grad_norm, grad_sync
         net = model.module if hasattr(model, 'module') else model
@@ -270,14 +278,18 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            nxt = dict(self.static_next)
-            preds = model(dict(self.static, geometry_plan=self.plan, prefetch_next=nxt))
+            if geometry == 'captured':
+                nxt = dict(self.static_next)
+                preds = model(dict(self.static, geometry_plan=self.plan, prefetch_next=nxt))
+            else:
+                preds = model(dict(self.static, geometry_plan=self.plan))
             self.loss = loss_fn(preds, self.static)['seg_loss']
             self.loss.backward()
-            new_plan = nxt['geometry_plan']
-            torch.cuda.current_stream(dev).wait_event(new_plan['event'])  # join the side stream
-            for dst, src in zip(_plan_tensors(self.plan), _plan_tensors(new_plan)):
-                dst.copy_(src)
+            if geometry == 'captured':
+                new_plan = nxt['geometry_plan']
+                torch.cuda.current_stream(dev).wait_event(new_plan['event'])  # join the side stream
+                for dst, src in zip(_plan_tensors(self.plan), _plan_tensors(new_plan)):
+                    dst.copy_(src)
             self.preds = preds
 
     def step(self, batch=None, next_batch=None):
@@ -289,7 +301,19 @@ class GraphedTrainStep:
             for k, dst in self.static_next.items():
                 if next_batch[k].data_ptr() != dst.data_ptr():
                     dst.copy_(next_batch[k])
-        self.graph.replay()
+        if self.geometry == 'eager':
+            # geometry of the next batch on the side stream, eagerly, next to the replay; handed over after it
+            net = self.model.module if hasattr(self.model, 'module') else self.model
+            new_plan = prefetch_geometry(self.model, dict(self.static_next))['geometry_plan']
+            self.graph.replay()
+            cur = torch.cuda.current_stream(self.static['points'].device)
+            cur.wait_event(new_plan['event'])
+            dst, src = _plan_tensors(self.plan), _plan_tensors(new_plan)
+            for dt in {t.dtype for t in dst}:
+                torch._foreach_copy_([d for d in dst if d.dtype == dt], [x for d, x in zip(dst, src) if d.dtype == dt])
+            del net
+        else:
+            self.graph.replay()
         if self.grad_sync is not None:
             self.grad_sync(weight_sum=getattr(self.loss_fn, 'last_weight_sum', None))
         if self.max_grad_norm > 0:

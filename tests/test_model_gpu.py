@@ -203,7 +203,8 @@ def test_mvpnet3d_full_chunk(dev):
         np.testing.assert_allclose(logit.cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])
 
 
-def test_graphed_train_step_matches_eager(dev):
+@pytest.mark.parametrize('geometry', ['eager', 'captured'])
+def test_graphed_train_step_matches_eager(dev, geometry):
     """mvpnet3d.GraphedTrainStep (forward + backward replayed from one HIP graph, geometry of the next batch forked inside it)
     follows the eager train_step: three iterations on two alternating batches (input copies, the geometry hand-over between
     replays and the static gradients are all exercised; longer trajectories diverge chaotically at B = 2 from the 1e-7 noise of
@@ -245,7 +246,7 @@ def test_graphed_train_step_matches_eager(dev):
     o2 = torch.optim.SGD(m2.parameters(), lr=0.05)
     static_feat = fa.clone()
     m2.net_2d.feature = static_feat
-    g = GraphedTrainStep(m2, SegLoss(), o2, dict(ba), dict(bb), warmup=1)
+    g = GraphedTrainStep(m2, SegLoss(), o2, dict(ba), dict(bb), warmup=1, geometry=geometry)
     # the warm-up iterations inside the constructor trained nothing (no optimizer step) but moved BN running statistics
     m2.load_state_dict(copy.deepcopy(build().state_dict()))
     graphed = []
