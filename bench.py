@@ -171,7 +171,7 @@ def main():
     ap.add_argument('--train-only', action='store_true', help='skip the extra forward-only (configs[1]) measurement (profiling runs)')
     ap.add_argument('--graph', action='store_true', help='replay forward + backward from ONE captured HIP graph (mvpnet3d.GraphedTrainStep) instead '
                                                          'of ~400 eager launches; same GPU time on an idle host, immune to a busy one')
-    ap.add_argument('--graph-geometry', default='eager', choices=['eager', 'captured'], help='with --graph: next batch geometry issued eagerly on the side '
+    ap.add_argument('--graph-geometry', default='captured', choices=['eager', 'captured'], help='with --graph: next batch geometry issued eagerly on the side '
                     'stream next to the replay (default) or forked inside the captured graph')
     ap.add_argument('--host-profile', action='store_true', help='cProfile the timed loop (host/launch cost), top entries to stderr')
     ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
