@@ -277,6 +277,15 @@ class GraphedTrainStep:
         self.plan = {'sa': plan['sa'], 'fp': plan['fp'], 'event': None, 'stream': None}  # static geometry of the CURRENT batch
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
+        # the weight gradients stay on the captured stream: inside a graph the extra fork / join edges cost more than the overlap
+        # returns (measured B = 32: 9.56 ms captured without them, 9.80 ms with; the eager step gains 0.2 ms from them)
+        aside, R.DW_SIDE_STREAM = R.DW_SIDE_STREAM, False
+        try:
+            self._capture(model, loss_fn, dev, geometry)
+        finally:
+            R.DW_SIDE_STREAM = aside
+
+    def _capture(self, model, loss_fn, dev, geometry):
         with torch.cuda.graph(self.graph):
             if geometry == 'captured':
                 nxt = dict(self.static_next)

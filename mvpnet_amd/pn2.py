@@ -111,18 +111,20 @@ class SetAbstraction(nn.Module):
             #    inside the grouping kernel (same operation order as modules.py:27 + conv; no cancellation).
             w1 = l0.conv.weight.reshape(c1, -1)                       # columns [feature (C) | xyz (3)]
             zf = None
+            # one gradient buffer for the weight's two column groups (feature columns here, coordinate columns in the grouping kernel)
+            sink = R.WeightGradSink(l0.conv.weight, 2) if (use_feature and torch.is_grad_enabled() and l0.conv.weight.requires_grad) else None
             if use_feature:
                 cf = feature.size(2)
                 pad = (-cf) % 4
                 f = torch.nn.functional.pad(feature, (0, pad)) if pad else feature
-                zf = R.linear_rows(f.reshape(B * N, -1), l0.conv.weight, cols=(0, cf)).view(B, N, c1)
+                zf = R.linear_rows(f.reshape(B * N, -1), l0.conv.weight, cols=(0, cf), sink=sink).view(B, N, c1)
             bn_training = l0.bn.training
             if not bn_training and not torch.is_grad_enabled():
                 # inference: gather -> 3 layers -> max in ONE kernel, nothing between the gathered rows and (B,M,C_3) touches HBM
                 fused = R.sa_fused_eval(zf, xyz, new_xyz, ball, self.mlp)
                 if fused is not None:
                     return new_xyz, fused
-            y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=bn_training, csr=csr)  # (B,M,K,C_1): conv output of layer 1
+            y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=bn_training, csr=csr, sink=sink)  # (B,M,K,C_1): conv output of layer 1
             stat1 = None
             if bn_training:
                 y1, stat1 = y1
@@ -235,10 +237,13 @@ class FeaturePropagation(nn.Module):
                 index, weight = geometry[0], geometry[1]
                 csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
                 w1 = l0.conv.weight.reshape(c1, -1)                    # columns [interpolated (C2) | skip (C1)]
-                z = R.linear_rows(sparse_feature.reshape(B * M, c2), l0.conv.weight, cols=(0, c2)).view(B, M, c1)
+                sink = None
+                if dense_feature is not None and torch.is_grad_enabled() and l0.conv.weight.requires_grad:
+                    sink = R.WeightGradSink(l0.conv.weight, 2)  # one gradient buffer for the weight's two column groups
+                z = R.linear_rows(sparse_feature.reshape(B * M, c2), l0.conv.weight, cols=(0, c2), sink=sink).view(B, M, c1)
                 zs = None
                 if dense_feature is not None:
-                    zs = R.linear_rows(dense_feature.reshape(B * N, -1), l0.conv.weight, cols=(c2, w1.size(1))).view(B, N, c1)
+                    zs = R.linear_rows(dense_feature.reshape(B * N, -1), l0.conv.weight, cols=(c2, w1.size(1)), sink=sink).view(B, N, c1)
                 bn_training = l0.bn.training
                 y1 = R.interp_add_rows(z, index, weight, zs, want_stat=bn_training, csr=csr)
                 stat1 = None

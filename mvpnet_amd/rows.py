@@ -122,6 +122,82 @@ class ZeroPool:
 zero_pool = ZeroPool()
 
 
+# Weight gradients of the wide layers (mvp_mlp_weight_grad_f32: one launch per layer) run on a second HIP stream beside the
+# input-gradient chain: each of these kernels alone leaves most of the chip's issue slots and HBM bandwidth idle
+# (profiles/r02_step_kernel_stats.csv), so the two streams overlap.  Nothing may read such a gradient on the calling stream before the
+# join, and autograd does read a returned gradient right away when it has to ADD it (a weight used through several column slices, or
+# a parameter whose .grad already exists).  So only the shared-MLP chain does this, for weights that are leaves used exactly once and
+# whose .grad was None at forward time (autograd then just stores the tensor); the join is an end-of-backward callback of the autograd
+# engine, so .grad is complete on the caller's stream when backward() returns.  Fork and join are plain stream waits: they are captured
+# with the step under a hipGraph.  Measured: DESIGN.md section 5.
+DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
+
+
+class SideStream:
+    def __init__(self):
+        self.streams = {}
+        self.open = set()
+
+    def _join(self):
+        for dev in list(self.open):
+            torch.cuda.current_stream(dev).wait_stream(self.streams[dev])
+        self.open.clear()
+
+    def run(self, dev, fn, *tensors):
+        """fn() launched on the side stream after everything queued so far on the current one; `tensors` = what it touches.
+        Only inside an autograd backward pass (the join is queued as its final callback)."""
+        side = self.streams.get(dev)
+        if side is None:
+            side = self.streams[dev] = torch.cuda.Stream(device=dev)
+        if not self.open:
+            torch.autograd.Variable._execution_engine.queue_callback(self._join)
+        self.open.add(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+
+
+side_stream = SideStream()
+
+
+class WeightGradSink:
+    """ONE gradient buffer for a conv weight that is used through several column slices in one forward (the linear-first
+    factorisations in pn2.SetAbstraction / FeaturePropagation: feature columns per point, coordinate or skip columns elsewhere).
+    Every user adds its columns into the same zeroed (C_out, C_tot) buffer and the user whose backward runs LAST hands it to autograd:
+    one gradient per weight instead of one full-size zero-filled tensor per slice plus autograd's additions -- and, as nothing reads
+    the buffer before the end of backward, the slice kernels can run on the side stream (`aside`, same conditions as SideStream)."""
+
+    def __init__(self, weight, users):
+        self.shape = tuple(weight.shape)
+        self.numel = weight.numel()
+        self.users = self.left = users
+        self.buf = None
+        self.aside = bool(DW_SIDE_STREAM and weight.is_leaf and weight.grad is None and not weight._backward_hooks)
+
+    def buffer(self, dev):
+        if self.buf is None:
+            self.buf = zero_pool.zeros(self.numel + 4, torch.float32, dev)  # + 4: slack for the 4-column coordinate operand
+        return self.buf
+
+    def run(self, dev, fn, *tensors):
+        if self.aside:
+            side_stream.run(dev, fn, self.buf, *tensors)
+        else:
+            fn()
+
+    def done(self):
+        """-> the gradient when this was the last user, else None."""
+        self.left -= 1
+        if self.left > 0:
+            return None
+        g = self.buf[:self.numel].view(self.shape)
+        self.buf, self.left = None, self.users
+        return g
+
+
 class EvalInvStd:
     """1/sqrt(running_var + eps) of ALL BatchNorm layers of a model in two multi-tensor launches per eval-mode forward,
     instead of an add and an rsqrt launch per layer (50 launches of ~4 us each in PN2SSG, 5 % of the forward).  Filled by
@@ -202,7 +278,8 @@ class GroupLinRows(torch.autograd.Function):
     gradient on this path (the reference computes them under no_grad too: fps.py:11-13, modules.py:22-27 on leaf points)."""
 
     @staticmethod
-    def forward(ctx, zf, xyz, centre, wxyz, index, want_stat, offsets=None, slots=None):
+    def forward(ctx, zf, xyz, centre, wxyz, index, want_stat, offsets=None, slots=None, sink=None):
+        ctx.sink = sink
         # wxyz: a weight whose LAST three columns multiply the coordinates -- a (C,3) matrix, or the layer's whole conv weight
         # (C, C_in + 3 [,1,1]): the slice is taken here and its gradient written into the full-size gradient below, so autograd
         # sees no slicing (which costs a zero fill and a strided copy per slice in backward).
@@ -252,7 +329,13 @@ class GroupLinRows(torch.autograd.Function):
             for d in ctx.w_shape:
                 numel *= d
             ctot = numel // C
-            if ctot >= 4:
+            sink = ctx.sink
+            if sink is not None:  # the weight's other slices add their columns into the same buffer (WeightGradSink)
+                buf = sink.buffer(g.device)
+                sink.run(g.device, lambda: L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None,
+                                                  None, L.ptr_at(buf, ctot - 3), ctot), g, diff)
+                gw = sink.done()
+            elif ctot >= 4:
                 buf = zero_pool.zeros(numel + 4, torch.float32, g.device)
                 gw = buf[:numel].view(ctx.w_shape)
                 L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None,
@@ -261,16 +344,16 @@ class GroupLinRows(torch.autograd.Function):
                 gw4 = zero_pool.zeros((C, 4), torch.float32, g.device)
                 L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4), 4)
                 gw = gw4[:, :3].contiguous().view(ctx.w_shape)
-        return gz, None, None, gw, None, None, None, None
+        return gz, None, None, gw, None, None, None, None, None
 
 
-def group_lin_rows(zf, xyz, centre, wxyz, index, want_stat=False, csr=None):
+def group_lin_rows(zf, xyz, centre, wxyz, index, want_stat=False, csr=None, sink=None):
     """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3) -- or the whole conv weight (C, C_in+3[,1,1]) whose last
     three columns are used --, index (B,M,K) -> (B,M,K,C) [, stat (2C) float64].
     csr: (offsets, slots) of build_csr(index, N) when the geometry plan already holds it."""
     offsets, slots = csr if csr is not None else (None, None)
     return GroupLinRows.apply(None if zf is None else zf.contiguous(), xyz.contiguous(), centre.contiguous(), wxyz,
-                              index.contiguous(), bool(want_stat), offsets, slots)
+                              index.contiguous(), bool(want_stat), offsets, slots, sink)
 
 
 class InterpRows(torch.autograd.Function):
@@ -470,6 +553,8 @@ class MLPChainRows(torch.autograd.Function):
         nl = len(params) // 3
         R = x0.size(0)
         dev = x0.device
+        ctx.dw_aside = bool(pool_sum & 2)  # weight gradients may run on the side stream (see SideStream)
+        pool_sum = bool(pool_sum & 1)
         ys, means, invstds = [], [], []
         act = (None, None, None, None)
         x = x0
@@ -647,8 +732,13 @@ class MLPChainRows(torch.autograd.Function):
                 if pending is not None:
                     grads[3 * i + 1], grads[3 * i + 2] = dgb[0], dgb[1]
             else:
-                L.call('mvp_mlp_weight_grad_f32', gcur, L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
-                       L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin)
+                def weight_grad():
+                    L.call('mvp_mlp_weight_grad_f32', gcur, L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
+                           L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin)
+                if ctx.dw_aside:
+                    side_stream.run(dev, weight_grad, gcur, src, dw, *act)
+                else:
+                    weight_grad()
                 if need_dz and i > 0:
                     # d(input) = dy . W with the previous layer's ReLU mask and BN-backward column sums in the epilogue
                     pm, pi, pg, pb = act
@@ -690,7 +780,8 @@ class LinearRows(torch.autograd.Function):
     """y = x . W^T (+ bias) on rows with the fp32-MFMA kernels (forward, input gradient, weight gradient)."""
 
     @staticmethod
-    def forward(ctx, x, w_full, bias, c0=0, c1=None):
+    def forward(ctx, x, w_full, bias, c0=0, c1=None, sink=None):
+        ctx.sink = sink
         # w_full (C_out, C_tot[,1[,1]]); columns [c0, c1) multiply x (R, >= c1 - c0 columns; extra columns are zero padding).
         # The slice is copied here (one small kernel) and its gradient is written straight into a full-size zeroed gradient
         # (lddw), so autograd sees no slicing: that costs a zero fill and a strided copy per slice in backward.
@@ -724,19 +815,27 @@ class LinearRows(torch.autograd.Function):
             L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None)
         if ctx.needs_input_grad[1]:
             c0, ncol, shape = ctx.slice
-            gw = zero_pool.zeros(shape, torch.float32, w.device)  # accumulated into; columns outside the slice stay zero
-            L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None, L.ptr_at(gw, c0),
-                   gw.numel() // cout)
+            sink = ctx.sink
+            if sink is not None:  # the weight's other slices add their columns into the same buffer (WeightGradSink)
+                buf = sink.buffer(gy.device)
+                sink.run(gy.device, lambda: L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None,
+                                                   None, L.ptr_at(buf, c0), sink.numel // cout), gy, x)
+                gw = sink.done()
+            else:
+                # (on the calling stream: without a sink, autograd adds the gradients of a weight's several slices straight away)
+                gw = zero_pool.zeros(shape, torch.float32, w.device)  # accumulated into; columns outside the slice stay zero
+                L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None, L.ptr_at(gw, c0),
+                       gw.numel() // cout)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def linear_rows(x, weight, bias=None, cols=None):
+def linear_rows(x, weight, bias=None, cols=None, sink=None):
     """x (R, C_in) float32, weight (C_out, C_in[,1[,1]]), bias (C_out) or None -> (R, C_out).
     cols=(c0, c1): use only those columns of `weight` (x then has c1 - c0 columns, plus optional zero padding)."""
     c0, c1 = (0, None) if cols is None else cols
-    return LinearRows.apply(x.contiguous(), weight, bias, c0, c1)
+    return LinearRows.apply(x.contiguous(), weight, bias, c0, c1, sink)
 
 
 SA_FUSED_EVAL = os.environ.get('MVP_SA_FUSED', '1') != '0'
@@ -799,8 +898,9 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             params += [w, layer.bn.weight, layer.bn.bias]
             buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
+        aside = DW_SIDE_STREAM and all(l.conv.weight.is_leaf and l.conv.weight.grad is None and not l.conv.weight._backward_hooks for l in mlp)
         out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None,
-                                 reduce == 'sum' and K > 1, *params)
+                                 int(reduce == 'sum' and K > 1) + 2 * int(aside), *params)
         return F.dropout(out, p=dropout_p, training=training, inplace=False) if dropout_p > 0 else out
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     if K > 255:  # the pooled BatchNorm kernel keeps its arg-max in one byte: pool with torch after a K = 1 pass

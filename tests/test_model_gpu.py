@@ -257,6 +257,46 @@ def test_graphed_train_step_matches_eager(dev, geometry):
     np.testing.assert_allclose(graphed[2], eager[2], rtol=5e-3)  # third step: the 1e-7 run-to-run noise of the fp32 atomics, amplified by two SGD steps at B = 2
 
 
+def test_weight_gradients_on_the_side_stream(dev):
+    """rows.SideStream: the wide layers' weight gradients run on a second stream and are joined when backward() ends.  Same
+    gradients as on one stream (up to the fp32-atomics noise), also when .grad already exists (accumulation: autograd then ADDS on the
+    calling stream, so those passes must not use the side stream) -- repeated, a missed join shows up as missing partial sums."""
+    from mvpnet_amd import rows as R
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss
+    torch.manual_seed(11)
+    model = MVPNet3D(StubNet2D(), '', PN2SSG(16, 20, dropout_prob=0.0, **CFG), in_channels=16, mlp_channels=(16, 16, 16)).to(dev).eval()
+    cs = [make_chunk(900 + i, nb_pts=1024, nv=2, h=30, w=40, channels=16) for i in range(4)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    st = lambda k: np.stack([c[k] for c in cs])
+    batch = {'images': torch.zeros(4, 2, 3, 30, 40, device=dev), 'points': t(st('points').transpose(0, 2, 1)),
+             'seg_label': t(np.maximum(st('seg_label'), 0)), 'depth': t(st('depth_mm').astype(np.int16)),
+             'cam_matrix': t(np.stack([np.repeat(c['cam_matrix'][None, :3, :3], 2, 0) for c in cs])), 'kinv': t(st('kinv')),
+             'pose': t(st('pose')), 'pixel_box': t(st('pixel_box')), 'k': 3}
+    model.net_2d.feature = t(st('feature_2d')).view(8, 30, 40, 16).permute(0, 3, 1, 2)
+    loss_fn = SegLoss()
+
+    def grads(aside, passes=1):
+        R.DW_SIDE_STREAM = aside
+        model.zero_grad(set_to_none=True)
+        for _ in range(passes):
+            out = model(dict(batch))
+            loss_fn(out, batch)['seg_loss'].backward()
+        return [p.grad.detach().clone() for p in model.parameters() if p.grad is not None]
+
+    try:
+        one = grads(False)
+        assert any(p.dim() >= 2 and p.size(0) > 64 for p in model.parameters()), 'no layer wide enough for the separate weight-gradient kernel'
+        for rep in range(4):
+            for passes in (1, 2):
+                got = grads(True, passes)
+                for a, e in zip(got, one):
+                    tol = 2e-5 * float(e.abs().max()) + 1e-9
+                    assert float((a - passes * e).abs().max()) <= passes * tol, (rep, passes, tuple(e.shape))
+    finally:
+        R.DW_SIDE_STREAM = True
+
+
 def test_unet_resnet34_frozen_channels_last(dev):
     """UNetResNet34 in its frozen form on the GPU (BatchNorm folded, channels_last, MIOpen convolutions) against the golden
     vectors of the imported reference class, and feeding MVPNet3D's device lifting without a layout copy."""
