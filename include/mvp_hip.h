@@ -180,6 +180,12 @@ int mvp_lift_aug_f32(const void* depth, int depth_is_u16, const float* kinv, con
  * / `image_xyz` (scannet_2d3d.py:400-409) for tensors that did not go through mvp_lift_aug_f32.  In place allowed. */
 int mvp_rotate_rows_f32(const float* xyz, const double* rot, int64_t B, int64_t R, float* out, mvp_stream_t stream);
 
+/* Column slices of several row-major float matrices in one launch (host-side helper of the shared-MLP path: the reference slices
+ * nothing -- it concatenates the inputs instead, modules.py:32-35,178-186 -- the linear-first factorisation of those layers needs
+ * each column group of the weight as its own aligned operand).  table: n x 6 int64 ON THE DEVICE, per entry
+ * {src pointer, dst pointer, src row stride, dst row stride, rows, cols} in floats; dst[r*ldd + c] = src[r*lds + c], c < cols. */
+int mvp_copy_slices_f32(const int64_t* table, int64_t n, mvp_stream_t stream);
+
 /* ---- channels-last ("rows") PointNet++ kernels ---------------------------------------------
  * Same mathematics as the channel-major ops above with a point's C features stored as one
  * contiguous row; these are what the model pipeline runs (mvpnet_amd/pn2.py).  All C, ld % 4 == 0.

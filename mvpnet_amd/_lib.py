@@ -47,6 +47,7 @@ _SIGNATURES = {
     'mvp_lift_aug_f32': [_ptr, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr,
                          _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_rotate_rows_f32': [_ptr, _ptr, _i64, _i64, _ptr],
+    'mvp_copy_slices_f32': [_ptr, _i64],
     'mvp_group_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_rows_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_lin_rows_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr],

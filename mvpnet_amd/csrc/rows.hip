@@ -1188,3 +1188,31 @@ MVP_API int64_t mvp_colstats_partial_count(int64_t R, int64_t C) {
   if (R <= 0 || C <= 0) return 0;
   return colstats_blocks_partial(R, C) * 2 * C;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Column slices of several (weight) matrices in ONE launch.  The linear-first factorisations (pn2.SetAbstraction /
+// FeaturePropagation) apply column groups of a layer's weight separately, each as a contiguous, 16-byte aligned, zero-padded
+// operand: ~16 strided copies of a few KB per training step as separate launches.
+// table: n entries of 6 int64 on the device: {src pointer, dst pointer, src row stride, dst row stride, rows, cols} (floats);
+// dst[r * ldd + c] = src[r * lds + c] for c < cols (the padding columns of dst are never written: the caller zeroes them once).
+namespace {
+__global__ __launch_bounds__(256) void copy_slices_kernel(const int64_t* __restrict__ table) {
+  const int64_t* e = table + (size_t)blockIdx.y * 6;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  float* dst = reinterpret_cast<float*>(e[1]);
+  const int64_t lds = e[2], ldd = e[3], rows = e[4], cols = e[5];
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols, c = i - r * cols;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+}  // namespace
+
+MVP_API int mvp_copy_slices_f32(const int64_t* table, int64_t n, mvp_stream_t stream) {
+  MVP_REQUIRE(n >= 0 && n < 65536);
+  if (n == 0) return MVP_OK;
+  MVP_NONNULL(table);
+  hipLaunchKernelGGL(copy_slices_kernel, dim3(32, (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), table);
+  return mvp_launch_status();
+}

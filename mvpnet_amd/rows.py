@@ -95,6 +95,8 @@ class ZeroPool:
                 p.capacity = max(p.demand, p.cursor)  # what the last step asked for in total
                 p.buf = torch.zeros(p.capacity // 8, dtype=torch.float64, device=self.dev) if p.capacity else None
                 p.cursor = p.demand = 0
+                if self.dev.type == 'cuda':
+                    weight_slices.refresh(self.dev)
             p.depth += 1
 
         def __exit__(self, *exc):
@@ -120,6 +122,79 @@ class ZeroPool:
 
 
 zero_pool = ZeroPool()
+
+
+class WeightSlices:
+    """Column groups of conv weights as the kernels take them -- contiguous, 16-byte aligned rows, zero padded to the operand's row
+    length -- in persistent buffers that ONE launch (mvp_copy_slices_f32) refreshes at the start of a forward, instead of a strided
+    copy per slice and forward (~16 per training step; none at all in inference, where the weights do not change).
+
+    get() returns the operand for the weight's CURRENT version (a miss -- first use, or the weight changed after the refresh --
+    copies at once).  Every slice has two buffers and a refresh writes the one not handed out last, so the operand a forward saved
+    for its backward stays intact until the second optimizer step after it."""
+
+    ENABLED = os.environ.get('MVP_WEIGHT_SLICES', '1') != '0'
+
+    class Entry:
+        __slots__ = ('weight', 'c0', 'cols', 'bufs', 'cur', 'version', 'ptr')
+
+    def __init__(self):
+        self.entries = {}
+        self.tables = {}   # device -> ([table writing bufs[0], table writing bufs[1]] on the device, entries in table order)
+
+    @staticmethod
+    def _src(e):
+        return e.weight.detach().reshape(e.weight.size(0), -1)[:, e.c0:e.c0 + e.cols]
+
+    def get(self, weight, c0, c1, ld):
+        if not WeightSlices.ENABLED:  # a fresh copy per call (A/B switch)
+            w = weight.detach().reshape(weight.size(0), -1)[:, c0:c1]
+            return (F.pad(w, (0, ld - (c1 - c0))) if ld != c1 - c0 else w).contiguous()
+        key = (id(weight), c0, c1, ld)
+        e = self.entries.get(key)
+        if e is None or e.weight is not weight or e.bufs[0].device != weight.device:
+            e = WeightSlices.Entry()
+            e.weight, e.c0, e.cols, e.cur, e.version, e.ptr = weight, c0, c1 - c0, 0, None, None
+            e.bufs = [torch.zeros((weight.size(0), ld), dtype=torch.float32, device=weight.device) for _ in range(2)]
+            if not torch.cuda.is_current_stream_capturing():
+                self.entries[key] = e
+                self.tables.pop(weight.device, None)
+        if e.version != weight._version or e.ptr != weight.data_ptr():
+            e.cur ^= 1
+            e.bufs[e.cur][:, :e.cols].copy_(self._src(e))
+            e.version, e.ptr = weight._version, weight.data_ptr()
+        return e.bufs[e.cur]
+
+    def refresh(self, dev):
+        """Top of a forward: bring every slice of a changed weight up to date, all of them in one launch."""
+        if not WeightSlices.ENABLED:
+            return
+        mine = [e for e in self.entries.values() if e.bufs[0].device == dev]
+        if not mine:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        tab = self.tables.get(dev)
+        if (tab is None or any(e.weight.data_ptr() != p for e, p in zip(tab[1], tab[2]))) and not capturing:
+            rows = [[], []]
+            for e in mine:
+                w2 = e.weight.detach().reshape(e.weight.size(0), -1)
+                for par in (0, 1):
+                    rows[par].append([w2.data_ptr() + 4 * e.c0, e.bufs[par].data_ptr(), w2.stride(0), e.bufs[par].stride(0), w2.size(0), e.cols])
+            tab = self.tables[dev] = ([torch.tensor(r, dtype=torch.int64).to(dev) for r in rows], mine, [e.weight.data_ptr() for e in mine])
+        if tab is None:
+            return  # (inside a capture, before any table exists: get() copies slice by slice)
+        stale = [e.version != e.weight._version or e.ptr != e.weight.data_ptr() for e in tab[1]]
+        if not capturing and not any(stale):
+            return
+        # every slice moves to its other buffer together (one table per parity): slices that were up to date are copied again
+        # (a slice whose parity drifted -- a miss in get() since the last refresh -- is simply re-aligned here)
+        par = tab[1][0].cur ^ 1
+        L.call('mvp_copy_slices_f32', tab[0][par], L.ptr(tab[0][par]), len(tab[1]))
+        for e in tab[1]:
+            e.cur, e.version, e.ptr = par, e.weight._version, e.weight.data_ptr()
+
+
+weight_slices = WeightSlices()
 
 
 # Weight gradients of the wide layers (mvp_mlp_weight_grad_f32: one launch per layer) run on a second HIP stream beside the
@@ -284,7 +359,11 @@ class GroupLinRows(torch.autograd.Function):
         # (C, C_in + 3 [,1,1]): the slice is taken here and its gradient written into the full-size gradient below, so autograd
         # sees no slicing (which costs a zero fill and a strided copy per slice in backward).
         w_full = wxyz
-        wxyz = w_full.detach().reshape(w_full.size(0), -1)[:, -3:].contiguous()
+        ctot_ = w_full.numel() // w_full.size(0)
+        if w_full.is_cuda and w_full.dtype == torch.float32:
+            wxyz = weight_slices.get(w_full, ctot_ - 3, ctot_, 3)
+        else:
+            wxyz = w_full.detach().reshape(w_full.size(0), -1)[:, -3:].contiguous()
         L.require_gpu(xyz, centre, wxyz, index)
         B, N, _ = xyz.shape
         _, M, K = index.shape
@@ -789,10 +868,13 @@ class LinearRows(torch.autograd.Function):
         c1 = w2.size(1) if c1 is None else c1
         R, ldx = x.shape
         cin = c1 - c0
-        w = w2[:, c0:c1]
-        if ldx != cin:
-            w = torch.nn.functional.pad(w, (0, ldx - cin))
-        w = w.contiguous()
+        if w2.is_cuda and w2.dtype == torch.float32:
+            w = weight_slices.get(w_full, c0, c1, ldx)  # persistent operand buffer, refreshed once per forward for all slices
+        else:
+            w = w2[:, c0:c1]
+            if ldx != cin:
+                w = torch.nn.functional.pad(w, (0, ldx - cin))
+            w = w.contiguous()
         L.require_gpu(x, w, bias)
         cout = w.size(0)
         y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
@@ -860,8 +942,9 @@ def sa_fused_eval(zf, xyz, centre, index, mlp):
     bn = []
     for l in mlp:
         bn += [l.bn.running_mean, eval_invstd.get(l.bn.running_var, l.bn.eps), l.bn.weight, l.bn.bias]
-    w1 = mlp[0].conv.weight.detach().reshape(c1, -1)
-    wxyz = w1[:, -3:].contiguous()
+    w1 = mlp[0].conv.weight
+    ctot_ = w1.numel() // c1
+    wxyz = weight_slices.get(w1, ctot_ - 3, ctot_, 3)
     w2 = mlp[1].conv.weight.detach().reshape(c2, c1).contiguous()
     w3 = mlp[2].conv.weight.detach().reshape(c3, c2).contiguous()
     out = torch.empty((B, M, c3), dtype=torch.float32, device=xyz.device)

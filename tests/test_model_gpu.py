@@ -297,6 +297,49 @@ def test_weight_gradients_on_the_side_stream(dev):
         R.DW_SIDE_STREAM = True
 
 
+def test_weight_slice_operands_follow_the_optimizer(dev):
+    """rows.WeightSlices: the column-group operands of the sliced first-layer weights live in persistent buffers that one launch
+    refreshes per forward.  A weight changed behind the cache's back (no top-level forward in between) is picked up by get() itself;
+    three SGD steps give the losses of the copy-per-call path."""
+    from mvpnet_amd import rows as R
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss, train_step
+    cs = [make_chunk(950 + i, nb_pts=1024, nv=2, h=30, w=40, channels=16) for i in range(2)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    st = lambda k: np.stack([c[k] for c in cs])
+    batch = {'images': torch.zeros(2, 2, 3, 30, 40, device=dev), 'points': t(st('points').transpose(0, 2, 1)),
+             'seg_label': t(np.maximum(st('seg_label'), 0)), 'depth': t(st('depth_mm').astype(np.int16)),
+             'cam_matrix': t(np.stack([np.repeat(c['cam_matrix'][None, :3, :3], 2, 0) for c in cs])), 'kinv': t(st('kinv')),
+             'pose': t(st('pose')), 'pixel_box': t(st('pixel_box')), 'k': 3}
+    feat = t(st('feature_2d')).view(4, 30, 40, 16).permute(0, 3, 1, 2)
+
+    def run(enabled):
+        R.WeightSlices.ENABLED = enabled
+        torch.manual_seed(3)
+        model = MVPNet3D(StubNet2D(), '', PN2SSG(16, 20, dropout_prob=0.0, **CFG), in_channels=16, mlp_channels=(16, 16, 16)).to(dev).eval()
+        model.net_2d.feature = feat
+        # a change without a top-level forward: the set-abstraction module alone must see it
+        sa = model.net_3d.sa_modules[1]
+        xyz = torch.rand(2, 256, 3, device=dev)
+        f = torch.rand(2, 256, sa.mlp[0].conv.weight.size(1) - 3, device=dev)
+        with torch.no_grad():
+            a = sa.forward_rows(xyz, f)[1].clone()
+            sa.mlp[0].conv.weight.mul_(1.5)
+            b = sa.forward_rows(xyz, f)[1].clone()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = [float(train_step(model, SegLoss(), opt, dict(batch))[0]) for _ in range(3)]
+        return losses, a, b
+
+    try:
+        ref, ra, rb = run(False)
+        got, ga, gb = run(True)
+    finally:
+        R.WeightSlices.ENABLED = True
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-5)
+    np.testing.assert_allclose(got[2], ref[2], rtol=5e-3)  # (fp32-atomics noise through two SGD steps, see the graphed-step test)
+    assert torch.equal(ga, ra) and torch.equal(gb, rb) and not torch.equal(ga, gb)
+
+
 def test_unet_resnet34_frozen_channels_last(dev):
     """UNetResNet34 in its frozen form on the GPU (BatchNorm folded, channels_last, MIOpen convolutions) against the golden
     vectors of the imported reference class, and feeding MVPNet3D's device lifting without a layout copy."""
