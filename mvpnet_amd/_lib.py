@@ -190,6 +190,14 @@ def suffix(t):
     raise RuntimeError('expected a float32 or float64 tensor, got {}'.format(t.dtype))
 
 
+def call_on(stream, name, *args):
+    """Invoke `name(*args, stream)` on the given torch.cuda.Stream of the CURRENT device (no stream-context switch on the host)."""
+    fn = getattr(_lib if _lib is not None else lib(), name)
+    code = fn(*args, ctypes.c_void_p(stream.cuda_stream))
+    if code != 0:
+        check(code, name)
+
+
 def call(name, tensor_for_device, *args):
     """Invoke `name(*args, stream)` on the current stream of tensor_for_device's device."""
     dev = tensor_for_device.device

@@ -210,29 +210,34 @@ DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
 
 class SideStream:
     def __init__(self):
-        self.streams = {}
+        self.streams = {}   # device -> (side stream, fork event)
         self.open = set()
+        self.keep = []      # what the side-stream kernels touch, alive until the join (instead of record_stream per tensor)
 
     def _join(self):
         for dev in list(self.open):
-            torch.cuda.current_stream(dev).wait_stream(self.streams[dev])
+            torch.cuda.current_stream(dev).wait_stream(self.streams[dev][0])
         self.open.clear()
+        self.keep.clear()  # freed behind the join on the calling stream: the allocator hands the blocks to later work of that stream only
 
-    def run(self, dev, fn, *tensors):
-        """fn() launched on the side stream after everything queued so far on the current one; `tensors` = what it touches.
-        Only inside an autograd backward pass (the join is queued as its final callback)."""
-        side = self.streams.get(dev)
-        if side is None:
-            side = self.streams[dev] = torch.cuda.Stream(device=dev)
+    def run(self, dev, name, args, tensors):
+        """Library entry point `name(*args, stream)` on the side stream, after everything queued so far on the current one;
+        `tensors` = what it touches.  Only inside an autograd backward pass (the join is queued as its final callback)."""
+        st = self.streams.get(dev)
+        if st is None:
+            st = self.streams[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Event())
         if not self.open:
             torch.autograd.Variable._execution_engine.queue_callback(self._join)
         self.open.add(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            fn()
-        for t in tensors:
-            if t is not None:
-                t.record_stream(side)
+        side, fork = st
+        fork.record(torch.cuda.current_stream(dev))
+        side.wait_event(fork)
+        if dev.index == torch.cuda.current_device():
+            L.call_on(side, name, *args)
+        else:
+            with torch.cuda.stream(side):
+                L.call(name, tensors[0], *args)
+        self.keep.extend(tensors)
 
 
 side_stream = SideStream()
@@ -257,11 +262,11 @@ class WeightGradSink:
             self.buf = zero_pool.zeros(self.numel + 4, torch.float32, dev)  # + 4: slack for the 4-column coordinate operand
         return self.buf
 
-    def run(self, dev, fn, *tensors):
+    def run(self, dev, name, args, tensors):
         if self.aside:
-            side_stream.run(dev, fn, self.buf, *tensors)
+            side_stream.run(dev, name, args, [self.buf] + list(tensors))
         else:
-            fn()
+            L.call(name, tensors[0], *args)
 
     def done(self):
         """-> the gradient when this was the last user, else None."""
@@ -411,8 +416,8 @@ class GroupLinRows(torch.autograd.Function):
             sink = ctx.sink
             if sink is not None:  # the weight's other slices add their columns into the same buffer (WeightGradSink)
                 buf = sink.buffer(g.device)
-                sink.run(g.device, lambda: L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None,
-                                                  None, L.ptr_at(buf, ctot - 3), ctot), g, diff)
+                sink.run(g.device, 'mvp_mlp_weight_grad_f32', (L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None,
+                                                               L.ptr_at(buf, ctot - 3), ctot), (g, diff))
                 gw = sink.done()
             elif ctot >= 4:
                 buf = zero_pool.zeros(numel + 4, torch.float32, g.device)
@@ -811,13 +816,12 @@ class MLPChainRows(torch.autograd.Function):
                 if pending is not None:
                     grads[3 * i + 1], grads[3 * i + 2] = dgb[0], dgb[1]
             else:
-                def weight_grad():
-                    L.call('mvp_mlp_weight_grad_f32', gcur, L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]),
-                           L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin)
+                wg_args = (L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]),
+                           L.ptr(dw), cin)
                 if ctx.dw_aside:
-                    side_stream.run(dev, weight_grad, gcur, src, dw, *act)
+                    side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, src, dw) + tuple(t for t in act if t is not None))
                 else:
-                    weight_grad()
+                    L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args)
                 if need_dz and i > 0:
                     # d(input) = dy . W with the previous layer's ReLU mask and BN-backward column sums in the epilogue
                     pm, pi, pg, pb = act
@@ -900,8 +904,8 @@ class LinearRows(torch.autograd.Function):
             sink = ctx.sink
             if sink is not None:  # the weight's other slices add their columns into the same buffer (WeightGradSink)
                 buf = sink.buffer(gy.device)
-                sink.run(gy.device, lambda: L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None,
-                                                   None, L.ptr_at(buf, c0), sink.numel // cout), gy, x)
+                sink.run(gy.device, 'mvp_mlp_weight_grad_f32', (L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None,
+                                                                L.ptr_at(buf, c0), sink.numel // cout), (gy, x))
                 gw = sink.done()
             else:
                 # (on the calling stream: without a sink, autograd adds the gradients of a weight's several slices straight away)
