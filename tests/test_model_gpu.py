@@ -340,6 +340,41 @@ def test_weight_slice_operands_follow_the_optimizer(dev):
     assert torch.equal(ga, ra) and torch.equal(gb, rb) and not torch.equal(ga, gb)
 
 
+def test_geometry_of_several_batches_in_one_plan(dev):
+    """mvpnet3d.prefetch_geometry_many: FPS / ball query / 3-NN of two upcoming batches in ONE plan, sliced per batch -- the logits of
+    each batch are those of planning it on its own (the geometry is index work: bit-equal), also through `prefetch_next=[...]`."""
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, prefetch_geometry_many
+    torch.manual_seed(21)
+    model = MVPNet3D(StubNet2D(), '', PN2SSG(16, 20, dropout_prob=0.0, **CFG), in_channels=16, mlp_channels=(16, 16, 16)).to(dev).eval()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def batch_of(ids):
+        cs = [make_chunk(700 + i, nb_pts=1024, nv=2, h=30, w=40, channels=16) for i in ids]
+        st = lambda k: np.stack([c[k] for c in cs])
+        b = {'images': torch.zeros(len(ids), 2, 3, 30, 40, device=dev), 'points': t(st('points').transpose(0, 2, 1)),
+             'depth': t(st('depth_mm').astype(np.int16)), 'cam_matrix': t(np.stack([np.repeat(c['cam_matrix'][None, :3, :3], 2, 0) for c in cs])),
+             'kinv': t(st('kinv')), 'pose': t(st('pose')), 'pixel_box': t(st('pixel_box')), 'k': 3}
+        return b, t(st('feature_2d')).view(len(ids) * 2, 30, 40, 16).permute(0, 3, 1, 2)
+
+    (a, fa), (b, fb), (c, fc) = batch_of([0, 1]), batch_of([2, 3, 4]), batch_of([5])
+    with torch.no_grad():
+        ref = []
+        for bt, f in ((a, fa), (b, fb), (c, fc)):
+            model.net_2d.feature = f
+            ref.append(model(dict(bt))['seg_logit'].clone())
+        a2, b2, c2 = dict(a), dict(b), dict(c)
+        prefetch_geometry_many(model, [a2, b2])
+        assert 'geometry_plan' in a2 and 'geometry_plan' in b2
+        model.net_2d.feature = fa
+        got_a = model(dict(a2, prefetch_next=[c2]))['seg_logit'].clone()   # a list of one: planned on its own
+        model.net_2d.feature = fb
+        got_b = model(b2)['seg_logit'].clone()
+        model.net_2d.feature = fc
+        got_c = model(c2)['seg_logit'].clone()
+    assert torch.equal(got_a, ref[0]) and torch.equal(got_b, ref[1]) and torch.equal(got_c, ref[2])
+
+
 def test_unet_resnet34_frozen_channels_last(dev):
     """UNetResNet34 in its frozen form on the GPU (BatchNorm folded, channels_last, MIOpen convolutions) against the golden
     vectors of the imported reference class, and feeding MVPNet3D's device lifting without a layout copy."""
