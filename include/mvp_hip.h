@@ -41,6 +41,11 @@ const char* mvp_version(void);
 /* human readable text for a return code of this library (static storage) */
 const char* mvp_strerror(int code);
 
+/* Launch shape of the sampling kernels for 4096 < N <= 8192 points (returns the previous mode): 0 (default) = the shortest dependency
+ * chain (16 waves per cloud), 1 = the fewest issue slots (one wave per SIMD; 22 % longer chain) for batches of >= 8 clouds whose chain runs
+ * hidden beside other kernels -- the prefetched geometry of a training step.  Same results either way (bit-exact goldens). */
+int mvp_set_fps_mode(int mode);
+
 /* ---- farthest point sampling -------------------------------------------------------
  * replaces fps_cuda.farthest_point_sample  (mvpnet/ops/cuda/fps.cpp:7-13,
  * mvpnet/ops/cuda/fps_kernel.cu:144-180).  points (B,N,D) D in {2,3}; index (B,M).

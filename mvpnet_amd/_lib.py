@@ -84,7 +84,7 @@ _SIGNATURES = {
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
-           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward'] + sorted(_SIGNATURES)
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_set_fps_mode'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -117,6 +117,8 @@ def lib():
         _lib = handle
         handle.mvp_set_mlp_stream.restype = ctypes.c_int
         handle.mvp_set_mlp_stream.argtypes = [ctypes.c_int]
+        handle.mvp_set_fps_mode.restype = ctypes.c_int
+        handle.mvp_set_fps_mode.argtypes = [ctypes.c_int]
         if os.environ.get('MVP_MLP_STREAM') is not None:
             handle.mvp_set_mlp_stream(int(os.environ['MVP_MLP_STREAM']))
         handle.mvp_set_mlp_precision_backward.restype = ctypes.c_int

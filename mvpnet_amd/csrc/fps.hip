@@ -354,6 +354,8 @@ int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipS
   return mvp_launch_status();
 }
 
+int g_fps_mode = 0;  // mvp_set_fps_mode: 0 = shortest chain, 1 = fewest issue slots (the chain is hidden under other work)
+
 template <typename T, int D>
 int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
   // (threads, points/thread): one wave per SIMD (256 threads) keeps the per-iteration barrier
@@ -366,9 +368,14 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStr
   if (N <= 2048) return launch_cfg<T, D, 8, 256>(pts, B, N, M, out, s);
   if (N <= 4096) return launch_cfg<T, D, 8, 512>(pts, B, N, M, out, s);
   if (N <= 8192) {
-    const char* e = getenv("MVP_FPS_CFG");  // tuning knob: threads per cloud for 4096 < N <= 8192
-    if (e && e[0] == '2') return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s);
-    if (e && e[0] == '5') return launch_cfg<T, D, 16, 512>(pts, B, N, M, out, s);
+    // Threads per cloud for 4096 < N <= 8192.  16 waves (1024 threads) give the shortest chain: 2.44 ms for 2048 samples of 8192
+    // points -- the choice when the chain is what one waits for (inference, a single chunk).  One wave per SIMD (256 threads, 32
+    // points per lane) takes 2.98 ms with a quarter of the issue slots: the choice when the chain hides under other kernels
+    // anyway (mvp_set_fps_mode(1): the training step's prefetched geometry, 9.16 -> 9.03 ms per step; exposed chains lose:
+    // whole-scene inference 7.7 -> 8.2 ms).  MVP_FPS_CFG = 1 / 2 / 5 forces 1024 / 256 / 512 threads.
+    static const char cfg = []() { const char* e = getenv("MVP_FPS_CFG"); return e ? e[0] : '0'; }();
+    if (cfg == '2' || (cfg == '0' && g_fps_mode == 1 && B >= 8)) return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s);
+    if (cfg == '5') return launch_cfg<T, D, 16, 512>(pts, B, N, M, out, s);
     return launch_cfg<T, D, 8, 1024>(pts, B, N, M, out, s);
   }
   if (N <= 16384) return launch_cfg<T, D, 16, 1024>(pts, B, N, M, out, s);
@@ -388,6 +395,12 @@ int fps_entry(const T* points, int64_t B, int64_t N, int64_t D, int64_t M, int64
 }
 
 }  // namespace
+
+MVP_API int mvp_set_fps_mode(int mode) {
+  const int old = g_fps_mode;
+  g_fps_mode = mode == 1 ? 1 : 0;
+  return old;
+}
 
 MVP_API int mvp_fps_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index,
                         mvp_stream_t stream) {

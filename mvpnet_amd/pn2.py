@@ -14,6 +14,7 @@ import torch.nn as nn
 from .nn import SharedMLP, SharedMLPDO, batch_index_select, xavier_uniform
 from . import ops
 from . import rows as R
+from . import _lib as L
 
 
 class QueryGrouper(nn.Module):
@@ -320,6 +321,8 @@ class PN2SSG(nn.Module):
                 s2.wait_event(ev)
                 return fn()
 
+        # a training step's prefetched chain hides under forward + backward: sample with one wave per SIMD (mvp_set_fps_mode)
+        fps_mode = L.lib().mvp_set_fps_mode(1 if (with_csr and stream is not None) else 0) if xyz.is_cuda else 0
         with torch.cuda.stream(stream if stream is not None else cur):
             run = torch.cuda.current_stream(xyz.device)
             sa, xyzs = [], [xyz]
@@ -341,6 +344,8 @@ class PN2SSG(nn.Module):
                 run.wait_stream(s2)
             event = torch.cuda.Event()
             event.record()
+        if xyz.is_cuda:
+            L.lib().mvp_set_fps_mode(fps_mode)
         # `xyz` is read by the side stream long after this function returns (ball query / 3-NN of level 1 run after the 2.4 ms
         # FPS): the plan keeps it alive, otherwise the caller's stream may recycle its memory while it is still being read.
         plan = {'sa': sa, 'fp': fp, 'event': event, 'stream': stream, 'xyz': xyz}

@@ -66,6 +66,30 @@ def test_fps_vs_oracle(dev, B, N, M, D):
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
 
+@pytest.mark.parametrize('kind', ['uniform', 'lattice'])
+def test_fps_throughput_launch_shape(dev, kind):
+    """mvp_set_fps_mode(1): one wave per SIMD and 32 points per lane for batches of >= 8 clouds of 4097..8192 points (the training
+    step's prefetched geometry).  Same indices as the default shape on all clouds and as the oracle on two of them, ties included."""
+    from mvpnet_amd import _lib as L
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(77)
+    pts = rs.rand(9, 8192, 3)
+    if kind == 'lattice':
+        pts = np.round(pts * 1.9 / 0.02) * 0.02
+    pts = pts.astype(np.float32)
+    x = g(pts, dev)
+    ref = farthest_point_sample(x, 512, transpose=False)
+    old = L.lib().mvp_set_fps_mode(1)
+    try:
+        got = farthest_point_sample(x, 512, transpose=False)
+        got5 = farthest_point_sample(x[:, :5000].contiguous(), 300, transpose=False)
+    finally:
+        L.lib().mvp_set_fps_mode(old)
+    assert old == 0 and torch.equal(got, ref)
+    np.testing.assert_array_equal(got[:2].cpu().numpy(), O().fps(pts[:2], 512))
+    np.testing.assert_array_equal(got5[7:].cpu().numpy(), O().fps(pts[7:, :5000], 300))
+
+
 def test_fps_f64_vs_oracle(dev):
     from mvpnet_amd.ops import farthest_point_sample
     pts = np.random.RandomState(3).rand(2, 3000, 3)
@@ -1016,3 +1040,27 @@ def test_fps_exact_on_structured_clouds(dev, kind, N, M):
         M = N // 2  # keep the oracle's O(N M) run short
     idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
     np.testing.assert_array_equal(idx, O().fps(pts, M))
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'lattice'])
+def test_fps_throughput_launch_shape(dev, kind):
+    """mvp_set_fps_mode(1): one wave per SIMD and 32 points per lane for batches of >= 8 clouds of 4097..8192 points (the training
+    step's prefetched geometry).  Same indices as the default shape on all clouds and as the oracle on two of them, ties included."""
+    from mvpnet_amd import _lib as L
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(77)
+    pts = rs.rand(9, 8192, 3)
+    if kind == 'lattice':
+        pts = np.round(pts * 1.9 / 0.02) * 0.02
+    pts = pts.astype(np.float32)
+    x = g(pts, dev)
+    ref = farthest_point_sample(x, 512, transpose=False)
+    old = L.lib().mvp_set_fps_mode(1)
+    try:
+        got = farthest_point_sample(x, 512, transpose=False)
+        got5 = farthest_point_sample(x[:, :5000].contiguous(), 300, transpose=False)
+    finally:
+        L.lib().mvp_set_fps_mode(old)
+    assert old == 0 and torch.equal(got, ref)
+    np.testing.assert_array_equal(got[:2].cpu().numpy(), O().fps(pts[:2], 512))
+    np.testing.assert_array_equal(got5[7:].cpu().numpy(), O().fps(pts[7:, :5000], 300))
