@@ -354,6 +354,67 @@ int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipS
   return mvp_launch_status();
 }
 
+// ---- any N: running distances in global memory ----------------------------------------------------
+// Clouds beyond the register-resident kernels (N > 32768: dense whole-scene chunks fed with all their points, test_mvpnet_3d.py
+// nb_pts = -1).  One workgroup per cloud; every iteration streams the cloud once (coordinates + running distance, L2 resident:
+// 16 N bytes), each thread keeps the first maximum of its ascending stride, then the same key reduction as above.  Same
+// results as the reference kernel (fps_kernel.cu:60-135: first maximum = lowest index); slower per point, but complete.
+template <typename T, int D, int NT>
+__global__ __launch_bounds__(NT) void fps_global_kernel(const T* __restrict__ pts, int N, int M, T* __restrict__ mind,
+                                                        int64_t* __restrict__ out) {
+  constexpr int NW = NT / kWave;
+  using K = Key<T>;
+  __shared__ K part[2][16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const T* p = pts + (size_t)b * N * D;
+  T* md = mind + (size_t)b * N;
+  int64_t* o = out + (size_t)b * M;
+  for (int j = tid; j < N; j += NT) md[j] = INFINITY;
+  T cx = p[0], cy = p[1], cz = D == 3 ? p[2] : T(0);
+  if (tid == 0) o[0] = 0;
+  for (int it = 1; it < M; ++it) {
+    T bv = T(-1);
+    int bi = 0;
+    for (int j = tid; j < N; j += NT) {  // (each thread only ever touches its own md[j]: no barrier needed for them)
+      const T x = p[(size_t)j * D + 0], y = p[(size_t)j * D + 1], z = D == 3 ? p[(size_t)j * D + 2] : T(0);
+      const T d = D == 3 ? dist2_3(x, y, z, cx, cy, cz) : dist2_2(x, y, cx, cy);
+      const T old = md[j];
+      const T m = d < old ? d : old;
+      md[j] = m;
+      if (m > bv) {  // strict: j ascends, the thread's first maximum is kept
+        bv = m;
+        bi = j;
+      }
+    }
+    K k = bv >= T(0) ? K::make(bv, bi) : K::none();
+    key_max_wave_to_lane63(k);
+    K* cur = part[it & 1];
+    if (lane == 63) cur[wave] = k;
+    __syncthreads();
+    k = cur[lane & (NW - 1)];
+    key_max_row<K, NW>(k);
+    const int win = k.index();
+    if (tid == 0) o[it] = win;
+    cx = p[(size_t)win * D + 0];
+    cy = p[(size_t)win * D + 1];
+    if (D == 3) cz = p[(size_t)win * D + 2];
+  }
+}
+
+template <typename T, int D>
+int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+  if (N >= (1ll << 31) / 4) return MVP_EUNSUPPORTED;
+  T* mind = nullptr;  // stream-ordered scratch owned by this call
+  if (hipMallocAsync(reinterpret_cast<void**>(&mind), sizeof(T) * (size_t)B * (size_t)N, s) != hipSuccess || !mind) {
+    (void)hipGetLastError();
+    return MVP_EINVAL;
+  }
+  hipLaunchKernelGGL((fps_global_kernel<T, D, 1024>), dim3((unsigned)B), dim3(1024), 0, s, pts, (int)N, (int)M, mind, out);
+  const int rc = mvp_launch_status();
+  (void)hipFreeAsync(mind, s);
+  return rc;
+}
+
 int g_fps_mode = 0;  // mvp_set_fps_mode: 0 = shortest chain, 1 = fewest issue slots (the chain is hidden under other work)
 
 template <typename T, int D>
@@ -380,7 +441,7 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStr
   }
   if (N <= 16384) return launch_cfg<T, D, 16, 1024>(pts, B, N, M, out, s);
   if (N <= 32768) return launch_cfg<T, D, 32, 1024>(pts, B, N, M, out, s);
-  return MVP_EUNSUPPORTED;  // > 32768 points per cloud: not covered by the register-resident kernel
+  return launch_global<T, D>(pts, B, N, M, out, s);  // > 32768 points per cloud: running distances in global memory
 }
 
 template <typename T>

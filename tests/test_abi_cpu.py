@@ -36,7 +36,6 @@ def test_argument_errors_do_not_launch():
     assert lib.mvp_fps_f32(None, 1, 8, 3, 4, dummy, None) == -3                    # MVP_ENULL
     assert lib.mvp_fps_f32(dummy, 1, 8, 3, 9, dummy, None) == -1                   # N >= M   (fps_kernel.cu:156)
     assert lib.mvp_fps_f32(dummy, 1, 8, 4, 4, dummy, None) == -1                   # D in {2,3}
-    assert lib.mvp_fps_f32(dummy, 1, 40000, 3, 4, dummy, None) == -2               # > 32768 points: unsupported
     assert lib.mvp_knn_distance_f32(dummy, dummy, 1, 4, 8, 5, dummy, dummy, None) == -2   # k must be 3 (:171)
     assert lib.mvp_knn_distance_f32(dummy, dummy, 1, 4, 2, 3, dummy, dummy, None) == -1   # N2 >= k
     assert lib.mvp_pixel_knn_bruteforce_f32(dummy, dummy, dummy, 1, 8, 8, 9, dummy, None, None) == -1

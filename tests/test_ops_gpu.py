@@ -66,6 +66,24 @@ def test_fps_vs_oracle(dev, B, N, M, D):
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
 
+@pytest.mark.parametrize('B,N,M,D,kind', [(2, 40000, 300, 3, 'uniform'), (1, 33000, 128, 2, 'uniform'), (1, 50000, 200, 3, 'lattice'),
+                                          (1, 36000, 40, 3, 'coincident')])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_fps_beyond_the_register_resident_sizes(dev, B, N, M, D, kind, dtype):
+    """N > 32768 points per cloud (dense whole-scene chunks fed with all their points): the running distances live in a
+    stream-ordered scratch in global memory (fps_global_kernel).  Same indices as the oracle, ties and all-zero distances included."""
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(N + M)
+    pts = rs.rand(B, N, D)
+    if kind == 'lattice':
+        pts = np.round(pts * 1.9 / 0.02) * 0.02
+    elif kind == 'coincident':
+        pts = np.tile(pts[:, :1], (1, N, 1))
+    pts = pts.astype(dtype)
+    idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
+    np.testing.assert_array_equal(idx, O().fps(pts, M))
+
+
 @pytest.mark.parametrize('kind', ['uniform', 'lattice'])
 def test_fps_throughput_launch_shape(dev, kind):
     """mvp_set_fps_mode(1): one wave per SIMD and 32 points per lane for batches of >= 8 clouds of 4097..8192 points (the training
@@ -1038,6 +1056,24 @@ def test_fps_exact_on_structured_clouds(dev, kind, N, M):
     pts = pts.astype(np.float32)
     if M == N and kind not in ('uniform', 'duplicates'):
         M = N // 2  # keep the oracle's O(N M) run short
+    idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
+    np.testing.assert_array_equal(idx, O().fps(pts, M))
+
+
+@pytest.mark.parametrize('B,N,M,D,kind', [(2, 40000, 300, 3, 'uniform'), (1, 33000, 128, 2, 'uniform'), (1, 50000, 200, 3, 'lattice'),
+                                          (1, 36000, 40, 3, 'coincident')])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_fps_beyond_the_register_resident_sizes(dev, B, N, M, D, kind, dtype):
+    """N > 32768 points per cloud (dense whole-scene chunks fed with all their points): the running distances live in a
+    stream-ordered scratch in global memory (fps_global_kernel).  Same indices as the oracle, ties and all-zero distances included."""
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(N + M)
+    pts = rs.rand(B, N, D)
+    if kind == 'lattice':
+        pts = np.round(pts * 1.9 / 0.02) * 0.02
+    elif kind == 'coincident':
+        pts = np.tile(pts[:, :1], (1, N, 1))
+    pts = pts.astype(dtype)
     idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
