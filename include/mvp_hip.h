@@ -266,6 +266,16 @@ int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t*
                              const float* invstd, const float* gamma, const float* beta, int64_t G, int64_t K, int64_t C,
                              int relu, int training, double* stat, float* dy, float* dgamma, float* dbeta, double* partial,
                              mvp_stream_t stream);
+/* The K = 1 forms with DROPOUT behind the activation (SharedMLPDO: Conv + BN + ReLU + Dropout, common/nn/modules/mlp.py:86-92; the
+ * reference runs nn.Dropout as its own pass and keeps the mask): out = act(bn(y)) * keep / (1 - drop_p) with keep a counter-based hash of
+ * (seed, row * C + column) that forward and backward regenerate -- no mask tensor.  0 <= drop_p < 1, R * C < 2^32.  Independent
+ * Bernoulli(1 - drop_p) per element like torch's, not the same random stream. */
+int mvp_bn_rows_forward_dropout_f32(const float* y, const float* gamma, const float* beta, int64_t R, int64_t C, int training, float eps,
+                                    float momentum, int relu, float* running_mean, float* running_var, double* stat, float* mean,
+                                    float* invstd, float* out, double* partial, float drop_p, uint64_t seed, mvp_stream_t stream);
+int mvp_bn_rows_backward_dropout_f32(const float* dsrc, const float* y, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, int64_t R, int64_t C, int relu, int training, double* stat, float* dy,
+                                     float* dgamma, float* dbeta, double* partial, float drop_p, uint64_t seed, mvp_stream_t stream);
 /* second half of the BatchNorm backward with known column sums stat = [sum dz | sum dz*xhat] (from mvp_mlp_input_grad_f32) */
 int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, int64_t R, int64_t C, int training,

@@ -62,6 +62,10 @@ _SIGNATURES = {
                                 _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_rows_backward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, _ptr,
                                  _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_bn_rows_forward_dropout_f32': [_ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _f32, _f32, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                        _ptr, _f32, ctypes.c_uint64],
+    'mvp_bn_rows_backward_dropout_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, ctypes.c_int, _ptr, _ptr, _ptr, _ptr,
+                                         _ptr, _f32, ctypes.c_uint64],
     'mvp_bn_rows_backward_finish_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_finalize_f32': [_ptr, _i64, _i64, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],

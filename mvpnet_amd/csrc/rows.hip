@@ -409,14 +409,36 @@ __device__ __forceinline__ ColParams load_col_params(const float* mean, const fl
   p.bb[0] = be.x; p.bb[1] = be.y; p.bb[2] = be.z; p.bb[3] = be.w;
   return p;
 }
+// Dropout folded into the BatchNorm + ReLU passes of a layer (SharedMLPDO, mlp.py:86-92: dropout behind the layer): the keep mask is a
+// counter-based hash of (seed, element index), so forward and backward regenerate it instead of storing it -- no mask tensor, no
+// fused_dropout / masked_scale launches.  (The reference draws its mask from torch's Philox stream: the masks differ, the
+// distribution -- independent Bernoulli(1 - p) per element, kept values scaled by 1 / (1 - p) -- is the same.)
+struct Dropout {
+  unsigned thresh;  // keep when hash >= thresh; 0 = no dropout
+  unsigned seed;
+  float scale;      // 1 / (1 - p)
+  __device__ __forceinline__ float factor(unsigned e) const {  // e = r * C + c
+    unsigned x = e + seed * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;  // lowbias32
+    return x >= thresh ? scale : 0.f;
+  }
+};
+
 struct BwdAct {  // f = dz, g = dz * xhat with dz = da * [bn(y) > 0] (relu) : BatchNorm backward sums
   const float *da, *y, *mean, *invstd, *gamma, *beta;
   int relu;
+  Dropout drop;
   typedef ColParams Params;
   __device__ __forceinline__ Params params(int c) const { return load_col_params(mean, invstd, gamma, beta, c); }
   __device__ __forceinline__ void at(const Params& p, int64_t r, int c, int C, float4& f, float4& g) const {
     const float4 yy = ld4(y + (size_t)r * C + c), d = ld4(da + (size_t)r * C + c);
-    const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, dd[4] = {d.x, d.y, d.z, d.w};
+    const float yv[4] = {yy.x, yy.y, yy.z, yy.w};
+    float dd[4] = {d.x, d.y, d.z, d.w};
+    if (drop.thresh) {
+      const unsigned e = (unsigned)(r * C + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dd[i] *= drop.factor(e + i);
+    }
     float fo[4], go[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -681,7 +703,8 @@ __global__ __launch_bounds__(kRT) void bn_act_kernel(const float* __restrict__ y
 template <bool RELU>
 __global__ __launch_bounds__(kRT) void bn_act_rows_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int64_t R, int C, float* __restrict__ out) {
+                                                          const float* __restrict__ beta, int64_t R, int C, float* __restrict__ out,
+                                                          Dropout drop) {
   const int C4 = C >> 2;
   const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
   const int64_t rg = t / C4;
@@ -703,6 +726,11 @@ __global__ __launch_bounds__(kRT) void bn_act_rows_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = a[i] > 0.f ? a[i] : 0.f;
       }
+      if (drop.thresh) {
+        const unsigned e = (unsigned)((r0 + h + u) * C + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] *= drop.factor(e + i);
+      }
       st4(out + (size_t)(r0 + h + u) * C + c, make_float4(a[0], a[1], a[2], a[3]));
     }
   }
@@ -719,7 +747,7 @@ __global__ __launch_bounds__(kRT) void bn_rows_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const double* __restrict__ stat, int64_t R, int C, int batch_terms,
                                                           float* __restrict__ dy, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta) {
+                                                          float* __restrict__ dbeta, Dropout drop) {
   const int C4 = C >> 2;
   if (blockIdx.x == 0 && dgamma)
     for (int j = threadIdx.x; j < C; j += kRT) {
@@ -764,6 +792,7 @@ __global__ __launch_bounds__(kRT) void bn_rows_bwd_kernel(const float* __restric
       for (int i = 0; i < 4; ++i) {
         const float xh = (yv[i] - mm[i]) * ii[i];
         float dz = dv[i];
+        if (drop.thresh) dz *= drop.factor((unsigned)(r * C + c) + i);
         if (RELU && !(xh * gg[i] + bb[i] > 0.f)) dz = 0.f;
         res[i] = sc[i] * ((dz - db[i]) - xh * dg[i]);
       }
@@ -991,10 +1020,23 @@ MVP_API int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* i
   return mvp_launch_status();
 }
 
-MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K,
+namespace {
+// p in [0, 1): keep threshold on a 32-bit hash; R * C must fit the 32-bit element counter
+inline int make_dropout(float p, uint64_t seed, int64_t R, int64_t C, int64_t K, Dropout* d) {
+  *d = Dropout{0u, 0u, 1.0f};
+  if (p == 0.f) return MVP_OK;
+  if (!(p > 0.f && p < 1.f) || K != 1 || R * C >= (1ll << 32)) return MVP_EINVAL;
+  double t = (double)p * 4294967296.0;
+  if (t < 1.0) t = 1.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  *d = Dropout{(unsigned)t, (unsigned)(seed ^ (seed >> 32)), 1.0f / (1.0f - p)};
+  return MVP_OK;
+}
+
+int bn_rows_forward_impl(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K,
                                     int64_t C, int training, float eps, float momentum, int relu, float* running_mean,
                                     float* running_var, double* stat, float* mean, float* invstd, float* out,
-                                    uint8_t* arg, double* partial, mvp_stream_t stream) {
+                                    uint8_t* arg, double* partial, Dropout drop, mvp_stream_t stream) {
   MVP_NONNULL(y);
   MVP_NONNULL(gamma);
   MVP_NONNULL(beta);
@@ -1017,9 +1059,9 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
   if (K == 1) {
     dim3 rgrid((unsigned)cdiv(cdiv(R, 8) * (C / 4), kRT));
     if (relu)
-      hipLaunchKernelGGL(bn_act_rows_kernel<true>, rgrid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, R, (int)C, out);
+      hipLaunchKernelGGL(bn_act_rows_kernel<true>, rgrid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, R, (int)C, out, drop);
     else
-      hipLaunchKernelGGL(bn_act_rows_kernel<false>, rgrid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, R, (int)C, out);
+      hipLaunchKernelGGL(bn_act_rows_kernel<false>, rgrid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, R, (int)C, out, drop);
     return mvp_launch_status();
   }
   dim3 grid((unsigned)cdiv(G * (C / 4), kRT));
@@ -1029,11 +1071,33 @@ MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const fl
     hipLaunchKernelGGL(bn_act_kernel<false>, grid, dim3(kRT), 0, s, y, mean, invstd, gamma, beta, G, (int)K, (int)C, out, arg);
   return mvp_launch_status();
 }
+}  // namespace
 
-MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y,
+MVP_API int mvp_bn_rows_forward_f32(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K,
+                                    int64_t C, int training, float eps, float momentum, int relu, float* running_mean,
+                                    float* running_var, double* stat, float* mean, float* invstd, float* out,
+                                    uint8_t* arg, double* partial, mvp_stream_t stream) {
+  return bn_rows_forward_impl(y, gamma, beta, G, K, C, training, eps, momentum, relu, running_mean, running_var, stat, mean, invstd, out, arg,
+                              partial, Dropout{0u, 0u, 1.0f}, stream);
+}
+
+// mvp_bn_rows_forward_f32 for K = 1 with dropout behind the activation: out = act(bn(y)) * keep / (1 - p), keep = hash(seed, element)
+// (see struct Dropout).  R * C < 2^32.  The same (p, seed) go to mvp_bn_rows_backward_dropout_f32.
+MVP_API int mvp_bn_rows_forward_dropout_f32(const float* y, const float* gamma, const float* beta, int64_t R, int64_t C, int training,
+                                            float eps, float momentum, int relu, float* running_mean, float* running_var, double* stat,
+                                            float* mean, float* invstd, float* out, double* partial, float drop_p, uint64_t seed,
+                                            mvp_stream_t stream) {
+  Dropout drop;
+  if (make_dropout(drop_p, seed, R, C, 1, &drop) != MVP_OK) return MVP_EINVAL;
+  return bn_rows_forward_impl(y, gamma, beta, R, 1, C, training, eps, momentum, relu, running_mean, running_var, stat, mean, invstd, out,
+                              nullptr, partial, drop, stream);
+}
+
+namespace {
+int bn_rows_backward_impl(const float* dsrc, const float* out, const uint8_t* arg, const float* y,
                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                                      int64_t G, int64_t K, int64_t C, int relu, int training, double* stat, float* dy,
-                                     float* dgamma, float* dbeta, double* partial, mvp_stream_t stream) {
+                                     float* dgamma, float* dbeta, double* partial, Dropout drop, mvp_stream_t stream) {
   MVP_NONNULL(dsrc);
   MVP_NONNULL(y);
   MVP_NONNULL(mean);
@@ -1050,7 +1114,7 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t R = G * K;
   if (K == 1)
-    rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu}, R, C, stat, partial, true, s);
+    rc = launch_colstats(BwdAct{dsrc, y, mean, invstd, gamma, beta, relu, drop}, R, C, stat, partial, true, s);
   else if (arg == nullptr)
     rc = launch_colstats(BwdSum{dsrc, y, mean, invstd, gamma, beta, (int)K, relu}, R, C, stat, partial, true, s);
   else
@@ -1069,11 +1133,32 @@ MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const 
   dim3 grid((unsigned)cdiv(cdiv(R, kBwdRows) * (C / 4), kRT));
   if (relu)
     hipLaunchKernelGGL(bn_rows_bwd_kernel<true>, grid, dim3(kRT), 0, s, dsrc, y, mean, invstd, gamma, beta, stat, R, (int)C, training,
-                       dy, dgamma, dbeta);
+                       dy, dgamma, dbeta, drop);
   else
     hipLaunchKernelGGL(bn_rows_bwd_kernel<false>, grid, dim3(kRT), 0, s, dsrc, y, mean, invstd, gamma, beta, stat, R, (int)C, training,
-                       dy, dgamma, dbeta);
+                       dy, dgamma, dbeta, drop);
   return mvp_launch_status();
+}
+}  // namespace
+
+MVP_API int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t* arg, const float* y,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     int64_t G, int64_t K, int64_t C, int relu, int training, double* stat, float* dy,
+                                     float* dgamma, float* dbeta, double* partial, mvp_stream_t stream) {
+  return bn_rows_backward_impl(dsrc, out, arg, y, mean, invstd, gamma, beta, G, K, C, relu, training, stat, dy, dgamma, dbeta, partial,
+                               Dropout{0u, 0u, 1.0f}, stream);
+}
+
+// Backward of mvp_bn_rows_forward_dropout_f32: dsrc is the gradient w.r.t. the dropped-out output; the mask is regenerated from
+// (drop_p, seed).
+MVP_API int mvp_bn_rows_backward_dropout_f32(const float* dsrc, const float* y, const float* mean, const float* invstd, const float* gamma,
+                                             const float* beta, int64_t R, int64_t C, int relu, int training, double* stat, float* dy,
+                                             float* dgamma, float* dbeta, double* partial, float drop_p, uint64_t seed,
+                                             mvp_stream_t stream) {
+  Dropout drop;
+  if (make_dropout(drop_p, seed, R, C, 1, &drop) != MVP_OK) return MVP_EINVAL;
+  return bn_rows_backward_impl(dsrc, nullptr, nullptr, y, mean, invstd, gamma, beta, R, 1, C, relu, training, stat, dy, dgamma, dbeta, partial,
+                               drop, stream);
 }
 
 // Pooled output of a layer that ran through mvp_mlp_forward_pool_f32: out (G,C) = max_k act(bn(y_k)), arg (G,C) = its row, ysel (G,C) =
@@ -1145,7 +1230,7 @@ MVP_API int mvp_bn_rows_backward_finish_f32(const float* dz, const float* y, con
   if (rc || R == 0) return rc;
   dim3 grid((unsigned)cdiv(cdiv(R, kBwdRows) * (C / 4), kRT));
   hipLaunchKernelGGL(bn_rows_bwd_kernel<false>, grid, dim3(kRT), 0, static_cast<hipStream_t>(stream), dz, y, mean, invstd, gamma, beta,
-                     stat, R, (int)C, training, dy, dgamma, dbeta);
+                     stat, R, (int)C, training, dy, dgamma, dbeta, Dropout{0u, 0u, 1.0f});
   return mvp_launch_status();
 }
 

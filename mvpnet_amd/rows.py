@@ -24,6 +24,8 @@ FUSE_BWD_MAX_CIN = int(os.environ.get('MVP_BWD_FUSE_MAXCIN', '96'))
 # forward leaves per-ball max / min of the pre-BN values (mvp_mlp_forward_pool_f32), backward re-computes the layer from its input inside
 # the one-kernel layer backward (POOL front end).  Needs C_out, C_in <= 64 and >= 32768 rows (levels 1 and, with 64-wide MLPs, 2).
 POOL_WITHOUT_Y = os.environ.get('MVP_POOL_NO_Y', '1') != '0'
+# Dropout behind a single-layer SharedMLPDO chain (the segmentation head) inside the BatchNorm + ReLU kernels, mask regenerated in backward.
+FUSE_DROPOUT = os.environ.get('MVP_FUSE_DROPOUT', '1') != '0'
 
 
 def _round4(c):
@@ -637,8 +639,12 @@ class MLPChainRows(torch.autograd.Function):
         nl = len(params) // 3
         R = x0.size(0)
         dev = x0.device
+        drop_p, drop_seed = 0.0, 0
+        if isinstance(pool_sum, tuple):  # (flags, dropout probability, dropout seed): dropout behind the last layer, K = 1 (SharedMLPDO)
+            pool_sum, drop_p, drop_seed = pool_sum
         ctx.dw_aside = bool(pool_sum & 2)  # weight gradients may run on the side stream (see SideStream)
         pool_sum = bool(pool_sum & 1)
+        ctx.dropout = (float(drop_p), int(drop_seed))
         ys, means, invstds = [], [], []
         act = (None, None, None, None)
         x = x0
@@ -721,7 +727,12 @@ class MLPChainRows(torch.autograd.Function):
             x = y
         cl = ys[-1].size(1)
         G = R // K
-        if not pooled:
+        if not pooled and drop_p > 0:
+            assert K == 1
+            out, arg = torch.empty((R, cl), dtype=torch.float32, device=dev), None
+            L.call('mvp_bn_rows_forward_dropout_f32', x0, L.ptr(ys[-1]), L.ptr(params[-2]), L.ptr(params[-1]), R, cl, 0, 0.0, 0.0, 1, None, None,
+                   None, L.ptr(means[-1]), L.ptr(invstds[-1]), L.ptr(out), None, float(drop_p), int(drop_seed))
+        elif not pooled:
             out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, pool_sum)
         ctx.first_linear = params[0] is not None
         ctx.pooled = pooled
@@ -756,6 +767,14 @@ class MLPChainRows(torch.autograd.Function):
                    L.ptr(stat_l), L.ptr(_cs_partial(G, cl, g.device)))
             pool = (g, out, arg)
             dy, dgam, dbet = None, None, None
+        elif ctx.dropout[0] > 0:  # the keep mask is regenerated from (p, seed) inside the BatchNorm-backward passes
+            stat_d = torch.empty(2 * cl, dtype=torch.float64, device=g.device)
+            dy = torch.empty_like(ys[-1])
+            dgb = torch.empty((2, cl), dtype=torch.float32, device=g.device)
+            L.call('mvp_bn_rows_backward_dropout_f32', g, L.ptr(g), L.ptr(ys[-1]), L.ptr(means[-1]), L.ptr(invstds[-1]), L.ptr(params[-2]),
+                   L.ptr(params[-1]), R, cl, 1, int(training), L.ptr(stat_d), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]),
+                   L.ptr(_cs_partial(R, cl, g.device)), ctx.dropout[0], ctx.dropout[1])
+            dgam, dbet = dgb[0], dgb[1]
         else:
             dy, dgam, dbet = _bn_backward(g, out, arg, ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, training)
         dx0 = None
@@ -986,9 +1005,16 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
         aside = DW_SIDE_STREAM and all(l.conv.weight.is_leaf and l.conv.weight.grad is None and not l.conv.weight._backward_hooks for l in mlp)
-        out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None,
-                                 int(reduce == 'sum' and K > 1) + 2 * int(aside), *params)
-        return F.dropout(out, p=dropout_p, training=training, inplace=False) if dropout_p > 0 else out
+        flags = int(reduce == 'sum' and K > 1) + 2 * int(aside)
+        # dropout behind the (single) layer: folded into the BatchNorm + ReLU passes (mvp_bn_rows_forward_dropout_f32) unless a graph is
+        # being captured (the seed would be baked into the capture; torch's own dropout advances its Philox offset per replay)
+        fold = dropout_p > 0 and training and K == 1 and 0 < dropout_p < 1 and FUSE_DROPOUT and x.size(0) * mlp[-1].conv.weight.size(0) < 2 ** 32 and \
+            not torch.cuda.is_current_stream_capturing()
+        if fold:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())  # torch's CPU generator: follows torch.manual_seed
+            flags = (flags, float(dropout_p), seed & 0x7fffffffffffffff)
+        out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, flags, *params)
+        return F.dropout(out, p=dropout_p, training=training, inplace=False) if (dropout_p > 0 and not fold) else out
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     if K > 255:  # the pooled BatchNorm kernel keeps its arg-max in one byte: pool with torch after a K = 1 pass
         x = shared_mlp_rows(x, mlp, 1, dropout_p, training)

@@ -1100,3 +1100,52 @@ def test_fps_throughput_launch_shape(dev, kind):
     assert old == 0 and torch.equal(got, ref)
     np.testing.assert_array_equal(got[:2].cpu().numpy(), O().fps(pts[:2], 512))
     np.testing.assert_array_equal(got5[7:].cpu().numpy(), O().fps(pts[7:, :5000], 300))
+
+
+@pytest.mark.parametrize('bn_train', [True, False])
+def test_dropout_inside_the_batchnorm_passes(dev, bn_train):
+    """SharedMLPDO head (Conv + BN + ReLU + Dropout, mlp.py:86-92) with the dropout folded into the BatchNorm kernels
+    (mvp_bn_rows_forward_dropout_f32 / ..._backward_dropout_f32): kept values are the undropped ones times 1 / (1 - p), the keep rate is
+    1 - p, every column and row sees both outcomes, and the gradients are those of the same chain with the SAME mask applied by torch."""
+    from mvpnet_amd import rows as R
+    from mvpnet_amd.nn import SharedMLPDO
+    torch.manual_seed(4)
+    rows, cin, cout, p = 40000, 64, 128, 0.5
+    mlp = SharedMLPDO(cin, (cout,), ndim=1, bn=True, p=p).to(dev)
+    mlp.train(bn_train)
+    x = torch.randn(rows, cin, device=dev)
+    up = torch.randn(rows, cout, device=dev)
+
+    def run(drop, mask=None):
+        for q in mlp.parameters():
+            q.grad = None
+        xi = x.clone().requires_grad_(True)
+        out = R.shared_mlp_rows(xi, mlp, dropout_p=p if drop else 0.0, training=True)
+        res = out if mask is None else out * mask
+        (res * up).sum().backward()
+        return out.detach(), xi.grad.clone(), [q.grad.clone() for q in mlp.parameters()]
+
+    old = R.FUSE_DROPOUT
+    try:
+        R.FUSE_DROPOUT = True
+        out_d, gx_d, gp_d = run(True)
+        out_d2 = run(True)[0]
+        out_0 = run(False)[0]
+        pos = out_0 > 0
+        keep = out_d != 0
+        assert not bool((keep & ~pos).any())                       # nothing appears where the activation was zero
+        rate = float(keep[pos].float().mean())
+        assert abs(rate - (1 - p)) < 5e-3, rate
+        np.testing.assert_allclose(out_d[keep].cpu().numpy(), (out_0[keep] / (1 - p)).cpu().numpy(), rtol=1e-6)
+        col = keep.float().sum(0) / pos.float().sum(0).clamp(min=1)
+        row = keep.float().sum(1) / pos.float().sum(1).clamp(min=1)
+        assert float(col.min()) > 0.4 and float(col.max()) < 0.6 and float(row.min()) > 0.1 and float(row.max()) < 0.9
+        assert not torch.equal(out_d != 0, out_d2 != 0)            # a new mask per call
+        # gradients: the undropped chain times the same mask, differentiated by autograd
+        mask = torch.where(pos, keep.float() / (1 - p), torch.zeros_like(out_0))
+        _, gx_r, gp_r = run(False, mask)
+        for a, e in zip([gx_d] + gp_d, [gx_r] + gp_r):
+            tol = 2e-5 * float(e.abs().max()) + 1e-9
+            assert float((a - e).abs().max()) <= tol, tuple(e.shape)
+    finally:
+        R.FUSE_DROPOUT = old
