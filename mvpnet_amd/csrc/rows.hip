@@ -65,24 +65,36 @@ __global__ __launch_bounds__(kRT) void group_rows_kernel(const float* __restrict
 // relation_rows: out (R*K, C+4) = [feat (R*K, C) | src (R*K, 3) - tgt (R, 3) | squared length], the input of FeatureAggregation's
 // MLP (mvpnet_3d.py:55-56) in ONE pass: one lane per 16 bytes of output, the last 16 bytes of a row are the relation columns
 // (pinned (dx*dx + dy*dy) + dz*dz).  ATen needs a subtract, a square, a sum and a 2.6 TB/s concatenation for the same tensor.
+constexpr int kRelU = 4;  // 16-byte pieces per lane, all loads issued before the first store
 __global__ __launch_bounds__(kRT) void relation_rows_kernel(const float* __restrict__ feat, const float* __restrict__ src,
                                                             const float* __restrict__ tgt, int64_t rows, int K, int C,
                                                             float* __restrict__ out) {
   const int L4 = (C >> 2) + 1;
-  const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
-  const int64_t e = t / L4;
-  const int c4 = (int)(t - e * L4);
-  if (e >= rows) return;
-  float4 v;
-  if (c4 < L4 - 1) {
-    v = ld4(feat + (size_t)e * C + c4 * 4);
-  } else {
-    const float* p = src + (size_t)e * 3;
-    const float* q = tgt + (size_t)(e / K) * 3;
-    const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
-    v = make_float4(dx, dy, dz, (dx * dx + dy * dy) + dz * dz);
+  const int64_t total = rows * L4;
+  const int64_t t0 = (int64_t)blockIdx.x * (kRT * kRelU) + threadIdx.x;
+  float4 v[kRelU];
+  int64_t dst[kRelU];
+#pragma unroll
+  for (int u = 0; u < kRelU; ++u) {
+    const int64_t t = t0 + (int64_t)u * kRT;  // consecutive lanes -> consecutive 16-byte pieces of the output
+    dst[u] = -1;
+    if (t < total) {
+      const int64_t e = t / L4;
+      const int c4 = (int)(t - e * L4);
+      dst[u] = e * (C + 4) + c4 * 4;
+      if (c4 < L4 - 1) {
+        v[u] = ld4(feat + (size_t)e * C + c4 * 4);
+      } else {
+        const float* p = src + (size_t)e * 3;
+        const float* q = tgt + (size_t)(e / K) * 3;
+        const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+        v[u] = make_float4(dx, dy, dz, (dx * dx + dy * dy) + dz * dz);
+      }
+    }
   }
-  st4(out + (size_t)e * (C + 4) + c4 * 4, v);
+#pragma unroll
+  for (int u = 0; u < kRelU; ++u)
+    if (dst[u] >= 0) st4(out + dst[u], v[u]);
 }
 
 // group_lin_rows: out[b,m,k,:] = Wxyz . (xyz[b,j] - centre[b,m]) + zf[b,j,:],  j = idx[b,m,k]   (C % 4 == 0)
@@ -918,7 +930,7 @@ MVP_API int mvp_relation_rows_f32(const float* feature, const float* src_xyz, co
   MVP_REQUIRE(R >= 0 && K >= 1 && C > 0 && C % 4 == 0 && C < (1 << 20) && R * K < (1ll << 40));
   if (R == 0) return MVP_OK;
   const int64_t rows = R * K;
-  hipLaunchKernelGGL(relation_rows_kernel, dim3((unsigned)cdiv(rows * (C / 4 + 1), kRT)), dim3(kRT), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(relation_rows_kernel, dim3((unsigned)cdiv(rows * (C / 4 + 1), (int64_t)kRT * kRelU)), dim3(kRT), 0, static_cast<hipStream_t>(stream),
                      feature, src_xyz, tgt_xyz, rows, (int)K, (int)C, out);
   return mvp_launch_status();
 }
