@@ -1,8 +1,7 @@
-python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -q -k "relation or mvpnet3d" 2>&1 | tail -2
+python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -q -k "csr or gather or pn2ssg or mvpnet3d" 2>&1 | tail -2
 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --train-only 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'): d=json.loads(l); print(d['ms_per_step'])"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/tr_rel -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --train-only > /dev/null 2>&1
-grep -E "relation_rows|fused_dropout|masked_scale" $GRAFT_REPO_ROOT/gpurun_out/tr_rel/p_kernel_stats.csv | cut -c1-60,200-330
