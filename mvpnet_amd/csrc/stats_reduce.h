@@ -86,12 +86,12 @@ __global__ __launch_bounds__(256) void stats_reduce_finalize_kernel(const double
     }
     __syncthreads();
   }
-  // ---- last workgroup: finalize
-  __threadfence();
+  // ---- last workgroup: finalize.  No __threadfence(): at device scope it writes back and invalidates the XCD's whole L2, once per
+  // workgroup here.  What crosses workgroups are the device-scope atomics on `stat` above (performed at the memory side; the barrier
+  // at the end of the loop waits for this workgroup's own) and the device-scope loads below.
   if (threadIdx.x == 0) last = atomicAdd(&g_stats_ticket[slot], 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!last) return;
-  __threadfence();
   const int C = C2 / 2;
   for (int c = threadIdx.x; c < C; c += 256) {
     const double s1 = __hip_atomic_load(stat + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
