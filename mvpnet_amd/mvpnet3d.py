@@ -10,6 +10,8 @@ Differences from the reference that do not change results:
     `pose` (and optionally `pixel_box`) are given: they are then computed on the device with the
     lifting kernels instead of by dataloader workers (scannet_2d3d.py:254-313).
 """
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -307,8 +309,9 @@ class GraphedTrainStep:
         R.weight_slices.refresh(dev)  # the slice table exists before the capture: the refresh launch becomes a node of the graph
         self.graph = torch.cuda.CUDAGraph()
         # the weight gradients stay on the captured stream: inside a graph the extra fork / join edges cost more than the overlap
-        # returns (measured B = 32: 9.56 ms captured without them, 9.80 ms with; the eager step gains 0.2 ms from them)
-        aside, R.DW_SIDE_STREAM = R.DW_SIDE_STREAM, False
+        # returns (measured B = 32: 9.25 ms captured without them, 9.72 ms with -- MVP_GRAPH_DW_SIDE=1 --; the eager step gains 0.2 ms from them)
+        aside = R.DW_SIDE_STREAM
+        R.DW_SIDE_STREAM = aside and os.environ.get('MVP_GRAPH_DW_SIDE', '0') == '1'
         try:
             self._capture(model, loss_fn, dev, geometry)
         finally:
