@@ -31,7 +31,7 @@ _SIGNATURES = {
     'mvp_group_points_backward_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_knn_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_knn_distance_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
-    'mvp_knn3_weights_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr, _ptr, _ptr],
+    'mvp_knn3_weights_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr, _ptr, _ptr, _ptr],
     'mvp_interpolate_forward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_forward_f64': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
@@ -45,9 +45,9 @@ _SIGNATURES = {
     'mvp_lift_f32': [_ptr, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr,
                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_lift_aug_f32': [_ptr, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr,
-                         _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
-    'mvp_rotate_rows_f32': [_ptr, _ptr, _i64, _i64, _ptr],
-    'mvp_copy_slices_f32': [_ptr, _i64],
+                         _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_rotate_rows_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr],
+    'mvp_copy_slices_f32': [_ptr, _i64, _ptr],
     'mvp_group_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_rows_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_lin_rows_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -63,23 +63,23 @@ _SIGNATURES = {
     'mvp_bn_rows_backward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int, _ptr,
                                  _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_rows_forward_dropout_f32': [_ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _f32, _f32, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                        _ptr, _f32, ctypes.c_uint64],
+                                        _ptr, _f32, ctypes.c_uint64, _ptr],
     'mvp_bn_rows_backward_dropout_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, ctypes.c_int, _ptr, _ptr, _ptr, _ptr,
-                                         _ptr, _f32, ctypes.c_uint64],
+                                         _ptr, _f32, ctypes.c_uint64, _ptr],
     'mvp_bn_rows_backward_finish_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_finalize_f32': [_ptr, _i64, _i64, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
     'mvp_mlp_input_grad_f32': [_ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_layer_backward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
-                                   _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+                                   _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_forward_pool_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32,
-                                 _ptr, _ptr, _ptr, _ptr, _ptr],
-    'mvp_pool_finalize_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr],
-    'mvp_pool_backward_stats_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr],
+                                 _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_pool_finalize_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr, _ptr],
+    'mvp_pool_backward_stats_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr],
     'mvp_sa_fused_forward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr,
-                                 _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+                                 _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_forward_bn_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr,
-                               _ptr, _ptr],
+                               _ptr, _ptr, _ptr],
     'mvp_mlp_forward_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],

@@ -27,6 +27,19 @@ def test_header_symbols_are_exported():
     assert lib.mvp_strerror(-1).startswith(b'invalid argument')
 
 
+def test_signature_table_matches_the_header_argument_counts():
+    """Every ctypes signature in mvpnet_amd/_lib.py has as many entries as the header's prototype has parameters (stream included):
+    ctypes accepts extra positional arguments silently, so a short table would go unnoticed."""
+    import re
+    from mvpnet_amd import _lib
+    text = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'mvp_hip.h')).read(), flags=re.S)
+    for name, sig in _lib._SIGNATURES.items():
+        m = re.search(r'\b' + name + r'\s*\(([^;]*?)\)\s*;', text, flags=re.S)
+        assert m, name
+        n = len([a for a in m.group(1).split(',') if a.strip()])
+        assert n == len(sig), (name, n, len(sig))
+
+
 def test_argument_errors_do_not_launch():
     """Precondition failures return MVP_E* before any HIP call (safe without a GPU)."""
     import ctypes
