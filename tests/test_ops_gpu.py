@@ -1149,3 +1149,20 @@ def test_dropout_inside_the_batchnorm_passes(dev, bn_train):
             assert float((a - e).abs().max()) <= tol, tuple(e.shape)
     finally:
         R.FUSE_DROPOUT = old
+
+
+def test_copy_slices_table_kernel(dev):
+    """mvp_copy_slices_f32: column slices of several matrices in one launch, straight through the C ABI (table on the device:
+    {src, dst, src stride, dst stride, rows, cols} per entry); padding columns of the destinations are left alone."""
+    from mvpnet_amd import _lib as L
+    rs = np.random.RandomState(5)
+    srcs = [torch.from_numpy(rs.randn(r, c).astype(np.float32)).to(dev) for r, c in ((32, 67), (64, 131), (128, 384), (5, 9))]
+    specs = [(0, 64, 64), (128, 131, 3), (256, 384, 128), (2, 9, 8)]   # (c0, c1, destination row length)
+    dsts = [torch.full((s.size(0), ld), -7.0, device=dev) for s, (_, _, ld) in zip(srcs, specs)]
+    table = torch.tensor([[s.data_ptr() + 4 * c0, d.data_ptr(), s.stride(0), d.stride(0), s.size(0), c1 - c0]
+                          for s, d, (c0, c1, _) in zip(srcs, dsts, specs)], dtype=torch.int64).to(dev)
+    L.call('mvp_copy_slices_f32', table, L.ptr(table), len(srcs))
+    for s, d, (c0, c1, ld) in zip(srcs, dsts, specs):
+        assert torch.equal(d[:, :c1 - c0], s[:, c0:c1])
+        assert bool((d[:, c1 - c0:] == -7.0).all())
+    L.call('mvp_copy_slices_f32', table, L.ptr(table), 0)  # n = 0: nothing to do
