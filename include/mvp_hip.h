@@ -9,7 +9,10 @@
  *     0            success (kernel(s) enqueued on `stream`; nothing is synchronised)
  *     < 0          MVP_E* argument error, nothing was launched
  *     > 0          hipError_t reported by the launch
- * No entry point allocates, frees, synchronises or keeps state; all are re-entrant.
+ * No entry point synchronises.  None allocates or keeps state either, with these exceptions: mvp_fps_* for clouds beyond 32768
+ * points takes and returns a stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`); the mvp_set_* switches are
+ * process-wide; the kernels that let their last workgroup finalize use self-resetting counters in static device memory (launches
+ * on different streams draw different counters).  Calls are meant for one host thread per process (one process per GPU).
  * All tensors are dense row-major ("contiguous") in the stated shape.
  * Index tensors are int64 as in the reference (all reference index outputs are int64).
  *
