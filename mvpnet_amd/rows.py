@@ -143,6 +143,7 @@ class WeightSlices:
     def __init__(self):
         self.entries = {}
         self.tables = {}   # device -> ([table writing bufs[0], table writing bufs[1]] on the device, entries in table order)
+        self.retired = []  # superseded tables stay allocated: a captured graph may still launch the refresh kernel with their address
 
     @staticmethod
     def _src(e):
@@ -160,7 +161,9 @@ class WeightSlices:
             e.bufs = [torch.zeros((weight.size(0), ld), dtype=torch.float32, device=weight.device) for _ in range(2)]
             if not torch.cuda.is_current_stream_capturing():
                 self.entries[key] = e
-                self.tables.pop(weight.device, None)
+                old = self.tables.pop(weight.device, None)
+                if old is not None:
+                    self.retired.append(old[0])
         if e.version != weight._version or e.ptr != weight.data_ptr():
             e.cur ^= 1
             e.bufs[e.cur][:, :e.cols].copy_(self._src(e))
@@ -182,6 +185,8 @@ class WeightSlices:
                 w2 = e.weight.detach().reshape(e.weight.size(0), -1)
                 for par in (0, 1):
                     rows[par].append([w2.data_ptr() + 4 * e.c0, e.bufs[par].data_ptr(), w2.stride(0), e.bufs[par].stride(0), w2.size(0), e.cols])
+            if tab is not None:
+                self.retired.append(tab[0])
             tab = self.tables[dev] = ([torch.tensor(r, dtype=torch.int64).to(dev) for r in rows], mine, [e.weight.data_ptr() for e in mine])
         if tab is None:
             return  # (inside a capture, before any table exists: get() copies slice by slice)
