@@ -570,6 +570,57 @@ def gen_modules_b8():
 # --------------------------------------------------------------------------- #
 # vote + train-step known answers (inline script code, re-typed: SURVEY.md sec.8c)
 # --------------------------------------------------------------------------- #
+def gen_module_special_cases():
+    """SetAbstraction / FeaturePropagation branches the four-level network never takes (modules.py:88-103,166-186): one global group
+    at the origin (num_centroids = 0, with <= 255 and with more points), no sampling (num_centroids = -1), features without
+    coordinates (use_xyz = False), and the propagation of a single global feature (num_neighbors = 0).  Outputs of the imported
+    reference classes in eval and train mode plus the gradient w.r.t. the input feature of a fixed upstream gradient."""
+    from mvpnet.models.pn2.modules import SetAbstraction, FeaturePropagation
+    out = {}
+    rs = np.random.RandomState(4242)
+    cases = {
+        'global200': (dict(in_channels=16, mlp_channels=(32, 64), num_centroids=0, radius=-1.0, max_neighbors=-1, use_xyz=True), 200),
+        'global600': (dict(in_channels=16, mlp_channels=(32, 64), num_centroids=0, radius=-1.0, max_neighbors=-1, use_xyz=True), 600),
+        'nosample': (dict(in_channels=16, mlp_channels=(32, 32), num_centroids=-1, radius=0.3, max_neighbors=16, use_xyz=True), 300),
+        'noxyz': (dict(in_channels=16, mlp_channels=(32, 32), num_centroids=64, radius=0.3, max_neighbors=16, use_xyz=False), 300),
+    }
+    for i, (name, (kw, n)) in enumerate(cases.items()):
+        xyz = torch.from_numpy(rs.rand(2, 3, n).astype(np.float32))
+        feat = torch.from_numpy(rs.randn(2, 16, n).astype(np.float32))
+        m = SetAbstraction(**kw)
+        shapes = load_into(m, seed=900 + i)
+        out[name + '_state_keys'] = np.asarray(json.dumps([[k, list(v)] for k, v in shapes.items()]))
+        out[name + '_xyz'], out[name + '_feature'] = xyz.numpy(), feat.numpy()
+        for mode in ('eval', 'train'):
+            m.train(mode == 'train')
+            f = feat.clone().requires_grad_(True)
+            new_xyz, new_f = m(xyz, f)
+            up = torch.from_numpy(np.random.RandomState(77 + i).randn(*new_f.shape).astype(np.float32))
+            (new_f * up).sum().backward()
+            out['{}_{}_new_xyz'.format(name, mode)] = new_xyz.detach().numpy()
+            out['{}_{}_new_feature'.format(name, mode)] = new_f.detach().numpy()
+            out['{}_{}_up'.format(name, mode)] = up.numpy()
+            out['{}_{}_grad_feature'.format(name, mode)] = f.grad.numpy()
+    # feature propagation of one global feature
+    n = 300
+    dense_xyz = torch.from_numpy(rs.rand(2, 3, n).astype(np.float32))
+    dense_f = torch.from_numpy(rs.randn(2, 16, n).astype(np.float32))
+    sparse_f = torch.from_numpy(rs.randn(2, 32, 1).astype(np.float32))
+    fp = FeaturePropagation(32, 16, (64, 32), 0)
+    shapes = load_into(fp, seed=950)
+    out['fpglobal_state_keys'] = np.asarray(json.dumps([[k, list(v)] for k, v in shapes.items()]))
+    out['fpglobal_dense_xyz'], out['fpglobal_dense_feature'], out['fpglobal_sparse_feature'] = dense_xyz.numpy(), dense_f.numpy(), sparse_f.numpy()
+    for mode in ('eval', 'train'):
+        fp.train(mode == 'train')
+        a, b = dense_f.clone().requires_grad_(True), sparse_f.clone().requires_grad_(True)
+        y = fp(dense_xyz, torch.zeros(2, 3, 1), a, b)
+        up = torch.from_numpy(np.random.RandomState(88).randn(*y.shape).astype(np.float32))
+        (y * up).sum().backward()
+        out['fpglobal_{}_out'.format(mode)], out['fpglobal_{}_up'.format(mode)] = y.detach().numpy(), up.numpy()
+        out['fpglobal_{}_grad_dense'.format(mode)], out['fpglobal_{}_grad_sparse'.format(mode)] = a.grad.numpy(), b.grad.numpy()
+    save('module_special_cases', **out)
+
+
 def gen_vote_trainstep():
     out = {}
     rs = np.random.RandomState(9)
@@ -899,6 +950,10 @@ def main():
         install_reference()
         gen_modules_b8()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'special':
+        install_reference()
+        gen_module_special_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'config_defaults':
         gen_config_defaults()
         return
@@ -918,6 +973,7 @@ def main():
     gen_lifting_aug()
     gen_modules(lifting)
     gen_modules_b8()
+    gen_module_special_cases()
     gen_vote_trainstep()
     gen_unet()
     gen_chunker()

@@ -375,6 +375,54 @@ def test_geometry_of_several_batches_in_one_plan(dev):
     assert torch.equal(got_a, ref[0]) and torch.equal(got_b, ref[1]) and torch.equal(got_c, ref[2])
 
 
+def _load_case(module, g, prefix, seed):
+    ref_keys = [(k, tuple(sh)) for k, sh in json.loads(str(g[prefix + '_state_keys']))]
+    assert [(k, tuple(v.shape)) for k, v in module.state_dict().items()] == ref_keys, 'state_dict keys/shapes differ from the reference'
+    sd = fill_state_dict(collections.OrderedDict(ref_keys), seed)
+    module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+@pytest.mark.parametrize('case,seed,kw', [
+    ('global200', 900, dict(in_channels=16, mlp_channels=(32, 64), num_centroids=0, radius=-1.0, max_neighbors=-1, use_xyz=True)),
+    ('global600', 901, dict(in_channels=16, mlp_channels=(32, 64), num_centroids=0, radius=-1.0, max_neighbors=-1, use_xyz=True)),
+    ('nosample', 902, dict(in_channels=16, mlp_channels=(32, 32), num_centroids=-1, radius=0.3, max_neighbors=16, use_xyz=True)),
+    ('noxyz', 903, dict(in_channels=16, mlp_channels=(32, 32), num_centroids=64, radius=0.3, max_neighbors=16, use_xyz=False))])
+def test_set_abstraction_special_cases(dev, case, seed, kw, mode):
+    """The SetAbstraction branches the four-level network never takes (modules.py:88-103): one global group at the origin
+    (num_centroids = 0; 200 points = fused max kernel, 600 = more rows than its one-byte arg-max holds), no sampling
+    (num_centroids = -1), features without coordinates (use_xyz = False) -- against the imported reference class."""
+    from mvpnet_amd.pn2 import SetAbstraction
+    g = load_golden('module_special_cases')
+    m = SetAbstraction(**kw)
+    _load_case(m, g, case, seed)
+    m = m.to(dev).train(mode == 'train')
+    xyz = torch.from_numpy(g[case + '_xyz']).to(dev)
+    f = torch.from_numpy(g[case + '_feature']).to(dev).requires_grad_(True)
+    new_xyz, new_f = m(xyz, f)
+    np.testing.assert_array_equal(new_xyz.detach().cpu().numpy(), g['{}_{}_new_xyz'.format(case, mode)])
+    np.testing.assert_allclose(new_f.detach().cpu().numpy(), g['{}_{}_new_feature'.format(case, mode)], rtol=0, atol=ATOL[mode])
+    (new_f * torch.from_numpy(g['{}_{}_up'.format(case, mode)]).to(dev)).sum().backward()
+    assert_grad_close(f.grad.cpu().numpy(), g['{}_{}_grad_feature'.format(case, mode)], mode)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_feature_propagation_of_one_global_feature(dev, mode):
+    """FeaturePropagation with num_neighbors = 0 (modules.py:166-170,178-182): the single sparse feature is broadcast to every dense point."""
+    from mvpnet_amd.pn2 import FeaturePropagation
+    g = load_golden('module_special_cases')
+    m = FeaturePropagation(32, 16, (64, 32), 0)
+    _load_case(m, g, 'fpglobal', 950)
+    m = m.to(dev).train(mode == 'train')
+    t = lambda k: torch.from_numpy(g['fpglobal_' + k]).to(dev)
+    a, b = t('dense_feature').requires_grad_(True), t('sparse_feature').requires_grad_(True)
+    y = m(t('dense_xyz'), torch.zeros(2, 3, 1, device=dev), a, b)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g['fpglobal_{}_out'.format(mode)], rtol=0, atol=ATOL[mode])
+    (y * t('{}_up'.format(mode))).sum().backward()
+    assert_grad_close(a.grad.cpu().numpy(), g['fpglobal_{}_grad_dense'.format(mode)], mode)
+    assert_grad_close(b.grad.cpu().numpy(), g['fpglobal_{}_grad_sparse'.format(mode)], mode)
+
+
 def test_unet_resnet34_frozen_channels_last(dev):
     """UNetResNet34 in its frozen form on the GPU (BatchNorm folded, channels_last, MIOpen convolutions) against the golden
     vectors of the imported reference class, and feeding MVPNet3D's device lifting without a layout copy."""
