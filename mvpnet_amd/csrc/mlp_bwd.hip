@@ -544,16 +544,17 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
     if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a); \
     else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a);        \
   } while (0)
-  // cross-tile prefetch costs registers: it pays where the kernel runs at one wave per SIMD anyway (measured per variant, profiles/)
-  static const int pf_mode = []() { const char* e = getenv("MVP_BWD_PREFETCH"); return e ? atoi(e) : -1; }();  // -1 auto, 0 off, 1 on
+  // cross-tile prefetch costs registers and measured slower on the step (8.77 vs 8.72 ms, tools/exp/README.md): only with
+  // MVP_BWD_PREFETCH=1
+  static const int pf_mode = []() { const char* e = getenv("MVP_BWD_PREFETCH"); return e ? atoi(e) : 0; }();  // 1 = on
 #define MVP_BWD(A_, B_)                                                       \
   do {                                                                        \
-    const bool pf = pf_mode < 0 ? ((A_) * (B_) >= 4) : pf_mode != 0;           \
+    const bool pf = pf_mode > 0;                                                \
     if (pf) MVP_BWD1(A_, B_, true); else MVP_BWD1(A_, B_, false);              \
   } while (0)
 #define MVP_BWD_POOL(A_, B_)                                                  \
   do {                                                                        \
-    const bool pf = pf_mode < 0 ? true : pf_mode != 0;                         \
+    const bool pf = pf_mode > 0;                                               \
     if (pf) MVP_BWD_POOL1(A_, B_, true); else MVP_BWD_POOL1(A_, B_, false);    \
   } while (0)
   if (pool_dout) {
