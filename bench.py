@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """Headline benchmark: chunks/sec of the MVPNet lifting + PointNet++ hot path, fwd+bwd.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 works either way: under an external `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE set:
+this process IS one rank), or as a plain `python bench.py --gpus N` -- the script then re-executes itself under
+torch.distributed.run on 127.0.0.1 with a free port, one process per GPU over RCCL (the reference's counterpart is the single-process
+nn.DataParallel of mvpnet/train_mvpnet_3d.py:68-70).  `--dry` replaces the device work by a host stand-in (gloo, no kernels): it exists
+so that the launcher, the rank plumbing, the gradient all-reduce, the logit all-gather and the JSON line are covered by a CPU test.
 
 One "step" = one pass of the hot path over one batch of synthetic chunks that are already
 resident in HBM (BASELINE.json configs[2]): device lifting (depth
@@ -162,6 +168,79 @@ def cpu_baseline(bt, batch_chunks=2):
                                                                                     torch.get_num_threads(), os.cpu_count())}
 
 
+def relaunch_under_torchrun(gpus, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one process per GPU, rendezvous on
+    127.0.0.1 (the container hostname may not resolve) at a free port.  Rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(gpus, 1) // 2)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The multi-rank skeleton of the bench with the device work replaced by a host stand-in: rank / world from the environment, gloo,
+    parameter broadcast, `steps` iterations of (stand-in step -> dist.GradSync all-reduce), barrier + MAX-over-ranks timing, the
+    sharded scene inference plumbing (shard_chunks -> all_gather_logits), one JSON line from rank 0.  Nothing here is a measurement."""
+    from mvpnet_amd import dist as D
+    rank, world, _ = D.init_from_env(backend='gloo')
+    assert world == args.gpus, 'WORLD_SIZE ({}) != --gpus ({})'.format(world, args.gpus)
+    torch.manual_seed(rank)
+    params = [torch.nn.Parameter(torch.randn(64, 67)), torch.nn.Parameter(torch.randn(64))]
+    module = torch.nn.ParameterList(params)
+    D.broadcast_parameters(module)
+    ref0 = [p.detach().clone() for p in params]
+    sync = D.GradSync(params) if world > 1 else None
+    batch = args.batch if args.batch > 0 else 4
+
+    def step():
+        for p in params:
+            p.grad = torch.full_like(p, float(rank + 1))
+        if sync is not None:
+            sync(weight_sum=torch.tensor(float(rank + 1)))
+        return params[0].grad[0, 0].item()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g00 = step()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tmax.item()
+    # weighted mean of the per-rank constant gradients r+1 with weights r+1: sum (r+1)^2 / sum (r+1)
+    expect = sum((r + 1) ** 2 for r in range(world)) / sum(r + 1 for r in range(world))
+    assert abs(g00 - expect) < 1e-5, (g00, expect)
+    n_chunks = 6
+    mine = D.shard_chunks(n_chunks, rank, world)
+    local = torch.stack([torch.full((3, 5), float(c)) for c in mine]) if mine else torch.zeros(0, 3, 5)
+    allc = D.all_gather_logits(local, n_chunks)
+    assert [int(allc[c, 0, 0]) for c in range(n_chunks)] == list(range(n_chunks))
+    same = all(torch.equal(a, b) for a, b in zip(ref0, [p.detach() for p in params]))
+    if rank == 0:
+        print(json.dumps({'metric': 'chunks/sec (8192 pts, 3x160x120 views) fwd+bwd', 'value': round(batch * world * args.steps / max(elapsed, 1e-9), 3),
+                          'unit': 'chunks/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(elapsed / max(args.steps, 1) * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'none', 'data': 'none (dry run: host stand-in, NOT a measurement)',
+                          'config': {'workload': 'dry run of the launcher / collectives', 'chunks_per_gpu': batch,
+                                     'parallelism': 'dp{} (gloo)'.format(world)}, 'dry': True, 'params_untouched': same}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -177,7 +256,14 @@ def main():
     ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
                                               'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml kept in tests/golden/configs.json')
     ap.add_argument('--batch', type=int, default=0, help='chunks per GPU per step (default: TRAIN.BATCH_SIZE of the config = 32)')
+    ap.add_argument('--dry', action='store_true', help='launcher / collective plumbing only: gloo on the host, no kernels (CPU test of the N > 1 path)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: become one (python bench.py --gpus N is a complete command)
+        sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
+    if args.dry:
+        return dry_run(args)
 
     from mvpnet_amd import dist as D
     from mvpnet_amd import _lib

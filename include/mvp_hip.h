@@ -11,8 +11,8 @@
  *     > 0          hipError_t reported by the launch
  * No entry point synchronises.  None allocates or keeps state either, with these exceptions: mvp_fps_* for clouds beyond 32768
  * points takes and returns a stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`); the mvp_set_* switches are
- * process-wide; the kernels that let their last workgroup finalize use self-resetting counters in static device memory (launches
- * on different streams draw different counters).  Calls are meant for one host thread per process (one process per GPU).
+ * process-wide DEFAULTS.  The kernels that let their last workgroup finalize keep their completion counter in caller memory (one extra
+ * element behind `stat` / `acc`, zero on entry), so there is no device-side state shared between launches, streams, threads or graphs.
  * All tensors are dense row-major ("contiguous") in the stated shape.
  * Index tensors are int64 as in the reference (all reference index outputs are int64).
  *
@@ -331,7 +331,7 @@ int mvp_mlp_forward_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, con
 /* mvp_mlp_forward_f32 (no bias) + the layer's training-mode BatchNorm finalize (what mvp_bn_finalize_f32 computes from `stat`: mean,
  * invstd with the biased variance; running_mean / running_var with momentum and the unbiased variance, may be NULL;
  * num_batches_tracked += 1, may be NULL) carried by the last workgroup of the statistics reduction: one launch fewer per layer.
- * stat (2*Cout float64) must be zero on entry (it receives the column sums). */
+ * stat: 2*Cout + 1 float64, ALL zero on entry: [column sums of y | of y^2 | completion counter of this launch (zero again on exit)]. */
 int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
                            const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* Y,
                            double* stat, double* partial, float eps, float momentum, float* mean, float* invstd, float* running_mean,
@@ -339,7 +339,7 @@ int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, 
 /* Last layer of a set-abstraction shared MLP, training mode, WITHOUT materialising its (R,Cout) output (reference shape being replaced:
  * the (B,C,M,32) tensor of mvpnet/models/pn2/modules.py:100-108 + torch.max over dim 3).  Rows are groups of K = 32 consecutive
  * neighbours (R = 32 G).  Leaves per group and column the largest / smallest PRE-BatchNorm value (ymax, ymin (G,Cout) float32) and the
- * first row attaining each (amax, amin (G,Cout) uint8), the layer's batch statistics (stat, zero on entry; partial = scratch of
+ * first row attaining each (amax, amin (G,Cout) uint8), the layer's batch statistics (stat, 2*Cout + 1 float64 zero on entry; partial = scratch of
  * ceil(R/128)*2*Cout doubles) and its BatchNorm finalize as mvp_mlp_forward_bn_f32.  mvp_pool_finalize_f32 then gives
  * out = max_k relu(bn(y_k)) (exact: bn o relu is monotone in y), arg, and ysel (the pre-BN value behind out: the backward's xhat).
  * MVP_EUNSUPPORTED unless split-bf16 precision, Cin, Cout <= 128, Cin % 4 == 0, Cout % 4 == 0, R % 32 == 0, R >= 32768. */

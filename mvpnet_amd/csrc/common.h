@@ -44,4 +44,11 @@ __device__ __forceinline__ double shfl_xor_t<double>(double v, int m) {
   return __shfl_xor(v, m, kWave);
 }
 
+// Completion wait for everything this lane has issued to memory so far.  On gfx9-family ISAs stores and NON-returning atomics count in
+// vmcnt like loads do, and the count drops when the operation has been performed at its coherence point (device-scope atomics: the
+// memory side).  `s_waitcnt vmcnt(0)` is therefore what orders "my atomics have landed" before a following ticket atomic -- without the
+// L2 write-back + invalidate that a device-scope release fence adds, and unlike a workgroup-scope fence, which emits no vm wait at all on
+// gfx950 (back-off barriers: the ticket could otherwise be performed while another channel still queues this lane's adds).
+__device__ __forceinline__ void wait_vm_complete() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

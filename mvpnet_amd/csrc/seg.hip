@@ -78,9 +78,9 @@ __global__ __launch_bounds__(kST) void seg_loss_kernel(const float* __restrict__
   if (threadIdx.x == 0) {
     atomicAdd(acc + 0, t0);
     atomicAdd(acc + 1, t1);
-    // the two device-scope atomics are complete (performed at the memory side) before the ticket is drawn: a wait, not a
-    // device-scope fence (that would write back and invalidate the XCD's L2 once per workgroup)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // the two device-scope atomics must be complete (performed at the memory side) before the ticket is drawn: a completion wait
+    // (common.h), not a device-scope fence (that would write back and invalidate the XCD's L2 once per workgroup)
+    wait_vm_complete();
     const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long*>(acc + 2), 1ull);
     if (ticket == (unsigned long long)gridDim.x - 1) {
       const double a0 = atomicAdd(acc + 0, 0.0), a1 = atomicAdd(acc + 1, 0.0);

@@ -53,10 +53,10 @@ struct BnFinalize {
   int64_t* num_batches_tracked;  // or nullptr
 };
 
-__device__ unsigned g_stats_ticket[64];  // one counter per in-flight launch (host rotates), self-resetting
-
+// The launch's completion counter lives in the CALLER's memory: stat[C2] (one extra float64 behind the 2*Cout sums, zero on entry like
+// the sums, left zero again by the last workgroup).  No static device state, nothing shared between launches, streams, threads or graphs.
 __global__ __launch_bounds__(256) void stats_reduce_finalize_kernel(const double* __restrict__ partial, int64_t nblk, int C2,
-                                                                    double* __restrict__ stat, BnFinalize fin, int slot) {
+                                                                    double* __restrict__ stat, BnFinalize fin) {
   __shared__ double red[256];
   __shared__ unsigned last;
   const int64_t per = (nblk + gridDim.x - 1) / gridDim.x;
@@ -87,9 +87,13 @@ __global__ __launch_bounds__(256) void stats_reduce_finalize_kernel(const double
     __syncthreads();
   }
   // ---- last workgroup: finalize.  No __threadfence(): at device scope it writes back and invalidates the XCD's whole L2, once per
-  // workgroup here.  What crosses workgroups are the device-scope atomics on `stat` above (performed at the memory side; the barrier
-  // at the end of the loop waits for this workgroup's own) and the device-scope loads below.
-  if (threadIdx.x == 0) last = atomicAdd(&g_stats_ticket[slot], 1u) == gridDim.x - 1 ? 1u : 0u;
+  // workgroup here.  What crosses workgroups are the device-scope atomics on `stat` above and the device-scope loads below; every lane
+  // waits for ITS atomics to have been performed (wait_vm_complete) before the barrier, so the ticket drawn after the barrier is
+  // ordered behind all of this workgroup's adds whatever channel they went to.
+  wait_vm_complete();
+  __syncthreads();
+  unsigned* ticket = reinterpret_cast<unsigned*>(stat + C2);
+  if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!last) return;
   const int C = C2 / 2;
@@ -109,15 +113,13 @@ __global__ __launch_bounds__(256) void stats_reduce_finalize_kernel(const double
   }
   if (threadIdx.x == 0) {
     if (fin.num_batches_tracked) *fin.num_batches_tracked += 1;
-    g_stats_ticket[slot] = 0u;  // ready for the next launch that draws this slot
+    *ticket = 0u;  // the caller's buffer is all sums again
   }
 }
 
 static inline void launch_stats_reduce_finalize(const double* partial, int64_t nblk, int C2, double* stat, const BnFinalize& fin, hipStream_t s) {
-  static unsigned next_slot = 0;  // host side, one process per GPU: consecutive launches never share a counter
-  const int slot = (int)(next_slot++ & 63u);
   const int64_t blocks = nblk < 16 ? 1 : (nblk / 16 > 128 ? 128 : nblk / 16);
-  hipLaunchKernelGGL(stats_reduce_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, nblk, C2, stat, fin, slot);
+  hipLaunchKernelGGL(stats_reduce_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, nblk, C2, stat, fin);
 }
 
 static inline void launch_stats_reduce(const double* partial, int64_t nblk, int C2, double* stat, hipStream_t s) {

@@ -85,8 +85,17 @@ def broadcast_parameters(module, src=0):
     """Make every rank start from rank `src`'s weights (DataParallel replicates per step)."""
     if world_size() == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src)
+    # Collectives write the storage without bumping the tensors' version counters, so nothing that caches by version sees the new
+    # values: drop the cached column-slice operands of the rows kernels and rebuild the folded runtime copy of a frozen 2D network
+    # (not a registered sub-module: the loop above did not reach it) from the weights just received.
+    from . import rows as R
+    R.weight_slices.invalidate()
+    for m in module.modules():
+        if m.__dict__.get('_fast') is not None and hasattr(m, '_refold'):
+            m._refold()
 
 
 def all_gather_logits(local_logits, num_chunks):

@@ -7,6 +7,7 @@ common/nn/modules/conv.py:41-51) but on (rows, C) matrices, so gathers / scatter
 coalesced row accesses and a shared-MLP layer is one row-major GEMM.
 """
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -170,6 +171,12 @@ class WeightSlices:
             e.version, e.ptr = weight._version, weight.data_ptr()
         return e.bufs[e.cur]
 
+    def invalidate(self):
+        """Forget what the buffers hold: the next get() / refresh() copies every slice again.  Needed after writes that do not bump
+        the weights' version counters -- `.data` assignments, collectives (dist.broadcast_parameters calls this)."""
+        for e in self.entries.values():
+            e.version = None
+
     def refresh(self, dev):
         """Top of a forward: bring every slice of a changed weight up to date, all of them in one launch."""
         if not WeightSlices.ENABLED:
@@ -215,11 +222,42 @@ weight_slices = WeightSlices()
 DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
 
 
+class WeightUse:
+    """One forward use of some conv weights whose gradient kernels may run on the side stream.  That is only safe while autograd has
+    nothing to ADD the returned gradient to before the end-of-backward join: the weight is used by exactly ONE pending forward (two
+    forwards before one backward, forward-forward-backward-backward micro-batching or a Parameter shared by two layers make the engine
+    sum the gradients on the calling stream while the side stream still writes them), its .grad is None when the backward runs, and
+    it carries no hooks (post-accumulate hooks such as DDP's read the gradient at once).  Every use registers a weak reference on its
+    weights; a use that finds another PENDING one (alive, its backward not run yet) marks BOTH as shared, for good.  Checked again at
+    backward time (`aside_ok`); the backward marks its use `done` (the autograd graph, and with it this object, may live on in the
+    caller's `preds` long after)."""
+    __slots__ = ('weights', 'shared', 'done', '__weakref__')
+
+    def __init__(self, weights):
+        self.weights = list(weights)
+        self.shared = False
+        self.done = False
+        me = weakref.ref(self)
+        for w in self.weights:
+            live = [r for r in w.__dict__.get('_mvp_uses', ()) if r() is not None and not r().done]
+            for r in live:
+                r().shared = True
+            if live:
+                self.shared = True
+            live.append(me)
+            w.__dict__['_mvp_uses'] = live
+
+    def aside_ok(self):
+        return not self.shared and all(w.is_leaf and w.grad is None and not w._backward_hooks and not w._post_accumulate_grad_hooks
+                                       for w in self.weights)
+
+
 class SideStream:
     def __init__(self):
         self.streams = {}   # device -> (side stream, fork event)
         self.open = set()
         self.keep = []      # what the side-stream kernels touch, alive until the join (instead of record_stream per tensor)
+        self.task = None    # autograd graph task the join callback is queued on
 
     def _join(self):
         for dev in list(self.open):
@@ -233,8 +271,12 @@ class SideStream:
         st = self.streams.get(dev)
         if st is None:
             st = self.streams[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Event())
-        if not self.open:
+        task = torch._C._current_graph_task_id()
+        if task != self.task or not self.open:
+            # one join per backward pass (keyed on the graph task: a backward that raised leaves `open` non-empty, and the next
+            # pass must still get its own callback; _join is idempotent)
             torch.autograd.Variable._execution_engine.queue_callback(self._join)
+            self.task = task
         self.open.add(dev)
         side, fork = st
         fork.record(torch.cuda.current_stream(dev))
@@ -262,7 +304,8 @@ class WeightGradSink:
         self.numel = weight.numel()
         self.users = self.left = users
         self.buf = None
-        self.aside = bool(DW_SIDE_STREAM and weight.is_leaf and weight.grad is None and not weight._backward_hooks)
+        self.use = WeightUse([weight]) if DW_SIDE_STREAM else None
+        self.aside = None  # decided by the first run() of a backward pass, the same for all the weight's slices
 
     def buffer(self, dev):
         if self.buf is None:
@@ -270,6 +313,8 @@ class WeightGradSink:
         return self.buf
 
     def run(self, dev, name, args, tensors):
+        if self.aside is None:
+            self.aside = bool(DW_SIDE_STREAM and self.use is not None and self.use.aside_ok())
         if self.aside:
             side_stream.run(dev, name, args, [self.buf] + list(tensors))
         else:
@@ -281,7 +326,9 @@ class WeightGradSink:
         if self.left > 0:
             return None
         g = self.buf[:self.numel].view(self.shape)
-        self.buf, self.left = None, self.users
+        self.buf, self.left, self.aside = None, self.users, None
+        if self.use is not None:
+            self.use.done = True
         return g
 
 
@@ -644,18 +691,20 @@ class MLPChainRows(torch.autograd.Function):
         nl = len(params) // 3
         R = x0.size(0)
         dev = x0.device
-        drop_p, drop_seed = 0.0, 0
-        if isinstance(pool_sum, tuple):  # (flags, dropout probability, dropout seed): dropout behind the last layer, K = 1 (SharedMLPDO)
-            pool_sum, drop_p, drop_seed = pool_sum
-        ctx.dw_aside = bool(pool_sum & 2)  # weight gradients may run on the side stream (see SideStream)
-        pool_sum = bool(pool_sum & 1)
+        # pool_sum: plain bool, or a dict of options {'sum', 'drop_p', 'drop_seed' (dropout behind the last layer, K = 1: SharedMLPDO),
+        # 'use' (WeightUse: the weight gradients may run on the side stream, see SideStream)}
+        opts = pool_sum if isinstance(pool_sum, dict) else {'sum': bool(pool_sum)}
+        drop_p, drop_seed = opts.get('drop_p', 0.0), opts.get('drop_seed', 0)
+        ctx.dw_use = opts.get('use')
+        pool_sum = bool(opts.get('sum', False))
         ctx.dropout = (float(drop_p), int(drop_seed))
         ys, means, invstds = [], [], []
         act = (None, None, None, None)
         x = x0
         couts = [x0.size(1) if params[3 * i] is None else params[3 * i].size(0) for i in range(nl)]
         # the kernels ADD their column sums to `stat`: one zeroed arena for the whole chain instead of a memset per layer
-        arena = zero_pool.zeros(2 * sum(couts), torch.float64, dev) if training else None
+        # (+ 1 per layer: the completion counter of the "last workgroup finalizes" reduction lives behind the layer's sums)
+        arena = zero_pool.zeros(2 * sum(couts) + nl, torch.float64, dev) if training else None
         wl = params[3 * (nl - 1)]
         pooled = bool(POOL_WITHOUT_Y and training and K == 32 and not pool_sum and nl >= 2 and wl is not None and R % 32 == 0 and R >= 32768 and
                       L.get_mlp_precision() != 'fp32' and wl.size(0) <= min(64, FUSE_BWD_MAX_COUT) and wl.size(1) <= 64 and
@@ -664,8 +713,8 @@ class MLPChainRows(torch.autograd.Function):
         for i in range(nl):
             w, gamma, beta = params[3 * i], params[3 * i + 1], params[3 * i + 2]
             eps, mom = eps_mom[i]
-            stat = arena[off:off + 2 * couts[i]] if training else None
-            off += 2 * couts[i]
+            stat = arena[off:off + 2 * couts[i] + 1] if training else None
+            off += 2 * couts[i] + 1
             if w is None:  # x0 already IS this layer's pre-BN output (the linear part ran before the grouping)
                 assert i == 0
                 cout = x0.size(1)
@@ -797,6 +846,7 @@ class MLPChainRows(torch.autograd.Function):
         gcur, pending = dy, None
         if pool is not None:
             gcur, pending = None, stat_l
+        dw_aside = bool(DW_SIDE_STREAM and ctx.dw_use is not None and ctx.dw_use.aside_ok())
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
             cout = ys[i].size(1)
@@ -842,7 +892,7 @@ class MLPChainRows(torch.autograd.Function):
             else:
                 wg_args = (L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]),
                            L.ptr(dw), cin)
-                if ctx.dw_aside:
+                if dw_aside:
                     side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, src, dw) + tuple(t for t in act if t is not None))
                 else:
                     L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args)
@@ -857,6 +907,8 @@ class MLPChainRows(torch.autograd.Function):
                 gcur, pending = dz, stat
             elif need_dz:
                 dx0 = dz if x0.size(1) == cin else F.pad(dz, (0, x0.size(1) - cin))
+        if ctx.dw_use is not None:
+            ctx.dw_use.done = True
         return (dx0, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -1009,16 +1061,17 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             params += [w, layer.bn.weight, layer.bn.bias]
             buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
-        aside = DW_SIDE_STREAM and all(l.conv.weight.is_leaf and l.conv.weight.grad is None and not l.conv.weight._backward_hooks for l in mlp)
-        flags = int(reduce == 'sum' and K > 1) + 2 * int(aside)
+        opts = {'sum': bool(reduce == 'sum' and K > 1)}
+        if DW_SIDE_STREAM and torch.is_grad_enabled():  # (a first layer that ran before the grouping has its own use: WeightGradSink)
+            opts['use'] = WeightUse([l.conv.weight for li, l in enumerate(mlp) if not (first_done and li == 0)])
         # dropout behind the (single) layer: folded into the BatchNorm + ReLU passes (mvp_bn_rows_forward_dropout_f32) unless a graph is
         # being captured (the seed would be baked into the capture; torch's own dropout advances its Philox offset per replay)
         fold = dropout_p > 0 and training and K == 1 and 0 < dropout_p < 1 and FUSE_DROPOUT and x.size(0) * mlp[-1].conv.weight.size(0) < 2 ** 32 and \
             not torch.cuda.is_current_stream_capturing()
         if fold:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())  # torch's CPU generator: follows torch.manual_seed
-            flags = (flags, float(dropout_p), seed & 0x7fffffffffffffff)
-        out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, flags, *params)
+            opts['drop_p'], opts['drop_seed'] = float(dropout_p), seed & 0x7fffffffffffffff
+        out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, opts, *params)
         return F.dropout(out, p=dropout_p, training=training, inplace=False) if (dropout_p > 0 and not fold) else out
     assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
     if K > 255:  # the pooled BatchNorm kernel keeps its arg-max in one byte: pool with torch after a K = 1 pass

@@ -96,9 +96,25 @@ class UNetResNet34(nn.Module):
     def get_conv(c_in, c_out):
         return nn.Sequential(nn.Conv2d(c_in, c_out, kernel_size=3, padding=1), nn.BatchNorm2d(c_out), nn.ReLU(inplace=True))
 
+    def train(self, mode=True):
+        """A frozen instance (frozen_inference()) STAYS in eval mode: `model.train()` on the enclosing MVPNet3D must neither switch the
+        2D branch's BatchNorms to batch statistics nor move their running statistics (they would end up in the next checkpoint).  The
+        reference gets the same effect by re-applying its Freezer after every `model.train()` (mvpnet/train_3d.py:142-143,
+        common/nn/freezer.py); here the module refuses to leave eval mode until `unfreeze()`."""
+        if self.__dict__.get('_fast') is not None:
+            mode = False
+        return super().train(mode)
+
+    def unfreeze(self):
+        """Undo frozen_inference(): drop the folded runtime copy, parameters trainable again, train() works normally."""
+        self.__dict__.pop('_fast', None)
+        for p in self.parameters():
+            p.requires_grad_(True)
+        return self
+
     def forward(self, data_dict):
         fast = self.__dict__.get('_fast')
-        if fast is not None and not self.training:
+        if fast is not None:  # frozen: always the folded, channels-last runtime copy (train() cannot leave eval mode, see above)
             return fast(data_dict)
         x = data_dict['image']
         h, w = x.shape[2], x.shape[3]

@@ -1,0 +1,41 @@
+"""`python bench.py --gpus N` is a complete command: without a launcher around it the script re-executes itself
+under torch.distributed.run (one process per rank, 127.0.0.1, free port) and rank 0 prints the one JSON line.  Runs here with `--dry`
+(gloo, host stand-in for the device work): what is covered is the launcher, RANK / WORLD_SIZE plumbing, dist.GradSync with weight masses,
+dist.all_gather_logits over round-robin chunk shards and the JSON contract -- not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config')
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout  # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('n', [1, 2, 3])
+def test_bench_launches_itself(n):
+    line = _run([sys.executable, 'bench.py', '--gpus', str(n), '--steps', '3', '--warmup', '1', '--dry'])
+    for k in KEYS:
+        assert k in line, k
+    assert line['n_gpus'] == n and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak' and line['dry'] is True
+    assert line['params_untouched'] is True  # broadcast made the ranks equal to rank 0, nothing else wrote the parameters
+
+
+def test_bench_under_an_external_launcher():
+    """The driver's command shape: torch.distributed.run around bench.py --gpus N."""
+    line = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                 '--master-port', '29713', 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--dry'])
+    assert line['n_gpus'] == 2

@@ -293,6 +293,28 @@ def test_weight_gradients_on_the_side_stream(dev):
                 for a, e in zip(got, one):
                     tol = 2e-5 * float(e.abs().max()) + 1e-9
                     assert float((a - passes * e).abs().max()) <= passes * tol, (rep, passes, tuple(e.shape))
+        # TWO forwards before ONE backward ((l1 + l2).backward()) and forward-forward-backward-backward: the engine adds the
+        # two gradients of every weight on the calling stream as they arrive, so neither use may fork (rows.WeightUse marks both shared)
+        R.DW_SIDE_STREAM = True
+        for rep in range(3):
+            model.zero_grad(set_to_none=True)
+            l1 = loss_fn(model(dict(batch)), batch)['seg_loss']
+            l2 = loss_fn(model(dict(batch)), batch)['seg_loss']
+            (l1 + l2).backward()
+            for p, e in zip([p for p in model.parameters() if p.grad is not None], one):
+                assert float((p.grad - 2 * e).abs().max()) <= 2 * (2e-5 * float(e.abs().max()) + 1e-9), (rep, tuple(e.shape))
+            model.zero_grad(set_to_none=True)
+            l1 = loss_fn(model(dict(batch)), batch)['seg_loss']
+            l2 = loss_fn(model(dict(batch)), batch)['seg_loss']
+            l1.backward()
+            l2.backward()
+            for p, e in zip([p for p in model.parameters() if p.grad is not None], one):
+                assert float((p.grad - 2 * e).abs().max()) <= 2 * (2e-5 * float(e.abs().max()) + 1e-9), (rep, tuple(e.shape))
+        # and a plain single pass afterwards forks again (the earlier uses are done)
+        got = grads(True, 1)
+        assert not R.side_stream.open
+        for a, e in zip(got, one):
+            assert float((a - e).abs().max()) <= 2e-5 * float(e.abs().max()) + 1e-9
     finally:
         R.DW_SIDE_STREAM = True
 

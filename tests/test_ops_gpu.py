@@ -914,7 +914,7 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
 def test_mlp_forward_with_bn_finalize(dev, R, Cin, Cout, stream):
     """mvp_mlp_forward_bn_f32 (BatchNorm finalize in the last workgroup of the statistics reduction) == mvp_mlp_forward_f32 followed by
     mvp_bn_finalize_f32: outputs, mean, invstd, running statistics, num_batches_tracked -- on the atomics path (few rows), the
-    scratch-slot path and the persistent streaming kernel; repeated calls (the ticket counters reset themselves)."""
+    scratch-slot path and the persistent streaming kernel; repeated calls."""
     from mvpnet_amd import _lib as L
     old = L.lib().mvp_set_mlp_stream(stream)
     try:
@@ -933,13 +933,14 @@ def test_mlp_forward_with_bn_finalize(dev, R, Cin, Cout, stream):
             L.call('mvp_bn_finalize_f32', y1, L.ptr(st1), R, Cout, 1e-5, 0.1, L.ptr(m1), L.ptr(i1), L.ptr(rm1), L.ptr(rv1), L.ptr(n1))
             # one call
             y2 = torch.empty(R, Cout, device=dev)
-            st2 = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+            st2 = torch.zeros(2 * Cout + 1, dtype=torch.float64, device=dev)  # + the launch's completion counter
             m2, i2, rm2, rv2 = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev), rm0.clone(), rv0.clone()
             n2 = torch.zeros((), dtype=torch.int64, device=dev)
             L.call('mvp_mlp_forward_bn_f32', x, L.ptr(x), R, Cin, Cin, L.ptr(w), Cin, Cout, None, None, None, None, L.ptr(y2), L.ptr(st2), L.ptr(part()),
                    1e-5, 0.1, L.ptr(m2), L.ptr(i2), L.ptr(rm2), L.ptr(rv2), L.ptr(n2))
             assert torch.equal(y1, y2) and int(n2) == 1
-            np.testing.assert_allclose(st2.cpu().numpy(), st1.cpu().numpy(), rtol=1e-12, atol=1e-9 * R)
+            np.testing.assert_allclose(st2[:-1].cpu().numpy(), st1.cpu().numpy(), rtol=1e-12, atol=1e-9 * R)
+            assert st2[-1].item() == 0.0  # the counter is zero again
             for a, b in ((m1, m2), (i1, i2), (rm1, rm2), (rv1, rv2)):
                 np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-7)
     finally:
@@ -1060,48 +1061,6 @@ def test_fps_exact_on_structured_clouds(dev, kind, N, M):
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
 
-@pytest.mark.parametrize('B,N,M,D,kind', [(2, 40000, 300, 3, 'uniform'), (1, 33000, 128, 2, 'uniform'), (1, 50000, 200, 3, 'lattice'),
-                                          (1, 36000, 40, 3, 'coincident')])
-@pytest.mark.parametrize('dtype', [np.float32, np.float64])
-def test_fps_beyond_the_register_resident_sizes(dev, B, N, M, D, kind, dtype):
-    """N > 32768 points per cloud (dense whole-scene chunks fed with all their points): the running distances live in a
-    stream-ordered scratch in global memory (fps_global_kernel).  Same indices as the oracle, ties and all-zero distances included."""
-    from mvpnet_amd.ops import farthest_point_sample
-    rs = np.random.RandomState(N + M)
-    pts = rs.rand(B, N, D)
-    if kind == 'lattice':
-        pts = np.round(pts * 1.9 / 0.02) * 0.02
-    elif kind == 'coincident':
-        pts = np.tile(pts[:, :1], (1, N, 1))
-    pts = pts.astype(dtype)
-    idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
-    np.testing.assert_array_equal(idx, O().fps(pts, M))
-
-
-@pytest.mark.parametrize('kind', ['uniform', 'lattice'])
-def test_fps_throughput_launch_shape(dev, kind):
-    """mvp_set_fps_mode(1): one wave per SIMD and 32 points per lane for batches of >= 8 clouds of 4097..8192 points (the training
-    step's prefetched geometry).  Same indices as the default shape on all clouds and as the oracle on two of them, ties included."""
-    from mvpnet_amd import _lib as L
-    from mvpnet_amd.ops import farthest_point_sample
-    rs = np.random.RandomState(77)
-    pts = rs.rand(9, 8192, 3)
-    if kind == 'lattice':
-        pts = np.round(pts * 1.9 / 0.02) * 0.02
-    pts = pts.astype(np.float32)
-    x = g(pts, dev)
-    ref = farthest_point_sample(x, 512, transpose=False)
-    old = L.lib().mvp_set_fps_mode(1)
-    try:
-        got = farthest_point_sample(x, 512, transpose=False)
-        got5 = farthest_point_sample(x[:, :5000].contiguous(), 300, transpose=False)
-    finally:
-        L.lib().mvp_set_fps_mode(old)
-    assert old == 0 and torch.equal(got, ref)
-    np.testing.assert_array_equal(got[:2].cpu().numpy(), O().fps(pts[:2], 512))
-    np.testing.assert_array_equal(got5[7:].cpu().numpy(), O().fps(pts[7:, :5000], 300))
-
-
 @pytest.mark.parametrize('bn_train', [True, False])
 def test_dropout_inside_the_batchnorm_passes(dev, bn_train):
     """SharedMLPDO head (Conv + BN + ReLU + Dropout, mlp.py:86-92) with the dropout folded into the BatchNorm kernels
@@ -1166,3 +1125,79 @@ def test_copy_slices_table_kernel(dev):
         assert torch.equal(d[:, :c1 - c0], s[:, c0:c1])
         assert bool((d[:, c1 - c0:] == -7.0).all())
     L.call('mvp_copy_slices_f32', table, L.ptr(table), 0)  # n = 0: nothing to do
+
+
+def test_last_workgroup_finalize_under_stress(dev):
+    """VERDICT r2 next #8 / ADVICE r2: the "last workgroup finalizes" kernels order their statistics atomics before the ticket with a
+    completion wait (s_waitcnt vmcnt(0)), not with a device-scope fence.  Thousands of back-to-back launches over many grid sizes and
+    widths on TWO concurrent streams; every mean / invstd / running statistic must equal, bit for bit, what the two-launch path
+    (mvp_mlp_forward_f32 -> mvp_bn_finalize_f32 from the SAME sums) gives.  The counters live in the callers' buffers: concurrent
+    launches cannot meet."""
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(11)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    shapes = [(65536 + 128 * g, cin, cout) for g, cin, cout in ((0, 32, 32), (5, 32, 64), (37, 64, 64), (64, 64, 128), (200, 32, 256), (511, 64, 512))]
+    shapes += [(1000, 32, 32), (4096, 64, 128)]  # atomics path (no scratch slots): a one-workgroup finalize
+    cases = []
+    for R, cin, cout in shapes:
+        x = torch.randn(R, cin, device=dev)
+        w = torch.randn(cout, cin, device=dev) * 0.2
+        cases.append((R, cin, cout, x, w))
+    torch.cuda.synchronize()
+    n_launch, bad = 0, 0
+    rounds = 40
+    results = []
+    for rnd in range(rounds):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                for R, cin, cout, x, w in cases[si::2] if rnd % 2 else cases[(1 - si)::2]:
+                    for rep in range(8):
+                        part = torch.empty(((R + 127) // 128) * 2 * cout, dtype=torch.float64, device=dev) if R >= 65536 else None
+                        y = torch.empty(R, cout, device=dev)
+                        stat = torch.zeros(2 * cout + 1, dtype=torch.float64, device=dev)
+                        mean, inv = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+                        rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+                        L.call('mvp_mlp_forward_bn_f32', x, L.ptr(x), R, cin, cin, L.ptr(w), cin, cout, None, None, None, None, L.ptr(y), L.ptr(stat),
+                               L.ptr(part), 1e-5, 0.1, L.ptr(mean), L.ptr(inv), L.ptr(rm), L.ptr(rv), None)
+                        # the two-launch finalize FROM THE SAME SUMS (so the comparison is bit for bit whatever the atomics' order was)
+                        m2, i2 = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+                        rm2, rv2 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+                        L.call('mvp_bn_finalize_f32', y, L.ptr(stat), R, cout, 1e-5, 0.1, L.ptr(m2), L.ptr(i2), L.ptr(rm2), L.ptr(rv2), None)
+                        results.append((mean, m2, inv, i2, rm, rm2, rv, rv2, stat))
+                        n_launch += 1
+        if len(results) >= 512 or rnd == rounds - 1:
+            torch.cuda.synchronize()
+            for mean, m2, inv, i2, rm, rm2, rv, rv2, stat in results:
+                if not (torch.equal(mean, m2) and torch.equal(inv, i2) and torch.equal(rm, rm2) and torch.equal(rv, rv2) and stat[-1].item() == 0.0):
+                    bad += 1
+            results = []
+    print('last-workgroup finalize: {} launches on 2 streams, {} mismatches'.format(n_launch, bad))
+    assert n_launch >= 2000 and bad == 0
+
+
+def test_seg_loss_ticket_under_stress(dev):
+    """The loss kernel's last workgroup divides the two sums: 3000 launches over varying grids on two streams, each equal to the
+    division of its own accumulators."""
+    from mvpnet_amd.mvpnet3d import SegLoss
+    torch.manual_seed(3)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    w = torch.linspace(0.5, 1.5, 20, device=dev)
+    data = []
+    for n in (257, 4096, 8192, 50000, 262144):
+        logit = torch.randn(2, 20, n, device=dev)
+        label = torch.randint(0, 20, (2, n), device=dev)
+        label[0, ::7] = -100
+        data.append((logit, label))
+    torch.cuda.synchronize()
+    out = []
+    from mvpnet_amd.mvpnet3d import _SegLossFn
+    for rnd in range(300):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                for logit, label in data:
+                    loss = _SegLossFn.apply(logit, label, w, -100)
+                    out.append((loss, _SegLossFn.last_acc))
+    torch.cuda.synchronize()
+    bad = sum(1 for loss, acc in out if float(loss) != float(np.float32(acc[0].item() / acc[1].item())))
+    print('seg loss ticket: {} launches, {} mismatches'.format(len(out), bad))
+    assert bad == 0

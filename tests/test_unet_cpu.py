@@ -47,3 +47,25 @@ def test_unet_folded_channels_last():
     scale = np.abs(g['b_feature']).max()
     np.testing.assert_allclose(out['feature'].numpy(), g['b_feature'], rtol=0, atol=2e-5 * scale)
     np.testing.assert_allclose(out['seg_logit'].numpy(), g['b_seg_logit'], rtol=0, atol=2e-5 * np.abs(g['b_seg_logit']).max())
+
+
+def test_frozen_unet_survives_model_train():
+    """model.train() on the enclosing network must not thaw the frozen 2D branch -- same features as in eval mode, running
+    statistics untouched, still the folded runtime copy (the reference re-applies its Freezer after every train(): train_3d.py:142-143)."""
+    g = load_golden('unet_resnet34')
+    model = _load(UNetResNet34(20), g).frozen_inference()
+    outer = torch.nn.Sequential(model)
+    x = {'image': torch.from_numpy(g['a_image'])}
+    with torch.no_grad():
+        ref = model(x)['feature'].clone()
+    before = {k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k}
+    outer.train()
+    assert not model.training and not any(m.training for m in model.modules())
+    with torch.no_grad():
+        out = model(x)['feature']
+    assert torch.equal(out, ref)
+    after = model.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items())
+    model.unfreeze()
+    outer.train()
+    assert model.training and all(p.requires_grad for p in model.parameters())
