@@ -168,6 +168,88 @@ def cpu_baseline(bt, batch_chunks=2):
                                                                                     torch.get_num_threads(), os.cpu_count())}
 
 
+DENSE_LIFT_BYTES_PER_CHUNK = 89092096  # 4P + 12N + 2*(4*C*N*k) + 8Nk + 12Nk, P = 5*320*240, N = 32768, C = 64, k = 5 (float-depth figure)
+
+
+def dense_extra(dev, chunks=2):
+    """BASELINE.json configs[4] ("dense stress": 5 views of 320x240, 32768 points per chunk, k = 5, centroids (8192, 2048, 512, 128)),
+    `chunks` chunks on this GPU: (a) the lifting launch alone (HIP events around mvp_lift_f32) against its 89.1 MB/chunk of algorithmic
+    traffic, (b) lifting + aggregation + PN2SSG forward, eval mode.  Extra field; parity of this configuration: tests/test_dense_gpu.py."""
+    from mvpnet_amd.synthetic import make_batch
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D
+    from mvpnet_amd import ops
+    dense = dict(nb_pts=32768, nv=5, h=240, w=320, channels=64)
+    bt = make_batch(900, chunks, **dense)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam = t(np.repeat(bt['cam_matrix'][None, None, :3, :3], dense['nv'], 1).repeat(chunks, 0))
+    depth, kinv, pose, box, pts, feat = t(bt['depth_mm'].astype(np.int16)), t(bt['kinv']), t(bt['pose']), t(bt['pixel_box']), t(bt['points']), t(bt['feature_2d'])
+    for _ in range(3):
+        ops.lift(feat, depth, kinv, cam, pose, pts, k=5, box=box)
+    pairs = []
+    for _ in range(10):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        ops.lift(feat, depth, kinv, cam, pose, pts, k=5, box=box)
+        e.record()
+        pairs.append((s, e))
+    torch.cuda.synchronize()
+    lift_ms = float(np.mean([s.elapsed_time(e) for s, e in pairs]))
+    achieved = DENSE_LIFT_BYTES_PER_CHUNK * chunks / (lift_ms * 1e-3) / 1e9
+    torch.manual_seed(0)
+    net2d = SuppliedFeature2D()
+    net2d.feature = feat.view(chunks * dense['nv'], dense['h'], dense['w'], 64).permute(0, 3, 1, 2)
+    model = MVPNet3D(net2d, '', PN2SSG(64, 20, num_centroids=(8192, 2048, 512, 128)), in_channels=64).to(dev).eval()
+    batch = {'images': torch.zeros(chunks, dense['nv'], 3, dense['h'], dense['w'], device=dev), 'points': pts.transpose(1, 2).contiguous(),
+             'depth': depth, 'cam_matrix': cam, 'kinv': kinv, 'pose': pose, 'pixel_box': box, 'k': 5}
+    with torch.no_grad():
+        for _ in range(2):
+            model(dict(batch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            model(dict(batch))
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t0) / 5 * 1e3
+    return {'workload': 'configs[4]: 5 views of 320x240, 32768 points per chunk, k = 5, centroids (8192, 2048, 512, 128); {} chunks on this GPU'.format(chunks),
+            'lift': {'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': DENSE_LIFT_BYTES_PER_CHUNK * chunks,
+                     'achieved_GBps': round(achieved, 1), 'frac_of_hbm_peak': round(achieved / HBM_PEAK_GBS, 4)},
+            'fwd_only': {'chunks_per_s_per_gpu': round(chunks / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3)}}
+
+
+def contraction_info():
+    """How the shared-MLP (1x1 conv) contractions are carried out: operands, accumulators and every stored tensor are fp32, but by
+    default the products run on the bf16 matrix pipe as a split of each fp32 operand into bf16 pieces."""
+    from mvpnet_amd import _lib
+    fwd = _lib.get_mlp_precision()
+    bwd = {0: 'fp32', 3: 'bf16x3', 6: 'bf16x6'}.get(_lib.lib().mvp_get_mlp_precision_backward(), '?') if fwd != 'fp32' else 'fp32'
+    note = {'fp32': 'fp32 MFMA (v_mfma_f32_32x32x2_f32)',
+            'bf16x6': '3 bf16 pieces per fp32 operand, 6 products of order <= 2 on v_mfma_f32_32x32x16_bf16: dropped terms <= 2^-25 |ab| (fp32-equivalent)',
+            'bf16x3': '2 bf16 pieces per operand, 3 products: ~2^-17 relative per product (NARROWER than fp32)'}
+    return {'storage': 'f32', 'accumulate': 'f32', 'forward': fwd, 'backward': bwd, 'forward_note': note[fwd], 'backward_note': note[bwd]}
+
+
+def parity_info():
+    """The parity bars the tests enforce and the measured operating-point numbers (a committed file written by
+    tests/test_operating_point_gpu.py on an MI355X; not re-measured by the bench)."""
+    out = {'eval_mode_logit_bar': 1e-4,
+           'train_mode_logit_bar': '3e-4 vs the reference fp32 fixture AND max |gpu - f64| <= 1.5 x max |reference fp32 - f64| (25 batch-statistics BatchNorms: the '
+                                   'reference fp32 path itself is ~2.7e-4 from the float64 value of its graph, so 1e-4 against it is not attainable by any fp32 implementation)',
+           'index_ops': 'bit-exact (FPS, ball query, 3-NN, pixel k-NN)'}
+    for name in ('r03_operating_point_B32.json', 'r02_operating_point_B8_bf16x6_bwd_bf16x3.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            with open(path) as f:
+                rep = json.load(f)
+            out['operating_point'] = {'file': 'profiles/' + name, 'B': rep.get('config', {}).get('B'),
+                                      'logit_gpu_vs_f64_max': rep['logit']['gpu_vs_f64_max'], 'logit_cpu32_vs_f64_max': rep['logit']['cpu32_vs_f64_max'],
+                                      'logit_gpu_vs_cpu32_max': rep['logit']['gpu_vs_cpu32_max'],
+                                      'worst_grad_relL2_gpu_vs_f64': rep['grads_worst']['gpu_vs_f64_relL2'],
+                                      'worst_grad_relL2_cpu32_vs_f64': rep['grads_worst']['cpu32_vs_f64_relL2']}
+            break
+    return out
+
+
 def relaunch_under_torchrun(gpus, argv):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one process per GPU, rendezvous on
     127.0.0.1 (the container hostname may not resolve) at a free port.  Rank 0 of the child job prints the JSON line."""
@@ -256,6 +338,8 @@ def main():
     ap.add_argument('--cfg', default='', help='experiment YAML (reference format); default: the parsed copy of '
                                               'configs/scannet/mvpnet_3d_unet_resnet34_pn2ssg.yaml kept in tests/golden/configs.json')
     ap.add_argument('--batch', type=int, default=0, help='chunks per GPU per step (default: TRAIN.BATCH_SIZE of the config = 32)')
+    ap.add_argument('--extras', default='auto', choices=['auto', 'all', 'none'], help='side measurements next to the headline: auto = all of them on '
+                    'one GPU, only forward-only + sharded scene inference for N > 1 (the scaling runs stay short)')
     ap.add_argument('--dry', action='store_true', help='launcher / collective plumbing only: gloo on the host, no kernels (CPU test of the N > 1 path)')
     args = ap.parse_args()
 
@@ -273,6 +357,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (there is no CPU fallback of the product path)'
     _lib.lib()
     rank, world, local = D.init_from_env()
+    side = (args.extras == 'all' or (args.extras == 'auto' and world == 1)) and not args.train_only  # B = 1 latency, fp32-MFMA step, 2D network, dense config
     assert world == args.gpus, 'WORLD_SIZE ({}) != --gpus ({})'.format(world, args.gpus)
     local = int(os.environ.get('MVP_DEVICE', local))  # debugging aid: several ranks on one GPU (with MVP_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
@@ -404,7 +489,7 @@ def main():
         # configs[1] at B = 1: the LATENCY of one chunk -- nothing to prefetch behind, the forward waits for its own
         # geometry (the FPS chain is a serial dependency of ~2700 steps), synchronised after every chunk
         b1_ms = float('nan')
-        if not args.train_only:
+        if side:
             one = {k: (v[:1] if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == args.batch else v) for k, v in batch.items()}
             net2d.feature = feature[:one['depth'].size(1)]
             for _ in range(3):
@@ -449,7 +534,7 @@ def main():
     # convolutions) produces the feature map from images every step instead of the resident one.  Extra field only: the 2D network
     # is outside the hot path and runs on the vendor convolution library.
     e2e = None
-    if not args.train_only:
+    if side:
         torch.manual_seed(0)
         model2 = C.build_model_mvpnet_3d(cfg, load_2d_ckpt=False).to(dev).train()
         model2.net_2d.eval()
@@ -479,6 +564,25 @@ def main():
         e2e['note'] = 'full train step INCLUDING the frozen UNetResNet34 forward on 3x160x120 images (mvpnet_amd/unet_resnet34.py)'
         del model2, opt2
     model.train()
+    # The same train step with the shared-MLP contractions on the fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the split-bf16 default:
+    # what the headline would be without the bf16x6 / bf16x3 contraction (side number, 8 steps).
+    fp32_mfma = None
+    if side:
+        before = _lib.get_mlp_precision()
+        _lib.set_mlp_precision('fp32')
+        try:
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(8):
+                eager_step()
+            torch.cuda.synchronize()
+            ms4 = (time.perf_counter() - t4) / 8 * 1e3
+            fp32_mfma = {'chunks_per_s_per_gpu': round(args.batch / (ms4 * 1e-3), 1), 'ms_per_step': round(ms4, 3)}
+        finally:
+            _lib.set_mlp_precision(before)
+    dense = dense_extra(dev) if side else None
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -492,7 +596,11 @@ def main():
                                    'PN2SSG full train step (fwd+loss+bwd+Adam), 2D CNN replaced by a resident 64-ch feature map',
                        'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world),
-                       'launch': 'hip graph (forward + backward; next-batch geometry {}), optimizer eager'.format(args.graph_geometry) if args.graph else 'eager'},
+                       'launch': 'hip graph (forward + backward; next-batch geometry {}), optimizer eager'.format(args.graph_geometry) if args.graph else 'eager',
+                       'contraction': contraction_info()},
+            'parity': parity_info(),
+            'fp32_mfma': fp32_mfma,
+            'dense': dense,
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
             'with_2d_network': e2e,
             'scene_inference': scene,

@@ -315,6 +315,7 @@ int mvp_get_mlp_precision(void);
 /* Split of the gradient contractions (dW, input gradient, mvp_mlp_layer_backward_f32) while the forward precision is a split one:
  * terms = 3 (default) or 6. */
 int mvp_set_mlp_precision_backward(int terms);
+int mvp_get_mlp_precision_backward(void);
 /* Switch (returns the previous value): 1 = long narrow forward layers (>= 32768 rows, C_in, C_out <= 128) run on the persistent
  * streaming kernel with the weight matrix resident in LDS; 0 (default: measured 1.2 % faster on the bench step) = the per-tile kernel. */
 int mvp_set_mlp_stream(int on);

@@ -88,7 +88,7 @@ _SIGNATURES = {
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
-           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_set_fps_mode'] + sorted(_SIGNATURES)
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_set_fps_mode'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -127,6 +127,8 @@ def lib():
             handle.mvp_set_mlp_stream(int(os.environ['MVP_MLP_STREAM']))
         handle.mvp_set_mlp_precision_backward.restype = ctypes.c_int
         handle.mvp_set_mlp_precision_backward.argtypes = [ctypes.c_int]
+        handle.mvp_get_mlp_precision_backward.restype = ctypes.c_int
+        handle.mvp_get_mlp_precision_backward.argtypes = []
         if os.environ.get('MVP_MLP_PRECISION_BWD'):
             check(handle.mvp_set_mlp_precision_backward(MLP_PRECISIONS[os.environ['MVP_MLP_PRECISION_BWD']]), 'mvp_set_mlp_precision_backward')
         env = os.environ.get('MVP_MLP_PRECISION')

@@ -311,6 +311,198 @@ __global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ 
   for (int i = tid; i < M; i += NT) o[i] = sout[i];
 }
 
+// ---- several samples per synchronisation ("rounds") -----------------------------------------------------------------------
+// Farthest point sampling is a chain: sample t+1 is the arg-max of the running distances AFTER sample t has been applied.  What the
+// per-sample kernels above pay per link is not the distance update (a few hundred instructions) but the fixed path around it: reduce
+// across waves through LDS, barrier, broadcast the winner, fetch its coordinates -- ~1 us.  This kernel takes SEVERAL exact samples
+// per such exchange.  Every 16-lane row of the workgroup publishes its best point (value, lowest index) and the value of its
+// SECOND best; B = the largest second-best bounds every point that is not a row's best.  One wave then walks the row winners in
+// descending (value, lowest index) order: the first is the true arg-max; the next one is the true next sample if its running
+// distance is still above B (every other point is at most B and distances only shrink) and no earlier pick of this round lies
+// closer to it than its running distance (then that distance is unchanged and it is still the first maximum).  The walk stops at the
+// first candidate that fails; the accepted picks are exactly the samples the one-at-a-time chain would have produced, in order.  All
+// waves then apply the accepted picks to their points in one pass.  Ties (lattices, duplicated points) make second-bests equal to
+// bests: the walk then accepts one pick per round and the kernel degrades to the per-sample scheme, never to a different result.
+template <int D, int PPT, int NT>
+__global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out) {
+  static_assert(PPT % 2 == 0, "points are processed in pairs");
+  constexpr int NR = NT / 16;  // rows = candidates per round (<= 64: one lane of the resolving wave each)
+  constexpr int NP = PPT / 2;
+  constexpr int kMaxPick = 32;
+  static_assert(NR <= kWave, "one resolver lane per row");
+  using K = Key<float>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [2][NR] row results (key hi, key lo, second-best value, pad), picked coordinates + count, output buffer, SoA copy of the cloud
+  uint4* part = reinterpret_cast<uint4*>(smem);
+  float* cen = reinterpret_cast<float*>(smem + 2 * kWave * 16);      // [kMaxPick][4]
+  int* npick = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 16);  // [2]
+  int* sout = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 16 + 16);
+  float* sx = reinterpret_cast<float*>(smem + 2 * kWave * 16 + kMaxPick * 16 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15));
+  float* sy = sx + N;
+  float* sz = sy + N;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid / kWave;
+  const float* p = pts + (size_t)b * N * D;
+  int64_t* o = out + (size_t)b * M;
+
+  f32x2 px[NP], py[NP], pz[NP], md[NP];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int j = tid + i * NT;
+    float x = 0.f, y = 0.f, z = 0.f, m = -2.f;  // padding slot: never a maximum (real distances are >= 0)
+    if (j < N) {
+      x = p[(size_t)j * D + 0];
+      y = p[(size_t)j * D + 1];
+      z = D == 3 ? p[(size_t)j * D + 2] : 0.f;
+      m = INFINITY;
+      sx[j] = x;
+      sy[j] = y;
+      if (D == 3) sz[j] = z;
+    }
+    px[i >> 1][i & 1] = x;
+    py[i >> 1][i & 1] = y;
+    pz[i >> 1][i & 1] = z;
+    md[i >> 1][i & 1] = m;
+  }
+  if (tid == 0) {
+    sout[0] = 0;
+    cen[0] = p[0];
+    cen[1] = p[1];
+    cen[2] = D == 3 ? p[2] : 0.f;
+    npick[0] = 1;
+  }
+  __syncthreads();
+
+  int it = 1;     // samples taken so far
+  int par = 0;    // parity of the pick list / row results being consumed
+  while (it < M) {
+    // ---- A. apply the picks of the last round (sample 0 first) to this lane's points ----
+    const int nc = npick[par];
+    for (int c = 0; c < nc; ++c) {
+      const float cx = cen[(par * kMaxPick / 2 + c) * 4 + 0], cy = cen[(par * kMaxPick / 2 + c) * 4 + 1], cz = cen[(par * kMaxPick / 2 + c) * 4 + 2];
+      const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const f32x2 dx = px[i] - c2x, dy = py[i] - c2y;
+        f32x2 d = dx * dx + dy * dy;  // -ffp-contract=off: every packed op rounds once, like the scalar oracle
+        if (D == 3) {
+          const f32x2 dz = pz[i] - c2z;
+          d = d + dz * dz;
+        }
+        f32x2 m = md[i];
+        m[0] = fminf(m[0], d[0]);
+        m[1] = fminf(m[1], d[1]);
+        md[i] = m;
+      }
+    }
+    // ---- B. this lane's best (value, first slot) and second-best value ----
+    float m1 = -3.f, m2 = -3.f;
+    int bi = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float x = md[i >> 1][i & 1];
+      m2 = __builtin_amdgcn_fmed3f(m1, m2, x);  // second largest of {m1 >= m2, x}
+      if (x > m1) {                             // strict: slots ascend with the index, the first maximum is kept
+        m1 = x;
+        bi = i;
+      }
+    }
+    // ---- C. row (16 lanes) best key and second-best value ----
+    K k = m1 >= 0.f ? K::make(m1, tid + bi * NT) : K::none();
+    const K mine = k;
+    key_max_row<K, 16>(k);  // every lane of the row holds the row's best key
+    const bool winner = (mine.hi == k.hi) && (mine.lo == k.lo) && (m1 >= 0.f);
+    float sec = winner ? m2 : m1;  // the winner lane offers its second best, the others their best
+    sec = fmax_dpp<kDppXor1>(sec);
+    sec = fmax_dpp<kDppXor2>(sec);
+    sec = fmax_dpp<kDppHalfMirror>(sec);
+    sec = fmax_dpp<kDppMirror>(sec);
+    uint4* cur = part + (par ^ 1) * kWave;
+    if ((lane & 15) == 0) cur[tid >> 4] = make_uint4(k.hi, k.lo, __float_as_uint(sec), 0u);
+    __syncthreads();
+    // ---- D. one wave walks the row winners ----
+    if (wave == 0) {
+      uint4 e = make_uint4(0u, 0u, __float_as_uint(-3.f), 0u);
+      if (lane < NR) e = cur[lane];
+      const unsigned hi = e.x, lo = e.y;
+      const float v = __uint_as_float(hi);
+      const bool valid = (hi | lo) != 0u;
+      float bound = __uint_as_float(e.z);  // B = the largest second-best of any row
+      bound = fmax_dpp<kDppXor1>(bound);
+      bound = fmax_dpp<kDppXor2>(bound);
+      bound = fmax_dpp<kDppHalfMirror>(bound);
+      bound = fmax_dpp<kDppMirror>(bound);
+      bound = fmax_dpp<kDppBcast15, 0xA>(bound);
+      bound = fmax_dpp<kDppBcast31, 0xC>(bound);
+      bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), 63));
+      K g{hi, lo};
+      key_max_wave_to_lane63(g);
+      const K gbest = g.lane(63);  // the true arg-max: always the first pick
+      const bool elig = valid && (v > bound || (hi == gbest.hi && lo == gbest.lo));
+      unsigned long long em = __ballot(elig);
+      const int cidx = (int)~lo;
+      float x = 0.f, y = 0.f, z = 0.f;
+      if (elig) {
+        x = sx[cidx];
+        y = sy[cidx];
+        z = D == 3 ? sz[cidx] : 0.f;
+      }
+      int rank = 0;
+      bool hit = false;  // an earlier (larger key) eligible candidate lies closer than this one's running distance
+      for (unsigned long long mm = em; mm != 0; mm &= mm - 1) {
+        const int j = __ffsll((long long)mm) - 1;
+        const unsigned jh = (unsigned)__builtin_amdgcn_readlane((int)hi, j), jl = (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+        const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j));
+        const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), j));
+        const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), j));
+        const bool before = jh > hi || (jh == hi && jl > lo);
+        const float d = D == 3 ? dist2_3(x, y, z, jx, jy, jz) : dist2_2(x, y, jx, jy);
+        rank += before ? 1 : 0;
+        hit = hit || (before && d < v);
+      }
+      // accepted = the eligible candidates of rank < L, L = the smallest rank that was hit (or all of them), capped
+      int L = elig && hit ? rank : 0x7fffffff;
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor1, 0xF, 0xF, false));
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor2, 0xF, 0xF, false));
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppHalfMirror, 0xF, 0xF, false));
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppMirror, 0xF, 0xF, false));
+      L = min(L, __shfl_xor(L, 16, kWave));
+      L = min(L, __shfl_xor(L, 32, kWave));
+      L = min(min(L, __popcll(em)), min(kMaxPick / 2, M - it));
+      if (elig && rank < L) {
+        float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + rank) * 4;
+        cdst[0] = x;
+        cdst[1] = y;
+        cdst[2] = z;
+        sout[it + rank] = cidx;
+      }
+      if (lane == 0) npick[par ^ 1] = L;
+    }
+    __syncthreads();
+    par ^= 1;
+    it += npick[par];
+  }
+  __syncthreads();
+  for (int i = tid; i < M; i += NT) o[i] = sout[i];
+}
+
+template <int D, int PPT, int NT>
+int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+  const size_t head = 2 * kWave * 16 + 32 * 16 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
+  const size_t bytes = head + (size_t)N * 3 * sizeof(float);
+  if (bytes > 150 * 1024) return MVP_EUNSUPPORTED;
+  auto k = fps_rounds_kernel<D, PPT, NT>;
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out);
+  return mvp_launch_status();
+}
+
 template <typename T, int D, int PPT, int NT>
 int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
   const size_t part_bytes = 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15);  // keys + output buffer
@@ -425,6 +617,20 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStr
   if (N <= 128) return launch_cfg<T, D, 2, 64>(pts, B, N, M, out, s);
   if (N <= 256) return launch_cfg<T, D, 1, 256>(pts, B, N, M, out, s);
   if (N <= 512) return launch_cfg<T, D, 2, 256>(pts, B, N, M, out, s);
+  // fp32 clouds of 257..8192 points: several exact samples per synchronisation (fps_rounds_kernel).  MVP_FPS_ROUNDS=0 keeps the
+  // one-sample-per-barrier kernels (A/B switch).
+  static const bool rounds = []() { const char* e = getenv("MVP_FPS_ROUNDS"); return !(e && e[0] == '0'); }();
+  if constexpr (std::is_same<T, float>::value) {
+    if (rounds && M > 1) {
+      int rc = MVP_EUNSUPPORTED;
+      if (N > 256 && N <= 512) rc = launch_rounds<D, 2, 256>(pts, B, N, M, out, s);
+      else if (N > 512 && N <= 1024) rc = launch_rounds<D, 4, 256>(pts, B, N, M, out, s);
+      else if (N > 1024 && N <= 2048) rc = launch_rounds<D, 4, 512>(pts, B, N, M, out, s);
+      else if (N > 2048 && N <= 4096) rc = launch_rounds<D, 4, 1024>(pts, B, N, M, out, s);
+      else if (N > 4096 && N <= 8192) rc = (g_fps_mode == 1 && B >= 8) ? launch_rounds<D, 16, 512>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024>(pts, B, N, M, out, s);
+      if (rc != MVP_EUNSUPPORTED) return rc;
+    }
+  }
   if (N <= 1024) return launch_cfg<T, D, 4, 256>(pts, B, N, M, out, s);
   if (N <= 2048) return launch_cfg<T, D, 8, 256>(pts, B, N, M, out, s);
   if (N <= 4096) return launch_cfg<T, D, 8, 512>(pts, B, N, M, out, s);

@@ -14,6 +14,7 @@
 // XCD-aware placement (workgroup L runs on XCD L % 8, observed, used for speed only) keeps each chunk's 0.9 MB of records in ONE
 // XCD's private 4 MB L2.
 #include "pixel_knn_core.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(kPrepThreads) void lift_prepare_kernel(const DepthT
 // L1 cost per point: 5 loads per view + one per survivor instead of 25 per view.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x3a __attribute__((ext_vector_type(3), aligned(4)));  // a 5-pixel window row: 6 halfwords from a 4-byte aligned start
 constexpr int kSurvCap = 32;
 
 template <int K>
@@ -120,142 +122,297 @@ __device__ __forceinline__ void up_insert(float (&ub)[K], float v) {  // ub asce
   ub[0] = fminf(ub[0], v);
 }
 
+// One view of one lane: projection of the query, window corner, error terms.
+struct ProbeGeom {
+  float xc, yc, zc;
+  int uc, vc;
+  bool ok;  // usable pin-hole view, query in front of it, 5x5 window touches the image
+};
+__device__ __forceinline__ ProbeGeom probe_geom(const ViewParam& V, int h, int w, float qx, float qy, float qz) {
+  ProbeGeom g;
+  const float dx = qx - V.t[0], dy = qy - V.t[1], dz = qz - V.t[2];
+  g.zc = V.r[2] * dx + V.r[5] * dy + V.r[8] * dz;  // R^T (p - t)
+  g.xc = V.r[0] * dx + V.r[3] * dy + V.r[6] * dz;
+  g.yc = V.r[1] * dx + V.r[4] * dy + V.r[7] * dz;
+  g.ok = V.usable && g.zc > 0.05f;
+  const float zs = g.ok ? g.zc : 1.f;
+  const float u0 = V.fx * (g.xc / zs) + V.cx, v0 = V.fy * (g.yc / zs) + V.cy;
+  g.uc = (int)rintf(fminf(fmaxf(u0, -1.0e6f), 1.0e6f));
+  g.vc = (int)rintf(fminf(fmaxf(v0, -1.0e6f), 1.0e6f));
+  g.ok = g.ok && !(g.uc < -2 || g.uc > w + 1 || g.vc < -2 || g.vc > h + 1);  // else the window misses the image
+  return g;
+}
+
+// sorted (ascending) K smallest 64-bit (distance bits : pixel id) keys; ~0 = empty slot
 template <int K>
-__device__ __forceinline__ void filtered_probe(const float4* __restrict__ crec, const uint16_t* __restrict__ cplane,
-                                               const ViewParam* __restrict__ vp, int nv, int h, int w, int pitch, float qx,
-                                               float qy, float qz, float (&bd)[K], int (&bi)[K], int* __restrict__ slist,
-                                               int tid) {
-  const int hw = h * w;
-  const size_t vstride = (size_t)plane_rows(h) * pitch;
-  float ub[K];
+__device__ __forceinline__ void key_insert(unsigned long long (&kk)[K], unsigned long long x) {
 #pragma unroll
-  for (int s = 0; s < K; ++s) ub[s] = INFINITY;
-  unsigned pend = 0;  // views (bit vi) to be probed from the records
-  int cnt = 0;
-  for (int vi = 0; vi < nv; ++vi) {
-    const ViewParam& V = vp[vi];
-    const float dx = qx - V.t[0], dy = qy - V.t[1], dz = qz - V.t[2];
-    const float zc = V.r[2] * dx + V.r[5] * dy + V.r[8] * dz;  // R^T (p - t)
-    if (!V.usable || !(zc > 0.05f)) continue;
-    const float xc = V.r[0] * dx + V.r[3] * dy + V.r[6] * dz;
-    const float yc = V.r[1] * dx + V.r[4] * dy + V.r[7] * dz;
-    const float u0 = V.fx * (xc / zc) + V.cx, v0 = V.fy * (yc / zc) + V.cy;
-    const int uc = (int)rintf(fminf(fmaxf(u0, -1.0e6f), 1.0e6f));
-    const int vc = (int)rintf(fminf(fmaxf(v0, -1.0e6f), 1.0e6f));
-    if (uc < -2 || uc > w + 1 || vc < -2 || vc > h + 1) continue;  // the window misses the image
-    const int sc = uc - 2 + kPlanePad;                              // padded column of the window's first pixel
-    const unsigned sh = (unsigned)(sc & 1) * 16u;
-    const uint16_t* p0 = cplane + vi * vstride + (size_t)(vc - 2 + kPlanePad) * pitch + (sc & ~1);
-    u32x4a rowv[5];
-#pragma unroll
-    for (int a = 0; a < 5; ++a) rowv[a] = *reinterpret_cast<const u32x4a*>(p0 + (size_t)a * pitch);
-    const float E = 1.25e-4f * V.rmax + 2.0e-4f * zc + 2.0e-5f + 4.0e-7f * V.tabs;
-    const float cu = 11.05f * E * E, cl = 9.05f * E * E;
-    float ax[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) ax[c] = ((float)(uc - 2 + c) - V.cx) * V.ifx;
-    const float by0 = ((float)(vc - 2) - V.cy) * V.ify;
-    float s2[25];
-#pragma unroll
-    for (int a = 0; a < 5; ++a) {
-      const unsigned w0 = __builtin_amdgcn_alignbit(rowv[a].y, rowv[a].x, sh);
-      const unsigned w1 = __builtin_amdgcn_alignbit(rowv[a].z, rowv[a].y, sh);
-      const unsigned w2 = __builtin_amdgcn_alignbit(rowv[a].w, rowv[a].z, sh);
-      const float by = by0 + (float)a * V.ify;
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        const unsigned q16 = c == 0 ? (w0 & 0xffffu) : c == 1 ? (w0 >> 16) : c == 2 ? (w1 & 0xffffu) : c == 3 ? (w1 >> 16) : (w2 & 0xffffu);
-        const float z = fmaf((float)q16, kPlaneUnit, 0.5f * kPlaneUnit);
-        const float ddx = fmaf(z, ax[c], -xc), ddy = fmaf(z, by, -yc), ddz = z - zc;
-        const float v = fmaf(ddx, ddx, fmaf(ddy, ddy, ddz * ddz));
-        s2[a * 5 + c] = v;
-        up_insert<K>(ub, fmaf(v, 1.1003f, cu));
-      }
-    }
-    const float U = ub[K - 1];
-    const float far = 16.38f - zc;
-    const float thr = (U + cl) * 1.1115f;  // 1 / 0.8998 rounded up
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < 25; ++i) m |= (s2[i] <= thr) ? (1u << i) : 0u;
-    // The filter is only sound while padding / invalid / saturated entries can be neither among the k smallest `up` nor
-    // survivors; a view where that does not hold yet, or whose survivors do not fit the list, is probed from its records.
-    if (!(zc < 16.0f) || !(U < 0.85f * far * far) || cnt + __popc(m) > kSurvCap) {
-      pend |= 1u << vi;
-      m = 0;
-    }
-    const int base = vi * hw + (vc - 2) * w + (uc - 2);
-    while (m != 0) {  // append this view's survivors to the lane's list (column tid of slist)
-      const int i = __ffs((int)m) - 1;
-      m &= m - 1;
-      const int a = (i * 13) >> 6;  // i / 5 for 0 <= i < 25
-      slist[cnt * kLFThreads + tid] = base + a * w + (i - 5 * a);
-      ++cnt;
-    }
+  for (int s = 0; s < K; ++s) {
+    const bool lt = x < kk[s];
+    const unsigned long long lo = lt ? x : kk[s];
+    x = lt ? kk[s] : x;
+    kk[s] = lo;
   }
-  // (distance, id) packed into one 64-bit key: distances are >= +0, so their bit patterns order like the values and one
-  // unsigned compare is the lexicographic (distance, id) order.
-  unsigned long long kk[K];
+}
+__device__ __forceinline__ unsigned long long exact_key(const float4* __restrict__ crec, int id, float qx, float qy, float qz) {
+  const float4 r = crec[id];
+  const float d = dist2_3(r.x, r.y, r.z, qx, qy, qz) + r.w;  // pinned arithmetic; + inf marks an invalid pixel
+  return d < INFINITY ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id) : ~0ull;
+}
+__device__ __forceinline__ float bcast_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int lane) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+}
+
+// The whole exact search of one query per lane: depth-plane filter over the 5x5 windows (per lane), exact evaluation of the
+// survivors (per lane), then the RARE work -- views whose window has to be read from the records ("pending"), ring growth beyond
+// the 5x5 windows, views without a projective bound -- done by the WHOLE WAVE for one lane at a time: the owner's rectangle is
+// spread over the 64 lanes (one record load each per step, all independent), candidates below the owner's current k-th key are
+// handed to the owner by ballot + readlane.  Per-lane loops made the wave pay ~25 records x 20 instructions for one lane with a
+// pending view and 7-13 DEPENDENT memory round trips for one lane with a ring (87 % of the workgroups have such a lane); the
+// cooperative form costs one round trip and ~100 instructions per such lane.  Candidates, arithmetic and the (distance, id)
+// order are those of the per-lane form (pixel_knn_core.h), so results are identical.
+// All 64 lanes of the wave must call this (`active` = the lane has a query).
+template <int K>
+__device__ __forceinline__ void filtered_search(const float4* __restrict__ crec, const uint16_t* __restrict__ cplane,
+                                                const ViewParam* __restrict__ vp, int nv, int h, int w, int pitch, bool active,
+                                                float qx, float qy, float qz, unsigned long long (&kk)[K],
+                                                int* __restrict__ slist, int tid) {
+  const int hw = h * w;
+  const int lane = tid & (kWave - 1);
+  const size_t vstride = (size_t)plane_rows(h) * pitch;
 #pragma unroll
   for (int s = 0; s < K; ++s) kk[s] = ~0ull;
-  auto key_insert = [&](unsigned long long x) {
+  unsigned pend = 0;  // views (bit vi) whose 5x5 window is read from the records
+  if (active) {
+    float ub[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      const bool lt = x < kk[s];
-      const unsigned long long lo = lt ? x : kk[s];
-      x = lt ? kk[s] : x;
-      kk[s] = lo;
-    }
-  };
-  auto exact_key = [&](int id) -> unsigned long long {
-    const float4 r = crec[id];
-    const float d = dist2_3(r.x, r.y, r.z, qx, qy, qz) + r.w;  // pinned arithmetic; + inf marks an invalid pixel
-    return d < INFINITY ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id) : ~0ull;
-  };
-  // exact evaluation of the survivors, 4 records in flight per lane
-  for (int s0 = 0; __any(s0 < cnt); s0 += 4) {
-    unsigned long long key[4];
+    for (int s = 0; s < K; ++s) ub[s] = INFINITY;
+    int cnt = 0;
+#ifndef MVP_PROBE_GROUP
+#define MVP_PROBE_GROUP 1
+#endif
+    // views per group: the window rows of a whole group are in flight together.  Measured: 1 (118 VGPRs) = 2 capped at 128 VGPRs; 3
+    // (156 VGPRs, three workgroups per CU) is 8 % slower -- the launch is bound by its HBM window, not by these round trips
+    constexpr int G = MVP_PROBE_GROUP;
+    for (int v0 = 0; v0 < nv; v0 += G) {
+      ProbeGeom geo[G];
+      u32x3a rowv[G][5];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) key[j] = (s0 + j < cnt) ? exact_key(slist[(s0 + j) * kLFThreads + tid]) : ~0ull;
+      for (int j = 0; j < G; ++j) {
+        const int vi = min(v0 + j, nv - 1);
+        geo[j] = probe_geom(vp[vi], h, w, qx, qy, qz);
+        geo[j].ok = geo[j].ok && (v0 + j < nv);
+        if (geo[j].ok) {
+          const int sc = geo[j].uc - 2 + kPlanePad;  // padded column of the window's first pixel
+          const uint16_t* p0 = cplane + vi * vstride + (size_t)(geo[j].vc - 2 + kPlanePad) * pitch + (sc & ~1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) key_insert(key[j]);
-  }
-  // views left pending: their whole 5x5 window from the records, in two batches of independent loads (15 + 10).  Every
-  // wave of the launch is resident at once, so the kernel ends with its slowest wave: this tail has to be short.
-  while (__any(pend != 0)) {
-    if (pend != 0) {
-      const int vi = __ffs((int)pend) - 1;
-      pend &= pend - 1;
-      int uc, vc;
-      float zc;
-      if (project_point(vp[vi], qx, qy, qz, uc, vc, zc)) {
+          for (int a = 0; a < 5; ++a) rowv[j][a] = *reinterpret_cast<const u32x3a*>(p0 + (size_t)a * pitch);
+        }
+      }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          constexpr int kRows[2] = {3, 2};
-          unsigned long long key[15];
+      for (int j = 0; j < G; ++j) {
+        if (!geo[j].ok) continue;
+        const int vi = v0 + j;
+        const ViewParam& V = vp[vi];
+        const float xc = geo[j].xc, yc = geo[j].yc, zc = geo[j].zc;
+        const int uc = geo[j].uc, vc = geo[j].vc;
+        const unsigned sh = (unsigned)((uc - 2 + kPlanePad) & 1) * 16u;
+        const float E = 1.25e-4f * V.rmax + 2.0e-4f * zc + 2.0e-5f + 4.0e-7f * V.tabs;
+        const float cu = 11.05f * E * E, cl = 9.05f * E * E;
+        float ax[5];
 #pragma unroll
-          for (int e = 0; e < 15; ++e) {
-            const int a = half * 3 + e / 5, c = e % 5;
-            const int vv = vc - 2 + a, uu = uc - 2 + c;
-            key[e] = (e < kRows[half] * 5 && vv >= 0 && vv < h && uu >= 0 && uu < w) ? exact_key(vi * hw + vv * w + uu) : ~0ull;
+        for (int c = 0; c < 5; ++c) ax[c] = ((float)(uc - 2 + c) - V.cx) * V.ifx;
+        const float by0 = ((float)(vc - 2) - V.cy) * V.ify;
+        float s2[25];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+          const unsigned w0 = __builtin_amdgcn_alignbit(rowv[j][a].y, rowv[j][a].x, sh);
+          const unsigned w1 = __builtin_amdgcn_alignbit(rowv[j][a].z, rowv[j][a].y, sh);
+          const unsigned w2 = rowv[j][a].z >> sh;  // (only its low half is used)
+          const float by = by0 + (float)a * V.ify;
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            const unsigned q16 = c == 0 ? (w0 & 0xffffu) : c == 1 ? (w0 >> 16) : c == 2 ? (w1 & 0xffffu) : c == 3 ? (w1 >> 16) : (w2 & 0xffffu);
+            const float z = fmaf((float)q16, kPlaneUnit, 0.5f * kPlaneUnit);
+            const float ddx = fmaf(z, ax[c], -xc), ddy = fmaf(z, by, -yc), ddz = z - zc;
+            const float v = fmaf(ddx, ddx, fmaf(ddy, ddy, ddz * ddz));
+            s2[a * 5 + c] = v;
+            up_insert<K>(ub, fmaf(v, 1.1003f, cu));
           }
+        }
+        const float U = ub[K - 1];
+        const float far = 16.38f - zc;
+        const float thr = (U + cl) * 1.1115f;  // 1 / 0.8998 rounded up
+        unsigned m = 0;
 #pragma unroll
-          for (int e = 0; e < 15; ++e)
-            if (e < kRows[half] * 5) key_insert(key[e]);
+        for (int i = 0; i < 25; ++i) m |= (s2[i] <= thr) ? (1u << i) : 0u;
+        // The filter is only sound while padding / invalid / saturated entries can be neither among the k smallest `up` nor
+        // survivors; a view where that does not hold yet, or whose survivors do not fit the list, is probed from its records.
+        if (!(zc < 16.0f) || !(U < 0.85f * far * far) || cnt + __popc(m) > kSurvCap) {
+          pend |= 1u << vi;
+          m = 0;
+        }
+        const int base = vi * hw + (vc - 2) * w + (uc - 2);
+        while (m != 0) {  // append this view's survivors to the lane's list (column tid of slist)
+          const int i = __ffs((int)m) - 1;
+          m &= m - 1;
+          const int a = (i * 13) >> 6;  // i / 5 for 0 <= i < 25
+          slist[cnt * kLFThreads + tid] = base + a * w + (i - 5 * a);
+          ++cnt;
         }
       }
     }
-  }
+    // exact evaluation of the survivors, MVP_SURV_FLIGHT records in flight per lane
+#ifndef MVP_SURV_FLIGHT
+#define MVP_SURV_FLIGHT 4
+#endif
+    constexpr int SF = MVP_SURV_FLIGHT;
+    for (int s0 = 0; __any(s0 < cnt); s0 += SF) {
+      unsigned long long key[SF];
 #pragma unroll
-  for (int s = 0; s < K; ++s) {
-    const bool has = kk[s] != ~0ull;
-    bd[s] = has ? __uint_as_float((unsigned)(kk[s] >> 32)) : INFINITY;
-    bi[s] = has ? (int)(unsigned)kk[s] : 0x7fffffff;
+      for (int j = 0; j < SF; ++j) key[j] = (s0 + j < cnt) ? exact_key(crec, slist[(s0 + j) * kLFThreads + tid], qx, qy, qz) : ~0ull;
+#pragma unroll
+      for (int j = 0; j < SF; ++j) key_insert<K>(kk, key[j]);
+    }
+  }
+  // ---- the rare work, one owner lane at a time, by the whole wave ----
+  int rv = 0;      // ring cursor: views < rv are finished
+  int wdone = 2;   // half-width already scanned in view rv (the 5x5 window)
+  for (;;) {
+    // every lane finds ITS next task: a pending view first, then rings view by view
+    bool has = false;
+    int t_vi = 0, t_ulo = 0, t_uhi = -1, t_vlo = 0, t_vhi = -1, t_iu0 = 1, t_iu1 = 0, t_iv0 = 1, t_iv1 = 0, t_wr = 0;
+    bool t_pend = false;
+    if (active) {
+      while (pend != 0 && !has) {
+        const int vi = __ffs((int)pend) - 1;
+        int uc, vc;
+        float zc;
+        if (project_point(vp[vi], qx, qy, qz, uc, vc, zc)) {
+          has = true;
+          t_pend = true;
+          t_vi = vi;
+          t_ulo = max(uc - 2, 0); t_uhi = min(uc + 2, w - 1);
+          t_vlo = max(vc - 2, 0); t_vhi = min(vc + 2, h - 1);
+          if (t_ulo > t_uhi || t_vlo > t_vhi) has = false;  // (cannot happen: pending views passed the window test)
+        }
+        if (!has) pend &= pend - 1;
+      }
+      while (!has && rv < nv) {
+        const ViewParam& V = vp[rv];
+        const float dx = qx - V.t[0], dy = qy - V.t[1], dz = qz - V.t[2];
+        const float zc = V.r[2] * dx + V.r[5] * dy + V.r[8] * dz;
+        const float kth = kk[K - 1] != ~0ull ? __uint_as_float((unsigned)(kk[K - 1] >> 32)) : INFINITY;
+        if (!V.usable || !(zc > 0.05f)) {
+          // no projective bound.  Every valid pixel has positive depth, so dist >= -zc for zc <= 0.
+          const float dk = kth < INFINITY ? sqrtf(kth) * 1.001f + 1.0e-5f : INFINITY;
+          if (!(zc <= 0.f && -zc * 0.999f > dk) && wdone >= 0) {
+            has = true;
+            t_vi = rv;
+            t_ulo = 0; t_uhi = w - 1; t_vlo = 0; t_vhi = h - 1;
+            t_wr = -1;  // marks "whole image": the view is finished afterwards
+          } else {
+            ++rv;
+            wdone = 2;
+          }
+          continue;
+        }
+        const float xc = V.r[0] * dx + V.r[3] * dy + V.r[6] * dz;
+        const float yc = V.r[1] * dx + V.r[4] * dy + V.r[7] * dz;
+        const float u0 = V.fx * (xc / zc) + V.cx, v0 = V.fy * (yc / zc) + V.cy;
+        const int uc = (int)rintf(fminf(fmaxf(u0, -1.0e6f), 1.0e6f));
+        const int vc = (int)rintf(fminf(fmaxf(v0, -1.0e6f), 1.0e6f));
+        const int wfull = max(max(uc, w - 1 - uc), max(vc, h - 1 - vc));  // beyond this the window covers the whole image
+        int wr = -1;
+        if (wdone < wfull) {
+          if (kth < INFINITY) {
+            // current k-th best distance, inflated: covers fp32 rounding of the distances, of the projection and of the
+            // stored coordinates (1e-3 relative + 10 um absolute);  need  zc (wr + 0.45) inv_scale > dk
+            const float dk = sqrtf(kth) * 1.001f + 1.0e-5f;
+            const float need = dk / (zc * V.inv_scale) - 0.45f;
+            wr = need < 0.f ? 0 : (need > 1.0e6f ? 1000000 : (int)ceilf(need));
+          } else {
+            wr = 2 * wdone + 2;  // fewer than k candidates so far: grow geometrically until some appear
+          }
+          wr = wr <= wdone ? -1 : min(wr, wfull);
+        }
+        if (wr < 0) {  // the bound already excludes everything outside the scanned window of this view
+          ++rv;
+          wdone = 2;
+          continue;
+        }
+        has = true;
+        t_vi = rv;
+        t_wr = wr;
+        t_ulo = max(uc - wr, 0); t_uhi = min(uc + wr, w - 1);
+        t_vlo = max(vc - wr, 0); t_vhi = min(vc + wr, h - 1);
+        t_iu0 = uc - wdone; t_iu1 = uc + wdone; t_iv0 = vc - wdone; t_iv1 = vc + wdone;  // already scanned
+      }
+    }
+    const unsigned long long tasks = __ballot(has);
+    if (tasks == 0) break;
+    const int owner = __ffsll((long long)tasks) - 1;
+    // the owner's task and query, wave-uniform
+    const int o_vi = bcast_i(t_vi, owner), o_ulo = bcast_i(t_ulo, owner), o_uhi = bcast_i(t_uhi, owner);
+    const int o_vlo = bcast_i(t_vlo, owner), o_vhi = bcast_i(t_vhi, owner);
+    const int o_iu0 = bcast_i(t_iu0, owner), o_iu1 = bcast_i(t_iu1, owner), o_iv0 = bcast_i(t_iv0, owner), o_iv1 = bcast_i(t_iv1, owner);
+    const float oqx = bcast_f(qx, owner), oqy = bcast_f(qy, owner), oqz = bcast_f(qz, owner);
+    unsigned long long okth = bcast_u64(kk[K - 1], owner);
+    const int RW = o_uhi - o_ulo + 1;
+    // lanes tile the rectangle: `cols` = RW rounded up to a power of two (<= 64) columns x 64 / cols rows per step
+    int lg = 0;
+    while ((1 << lg) < RW && lg < 6) ++lg;
+    const int cols = 1 << lg, rows_per_step = kWave >> lg;
+    const int lc = lane & (cols - 1), lr = lane >> lg;
+    const int rowbase0 = o_vi * hw;
+    for (int ub = o_ulo; ub <= o_uhi; ub += cols) {
+      for (int vb = o_vlo; vb <= o_vhi; vb += 4 * rows_per_step) {
+        unsigned long long key[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // four independent record loads per lane and step
+          const int vv = vb + j * rows_per_step + lr, uu = ub + lc;
+          const bool take = vv <= o_vhi && uu <= o_uhi && !(vv >= o_iv0 && vv <= o_iv1 && uu >= o_iu0 && uu <= o_iu1);
+          key[j] = take ? exact_key(crec, rowbase0 + vv * w + uu, oqx, oqy, oqz) : ~0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned long long pm = __ballot(key[j] < okth);
+          while (pm != 0) {
+            const int l = __ffsll((long long)pm) - 1;
+            const unsigned long long kx = bcast_u64(key[j], l);
+            if (lane == owner) key_insert<K>(kk, kx);
+            okth = bcast_u64(kk[K - 1], owner);
+            pm &= pm - 1;
+            pm &= __ballot(key[j] < okth);
+          }
+        }
+      }
+    }
+    if (lane == owner) {  // the owner's bookkeeping
+      if (t_pend) {
+        pend &= pend - 1;
+      } else if (t_wr < 0) {
+        ++rv;
+        wdone = 2;
+      } else {
+        wdone = t_wr;
+      }
+    }
   }
 }
 
+#ifdef MVP_LIFT_EXP
+__device__ unsigned long long g_lift_ts[4 * 8192];  // per workgroup: start, search done, gather done (100 MHz real-time clock)
+#endif
+
+#ifndef MVP_LIFT_WAVES
+#define MVP_LIFT_WAVES 1
+#endif
 template <int K>
-__global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float4* __restrict__ rec,
+__global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_LIFT_WAVES))) void lift_knn_gather_kernel(const float4* __restrict__ rec,
                                                                      const uint16_t* __restrict__ plane, int pitch,
                                                                      const float* __restrict__ points,
                                                                      const float* __restrict__ cam,
@@ -267,7 +424,7 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
                                                                      float* __restrict__ gxyz,
                                                                      const uint8_t* __restrict__ flip,
                                                                      const double* __restrict__ rot,
-                                                                     float* __restrict__ points_out) {
+                                                                     float* __restrict__ points_out, int sched) {
   __shared__ ViewParam vp[kMaxViews];
   __shared__ int sidx[kLFThreads * K];
   __shared__ int slist[kLFThreads * kSurvCap];
@@ -278,6 +435,9 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
   const int blk = jb % bpc;
   if (b >= B) return;  // uniform per workgroup
   const int tid = threadIdx.x;
+#ifdef MVP_LIFT_EXP
+  if (tid == 0 && L < 8192) g_lift_ts[4 * L + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (tid < nv) vp[tid] = make_view_param(cam + ((size_t)b * nv + tid) * 9, pose + ((size_t)b * nv + tid) * 16, h, w);
   __syncthreads();
 
@@ -285,19 +445,18 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
   const int P = nv * hw;
   const float4* crec = rec + (size_t)b * P;
   const int n = blk * kLFThreads + tid;
-  if (n < N) {
+  const bool active = n < N;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (active) {
     const float* q = points + ((size_t)b * N + n) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
-    float bd[K];
-    int bi[K];
-#pragma unroll
-    for (int s = 0; s < K; ++s) {
-      bd[s] = INFINITY;
-      bi[s] = 0x7fffffff;
-    }
-    PackedSource src{crec};
-    filtered_probe<K>(crec, plane + (size_t)b * nv * plane_rows(h) * pitch, vp, nv, h, w, pitch, qx, qy, qz, bd, bi, slist, tid);
-    projective_rings<K, 2>(src, vp, nv, h, w, qx, qy, qz, bd, bi);
+    qx = q[0]; qy = q[1]; qz = q[2];
+  }
+  unsigned long long kk[K];
+  filtered_search<K>(crec, plane + (size_t)b * nv * plane_rows(h) * pitch, vp, nv, h, w, pitch, active, qx, qy, qz, kk, slist, tid);
+#ifdef MVP_LIFT_EXP
+  if ((tid & 63) == 0 && L < 8192) g_lift_ts[4 * L + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (active) {
     // Augmentation of the loader, applied where the reference applies it: the flip changes which flat pixel id (and feature
     // row) a neighbour has (scannet_2d3d.py:293-307), the rotation about z acts on `points` and `image_xyz` AFTER the search
     // (:400-409; float64 product, one rounding to float32 -- scipy's Rotation.apply on float32 input).
@@ -317,10 +476,16 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
       }
     };
     if (points_out) rotate(qx, qy, qz, points_out + ((size_t)b * N + n) * 3);
+    float4 wrec[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) {  // the winners' coordinates: K independent loads
+      const bool found = kk[s] != ~0ull;
+      wrec[s] = (gxyz && found) ? crec[(int)(unsigned)kk[s]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-      const bool found = bd[s] < INFINITY;
-      const int id = found ? bi[s] : -1;
+      const bool found = kk[s] != ~0ull;
+      const int id = found ? (int)(unsigned)kk[s] : -1;
       int oid = id;  // id in the (possibly mirrored) public pixel order: what knn_indices holds and the feature map is indexed by
       if (flip && found) {
         const int vi = id / hw, rem = id - vi * hw;
@@ -332,20 +497,16 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
       sidx[tid * K + s] = oid;
       knn_index[((size_t)b * N + n) * K + s] = (int64_t)oid;
       if (gxyz) {
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (found) {
-          const float4 r = crec[id];
-          x = r.x;
-          y = r.y;
-          z = r.z;
-        }
         float* o = gxyz + (((size_t)b * N + n) * K + s) * 3;
-        if (found) rotate(x, y, z, o); else { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
+        if (found) rotate(wrec[s].x, wrec[s].y, wrec[s].z, o); else { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
       }
     }
   }
   if (!gfeat) return;
   __syncthreads();
+#ifdef MVP_LIFT_EXP
+  if (tid == 0 && L < 8192) g_lift_ts[4 * L + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- gather: rows (n0 .. n0+255) x K of C floats, contiguous in the output ----
   const int rows = min(kLFThreads, N - blk * kLFThreads) * K;
   const int C4 = C >> 2;               // C % 4 == 0 checked by the host entry
@@ -383,6 +544,10 @@ __global__ __launch_bounds__(kLFThreads) void lift_knn_gather_kernel(const float
       }
     }
   }
+#ifdef MVP_LIFT_EXP
+  __syncthreads();
+  if (tid == 0 && L < 8192) g_lift_ts[4 * L + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int K>
@@ -392,12 +557,22 @@ int launch_lift(const float4* rec, const uint16_t* plane, int pitch, const float
   const int bpc = (int)cdiv(N, kLFThreads);
   const int64_t groups = cdiv(B, kXcds);  // chunks per XCD (rounded up; surplus workgroups exit at once)
   dim3 grid((unsigned)(kXcds * groups * bpc));
+  int sched = 0;
+#ifdef MVP_LIFT_EXP
+  if (const char* e = getenv("MVP_LIFT_SCHED")) sched = atoi(e);
+#endif
   hipLaunchKernelGGL((lift_knn_gather_kernel<K>), grid, dim3(kLFThreads), 0, s, rec, plane, pitch, points, cam, pose, feature,
-                     (int)B, (int)nv, (int)h, (int)w, (int)N, (int)C, bpc, knn_index, gfeat, gxyz, flip, rot, points_out);
+                     (int)B, (int)nv, (int)h, (int)w, (int)N, (int)C, bpc, knn_index, gfeat, gxyz, flip, rot, points_out, sched);
   return mvp_launch_status();
 }
 
 }  // namespace
+
+#ifdef MVP_LIFT_EXP
+MVP_API int mvp_lift_exp_timestamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lift_ts), sizeof(unsigned long long) * 4 * (size_t)n);
+}
+#endif
 
 MVP_API int64_t mvp_lift_workspace_bytes(int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N) {
   if (B < 0 || nv < 0 || h < 0 || w < 0 || N < 0) return 0;

@@ -1084,6 +1084,7 @@ MVP_API int mvp_set_mlp_precision_backward(int terms) {
   g_mlp_terms_bwd = terms;
   return MVP_OK;
 }
+MVP_API int mvp_get_mlp_precision_backward(void) { return g_mlp_terms_bwd; }
 // Switch: 0 (default; measured 1.2 % faster on the bench step) routes every forward layer through the per-tile kernel (mlp_fwd_kernel), 1 lets long narrow layers
 // (>= 32768 rows, C_in and C_out <= 128, split-bf16) take the persistent streaming kernel (mlp_stream.hip).  Returns the old value.
 MVP_API int mvp_set_mlp_stream(int on) {

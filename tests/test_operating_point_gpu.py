@@ -104,9 +104,11 @@ def test_mvpnet3d_b8_train_mode_against_the_reference_fixture(dev):
     assert abs(gs.sum().item() - ref_sum) <= 5e-3 * ref_abs and abs(gs.abs().sum().item() - ref_abs) <= 5e-3 * ref_abs
 
 
-def test_full_train_step_at_the_bench_shape(dev):
+@pytest.mark.parametrize('B', [8, 32])
+def test_full_train_step_at_the_bench_shape(dev, B):
+    """B = 32 is the bench's own batch (yaml TRAIN.BATCH_SIZE): the oracle step on the host takes about two minutes there."""
     from tests import operating_point as OP
-    rep = OP.run(8, dev, write=os.path.join(ROOT, 'gpurun_out', 'operating_point_B8.json'))
+    rep = OP.run(B, dev, write=os.path.join(ROOT, 'gpurun_out', 'operating_point_B{}.json'.format(B)))
     lg, gw, rs = rep['logit'], rep['grads_worst'], rep['running_stats']
     print(json.dumps({k: rep[k] for k in ('feature_2d3d', 'logit', 'loss', 'grads_worst', 'running_stats', 'adam_update_max_err')}, indent=1))
     # logits: within 1e-4 of the reference arithmetic (CPU fp32), and as close to the float64 value of the graph as the CPU is
