@@ -44,9 +44,10 @@ const char* mvp_version(void);
 /* human readable text for a return code of this library (static storage) */
 const char* mvp_strerror(int code);
 
-/* Launch shape of the sampling kernels for 4096 < N <= 8192 points (returns the previous mode): 0 (default) = the shortest dependency
- * chain (16 waves per cloud), 1 = the fewest issue slots (one wave per SIMD; 22 % longer chain) for batches of >= 8 clouds whose chain runs
- * hidden beside other kernels -- the prefetched geometry of a training step.  Same results either way (bit-exact goldens). */
+/* Launch shape of the sampling kernels for 4096 < N <= 8192 points: 0 (default) = the shortest dependency chain (16 waves per cloud),
+ * 1 = half the waves (15 % longer chain, half the issue slots) for batches of >= 8 clouds whose chain runs hidden beside other kernels --
+ * the prefetched geometry of a training step.  Same results either way (bit-exact goldens).  mvp_fps_shape_* take the shape PER CALL;
+ * mvp_set_fps_mode only sets the process default that the reference-signature entry points mvp_fps_f32 / _f64 use (returns the old one). */
 int mvp_set_fps_mode(int mode);
 
 /* ---- farthest point sampling -------------------------------------------------------
@@ -56,6 +57,9 @@ int mvp_set_fps_mode(int mode);
  * Preconditions (fps_kernel.cu:154-156): M > 0, N >= M. */
 int mvp_fps_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, mvp_stream_t stream);
 int mvp_fps_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, mvp_stream_t stream);
+/* the same with the launch shape (0 / 1, see mvp_set_fps_mode) as an argument: nothing process-wide is read */
+int mvp_fps_shape_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, mvp_stream_t stream);
+int mvp_fps_shape_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, mvp_stream_t stream);
 
 /* ---- ball query ---------------------------------------------------------------------
  * replaces ball_query_cuda.ball_query (mvpnet/ops/cuda/ball_query.cpp:7-15,

@@ -21,6 +21,8 @@ _f32 = ctypes.c_float
 _SIGNATURES = {
     'mvp_fps_f32': [_ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_fps_f64': [_ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_fps_shape_f32': [_ptr, _i64, _i64, _i64, _i64, _ptr, ctypes.c_int, _ptr],
+    'mvp_fps_shape_f64': [_ptr, _i64, _i64, _i64, _i64, _ptr, ctypes.c_int, _ptr],
     'mvp_ball_query_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr],
     'mvp_ball_query_f64': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr],
     'mvp_ball_query_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],

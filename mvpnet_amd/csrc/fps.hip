@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ 
 // waves then apply the accepted picks to their points in one pass.  Ties (lattices, duplicated points) make second-bests equal to
 // bests: the walk then accepts one pick per round and the kernel degrades to the per-sample scheme, never to a different result.
 template <int D, int PPT, int NT>
-__global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out) {
+__global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out, int dbg) {
   static_assert(PPT % 2 == 0, "points are processed in pairs");
   constexpr int NR = NT / 16;  // rows = candidates per round (<= 64: one lane of the resolving wave each)
   constexpr int NP = PPT / 2;
@@ -348,10 +348,14 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
   const float* p = pts + (size_t)b * N * D;
   int64_t* o = out + (size_t)b * M;
 
+  // Point j lives in slot j / NT of thread (j0 % NR) * 16 + j0 / NR, j0 = j % NT: CONSECUTIVE indices sit in DIFFERENT rows.  The deeper
+  // set-abstraction levels sample clouds that are themselves in sampling order (the centroids of the level above), where the next
+  // samples are the next indices -- with consecutive indices in one row every round would accept a single pick.
+  const int pj = (tid & 15) * NR + (tid >> 4);  // this thread's point index within a block of NT
   f32x2 px[NP], py[NP], pz[NP], md[NP];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int j = tid + i * NT;
+    const int j = pj + i * NT;
     float x = 0.f, y = 0.f, z = 0.f, m = -2.f;  // padding slot: never a maximum (real distances are >= 0)
     if (j < N) {
       x = p[(size_t)j * D + 0];
@@ -378,11 +382,15 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
 
   int it = 1;     // samples taken so far
   int par = 0;    // parity of the pick list / row results being consumed
+  int rounds_done = 0;
   while (it < M) {
+    ++rounds_done;
     // ---- A. apply the picks of the last round (sample 0 first) to this lane's points ----
     const int nc = npick[par];
+    const float4* cenv = reinterpret_cast<const float4*>(cen) + par * (kMaxPick / 2);
     for (int c = 0; c < nc; ++c) {
-      const float cx = cen[(par * kMaxPick / 2 + c) * 4 + 0], cy = cen[(par * kMaxPick / 2 + c) * 4 + 1], cz = cen[(par * kMaxPick / 2 + c) * 4 + 2];
+      const float4 cc = cenv[c];
+      const float cx = cc.x, cy = cc.y, cz = cc.z;
       const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
       }
     }
     // ---- C. row (16 lanes) best key and second-best value ----
-    K k = m1 >= 0.f ? K::make(m1, tid + bi * NT) : K::none();
+    K k = m1 >= 0.f ? K::make(m1, pj + bi * NT) : K::none();
     const K mine = k;
     key_max_row<K, 16>(k);  // every lane of the row holds the row's best key
     const bool winner = (mine.hi == k.hi) && (mine.lo == k.lo) && (m1 >= 0.f);
@@ -438,10 +446,24 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
       bound = fmax_dpp<kDppBcast15, 0xA>(bound);
       bound = fmax_dpp<kDppBcast31, 0xC>(bound);
       bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), 63));
-      K g{hi, lo};
-      key_max_wave_to_lane63(g);
-      const K gbest = g.lane(63);  // the true arg-max: always the first pick
-      const bool elig = valid && (v > bound || (hi == gbest.hi && lo == gbest.lo));
+      // the true arg-max (always the first pick): the largest value, lowest index among equals
+      float vm = valid ? v : -3.f;
+      vm = fmax_dpp<kDppXor1>(vm);
+      vm = fmax_dpp<kDppXor2>(vm);
+      vm = fmax_dpp<kDppHalfMirror>(vm);
+      vm = fmax_dpp<kDppMirror>(vm);
+      vm = fmax_dpp<kDppBcast15, 0xA>(vm);
+      vm = fmax_dpp<kDppBcast31, 0xC>(vm);
+      vm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vm), 63));
+      const unsigned long long tops = __ballot(valid && v == vm);
+      bool is_best = valid && v == vm;
+      if (tops & (tops - 1)) {  // several rows hold the maximal value: the full (value, index) key decides
+        K g{hi, lo};
+        key_max_wave_to_lane63(g);
+        const K gbest = g.lane(63);
+        is_best = valid && hi == gbest.hi && lo == gbest.lo;
+      }
+      const bool elig = valid && (v > bound || is_best);
       unsigned long long em = __ballot(elig);
       const int cidx = (int)~lo;
       float x = 0.f, y = 0.f, z = 0.f;
@@ -469,8 +491,7 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
       L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor2, 0xF, 0xF, false));
       L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppHalfMirror, 0xF, 0xF, false));
       L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppMirror, 0xF, 0xF, false));
-      L = min(L, __shfl_xor(L, 16, kWave));
-      L = min(L, __shfl_xor(L, 32, kWave));
+      L = min(min(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 16)), min(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 48)));
       L = min(min(L, __popcll(em)), min(kMaxPick / 2, M - it));
       if (elig && rank < L) {
         float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + rank) * 4;
@@ -487,6 +508,7 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
   }
   __syncthreads();
   for (int i = tid; i < M; i += NT) o[i] = sout[i];
+  if (dbg && tid == 0) o[0] = rounds_done;  // (tools/exp: rounds taken; the first sample is always 0)
 }
 
 template <int D, int PPT, int NT>
@@ -499,7 +521,8 @@ int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* ou
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out);
+  static const int dbg = []() { const char* e = getenv("MVP_FPS_DEBUG"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out, dbg);
   return mvp_launch_status();
 }
 
@@ -607,10 +630,10 @@ int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, h
   return rc;
 }
 
-int g_fps_mode = 0;  // mvp_set_fps_mode: 0 = shortest chain, 1 = fewest issue slots (the chain is hidden under other work)
+int g_fps_mode = 0;  // mvp_set_fps_mode: the launch shape mvp_fps_f32 / _f64 use (a process default; mvp_fps_shape_* take it per call)
 
 template <typename T, int D>
-int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int shape, hipStream_t s) {
   // (threads, points/thread): one wave per SIMD (256 threads) keeps the per-iteration barrier
   // cheap while 4 SIMDs share the distance updates; small clouds shrink to a single wave.
   if (N <= 64) return launch_cfg<T, D, 1, 64>(pts, B, N, M, out, s);
@@ -627,7 +650,7 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStr
       else if (N > 512 && N <= 1024) rc = launch_rounds<D, 4, 256>(pts, B, N, M, out, s);
       else if (N > 1024 && N <= 2048) rc = launch_rounds<D, 4, 512>(pts, B, N, M, out, s);
       else if (N > 2048 && N <= 4096) rc = launch_rounds<D, 4, 1024>(pts, B, N, M, out, s);
-      else if (N > 4096 && N <= 8192) rc = (g_fps_mode == 1 && B >= 8) ? launch_rounds<D, 16, 512>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024>(pts, B, N, M, out, s);
+      else if (N > 4096 && N <= 8192) rc = (shape == 1 && B >= 8) ? launch_rounds<D, 16, 512>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024>(pts, B, N, M, out, s);
       if (rc != MVP_EUNSUPPORTED) return rc;
     }
   }
@@ -641,7 +664,7 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStr
     // anyway (mvp_set_fps_mode(1): the training step's prefetched geometry, 9.16 -> 9.03 ms per step; exposed chains lose:
     // whole-scene inference 7.7 -> 8.2 ms).  MVP_FPS_CFG = 1 / 2 / 5 forces 1024 / 256 / 512 threads.
     static const char cfg = []() { const char* e = getenv("MVP_FPS_CFG"); return e ? e[0] : '0'; }();
-    if (cfg == '2' || (cfg == '0' && g_fps_mode == 1 && B >= 8)) return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s);
+    if (cfg == '2' || (cfg == '0' && shape == 1 && B >= 8)) return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s);
     if (cfg == '5') return launch_cfg<T, D, 16, 512>(pts, B, N, M, out, s);
     return launch_cfg<T, D, 8, 1024>(pts, B, N, M, out, s);
   }
@@ -651,14 +674,15 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStr
 }
 
 template <typename T>
-int fps_entry(const T* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, mvp_stream_t stream) {
+int fps_entry(const T* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, mvp_stream_t stream) {
   MVP_NONNULL(points);
   MVP_NONNULL(index);
   MVP_REQUIRE(B >= 0 && (D == 2 || D == 3));
   MVP_REQUIRE(M > 0 && N >= M);  // fps_kernel.cu:154-156
   if (B == 0) return MVP_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return D == 3 ? dispatch<T, 3>(points, B, N, M, index, s) : dispatch<T, 2>(points, B, N, M, index, s);
+  MVP_REQUIRE(shape == 0 || shape == 1);
+  return D == 3 ? dispatch<T, 3>(points, B, N, M, index, shape, s) : dispatch<T, 2>(points, B, N, M, index, shape, s);
 }
 
 }  // namespace
@@ -671,9 +695,17 @@ MVP_API int mvp_set_fps_mode(int mode) {
 
 MVP_API int mvp_fps_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index,
                         mvp_stream_t stream) {
-  return fps_entry<float>(points, B, N, D, M, index, stream);
+  return fps_entry<float>(points, B, N, D, M, index, g_fps_mode, stream);
 }
 MVP_API int mvp_fps_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index,
                         mvp_stream_t stream) {
-  return fps_entry<double>(points, B, N, D, M, index, stream);
+  return fps_entry<double>(points, B, N, D, M, index, g_fps_mode, stream);
+}
+MVP_API int mvp_fps_shape_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape,
+                              mvp_stream_t stream) {
+  return fps_entry<float>(points, B, N, D, M, index, shape, stream);
+}
+MVP_API int mvp_fps_shape_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape,
+                              mvp_stream_t stream) {
+  return fps_entry<double>(points, B, N, D, M, index, shape, stream);
 }

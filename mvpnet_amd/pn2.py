@@ -62,12 +62,13 @@ class SetAbstraction(nn.Module):
         self.mlp = SharedMLP(self.in_channels, mlp_channels, ndim=2, bn=True)
         self.grouper = None if num_centroids == 0 else QueryGrouper(radius, max_neighbors)
 
-    def centroids(self, xyz):
-        """Farthest point sampling -> centroid coordinates (the sequential part of the geometry)."""
+    def centroids(self, xyz, fps_shape=None):
+        """Farthest point sampling -> centroid coordinates (the sequential part of the geometry).  fps_shape: launch shape of the
+        sampling kernel for this call (include/mvp_hip.h: mvp_fps_shape_f32)."""
         with torch.no_grad():
             if self.num_centroids == -1:
                 return xyz
-            index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False)
+            index = ops.farthest_point_sample(xyz, self.num_centroids, transpose=False, shape=fps_shape)
             return torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
 
     def neighbours(self, new_xyz, xyz, with_csr=False):
@@ -321,8 +322,9 @@ class PN2SSG(nn.Module):
                 s2.wait_event(ev)
                 return fn()
 
-        # a training step's prefetched chain hides under forward + backward: sample with one wave per SIMD (mvp_set_fps_mode)
-        fps_mode = L.lib().mvp_set_fps_mode(1 if (with_csr and stream is not None) else 0) if xyz.is_cuda else 0
+        # a training step's prefetched chain hides under forward + backward: sample with half the waves (passed per call, nothing
+        # process-wide is touched)
+        fps_shape = (1 if (with_csr and stream is not None) else 0) if xyz.is_cuda else None
         with torch.cuda.stream(stream if stream is not None else cur):
             run = torch.cuda.current_stream(xyz.device)
             sa, xyzs = [], [xyz]
@@ -332,7 +334,7 @@ class PN2SSG(nn.Module):
                     sa.append(None)
                     xyzs.append(xyz.new_zeros([xyz.size(0), 1, 3]))
                 else:
-                    new_xyz = m.centroids(xyzs[-1])
+                    new_xyz = m.centroids(xyzs[-1], fps_shape)
                     csr = with_csr and (level > 0 or self.in_channels > 0)
                     sa.append((new_xyz,) + on_second(run, lambda m=m, a=new_xyz, b=xyzs[-1], c=csr: m.neighbours(a, b, c)))
                     xyzs.append(new_xyz)
@@ -344,8 +346,6 @@ class PN2SSG(nn.Module):
                 run.wait_stream(s2)
             event = torch.cuda.Event()
             event.record()
-        if xyz.is_cuda:
-            L.lib().mvp_set_fps_mode(fps_mode)
         # `xyz` is read by the side stream long after this function returns (ball query / 3-NN of level 1 run after the 2.4 ms
         # FPS): the plan keeps it alive, otherwise the caller's stream may recycle its memory while it is still being read.
         plan = {'sa': sa, 'fp': fp, 'event': event, 'stream': stream, 'xyz': xyz}

@@ -104,6 +104,10 @@ def test_fps_throughput_launch_shape(dev, kind):
     finally:
         L.lib().mvp_set_fps_mode(old)
     assert old == 0 and torch.equal(got, ref)
+    # the same shape requested PER CALL (mvp_fps_shape_f32): nothing process-wide is touched
+    assert torch.equal(farthest_point_sample(x, 512, transpose=False, shape=1), ref)
+    assert torch.equal(farthest_point_sample(x, 512, transpose=False, shape=0), ref)
+    assert L.lib().mvp_set_fps_mode(0) == 0
     np.testing.assert_array_equal(got[:2].cpu().numpy(), O().fps(pts[:2], 512))
     np.testing.assert_array_equal(got5[7:].cpu().numpy(), O().fps(pts[7:, :5000], 300))
 
@@ -1201,3 +1205,42 @@ def test_seg_loss_ticket_under_stress(dev):
     bad = sum(1 for loss, acc in out if float(loss) != float(np.float32(acc[0].item() / acc[1].item())))
     print('seg loss ticket: {} launches, {} mismatches'.format(len(out), bad))
     assert bad == 0
+
+
+@pytest.mark.parametrize('kind', ['chunks', 'lattice', 'duplicates', 'plane2d'])
+def test_fps_chain_of_the_four_levels_vs_oracle(dev, kind):
+    """The sampling chain of PN2SSG at full size, 8192 -> 2048 -> 512 -> 128 -> 32, every level against the oracle on the
+    oracle's own centroids of the level above (the case in which the withdrawn bucketed variant once
+    disagreed).  The fp32 kernels for 257..8192 points take SEVERAL samples per synchronisation (fps_rounds_kernel): levels
+    2-4 sample clouds that are in sampling order themselves (the next samples are the next indices), lattices and duplicated
+    points tie everywhere -- the accepted picks must still be the one-at-a-time chain's, in order."""
+    from mvpnet_amd.ops import farthest_point_sample
+    from mvpnet_amd.synthetic import make_batch
+    rs = np.random.RandomState(91)
+    if kind == 'chunks':
+        pts = make_batch(4000, 3, config=3)['points'].astype(np.float32)
+    elif kind == 'lattice':
+        pts = (np.round(rs.rand(2, 8192, 3) * 1.9 / 0.02) * 0.02).astype(np.float32)
+    elif kind == 'duplicates':  # a chunk padded by re-drawing its own points (scannet_2d3d.py:374-381): 3000 distinct points
+        base = rs.rand(2, 3000, 3).astype(np.float32)
+        pts = np.concatenate([base, np.take_along_axis(base, rs.randint(0, 3000, (2, 5192, 1)).repeat(3, 2), 1)], 1)
+    else:
+        pts = rs.rand(2, 8192, 2).astype(np.float32)
+    cur = pts
+    for m in (2048, 512, 128, 32):
+        idx = farthest_point_sample(g(cur, dev), m, transpose=False).cpu().numpy()
+        exp = O().fps(cur, m)
+        np.testing.assert_array_equal(idx, exp, err_msg='{} -> {}'.format(cur.shape[1], m))
+        cur = np.take_along_axis(cur, exp[..., None].repeat(cur.shape[2], 2), 1)
+
+
+@pytest.mark.parametrize('N,M', [(257, 200), (300, 300), (1000, 999), (1025, 64), (2049, 1500), (4097, 33), (5000, 2500), (8192, 8192)])
+def test_fps_rounds_kernel_odd_sizes(dev, N, M):
+    """Sizes around the dispatch boundaries of fps_rounds_kernel, M up to N (every point sampled: the tail picks index 0 again
+    and again once all running distances are 0, as np.argmax does)."""
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(N * 7 + M)
+    pts = rs.rand(2, N, 3).astype(np.float32)
+    pts[1, N // 2:] = pts[1, :N - N // 2]  # second cloud: every point twice
+    idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
+    np.testing.assert_array_equal(idx, O().fps(pts, M))
