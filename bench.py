@@ -542,13 +542,7 @@ def main():
         b2 = dict(batch, images=torch.randn(args.batch, 3, 3, 120, 160, device=dev))
         e2e = {}
         for tag, ctx in (('fp32', None), ('bf16_2d_net', torch.bfloat16)):
-            fwd2d = model2.net_2d.forward
-            if ctx is not None:  # autocast only around the frozen 2D network; lifting / PointNet++ stay fp32
-                def cast_forward(data, _f=fwd2d):
-                    with torch.autocast('cuda', dtype=torch.bfloat16):
-                        out = _f(data)
-                    return {'feature': out['feature'].float()}
-                model2.net_2d.forward = cast_forward
+            model2.net_2d.__dict__['_fast_dtype'] = ctx  # frozen_inference(compute_dtype=...): autocast only around the frozen 2D network
             cur2 = prefetch_geometry(model2, fresh(b2))
             for i in range(7):
                 if i == 2:
@@ -560,7 +554,7 @@ def main():
             torch.cuda.synchronize()
             ms2 = (time.perf_counter() - t3) / 5 * 1e3
             e2e[tag] = {'chunks_per_s_per_gpu': round(args.batch / (ms2 * 1e-3), 1), 'ms_per_step': round(ms2, 3)}
-            model2.net_2d.forward = fwd2d
+        model2.net_2d.__dict__['_fast_dtype'] = None
         e2e['note'] = 'full train step INCLUDING the frozen UNetResNet34 forward on 3x160x120 images (mvpnet_amd/unet_resnet34.py)'
         del model2, opt2
     model.train()

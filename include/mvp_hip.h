@@ -405,6 +405,12 @@ int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t 
  * finish    : mean = sum / max(count,1); label = argmax (first max), count == 0 -> C. */
 int mvp_vote_accumulate_f32(const float* logit, int64_t ld_r, int64_t ld_c, const int64_t* chunk_ind, int64_t n,
                             int64_t C, float* sum, int32_t* count, mvp_stream_t stream);
+/* all chunks of a scene in ONE launch (the reference loop: mvpnet/test_mvpnet_3d.py:142-174): chunk_ind = the chunks' scene point ids back
+ * to back (total of them), offsets (num_chunks + 1 int64, offsets[0] = 0, offsets[num_chunks] = total) = each chunk's slice; chunk i's
+ * logits at logit + i*ld_chunk, element (r,c) of it at r*ld_r + c*ld_c.  Same sums as num_chunks calls of mvp_vote_accumulate_f32. */
+int mvp_vote_accumulate_batched_f32(const float* logit, int64_t ld_chunk, int64_t ld_r, int64_t ld_c, const int64_t* chunk_ind,
+                                    const int64_t* offsets, int64_t num_chunks, int64_t total, int64_t C, float* sum, int32_t* count,
+                                    mvp_stream_t stream);
 int mvp_vote_finish_f32(const float* sum, const int32_t* count, int64_t n_pts, int64_t C, float* mean, int64_t* label,
                         mvp_stream_t stream);
 

@@ -84,6 +84,7 @@ _SIGNATURES = {
                                _ptr, _ptr, _ptr],
     'mvp_mlp_forward_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_vote_accumulate_batched_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_seg_loss_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _ptr],
     'mvp_seg_loss_backward_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],

@@ -430,9 +430,15 @@ __global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_
   __shared__ int slist[kLFThreads * kSurvCap];
   // XCD-aware chunk placement: L % 8 = XCD; chunks b with b % 8 == xcd live on that XCD.
   const int L = blockIdx.x;
-  const int xcd = L % kXcds, jb = L / kXcds;
-  const int b = xcd + kXcds * (jb / bpc);
-  const int blk = jb % bpc;
+  int b, blk;
+  if (B >= kXcds) {
+    const int xcd = L % kXcds, jb = L / kXcds;
+    b = xcd + kXcds * (jb / bpc);
+    blk = jb % bpc;
+  } else {  // fewer chunks than XCDs (dense chunks, single-chunk latency): every chunk spreads over all XCDs instead of idling 8 - B of them
+    b = L / bpc;
+    blk = L - b * bpc;
+  }
   if (b >= B) return;  // uniform per workgroup
   const int tid = threadIdx.x;
 #ifdef MVP_LIFT_EXP
@@ -556,7 +562,7 @@ int launch_lift(const float4* rec, const uint16_t* plane, int pitch, const float
                 float* gxyz, const uint8_t* flip, const double* rot, float* points_out, hipStream_t s) {
   const int bpc = (int)cdiv(N, kLFThreads);
   const int64_t groups = cdiv(B, kXcds);  // chunks per XCD (rounded up; surplus workgroups exit at once)
-  dim3 grid((unsigned)(kXcds * groups * bpc));
+  dim3 grid((unsigned)(B >= kXcds ? kXcds * groups * bpc : B * bpc));
   int sched = 0;
 #ifdef MVP_LIFT_EXP
   if (const char* e = getenv("MVP_LIFT_SCHED")) sched = atoi(e);

@@ -137,6 +137,28 @@ __global__ __launch_bounds__(256) void vote_acc_kernel(const float* __restrict__
   if (c == 0) atomicAdd(cnt + p, 1);
 }
 
+// All chunks of a scene in one launch: `ind` = the chunks' scene point ids back to back, offsets[i] .. offsets[i+1] = chunk i's
+// slice; chunk i's logits at logit + i * ld_chunk, element (r, c) of the chunk at r * ld_r + c * ld_c.  One thread per (row, class);
+// the owning chunk of a row comes from a binary search over the (few hundred at most) offsets.
+__global__ __launch_bounds__(256) void vote_acc_batched_kernel(const float* __restrict__ logit, int64_t ld_chunk, int64_t ld_r,
+                                                               int64_t ld_c, const int64_t* __restrict__ ind,
+                                                               const int64_t* __restrict__ offsets, int num_chunks, int64_t total,
+                                                               int C, float* __restrict__ sum, int32_t* __restrict__ cnt) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t e = t / C;
+  const int c = (int)(t - e * C);
+  if (e >= total) return;
+  int lo = 0, hi = num_chunks;  // largest i with offsets[i] <= e
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offsets[mid] <= e) lo = mid; else hi = mid;
+  }
+  const int64_t r = e - offsets[lo];
+  const int64_t p = ind[e];
+  atomicAdd(sum + p * C + c, logit[(int64_t)lo * ld_chunk + r * ld_r + c * ld_c]);
+  if (c == 0) atomicAdd(cnt + p, 1);
+}
+
 __global__ __launch_bounds__(256) void vote_finish_kernel(const float* __restrict__ sum, const int32_t* __restrict__ cnt,
                                                           int64_t n_pts, int C, float* __restrict__ mean,
                                                           int64_t* __restrict__ label) {
@@ -221,6 +243,21 @@ MVP_API int mvp_vote_accumulate_f32(const float* logit, int64_t ld_r, int64_t ld
   if (n == 0) return MVP_OK;
   hipLaunchKernelGGL(vote_acc_kernel, dim3((unsigned)cdiv(n * C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      logit, ld_r, ld_c, chunk_ind, n, (int)C, sum, count);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_vote_accumulate_batched_f32(const float* logit, int64_t ld_chunk, int64_t ld_r, int64_t ld_c, const int64_t* chunk_ind,
+                                            const int64_t* offsets, int64_t num_chunks, int64_t total, int64_t C, float* sum, int32_t* count,
+                                            mvp_stream_t stream) {
+  MVP_NONNULL(logit);
+  MVP_NONNULL(chunk_ind);
+  MVP_NONNULL(offsets);
+  MVP_NONNULL(sum);
+  MVP_NONNULL(count);
+  MVP_REQUIRE(num_chunks >= 0 && total >= 0 && C > 0 && C < (1ll << 20) && num_chunks < (1ll << 30));
+  if (total == 0 || num_chunks == 0) return MVP_OK;
+  hipLaunchKernelGGL(vote_acc_batched_kernel, dim3((unsigned)cdiv(total * C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), logit,
+                     ld_chunk, ld_r, ld_c, chunk_ind, offsets, (int)num_chunks, total, (int)C, sum, count);
   return mvp_launch_status();
 }
 

@@ -127,10 +127,21 @@ def vote_scene(logits, chunk_inds, n_pts):
     C = logits.size(1)
     s = torch.zeros(n_pts, C, dtype=torch.float32, device=logits.device)
     cnt = torch.zeros(n_pts, dtype=torch.int32, device=logits.device)
-    for i, ind in enumerate(chunk_inds):
-        lg = logits[i]  # (C, N) view; only the first len(ind) columns are real points (padding beyond)
-        L.require_gpu(ind)
-        L.call('mvp_vote_accumulate_f32', s, L.ptr(lg), lg.stride(1), lg.stride(0), L.ptr(ind), ind.numel(), C, L.ptr(s), L.ptr(cnt))
+    # ONE accumulation launch for the whole scene (the reference loops over the chunks on the host: test_mvpnet_3d.py:142-174):
+    # the chunks' index lists back to back + their offsets; only the first len(ind) columns of a chunk are real points
+    if len(chunk_inds):
+        for ind in chunk_inds:
+            L.require_gpu(ind)
+        lens = [int(ind.numel()) for ind in chunk_inds]
+        if max(lens) > logits.size(2):
+            raise RuntimeError('vote_scene: a chunk lists {} points but its logits have {} columns'.format(max(lens), logits.size(2)))
+        flat = torch.cat([ind.reshape(-1) for ind in chunk_inds]) if len(chunk_inds) > 1 else chunk_inds[0].reshape(-1)
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        offsets = torch.tensor(offs, dtype=torch.int64).to(logits.device, non_blocking=True)
+        L.call('mvp_vote_accumulate_batched_f32', s, L.ptr(logits), logits.stride(0), logits.stride(2), logits.stride(1), L.ptr(flat),
+               L.ptr(offsets), len(chunk_inds), offs[-1], C, L.ptr(s), L.ptr(cnt))
     mean = torch.empty_like(s)
     label = torch.empty(n_pts, dtype=torch.int64, device=logits.device)
     L.call('mvp_vote_finish_f32', s, L.ptr(s), L.ptr(cnt), n_pts, C, L.ptr(mean), L.ptr(label))

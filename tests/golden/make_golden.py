@@ -759,6 +759,85 @@ def gen_unet():
     save('unet_resnet34', **out)
 
 
+def torchvision_resnet34_keys():
+    """state_dict keys and shapes of torchvision.models.resnet.resnet34 (the reference binds it at mvpnet/models/unet_resnet34.py:6,17;
+    environment.yml pins torchvision 0.4.0), written out from its published definition -- ResNet(BasicBlock, [3, 4, 6, 3]): a 7x7/2
+    stem, BasicBlock = conv3x3(stride) - BN - ReLU - conv3x3 - BN (+ identity, or conv1x1(stride) - BN when the shape changes) - ReLU,
+    planes 64 / 128 / 256 / 512 with strides 1 / 2 / 2 / 2, a 1000-way fc -- NOT read from this repo's module.  21 797 672 parameters."""
+    keys = collections.OrderedDict()
+
+    def bn(prefix, c):
+        keys[prefix + '.weight'] = (c,)
+        keys[prefix + '.bias'] = (c,)
+        keys[prefix + '.running_mean'] = (c,)
+        keys[prefix + '.running_var'] = (c,)
+        keys[prefix + '.num_batches_tracked'] = ()
+
+    keys['conv1.weight'] = (64, 3, 7, 7)
+    bn('bn1', 64)
+    inplanes = 64
+    for li, (planes, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], 1):
+        for b in range(blocks):
+            pre = 'layer{}.{}'.format(li, b)
+            keys[pre + '.conv1.weight'] = (planes, inplanes, 3, 3)
+            bn(pre + '.bn1', planes)
+            keys[pre + '.conv2.weight'] = (planes, planes, 3, 3)
+            bn(pre + '.bn2', planes)
+            if b == 0 and (stride != 1 or inplanes != planes):
+                keys[pre + '.downsample.0.weight'] = (planes, inplanes, 1, 1)
+                bn(pre + '.downsample.1', planes)
+            inplanes = planes
+    keys['fc.weight'] = (1000, 512)
+    keys['fc.bias'] = (1000,)
+    return keys
+
+
+def torchvision_resnet34_forward(sd, x):
+    """Functional restatement of torchvision's ResNet.forward up to layer4 (eval mode) on a torchvision-keyed state_dict: the
+    known-answer generator for the encoder this repo restates in mvpnet_amd/unet_resnet34.py.  Returns the stem (after bn1 + relu),
+    the max-pooled stem and the four stage outputs."""
+    import torch.nn.functional as F
+
+    def bn(t, prefix):
+        return F.batch_norm(t, sd[prefix + '.running_mean'], sd[prefix + '.running_var'], sd[prefix + '.weight'], sd[prefix + '.bias'],
+                            False, 0.1, 1e-5)
+
+    outs = collections.OrderedDict()
+    t = F.relu(bn(F.conv2d(x, sd['conv1.weight'], None, 2, 3), 'bn1'))
+    outs['stem'] = t
+    t = F.max_pool2d(t, kernel_size=3, stride=2, padding=1)
+    outs['pool'] = t
+    for li, (blocks, stride) in enumerate([(3, 1), (4, 2), (6, 2), (3, 2)], 1):
+        for b in range(blocks):
+            pre = 'layer{}.{}'.format(li, b)
+            s_ = stride if b == 0 else 1
+            identity = t
+            out = F.relu(bn(F.conv2d(t, sd[pre + '.conv1.weight'], None, s_, 1), pre + '.bn1'))
+            out = bn(F.conv2d(out, sd[pre + '.conv2.weight'], None, 1, 1), pre + '.bn2')
+            if pre + '.downsample.0.weight' in sd:
+                identity = bn(F.conv2d(t, sd[pre + '.downsample.0.weight'], None, s_, 0), pre + '.downsample.1')
+            t = F.relu(out + identity)
+            if b == 0:
+                outs['layer{}_block0'.format(li)] = t
+        outs['layer{}'.format(li)] = t
+    return outs
+
+
+def gen_resnet34_encoder():
+    """Known-answer vectors for the ResNet-34 encoder from the restatement above (torchvision itself is not installed here): seeded
+    torchvision-format state_dict -> stem / pooled stem / first block and output of every stage on a 2 x 3 x 64 x 96 input."""
+    from tests.golden.weights import fill_state_dict
+    shapes = torchvision_resnet34_keys()
+    n_params = sum(int(np.prod(v)) for k, v in shapes.items() if 'running' not in k and 'num_batches' not in k)
+    assert n_params == 21797672, n_params  # the published parameter count of resnet34
+    sd = {k: torch.from_numpy(v.copy()) for k, v in fill_state_dict(shapes, 515).items()}
+    x = np.random.RandomState(516).standard_normal((2, 3, 64, 96)).astype(np.float32)
+    with torch.no_grad():
+        outs = torchvision_resnet34_forward(sd, torch.from_numpy(x))
+    save('resnet34_encoder', state_keys=json.dumps([[k, list(v)] for k, v in shapes.items()]), image=x,
+         **{k: v.numpy() for k, v in outs.items()})
+
+
 def gen_chunker():
     """scene2chunks_legacy (mvpnet/utils/chunk_util.py:4-53, imported) and select_frames (scannet_2d3d.py:20-30; that module
     imports open3d, so its 9 lines are re-typed here) on seeded synthetic scenes."""
@@ -957,6 +1036,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'config_defaults':
         gen_config_defaults()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'resnet34':
+        gen_resnet34_encoder()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'mvpnet2d':
         install_reference()
         gen_mvpnet2d()
@@ -976,6 +1058,7 @@ def main():
     gen_module_special_cases()
     gen_vote_trainstep()
     gen_unet()
+    gen_resnet34_encoder()
     gen_chunker()
     gen_metrics()
     gen_mvpnet2d()

@@ -525,6 +525,27 @@ def test_vote_golden(dev):
     np.testing.assert_array_equal(label.cpu().numpy(), gd['label'])
 
 
+def test_vote_golden_one_launch_for_all_chunks(dev):
+    """The same known answer through dist.vote_scene = mvp_vote_accumulate_batched_f32: all chunks' index lists back to back,
+    one accumulation launch (ragged chunks: logits padded to the longest chunk, the padding never read)."""
+    from mvpnet_amd import dist as D
+    gd = load_golden('vote')
+    n_pts, C = gd['mean'].shape
+    inds = [g(gd['chunk{}_ind'.format(c)].astype(np.int64), dev) for c in range(6)]
+    width = max(int(i.numel()) for i in inds) + 5
+    logits = torch.full((6, C, width), float('nan'), device=dev)  # (num_chunks, C, N) as all_gather_logits returns it; padding = NaN
+    for c in range(6):
+        lg = g(gd['chunk{}_logit'.format(c)].T.copy(), dev)
+        logits[c, :, :lg.size(1)] = lg
+    mean, label, cnt = D.vote_scene(logits, inds, n_pts)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), gd['count'])
+    np.testing.assert_allclose(mean.cpu().numpy(), gd['mean'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(label.cpu().numpy(), gd['label'])
+    # a non-contiguous view of the gathered logits (what all_gather_logits hands over for W > 1) gives the same
+    mean2, label2, cnt2 = D.vote_scene(logits.transpose(1, 2).contiguous().transpose(1, 2), inds, n_pts)
+    assert torch.equal(label2, label) and torch.equal(cnt2, cnt)
+
+
 # ------------------------------------------------------------------ the reference's wrappers, unmodified
 def test_extension_modules_have_reference_names(dev):
     """`mvpnet_amd.ext.install()` makes `mvpnet.ops.<x>_cuda` importable with the pybind names

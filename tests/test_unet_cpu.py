@@ -69,3 +69,31 @@ def test_frozen_unet_survives_model_train():
     model.unfreeze()
     outer.train()
     assert model.training and all(p.requires_grad for p in model.parameters())
+
+
+def test_resnet34_encoder_against_the_torchvision_definition():
+    """the encoder this repo restates (torchvision is not installed) against known-answer vectors generated from
+    a second, functional restatement of torchvision's published resnet34 definition on a torchvision-keyed state_dict
+    (tests/golden/make_golden.py::torchvision_resnet34_forward): same key names / shapes / order (so torchvision-format and
+    reference-trained checkpoints load), the published parameter count, and stem / pool / first block and output of every stage."""
+    from mvpnet_amd.unet_resnet34 import ResNet34
+    g = load_golden('resnet34_encoder')
+    ref_keys = [(k, tuple(s)) for k, s in json.loads(str(g['state_keys']))]
+    net = ResNet34().eval()
+    mine = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert mine == [kv for kv in ref_keys if not kv[0].startswith('fc.')]  # the U-Net never uses the classifier head
+    assert sum(int(np.prod(s)) for k, s in ref_keys if 'running' not in k and 'num_batches' not in k) == 21_797_672
+    sd = fill_state_dict(collections.OrderedDict(ref_keys), 515)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items() if not k.startswith('fc.')})
+    x = torch.from_numpy(g['image'])
+    with torch.no_grad():
+        t = net.relu(net.bn1(net.conv1(x)))
+        np.testing.assert_allclose(t.numpy(), g['stem'], rtol=1e-5, atol=1e-6)
+        t = net.maxpool(t)
+        np.testing.assert_allclose(t.numpy(), g['pool'], rtol=1e-5, atol=1e-6)
+        for li, layer in enumerate((net.layer1, net.layer2, net.layer3, net.layer4), 1):
+            first = layer[0](t)
+            np.testing.assert_allclose(first.numpy(), g['layer{}_block0'.format(li)], rtol=1e-4, atol=1e-5)
+            t = layer(t)
+            scale = np.abs(g['layer{}'.format(li)]).max()
+            np.testing.assert_allclose(t.numpy(), g['layer{}'.format(li)], rtol=0, atol=2e-5 * scale)
