@@ -341,6 +341,17 @@ int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, 
                            const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* Y,
                            double* stat, double* partial, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                            float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
+/* A layer whose input is [X | rel] WITHOUT the concatenated tensor: Y = X (R,ldx)[:, :Cin] . W (Cout,ldw)[:, :Cin]^T + rel (R,4) . wrel (Cout,4)^T.
+ * Replaces the cat + first conv of FeatureAggregation (mvpnet/models/mvpnet_3d.py:55-58): X = the gathered feature rows, rel = the relation
+ * columns [src - tgt | squared length] (mvp_relation4_rows_f32), W = the conv weight with its own row stride (ldw = Cin + 4), wrel = its last
+ * four columns as a contiguous (Cout,4) matrix.  The relation part is evaluated in fp32 in the epilogue.  16-byte aligned operands,
+ * Cin, Cout, ldx, ldw multiples of 4.  stat (2*Cout + 1 float64, zero on entry), mean, invstd, running_*: as mvp_mlp_forward_bn_f32, or all
+ * NULL (no statistics: inference). */
+int mvp_mlp_forward_rel_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout, const float* rel,
+                               const float* wrel, float* Y, double* stat, double* partial, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
+/* out (R*K,4) = [src (R,K,3) - tgt (R,3) | squared length], the relation columns alone (pinned (dx*dx + dy*dy) + dz*dz) */
+int mvp_relation4_rows_f32(const float* src_xyz, const float* tgt_xyz, int64_t R, int64_t K, float* out, mvp_stream_t stream);
 /* Last layer of a set-abstraction shared MLP, training mode, WITHOUT materialising its (R,Cout) output (reference shape being replaced:
  * the (B,C,M,32) tensor of mvpnet/models/pn2/modules.py:100-108 + torch.max over dim 3).  Rows are groups of K = 32 consecutive
  * neighbours (R = 32 G).  Leaves per group and column the largest / smallest PRE-BatchNorm value (ymax, ymin (G,Cout) float32) and the
@@ -405,12 +416,15 @@ int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t 
  * finish    : mean = sum / max(count,1); label = argmax (first max), count == 0 -> C. */
 int mvp_vote_accumulate_f32(const float* logit, int64_t ld_r, int64_t ld_c, const int64_t* chunk_ind, int64_t n,
                             int64_t C, float* sum, int32_t* count, mvp_stream_t stream);
-/* all chunks of a scene in ONE launch (the reference loop: mvpnet/test_mvpnet_3d.py:142-174): chunk_ind = the chunks' scene point ids back
- * to back (total of them), offsets (num_chunks + 1 int64, offsets[0] = 0, offsets[num_chunks] = total) = each chunk's slice; chunk i's
- * logits at logit + i*ld_chunk, element (r,c) of it at r*ld_r + c*ld_c.  Same sums as num_chunks calls of mvp_vote_accumulate_f32. */
-int mvp_vote_accumulate_batched_f32(const float* logit, int64_t ld_chunk, int64_t ld_r, int64_t ld_c, const int64_t* chunk_ind,
-                                    const int64_t* offsets, int64_t num_chunks, int64_t total, int64_t C, float* sum, int32_t* count,
-                                    mvp_stream_t stream);
+/* all chunks of a scene in ONE launch (the reference loop: mvpnet/test_mvpnet_3d.py:142-174), atomics-free and in the reference's order of
+ * additions: chunk i's logits at logit + i*ld_chunk, element (r,c) of it at r*ld_r + c*ld_c; chunk_offsets (num_chunks + 1 int64): where each
+ * chunk's index list starts in the concatenation of all lists; point_offsets (n_pts + 1) / point_slots: the transposed index of that
+ * concatenation (mvp_csr_build_i64 with B = 1: for every scene point the flat positions that name it).  sum (n_pts,C) and count (n_pts)
+ * are WRITTEN (not accumulated): sum[p] = the logits of p's positions added in ascending position = chunk order, bit-identical to
+ * num_chunks calls of mvp_vote_accumulate_f32 in chunk order. */
+int mvp_vote_gather_f32(const float* logit, int64_t ld_chunk, int64_t ld_r, int64_t ld_c, const int64_t* chunk_offsets, int64_t num_chunks,
+                        const int32_t* point_offsets, const int32_t* point_slots, int64_t n_pts, int64_t C, float* sum, int32_t* count,
+                        mvp_stream_t stream);
 int mvp_vote_finish_f32(const float* sum, const int32_t* count, int64_t n_pts, int64_t C, float* mean, int64_t* label,
                         mvp_stream_t stream);
 

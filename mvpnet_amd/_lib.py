@@ -82,9 +82,11 @@ _SIGNATURES = {
                                  _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_forward_bn_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr,
                                _ptr, _ptr, _ptr],
+    'mvp_mlp_forward_rel_bn_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_relation4_rows_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr],
     'mvp_mlp_forward_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_vote_accumulate_f32': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
-    'mvp_vote_accumulate_batched_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_vote_gather_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_vote_finish_f32': [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_seg_loss_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _ptr],
     'mvp_seg_loss_backward_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
@@ -174,12 +176,14 @@ def stream_of(t):
 
 
 def ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device address of tensor t as a plain int (ctypes converts it for a c_void_p parameter; None = NULL): no ctypes object per
+    argument -- a training step passes ~600 of them."""
+    return None if t is None else t.data_ptr()
 
 
 def ptr_at(t, element_offset):
     """Device pointer `element_offset` elements into contiguous tensor t."""
-    return ctypes.c_void_p(t.data_ptr() + int(element_offset) * t.element_size())
+    return t.data_ptr() + int(element_offset) * t.element_size()
 
 
 def require_gpu(*tensors):
@@ -201,22 +205,34 @@ def suffix(t):
     raise RuntimeError('expected a float32 or float64 tensor, got {}'.format(t.dtype))
 
 
+_FN = {}  # entry point name -> bound ctypes function (one dict lookup per launch instead of a getattr on the CDLL)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)  # current stream handle as an int, no torch.cuda.Stream object per launch
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
+def _fn(name):
+    f = _FN.get(name)
+    if f is None:
+        f = _FN[name] = getattr(_lib if _lib is not None else lib(), name)
+    return f
+
+
 def call_on(stream, name, *args):
     """Invoke `name(*args, stream)` on the given torch.cuda.Stream of the CURRENT device (no stream-context switch on the host)."""
-    fn = getattr(_lib if _lib is not None else lib(), name)
-    code = fn(*args, ctypes.c_void_p(stream.cuda_stream))
+    code = _fn(name)(*args, stream.cuda_stream)
     if code != 0:
         check(code, name)
 
 
 def call(name, tensor_for_device, *args):
     """Invoke `name(*args, stream)` on the current stream of tensor_for_device's device."""
-    dev = tensor_for_device.device
-    fn = getattr(_lib if _lib is not None else lib(), name)
-    if dev.index == torch.cuda.current_device():  # the usual case (one process per GPU): no device-guard context per launch
-        code = fn(*args, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    index = tensor_for_device.device.index
+    if _raw_stream is not None and index == _raw_device():  # the usual case (one process per GPU): no device guard, no Stream object
+        code = _fn(name)(*args, _raw_stream(index))
+    elif index == torch.cuda.current_device():
+        code = _fn(name)(*args, torch.cuda.current_stream(tensor_for_device.device).cuda_stream)
     else:
-        with torch.cuda.device(dev):
-            code = fn(*args, stream_of(tensor_for_device))
+        with torch.cuda.device(tensor_for_device.device):
+            code = _fn(name)(*args, stream_of(tensor_for_device))
     if code != 0:
         check(code, name)

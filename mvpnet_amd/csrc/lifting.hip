@@ -137,26 +137,40 @@ __global__ __launch_bounds__(256) void vote_acc_kernel(const float* __restrict__
   if (c == 0) atomicAdd(cnt + p, 1);
 }
 
-// All chunks of a scene in one launch: `ind` = the chunks' scene point ids back to back, offsets[i] .. offsets[i+1] = chunk i's
-// slice; chunk i's logits at logit + i * ld_chunk, element (r, c) of the chunk at r * ld_r + c * ld_c.  One thread per (row, class);
-// the owning chunk of a row comes from a binary search over the (few hundred at most) offsets.
-__global__ __launch_bounds__(256) void vote_acc_batched_kernel(const float* __restrict__ logit, int64_t ld_chunk, int64_t ld_r,
-                                                               int64_t ld_c, const int64_t* __restrict__ ind,
-                                                               const int64_t* __restrict__ offsets, int num_chunks, int64_t total,
-                                                               int C, float* __restrict__ sum, int32_t* __restrict__ cnt) {
+// All chunks of a scene in ONE launch, without atomics and in the reference's order of additions: every scene point walks the list of
+// flat positions (chunk-major: `ind` = the chunks' index lists back to back) that name it -- the transposed index built by
+// mvp_csr_build_i64 -- in ASCENDING position, i.e. chunk after chunk as the host loop of test_mvpnet_3d.py:142-174 adds them, so the
+// float sums are bit-identical to the sequential accumulation on every rank and every run (one atomic launch over all chunks would add
+// in an arbitrary order).  A point's list comes unordered out of the counting sort; it is short (a point lies in a handful of
+// chunks), so the next larger position is found by a scan per step.  One thread per (point, class).
+__global__ __launch_bounds__(256) void vote_gather_kernel(const float* __restrict__ logit, int64_t ld_chunk, int64_t ld_r, int64_t ld_c,
+                                                          const int64_t* __restrict__ chunk_offsets, int num_chunks,
+                                                          const int32_t* __restrict__ pt_offsets, const int32_t* __restrict__ pt_slots,
+                                                          int64_t n_pts, int C, float* __restrict__ sum, int32_t* __restrict__ cnt) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t e = t / C;
-  const int c = (int)(t - e * C);
-  if (e >= total) return;
-  int lo = 0, hi = num_chunks;  // largest i with offsets[i] <= e
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (offsets[mid] <= e) lo = mid; else hi = mid;
+  const int64_t p = t / C;
+  const int c = (int)(t - p * C);
+  if (p >= n_pts) return;
+  const int lo0 = pt_offsets[p], hi0 = pt_offsets[p + 1];
+  float acc = 0.f;
+  int prev = -1;
+  for (int step = lo0; step < hi0; ++step) {
+    int e = 0x7fffffff;
+    for (int q = lo0; q < hi0; ++q) {  // smallest position above the previous one
+      const int s = pt_slots[q];
+      e = (s > prev && s < e) ? s : e;
+    }
+    prev = e;
+    int lo = 0, hi = num_chunks;  // largest i with chunk_offsets[i] <= e
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (chunk_offsets[mid] <= (int64_t)e) lo = mid; else hi = mid;
+    }
+    const int64_t r = (int64_t)e - chunk_offsets[lo];
+    acc += logit[(int64_t)lo * ld_chunk + r * ld_r + c * ld_c];
   }
-  const int64_t r = e - offsets[lo];
-  const int64_t p = ind[e];
-  atomicAdd(sum + p * C + c, logit[(int64_t)lo * ld_chunk + r * ld_r + c * ld_c]);
-  if (c == 0) atomicAdd(cnt + p, 1);
+  sum[p * C + c] = acc;
+  if (c == 0) cnt[p] = hi0 - lo0;
 }
 
 __global__ __launch_bounds__(256) void vote_finish_kernel(const float* __restrict__ sum, const int32_t* __restrict__ cnt,
@@ -246,18 +260,19 @@ MVP_API int mvp_vote_accumulate_f32(const float* logit, int64_t ld_r, int64_t ld
   return mvp_launch_status();
 }
 
-MVP_API int mvp_vote_accumulate_batched_f32(const float* logit, int64_t ld_chunk, int64_t ld_r, int64_t ld_c, const int64_t* chunk_ind,
-                                            const int64_t* offsets, int64_t num_chunks, int64_t total, int64_t C, float* sum, int32_t* count,
-                                            mvp_stream_t stream) {
+MVP_API int mvp_vote_gather_f32(const float* logit, int64_t ld_chunk, int64_t ld_r, int64_t ld_c, const int64_t* chunk_offsets,
+                                int64_t num_chunks, const int32_t* point_offsets, const int32_t* point_slots, int64_t n_pts, int64_t C,
+                                float* sum, int32_t* count, mvp_stream_t stream) {
   MVP_NONNULL(logit);
-  MVP_NONNULL(chunk_ind);
-  MVP_NONNULL(offsets);
+  MVP_NONNULL(chunk_offsets);
+  MVP_NONNULL(point_offsets);
+  MVP_NONNULL(point_slots);
   MVP_NONNULL(sum);
   MVP_NONNULL(count);
-  MVP_REQUIRE(num_chunks >= 0 && total >= 0 && C > 0 && C < (1ll << 20) && num_chunks < (1ll << 30));
-  if (total == 0 || num_chunks == 0) return MVP_OK;
-  hipLaunchKernelGGL(vote_acc_batched_kernel, dim3((unsigned)cdiv(total * C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), logit,
-                     ld_chunk, ld_r, ld_c, chunk_ind, offsets, (int)num_chunks, total, (int)C, sum, count);
+  MVP_REQUIRE(num_chunks >= 1 && n_pts >= 0 && C > 0 && C < (1ll << 20) && num_chunks < (1ll << 30));
+  if (n_pts == 0) return MVP_OK;
+  hipLaunchKernelGGL(vote_gather_kernel, dim3((unsigned)cdiv(n_pts * C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), logit, ld_chunk,
+                     ld_r, ld_c, chunk_offsets, (int)num_chunks, point_offsets, point_slots, n_pts, (int)C, sum, count);
   return mvp_launch_status();
 }
 

@@ -51,6 +51,11 @@ struct EpiBwd {
   const float* invstd;
   const float* gamma;
   const float* beta;
+  // Forward only: four EXTRA input columns that never enter the K loop.  y[r][co] += rel[r][0..3] . wrel[co][0..3] in plain fp32 in the
+  // epilogue (FeatureAggregation's relation columns [src - tgt | squared length] behind the 64 feature columns: as a third K slab of
+  // a 68-wide operand they cost a 214 MB concatenated tensor and 2.3x the layer's time).  rel (R,4), wrel (Cout,4); null = none.
+  const float* rel;
+  const float* wrel;
 };
 
 // WT = false: W is (Cout, ldw) row-major, element (output column co, k) at W[co * ldw + k]   (forward: the conv weight)
@@ -404,6 +409,18 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
   const int cl = lane & 31, rh = (lane >> 5) * 4;
+  const bool has_rel = VEC && !WT && epi.rel != nullptr;
+  if constexpr (VEC && !WT) {
+    if (has_rel) {  // the wave's 32 relation rows into the 4 spare floats behind each row of its transposition tile (row stride 36)
+      if (lane < 32) {
+        const int64_t r = row0 + wave * 32 + lane;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) v = *reinterpret_cast<const f32x4*>(epi.rel + (size_t)r * 4);
+        *reinterpret_cast<f32x4*>(Ss[wave] + lane * kLdS + 32) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int co = col0 + j * 32 + cl;
@@ -416,6 +433,8 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
       eg = epi.gamma[co];
       eb = epi.beta[co];
     }
+    f32x4 wr = {0.f, 0.f, 0.f, 0.f};
+    if (has_rel && co < Cout) wr = *reinterpret_cast<const f32x4*>(epi.wrel + (size_t)co * 4);
     float yst[16];
     if constexpr (VEC) {
       if (epi.y) {  // y_prev tile: 16-byte row loads into the wave's LDS tile, read back in the accumulator layout below
@@ -439,6 +458,12 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
       yst[i] = 0.f;
       if (r < R && co < Cout) {
         float y = acc[j][i] + bv;
+        if constexpr (VEC && !WT) {
+          if (has_rel) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(Ss[wave] + ((i & 3) + 8 * (i >> 2) + rh) * kLdS + 32);
+            y += (rv[0] * wr[0] + rv[1] * wr[1]) + (rv[2] * wr[2] + rv[3] * wr[3]);
+          }
+        }
         if (epi.y) {
           const float yp = VEC ? Ss[wave][((i & 3) + 8 * (i >> 2) + rh) * kLdS + cl] : epi.y[(size_t)r * Cout + co];
           const float xh = (yp - em) * ei;
@@ -865,17 +890,17 @@ namespace {
 int mlp_forward_impl(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout, const float* act_mean,
                      const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y, double* stat,
                      double* partial, float bn_eps, float bn_momentum, float* bn_mean, float* bn_invstd, float* bn_running_mean,
-                     float* bn_running_var, int64_t* bn_num_batches, hipStream_t s) {
+                     float* bn_running_var, int64_t* bn_num_batches, hipStream_t s, const float* rel = nullptr, const float* wrel = nullptr) {
   InAct act{act_mean, act_invstd, act_gamma, act_beta};
   const unsigned gx = (unsigned)cdiv(R, kBM);
   const BnFinalize fin{R, bn_eps, bn_momentum, bn_mean, bn_invstd, bn_running_mean, bn_running_var, bn_num_batches};
-  if (g_mlp_stream && std::max(Cin, Cout) >= g_mlp_min_width) {  // long narrow layers: resident weights, persistent row streaming
+  if (g_mlp_stream && !rel && std::max(Cin, Cout) >= g_mlp_min_width) {  // long narrow layers: resident weights, persistent row streaming
     const int rc = mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, bias, Y,
                                           stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, bn_eps, bn_momentum, bn_mean,
                                           bn_invstd, bn_running_mean, bn_running_var, bn_num_batches, nullptr, nullptr, nullptr, nullptr, s);
     if (rc != MVP_EUNSUPPORTED) return rc;
   }
-  launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr}, Y, stat,
+  launch_mlp<false>(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act, bias, EpiBwd{nullptr, nullptr, nullptr, nullptr, nullptr, rel, wrel}, Y, stat,
                     stat ? partial : nullptr, s);
   if (stat && bn_mean)  // with scratch slots: reduce + finalize; without (fp64 atomics in the main kernel): finalize only (no slots to add)
     launch_stats_reduce_finalize(partial, partial ? (int64_t)gx : 0, (int)(2 * Cout), stat, fin, s);
@@ -927,6 +952,33 @@ MVP_API int mvp_mlp_forward_bn_f32(const float* X, int64_t R, int64_t Cin, int64
   if (running_mean) MVP_NONNULL(running_var);
   return mlp_forward_impl(X, R, Cin, ldx, W, ldw, Cout, act_mean, act_invstd, act_gamma, act_beta, nullptr, Y, stat, partial, eps, momentum,
                           mean, invstd, running_mean, running_var, num_batches_tracked, static_cast<hipStream_t>(stream));
+}
+
+// Y = X (R,ldx)[:, :Cin] . W (Cout,ldw)[:, :Cin]^T + rel (R,4) . wrel (Cout,4)^T: a layer whose input is [X | rel] without the concatenated
+// tensor -- the first layer of FeatureAggregation's MLP (mvpnet/models/mvpnet_3d.py:55-56: cat[feature, src - tgt, |src - tgt|^2] -> conv):
+// X = the gathered feature rows as the lifting kernel left them, rel = the four relation columns, W = the conv weight itself with its
+// own row stride (ldw = Cin + 4), wrel = its last four columns.  The relation part is evaluated in plain fp32 in the epilogue.
+// stat / mean ... as mvp_mlp_forward_bn_f32 (stat: 2*Cout + 1 float64, zero on entry), or all NULL (inference: no statistics).
+MVP_API int mvp_mlp_forward_rel_bn_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+                                       const float* rel, const float* wrel, float* Y, double* stat, double* partial, float eps, float momentum,
+                                       float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                       mvp_stream_t stream) {
+  MVP_NONNULL(X);
+  MVP_NONNULL(W);
+  MVP_NONNULL(Y);
+  MVP_NONNULL(rel);
+  MVP_NONNULL(wrel);
+  MVP_REQUIRE(R > 0 && Cin >= 4 && Cout >= 4 && ldx >= Cin && ldw >= Cin && Cin < (1 << 20) && Cout < (1 << 20));
+  // the epilogue path that carries the relation columns is the 16-byte one
+  MVP_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && Cin % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)X) % 16 == 0 && ((uintptr_t)W) % 16 == 0 &&
+              ((uintptr_t)rel) % 16 == 0 && ((uintptr_t)wrel) % 16 == 0);
+  if (mean) {
+    MVP_NONNULL(stat);
+    MVP_NONNULL(invstd);
+  }
+  if (running_mean) MVP_NONNULL(running_var);
+  return mlp_forward_impl(X, R, Cin, ldx, W, ldw, Cout, nullptr, nullptr, nullptr, nullptr, nullptr, Y, stat, partial, eps, momentum, mean, invstd,
+                          running_mean, running_var, num_batches_tracked, static_cast<hipStream_t>(stream), rel, wrel);
 }
 
 // Last layer of a set-abstraction shared MLP in training mode WITHOUT its (rows, Cout) output tensor: the rows are groups of K = 32

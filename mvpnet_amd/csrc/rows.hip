@@ -97,6 +97,18 @@ __global__ __launch_bounds__(kRT) void relation_rows_kernel(const float* __restr
     if (dst[u] >= 0) st4(out + dst[u], v[u]);
 }
 
+// relation4_rows: out (R*K, 4) = [src (R*K, 3) - tgt (R, 3) | squared length]: the relation columns alone (the feature columns stay where
+// the lifting kernel wrote them; mvp_mlp_forward_rel_bn_f32 takes the two operands side by side).  Same arithmetic as relation_rows.
+__global__ __launch_bounds__(kRT) void relation4_rows_kernel(const float* __restrict__ src, const float* __restrict__ tgt, int64_t rows, int K,
+                                                             float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * kRT + threadIdx.x;
+  if (e >= rows) return;
+  const float* p = src + (size_t)e * 3;
+  const float* q = tgt + (size_t)(e / K) * 3;
+  const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+  st4(out + (size_t)e * 4, make_float4(dx, dy, dz, (dx * dx + dy * dy) + dz * dz));
+}
+
 // group_lin_rows: out[b,m,k,:] = Wxyz . (xyz[b,j] - centre[b,m]) + zf[b,j,:],  j = idx[b,m,k]   (C % 4 == 0)
 // The first shared-MLP layer of a set-abstraction level is linear, so W1.[f(j) | xyz(j) - c] = (W1f.f)(j) + W1xyz.(xyz(j) - c):
 // the feature part zf = W1f.f is a 1x1 conv over the N points instead of the M*K = 8N grouped rows, and the
@@ -948,6 +960,17 @@ MVP_API int mvp_relation_rows_f32(const float* feature, const float* src_xyz, co
   const int64_t rows = R * K;
   hipLaunchKernelGGL(relation_rows_kernel, dim3((unsigned)cdiv(rows * (C / 4 + 1), (int64_t)kRT * kRelU)), dim3(kRT), 0, static_cast<hipStream_t>(stream),
                      feature, src_xyz, tgt_xyz, rows, (int)K, (int)C, out);
+  return mvp_launch_status();
+}
+
+MVP_API int mvp_relation4_rows_f32(const float* src_xyz, const float* tgt_xyz, int64_t R, int64_t K, float* out, mvp_stream_t stream) {
+  MVP_NONNULL(src_xyz);
+  MVP_NONNULL(tgt_xyz);
+  MVP_NONNULL(out);
+  MVP_REQUIRE(R >= 0 && K >= 1 && R * K < (1ll << 40) && ((uintptr_t)out) % 16 == 0);
+  if (R == 0) return MVP_OK;
+  hipLaunchKernelGGL(relation4_rows_kernel, dim3((unsigned)cdiv(R * K, (int64_t)kRT)), dim3(kRT), 0, static_cast<hipStream_t>(stream), src_xyz,
+                     tgt_xyz, R * K, (int)K, out);
   return mvp_launch_status();
 }
 

@@ -119,6 +119,32 @@ def all_gather_logits(local_logits, num_chunks):
     return out[:num_chunks]
 
 
+_VOTE_PLANS = {}
+
+
+def _vote_plan(chunk_inds, n_pts, dev):
+    """The transposed index of a scene's chunk lists (for every scene point the flat positions, chunk-major, that name it): one counting
+    sort (mvp_csr_build_i64) per scene, cached on the identity of the index tensors."""
+    from . import _lib as L
+    from . import rows as R
+    key = (n_pts, tuple((int(i.data_ptr()), int(i.numel()), int(i._version)) for i in chunk_inds))
+    plan = _VOTE_PLANS.get(key)
+    if plan is None:
+        for ind in chunk_inds:
+            L.require_gpu(ind)
+        lens = [int(ind.numel()) for ind in chunk_inds]
+        flat = torch.cat([ind.reshape(-1) for ind in chunk_inds]) if len(chunk_inds) > 1 else chunk_inds[0].reshape(-1)
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        pt_offsets, pt_slots = R.build_csr(flat.view(1, -1), n_pts)
+        plan = {'chunk_offsets': torch.tensor(offs, dtype=torch.int64).to(dev), 'pt_offsets': pt_offsets, 'pt_slots': pt_slots,
+                'max_len': max(lens), 'keep': list(chunk_inds)}  # (the index tensors stay alive: their addresses are the key)
+        _VOTE_PLANS.clear()  # one scene at a time
+        _VOTE_PLANS[key] = plan
+    return plan
+
+
 def vote_scene(logits, chunk_inds, n_pts):
     """logits: (num_chunks, C, N) on the GPU; chunk_inds: list of int64 tensors (n_i <= N) of scene
     point ids per chunk.  Returns mean logits (n_pts, C), labels (n_pts,) with `count==0 -> C`,
@@ -126,22 +152,16 @@ def vote_scene(logits, chunk_inds, n_pts):
     from . import _lib as L
     C = logits.size(1)
     s = torch.zeros(n_pts, C, dtype=torch.float32, device=logits.device)
-    cnt = torch.zeros(n_pts, dtype=torch.int32, device=logits.device)
-    # ONE accumulation launch for the whole scene (the reference loops over the chunks on the host: test_mvpnet_3d.py:142-174):
-    # the chunks' index lists back to back + their offsets; only the first len(ind) columns of a chunk are real points
+    cnt = torch.zeros(n_pts, dtype=torch.int32, device=logits.device)  # (no chunks: every point is "no prediction")
+    # ONE accumulation launch for the whole scene (the reference loops over the chunks on the host: test_mvpnet_3d.py:142-174), without
+    # atomics and adding in chunk order (bit-identical on every rank): every scene point gathers through the transposed index of the
+    # concatenated chunk lists.  That index depends on the scene only and is kept for the next call on the same lists.
     if len(chunk_inds):
-        for ind in chunk_inds:
-            L.require_gpu(ind)
-        lens = [int(ind.numel()) for ind in chunk_inds]
-        if max(lens) > logits.size(2):
-            raise RuntimeError('vote_scene: a chunk lists {} points but its logits have {} columns'.format(max(lens), logits.size(2)))
-        flat = torch.cat([ind.reshape(-1) for ind in chunk_inds]) if len(chunk_inds) > 1 else chunk_inds[0].reshape(-1)
-        offs = [0]
-        for n in lens:
-            offs.append(offs[-1] + n)
-        offsets = torch.tensor(offs, dtype=torch.int64).to(logits.device, non_blocking=True)
-        L.call('mvp_vote_accumulate_batched_f32', s, L.ptr(logits), logits.stride(0), logits.stride(2), logits.stride(1), L.ptr(flat),
-               L.ptr(offsets), len(chunk_inds), offs[-1], C, L.ptr(s), L.ptr(cnt))
+        plan = _vote_plan(chunk_inds, n_pts, logits.device)
+        if plan['max_len'] > logits.size(2):
+            raise RuntimeError('vote_scene: a chunk lists {} points but its logits have {} columns'.format(plan['max_len'], logits.size(2)))
+        L.call('mvp_vote_gather_f32', s, L.ptr(logits), logits.stride(0), logits.stride(2), logits.stride(1), L.ptr(plan['chunk_offsets']),
+               len(chunk_inds), L.ptr(plan['pt_offsets']), L.ptr(plan['pt_slots']), n_pts, C, L.ptr(s), L.ptr(cnt))
     mean = torch.empty_like(s)
     label = torch.empty(n_pts, dtype=torch.int64, device=logits.device)
     L.call('mvp_vote_finish_f32', s, L.ptr(s), L.ptr(cnt), n_pts, C, L.ptr(mean), L.ptr(label))

@@ -22,6 +22,9 @@ from . import _lib as L
 from . import rows as R
 
 
+REL_EPILOGUE = os.environ.get('MVP_REL_EPILOGUE', '1') != '0'  # A/B switch: relation columns in the first layer's epilogue
+
+
 class FeatureAggregation(nn.Module):
     """cat[feature, src - tgt, |src - tgt|^2] -> SharedMLP -> reduce over k (mvpnet_3d.py:9-67)."""
 
@@ -49,6 +52,13 @@ class FeatureAggregation(nn.Module):
         if self.mlp is None:
             return gfeat.sum(2) if self.reduction_name == 'sum' else gfeat.max(2)[0]
         x = gfeat
+        if self.use_relation and REL_EPILOGUE and gfeat.is_cuda and gfeat.dtype == torch.float32 and C % 4 == 0 and R.mlp_chain_is_fused(self.mlp) \
+                and self.mlp[0].conv.weight.size(1) == C + 4:
+            # [feature | src - tgt | squared length] (:55-56) is never built: the first conv reads the gathered feature rows as they are,
+            # the four relation columns meet their weight columns in that kernel's epilogue (the 68-wide operand cost a 214 MB tensor and
+            # 2.3x the layer's time: csrc/mlp.hip, EpiBwd::rel)
+            rel = R.relation4_rows(gxyz, points)
+            return R.shared_mlp_rows(gfeat.reshape(B * N * k, C), self.mlp, K=k, reduce=self.reduction_name, rel=rel.view(B * N * k, 4)).view(B, N, -1)
         if self.use_relation and gfeat.is_cuda and gfeat.dtype == torch.float32 and C % 4 == 0:
             x = R.relation_rows(gfeat, gxyz, points)  # feature, diff, dist (:55-56) written in one pass
         elif self.use_relation:
@@ -237,15 +247,24 @@ def prefetch_geometry_many(model, batches):
     return batches
 
 
+PREFETCH_AT = os.environ.get('MVP_PREFETCH_AT', 'backward')  # where train_step starts the next batch's geometry: 'backward' | 'forward'
+
+
 def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, next_batch=None):
     """One iteration of the reference loop (mvpnet/train_mvpnet_3d.py:158-180,287-288):
     zero_grad -> forward -> SegLoss -> backward -> [grad all-reduce] -> [clip] -> step -> scheduler.
     next_batch: the batch of the NEXT iteration (already on the device); its geometry is prefetched."""
     optimizer.zero_grad()
-    if next_batch is not None:
+    if next_batch is not None and PREFETCH_AT == 'forward':
         data_batch = dict(data_batch, prefetch_next=next_batch)  # launched right after this batch's lifting
     preds = model(data_batch)
     loss = loss_fn(preds, data_batch)['seg_loss']
+    if next_batch is not None and PREFETCH_AT == 'backward':
+        # The next batch's coordinate-only work (FPS chain, ball queries, 3-NN, transposed indices: ~3 ms of side-stream kernels) starts
+        # HERE, beside the backward pass, not beside the forward: the forward's deep levels are chains of 10-40 us kernels that the
+        # geometry kernels delay badly (measured with HIP events: SA3 + SA4 forward 0.45 -> 1.20 ms beside them, the whole step
+        # 7.6 -> 8.9 ms), the backward is dominated by 100-350 us kernels that share the chip gracefully.
+        prefetch_geometry(model, next_batch)
     loss.backward()
     if grad_sync is not None:
         grad_sync(weight_sum=getattr(loss_fn, 'last_weight_sum', None))  # == the gradient of ONE loss over the gathered batch

@@ -220,6 +220,7 @@ weight_slices = WeightSlices()
 # engine, so .grad is complete on the caller's stream when backward() returns.  Fork and join are plain stream waits: they are captured
 # with the step under a hipGraph.  Measured: DESIGN.md section 5.
 DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
+_EXP_SKIP_DW = os.environ.get('MVP_EXP_SKIP_DW', '0') == '1'
 
 
 class WeightUse:
@@ -697,6 +698,10 @@ class MLPChainRows(torch.autograd.Function):
         drop_p, drop_seed = opts.get('drop_p', 0.0), opts.get('drop_seed', 0)
         ctx.dw_use = opts.get('use')
         pool_sum = bool(opts.get('sum', False))
+        # 'rel': (rel (R,4), first conv weight): the first layer's input is [x0 | rel] without the concatenated tensor -- its weight has
+        # x0.size(1) + 4 columns, the last four meet `rel` in the kernel's epilogue (mvp_mlp_forward_rel_bn_f32)
+        rel, w0_param = opts.get('rel', (None, None))
+        ctx.rel = (rel, w0_param)
         ctx.dropout = (float(drop_p), int(drop_seed))
         ys, means, invstds = [], [], []
         act = (None, None, None, None)
@@ -725,6 +730,28 @@ class MLPChainRows(torch.autograd.Function):
                     L.call('mvp_colstats_f32', y, L.ptr(y), R, cout, L.ptr(stat), L.ptr(_cs_partial(R, cout, dev)))
             else:
                 cout, cin = w.size(0), w.size(1)
+                if i == 0 and rel is not None:
+                    cin_f = x0.size(1)
+                    assert cin == cin_f + 4 and act[0] is None
+                    wrel = weight_slices.get(w0_param, cin_f, cin, 4)
+                    rm, rv, nbt = bn_buffers[i]
+                    y = torch.empty((R, cout), dtype=torch.float32, device=dev)
+                    if training:
+                        mean = torch.empty(cout, dtype=torch.float32, device=dev)
+                        invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+                        L.call('mvp_mlp_forward_rel_bn_f32', x, L.ptr(x), R, cin_f, cin_f, L.ptr(w), cin, cout, L.ptr(rel), L.ptr(wrel), L.ptr(y),
+                               L.ptr(stat), L.ptr(_partial(R, cout, dev)), float(eps), float(mom), L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv),
+                               L.ptr(nbt))
+                    else:
+                        L.call('mvp_mlp_forward_rel_bn_f32', x, L.ptr(x), R, cin_f, cin_f, L.ptr(w), cin, cout, L.ptr(rel), L.ptr(wrel), L.ptr(y),
+                               None, None, 0.0, 0.0, None, None, None, None, None)
+                        mean, invstd = rm, eval_invstd.get(rv, eps)
+                    ys.append(y)
+                    means.append(mean)
+                    invstds.append(invstd)
+                    act = (mean, invstd, gamma, beta)
+                    x = y
+                    continue
                 if pooled and i == nl - 1:
                     # last layer of a set-abstraction MLP: batch statistics + per-ball max / min of the pre-BN output, no (R, cout) tensor
                     G = R // K
@@ -854,7 +881,8 @@ class MLPChainRows(torch.autograd.Function):
             cin = 0 if w is None else w.size(1)
             src = None if w is None else (x0 if i == 0 else ys[i - 1])
             pool_here = pool is not None and i == nl - 1
-            fuse = pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and
+            rel, w0_param = ctx.rel if i == 0 else (None, None)
+            fuse = pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and rel is None and
                                  (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
             if pending is not None and not fuse:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)
@@ -877,7 +905,22 @@ class MLPChainRows(torch.autograd.Function):
             if i > 0:
                 stat = st_arena[st_off:st_off + 2 * cin]
                 st_off += 2 * cin
-            dz = torch.empty((R, cin), dtype=torch.float32, device=dev) if need_dz else None
+            dz = torch.empty((R, cin if rel is None else src.size(1)), dtype=torch.float32, device=dev) if need_dz else None
+            if rel is not None:
+                # first layer over [x0 | rel]: the feature columns and the four relation columns of dW from two launches (beside the chain
+                # when allowed), the input gradient (only when x0 needs one) from the feature columns of the weight
+                cin_f = src.size(1)
+                for xs, ncol, c0 in ((src, cin_f, 0), (rel, 4, cin_f)):
+                    wg_args = (L.ptr(gcur), L.ptr(xs), R, cout, ncol, ncol, None, None, None, None, L.ptr_at(dw, c0), cin)
+                    if dw_aside:
+                        side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, xs, dw))
+                    else:
+                        L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args)
+                if need_dz:
+                    wf = weight_slices.get(w0_param, 0, cin_f, cin_f)
+                    L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(wf), cin_f, None, None, None, None, None, L.ptr(dz), None, None)
+                    dx0 = dz
+                break
             if fuse:
                 dgb = torch.empty((2, cout), dtype=torch.float32, device=dev) if pending is not None else None
                 part = torch.empty(L.lib().mvp_mlp_layer_backward_partial_count(R, cin), dtype=torch.float64, device=dev) if (i > 0 and need_dz) else None
@@ -892,7 +935,9 @@ class MLPChainRows(torch.autograd.Function):
             else:
                 wg_args = (L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]),
                            L.ptr(dw), cin)
-                if dw_aside:
+                if _EXP_SKIP_DW:
+                    pass  # (timing experiment only: tools/exp/README.md, "what the graph step would cost with the weight gradients for free")
+                elif dw_aside:
                     side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, src, dw) + tuple(t for t in act if t is not None))
                 else:
                     L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args)
@@ -1043,13 +1088,27 @@ def mlp_chain_is_fused(mlp, dropout_p=0.0):
         all(l.conv.weight.size(0) % 4 == 0 and 256 % (l.conv.weight.size(0) // 4) == 0 for l in mlp)
 
 
-def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max'):
+def relation4_rows(src_xyz, tgt_xyz):
+    """src_xyz (B,N,k,3), tgt_xyz (B,N,3) -> (B,N,k,4) = [src - tgt | squared length]: FeatureAggregation's relation columns alone
+    (mvpnet_3d.py:55-56; coordinates carry no gradient on this path)."""
+    L.require_gpu(src_xyz, tgt_xyz)
+    B, N, k, _ = src_xyz.shape
+    with torch.no_grad():
+        s, t = src_xyz.contiguous(), tgt_xyz.contiguous()
+        out = torch.empty((B, N, k, 4), dtype=torch.float32, device=s.device)
+        L.call('mvp_relation4_rows_f32', s, L.ptr(s), L.ptr(t), B * N, k, L.ptr(out))
+    return out
+
+
+def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max', rel=None):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
     K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108), or their sum with reduce='sum'
     (FeatureAggregation, mvpnet_3d.py:40-41,59).
     first_done=True: x already is the first layer's conv output (the linear part was applied per point before
-    the grouping, see SetAbstraction.forward_rows); only its BatchNorm + ReLU and the remaining layers run here."""
+    the grouping, see SetAbstraction.forward_rows); only its BatchNorm + ReLU and the remaining layers run here.
+    rel (R,4): the first layer's input is [x | rel] -- its weight has x.size(1) + 4 columns -- without the concatenated tensor (fused
+    chains only: FeatureAggregation)."""
     n = len(mlp)
     # dropout follows EVERY layer of a SharedMLPDO (mlp.py:86-92): a single-layer chain can still be fused, dropout on its output
     fused = mlp_chain_is_fused(mlp, dropout_p) and K <= 255
@@ -1062,6 +1121,9 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
             eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
         opts = {'sum': bool(reduce == 'sum' and K > 1)}
+        if rel is not None:
+            assert not first_done and rel.dim() == 2 and rel.size(1) == 4 and rel.size(0) == x.size(0)
+            opts['rel'] = (rel.contiguous(), mlp[0].conv.weight)
         if DW_SIDE_STREAM and torch.is_grad_enabled():  # (a first layer that ran before the grouping has its own use: WeightGradSink)
             opts['use'] = WeightUse([l.conv.weight for li, l in enumerate(mlp) if not (first_done and li == 0)])
         # dropout behind the (single) layer: folded into the BatchNorm + ReLU passes (mvp_bn_rows_forward_dropout_f32) unless a graph is
@@ -1073,7 +1135,7 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             opts['drop_p'], opts['drop_seed'] = float(dropout_p), seed & 0x7fffffffffffffff
         out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, opts, *params)
         return F.dropout(out, p=dropout_p, training=training, inplace=False) if (dropout_p > 0 and not fold) else out
-    assert not first_done, 'first_done needs the fused path (BN + ReLU, no bias, no dropout)'
+    assert not first_done and rel is None, 'first_done / rel need the fused path (BN + ReLU, no bias, no dropout)'
     if K > 255:  # the pooled BatchNorm kernel keeps its arg-max in one byte: pool with torch after a K = 1 pass
         x = shared_mlp_rows(x, mlp, 1, dropout_p, training)
         x = x.view(-1, K, x.size(1))

@@ -526,7 +526,7 @@ def test_vote_golden(dev):
 
 
 def test_vote_golden_one_launch_for_all_chunks(dev):
-    """The same known answer through dist.vote_scene = mvp_vote_accumulate_batched_f32: all chunks' index lists back to back,
+    """The same known answer through dist.vote_scene = mvp_vote_gather_f32: every scene point gathers through the transposed index of the concatenated chunk lists,
     one accumulation launch (ragged chunks: logits padded to the longest chunk, the padding never read)."""
     from mvpnet_amd import dist as D
     gd = load_golden('vote')
@@ -1265,3 +1265,82 @@ def test_fps_rounds_kernel_odd_sizes(dev, N, M):
     pts[1, N // 2:] = pts[1, :N - N // 2]  # second cloud: every point twice
     idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
     np.testing.assert_array_equal(idx, O().fps(pts, M))
+
+
+@pytest.mark.parametrize('R,C,Cout', [(3000, 64, 64), (70001, 64, 64), (66000, 16, 32), (4100, 128, 256)])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x6'])
+def test_mlp_forward_with_relation_columns_in_the_epilogue(dev, R, C, Cout, prec):
+    """mvp_mlp_forward_rel_bn_f32: Y = [X | rel] . W^T with W (Cout, C + 4) read in place (row stride C + 4) and the four relation
+    columns applied in the epilogue -- against the float64 product of the concatenated operand (what mvpnet_3d.py:55-58 computes),
+    with the batch statistics / BatchNorm finalize of the result, and without statistics (inference)."""
+    from mvpnet_amd import _lib as L
+    before = L.get_mlp_precision()
+    L.set_mlp_precision(prec)
+    try:
+        torch.manual_seed(R + C)
+        x = torch.randn(R, C, device=dev)
+        rel = torch.randn(R, 4, device=dev) * 0.05
+        w = torch.randn(Cout, C + 4, device=dev) * 0.2
+        wrel = w[:, C:].contiguous()
+        ref = torch.cat([x, rel], 1).double() @ w.double().t()
+        tol = 3e-6 * float(ref.abs().max()) * (C ** 0.5)
+        y = torch.empty(R, Cout, device=dev)
+        stat = torch.zeros(2 * Cout + 1, dtype=torch.float64, device=dev)
+        part = torch.empty(((R + 127) // 128) * 2 * Cout, dtype=torch.float64, device=dev) if R >= 65536 else None
+        mean, inv = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+        rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        L.call('mvp_mlp_forward_rel_bn_f32', x, L.ptr(x), R, C, C, L.ptr(w), C + 4, Cout, L.ptr(rel), L.ptr(wrel), L.ptr(y), L.ptr(stat), L.ptr(part),
+               1e-5, 0.1, L.ptr(mean), L.ptr(inv), L.ptr(rm), L.ptr(rv), L.ptr(nbt))
+        assert float((y.double() - ref).abs().max()) <= tol
+        # (per-lane partial sums of 16 rows are fp32, everything above them float64)
+        np.testing.assert_allclose(stat[:Cout].cpu().numpy(), y.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()) * R ** 0.5)
+        np.testing.assert_allclose(mean.cpu().numpy(), ref.mean(0).cpu().numpy(), rtol=1e-4, atol=tol)
+        np.testing.assert_allclose(inv.cpu().numpy(), (1.0 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).cpu().numpy(), rtol=1e-4)
+        assert int(nbt) == 1 and stat[-1].item() == 0.0
+        y2 = torch.empty(R, Cout, device=dev)
+        L.call('mvp_mlp_forward_rel_bn_f32', x, L.ptr(x), R, C, C, L.ptr(w), C + 4, Cout, L.ptr(rel), L.ptr(wrel), L.ptr(y2), None, None, 0.0, 0.0,
+               None, None, None, None, None)
+        assert torch.equal(y2, y)
+    finally:
+        L.set_mlp_precision(before)
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_feature_aggregation_without_the_concatenated_tensor(dev, train):
+    """FeatureAggregation with the relation columns in the first layer's epilogue against the path that builds the (B,N,k,C+4)
+    tensor (mvpnet3d.REL_EPILOGUE off): outputs, input gradient and every parameter gradient."""
+    from mvpnet_amd import mvpnet3d as M
+    torch.manual_seed(5)
+    B, N, k, C = 3, 2048, 3, 64
+    agg = M.FeatureAggregation(C).to(dev).train(train)
+    gfeat = torch.randn(B, N, k, C, device=dev)
+    gxyz = torch.randn(B, N, k, 3, device=dev) * 0.05
+    pts = torch.randn(B, N, 3, device=dev) * 0.05
+    gout = torch.randn(B, N, 64, device=dev)
+
+    def run(flag):
+        old, M.REL_EPILOGUE = M.REL_EPILOGUE, flag
+        try:
+            for p in agg.parameters():
+                p.grad = None
+            sd = {kk: v.clone() for kk, v in agg.state_dict().items()}
+            f = gfeat.clone().requires_grad_(True)
+            out = agg(gxyz, pts, f, rows=True)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            grads = [p.grad.clone() for p in agg.parameters()]
+            agg.load_state_dict(sd)  # (running statistics moved in train mode)
+            return out.detach(), f.grad, grads
+        finally:
+            M.REL_EPILOGUE = old
+
+    o1, g1, p1 = run(True)
+    o0, g0, p0 = run(False)
+    assert float((o1 - o0).abs().max()) <= 2e-5 * float(o0.abs().max())
+    # gradients: relative L2 (a pre-activation within rounding of 0 may fall on either side of the ReLU in the two evaluation orders: a
+    # single element of the input gradient then differs by a whole weight x gradient product -- measured once at 4 % of the largest entry)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert rel(g1, g0) <= 1e-3 and float(((g1 - g0).abs() > 1e-4 * float(g0.abs().max())).float().mean()) <= 1e-4
+    for a, b, (name, _) in zip(p1, p0, agg.named_parameters()):
+        assert rel(a, b) <= 1e-3, name
