@@ -110,7 +110,7 @@ def lift_traffic(batch):
     """HBM bytes per mvp_lift_f32 launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE of the two lifting
     kernels INSIDE the train step at B = 32, tools/step_counters.sh; FETCH_SIZE doubled per the gfx950 calibration note).  A committed
     measurement, not a live counter read: None for any other batch size."""
-    path = os.path.join(ROOT, 'profiles', 'r02_step_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r03_step_traffic.json')
     if batch != 32 or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -604,7 +604,7 @@ def main():
                                  'latency_ms_B1 = one chunk alone, synchronised per chunk (bounded by the serial FPS chain)'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': lift_traffic(args.batch), 'traffic_source': 'profiles/r02_step_traffic.json (committed rocprofv3 PMC passes of this step at B=32, not read live)', 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
+                         'traffic': lift_traffic(args.batch), 'traffic_source': 'profiles/r03_step_traffic.json (committed rocprofv3 PMC passes of this step at B=32, not read live)', 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(bt)
