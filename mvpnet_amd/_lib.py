@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmvp_hip.so')
+LIB_PATH = os.environ.get('MVP_LIBRARY') or os.path.join(_HERE, 'libmvp_hip.so')  # MVP_LIBRARY: an experiment build of the same ABI (tools/exp)
 _lib = None
 MLP_PRECISIONS = {'fp32': 0, 'bf16x3': 3, 'bf16x6': 6}
 

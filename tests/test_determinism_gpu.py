@@ -1,0 +1,145 @@
+"""Run-to-run determinism of the kernels that exchange data between lanes through a wave-private LDS tile (round 3: the fused
+set-abstraction inference kernel turned out to give different results on a handful of balls from run to run -- a compiler scheduling
+issue around the tile, invisible to tolerance tests that pass most of the time).  Every kernel that is deterministic by construction (no
+float atomics on its outputs) must return bit-identical results over repeated launches on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _all_equal(fn, n=20):
+    ref = [t.clone() for t in fn()]
+    bad = 0
+    for _ in range(n):
+        out = fn()
+        bad += int(not all(torch.equal(a, b) for a, b in zip(out, ref)))
+    torch.cuda.synchronize()
+    return bad
+
+
+@pytest.mark.parametrize('cin,widths,N,M', [(0, (32, 32, 64), 8192, 2048), (64, (32, 32, 64), 8192, 2048), (64, (64, 64, 128), 2048, 512),
+                                            (16, (32, 64, 64), 2048, 512), (64, (64, 32, 128), 2048, 512)])
+@pytest.mark.parametrize('prec', ['bf16x6', 'bf16x3'])
+def test_fused_set_abstraction_is_deterministic_and_matches_the_layer_kernels(dev, cin, widths, N, M, prec):
+    from mvpnet_amd.pn2 import SetAbstraction
+    from mvpnet_amd import rows as R
+    from mvpnet_amd import _lib as L
+    before = L.get_mlp_precision()
+    L.set_mlp_precision(prec)
+    old = R.SA_FUSED_EVAL
+    try:
+        torch.manual_seed(1)
+        sa = SetAbstraction(cin, widths, M, 0.15, 32, use_xyz=True).to(dev).eval()
+        B = 16
+        xyz = torch.rand(B, N, 3, device=dev)
+        feat = torch.randn(B, N, cin, device=dev) if cin else None
+        geo = sa.geometry(xyz)
+        with torch.no_grad():
+            R.SA_FUSED_EVAL = False
+            ref = sa(xyz, feat, rows=True, geometry=geo)[1].clone()
+            R.SA_FUSED_EVAL = True
+            assert _all_equal(lambda: (sa(xyz, feat, rows=True, geometry=geo)[1],), 25) == 0
+            out = sa(xyz, feat, rows=True, geometry=geo)[1]
+        tol = (2e-5 if prec == 'bf16x6' else 2e-3) * float(ref.abs().max())
+        assert float((out - ref).abs().max()) <= tol
+    finally:
+        R.SA_FUSED_EVAL = old
+        L.set_mlp_precision(before)
+
+
+@pytest.mark.parametrize('R_,cin,cout', [(2097152, 32, 64), (524288, 64, 64), (70016, 32, 32)])
+def test_pooled_forward_and_layer_kernels_are_deterministic(dev, R_, cin, cout):
+    """mvp_mlp_forward_pool_f32 (per-ball max / min of a layer whose output is never stored), mvp_mlp_forward_bn_f32 and the dz output of
+    mvp_mlp_layer_backward_f32: same inputs -> same bits."""
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(R_ % 1000)
+    x = torch.randn(R_, cin, device=dev)
+    w = torch.randn(cout, cin, device=dev) * 0.2
+    mean, inv = torch.randn(cin, device=dev) * 0.1, torch.rand(cin, device=dev) + 0.5
+    gam, bet = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
+    G = R_ // 32
+
+    def pool():
+        ymax, ymin = torch.empty(G, cout, device=dev), torch.empty(G, cout, device=dev)
+        amax, amin = torch.empty(G, cout, dtype=torch.uint8, device=dev), torch.empty(G, cout, dtype=torch.uint8, device=dev)
+        stat = torch.zeros(2 * cout + 1, dtype=torch.float64, device=dev)
+        part = torch.empty(((R_ + 127) // 128) * 2 * cout, dtype=torch.float64, device=dev)
+        m, i = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        L.call('mvp_mlp_forward_pool_f32', x, L.ptr(x), R_, cin, cin, L.ptr(w), cin, cout, L.ptr(mean), L.ptr(inv), L.ptr(gam), L.ptr(bet),
+               L.ptr(ymax), L.ptr(ymin), L.ptr(amax), L.ptr(amin), L.ptr(stat), L.ptr(part), 1e-5, 0.1, L.ptr(m), L.ptr(i), None, None, None)
+        return ymax, ymin, amax, amin, m, i
+
+    def fwd():
+        y = torch.empty(R_, cout, device=dev)
+        stat = torch.zeros(2 * cout + 1, dtype=torch.float64, device=dev)
+        part = torch.empty(((R_ + 127) // 128) * 2 * cout, dtype=torch.float64, device=dev)
+        m, i = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        L.call('mvp_mlp_forward_bn_f32', x, L.ptr(x), R_, cin, cin, L.ptr(w), cin, cout, L.ptr(mean), L.ptr(inv), L.ptr(gam), L.ptr(bet), L.ptr(y),
+               L.ptr(stat), L.ptr(part), 1e-5, 0.1, L.ptr(m), L.ptr(i), None, None, None)
+        return y, m, i
+
+    if R_ >= 32768:
+        assert _all_equal(pool, 10) == 0
+    assert _all_equal(fwd, 10) == 0
+
+
+def test_eval_forward_of_the_whole_model_is_deterministic(dev):
+    """Two eval-mode forwards of MVPNet3D (device lifting, aggregation, fused set-abstraction levels, feature propagation) on the same
+    batch: bit-identical logits."""
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D
+    from mvpnet_amd.synthetic import make_batch
+
+    class Net2D(torch.nn.Module):
+        feature = None
+
+        def forward(self, data):
+            return {'feature': self.feature}
+
+    B = 4
+    bt = make_batch(60, B, config=3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    net2d = Net2D()
+    net2d.feature = t(bt['feature_2d']).view(B * 3, 120, 160, 64).permute(0, 3, 1, 2)
+    torch.manual_seed(2)
+    model = MVPNet3D(net2d, '', PN2SSG(64, 20), in_channels=64).to(dev).eval()
+    batch = {'images': torch.zeros(B, 3, 3, 120, 160, device=dev), 'points': t(bt['points'].transpose(0, 2, 1)),
+             'depth': t(bt['depth_mm'].astype(np.int16)), 'cam_matrix': t(np.repeat(bt['cam_matrix'][None, None, :3, :3], 3, 1).repeat(B, 0)),
+             'kinv': t(bt['kinv']), 'pose': t(bt['pose']), 'pixel_box': t(bt['pixel_box']), 'k': 3}
+    with torch.no_grad():
+        assert _all_equal(lambda: (model(dict(batch))['seg_logit'],), 8) == 0
+
+
+@pytest.mark.parametrize('chain,K,R_', [((32, (32, 64)), 32, 2097152), ((64, (64, 64, 64)), 3, 786432), ((64, (64, 128)), 32, 524288)])
+def test_chain_forward_and_input_gradient_are_deterministic(dev, chain, K, R_):
+    """A whole shared-MLP chain in training mode (pooled last layer where it qualifies, one-kernel layer backward): the pooled output
+    and the gradient w.r.t. the chain's input are free of float atomics -> bit-identical over repeated forward + backward passes (the
+    weight gradients are not: their row splits meet in fp32 atomics)."""
+    from mvpnet_amd import rows as R
+    from mvpnet_amd.nn import SharedMLP
+    torch.manual_seed(R_ % 997)
+    cin, widths = chain
+    mlp = SharedMLP(cin, widths, ndim=2, bn=True).to(dev).train()
+    x = torch.randn(R_, cin, device=dev)
+    g = torch.randn(R_ // K, widths[-1], device=dev)
+
+    def run():
+        for p in mlp.parameters():
+            p.grad = None
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        xi = x.clone().requires_grad_(True)
+        out = R.shared_mlp_rows(xi, mlp, K=K, reduce='sum' if K == 3 else 'max')
+        out.backward(g)
+        return out.detach(), xi.grad
+
+    assert _all_equal(run, 12) == 0
