@@ -320,6 +320,11 @@ int mvp_get_mlp_precision(void);
  * terms = 3 (default) or 6. */
 int mvp_set_mlp_precision_backward(int terms);
 int mvp_get_mlp_precision_backward(void);
+/* The two settings above are process-wide DEFAULTS.  mvp_mlp_precision_scope overrides them for the calls the CALLING host thread makes
+ * (thread-local; terms / terms_backward = -1 keeps the default): nothing global is written, so several models or threads in one process
+ * never see each other's choice.  Returns the previous override packed as (terms + 1) * 16 + (terms_backward + 1), MVP_EINVAL for other
+ * values.  The getters return what the calling thread's launches use. */
+int mvp_mlp_precision_scope(int terms, int terms_backward);
 /* Switch (returns the previous value): 1 = long narrow forward layers (>= 32768 rows, C_in, C_out <= 128) run on the persistent
  * streaming kernel with the weight matrix resident in LDS; 0 (default: measured 1.2 % faster on the bench step) = the per-tile kernel. */
 int mvp_set_mlp_stream(int on);

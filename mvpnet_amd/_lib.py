@@ -93,7 +93,7 @@ _SIGNATURES = {
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
-           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_set_fps_mode'] + sorted(_SIGNATURES)
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -134,6 +134,8 @@ def lib():
         handle.mvp_set_mlp_precision_backward.argtypes = [ctypes.c_int]
         handle.mvp_get_mlp_precision_backward.restype = ctypes.c_int
         handle.mvp_get_mlp_precision_backward.argtypes = []
+        handle.mvp_mlp_precision_scope.restype = ctypes.c_int
+        handle.mvp_mlp_precision_scope.argtypes = [ctypes.c_int, ctypes.c_int]
         if os.environ.get('MVP_MLP_PRECISION_BWD'):
             check(handle.mvp_set_mlp_precision_backward(MLP_PRECISIONS[os.environ['MVP_MLP_PRECISION_BWD']]), 'mvp_set_mlp_precision_backward')
         env = os.environ.get('MVP_MLP_PRECISION')
@@ -159,6 +161,29 @@ def set_mlp_precision_backward(name):
     if name not in ('bf16x3', 'bf16x6'):
         raise ValueError("backward mlp precision must be 'bf16x3' or 'bf16x6'")
     check(lib().mvp_set_mlp_precision_backward(MLP_PRECISIONS[name]), 'mvp_set_mlp_precision_backward')
+
+
+class mlp_precision:
+    """`with mlp_precision('fp32'): ...` / `with mlp_precision('bf16x6', backward='bf16x6'): ...` -- the contraction precision of the
+    shared-MLP launches made by THIS thread inside the block (mvp_mlp_precision_scope: a thread-local override, the process-wide defaults
+    of set_mlp_precision[_backward] are not touched).  Note that autograd runs backward functions on its own thread: wrap a training
+    step's backward in a scope entered from a backward hook, or use the process defaults, when the backward precision matters."""
+
+    def __init__(self, forward=None, backward=None):
+        self.terms = -1 if forward is None else MLP_PRECISIONS[forward]
+        self.bwd = -1 if backward is None else MLP_PRECISIONS[backward]
+        if self.bwd == 0:
+            raise ValueError("backward mlp precision must be 'bf16x3' or 'bf16x6'")
+
+    def __enter__(self):
+        old = lib().mvp_mlp_precision_scope(self.terms, self.bwd)
+        if old < 0:
+            check(old, 'mvp_mlp_precision_scope')
+        self.old = (old // 16 - 1, old % 16 - 1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().mvp_mlp_precision_scope(*self.old)
 
 
 def get_mlp_precision():

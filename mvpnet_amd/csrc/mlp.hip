@@ -32,6 +32,8 @@ int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const fl
 int g_mlp_terms = 6;       // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (default: fp32-level accuracy, measured) -- mvp_set_mlp_precision; shared with mlp_bwd.hip
 int g_mlp_terms_bwd = 3;   // gradient contractions: 3 products (2^-17 per product, far below the 1 % fp32 noise of the gradients themselves; measured)
 int g_mlp_min_width = 0;   // layers with max(Cin, Cout) below this stay on the fp32 MFMA
+thread_local int tl_mlp_terms = -1;
+thread_local int tl_mlp_terms_bwd = -1;
 int g_mlp_stream = 0;      // 1: long narrow forward layers take mlp_stream.hip (MVP_MLP_STREAM=0 / mvp_set_mlp_stream(0): tile kernel everywhere)
 
 namespace {
@@ -865,7 +867,7 @@ void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int l
   int bn = N <= 32 ? 32 : N <= 64 ? 64 : 128;
   while (bn > 32 && (int64_t)gx * cdiv(N, bn) < 256) bn >>= 1;
   // split-bf16 contraction (mvp_set_mlp_precision): vector path only, and only for layers at least g_mlp_min_width wide
-  const int fwd_pieces = g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0;
+  const int fwd_pieces = mlp_fwd_pieces();
   const int ns = (vec && std::max(K, N) >= g_mlp_min_width) ? (WT ? mlp_bwd_pieces() : fwd_pieces) : 0;
 #define MVP_MLP_BY_NS(BN)                                                                                                          \
   do {                                                                                                                             \
@@ -896,7 +898,7 @@ int mlp_forward_impl(const float* X, int64_t R, int64_t Cin, int64_t ldx, const 
   const BnFinalize fin{R, bn_eps, bn_momentum, bn_mean, bn_invstd, bn_running_mean, bn_running_var, bn_num_batches};
   if (g_mlp_stream && !rel && std::max(Cin, Cout) >= g_mlp_min_width) {  // long narrow layers: resident weights, persistent row streaming
     const int rc = mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, bias, Y,
-                                          stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, bn_eps, bn_momentum, bn_mean,
+                                          stat, partial, mlp_fwd_pieces(), bn_eps, bn_momentum, bn_mean,
                                           bn_invstd, bn_running_mean, bn_running_var, bn_num_batches, nullptr, nullptr, nullptr, nullptr, s);
     if (rc != MVP_EUNSUPPORTED) return rc;
   }
@@ -1008,7 +1010,7 @@ MVP_API int mvp_mlp_forward_pool_f32(const float* X, int64_t R, int64_t Cin, int
     MVP_NONNULL(act_beta);
   }
   return mvp_mlp_stream_forward(X, R, (int)Cin, (int)ldx, W, (int)ldw, (int)Cout, act_mean, act_invstd, act_gamma, act_beta, nullptr, nullptr,
-                                stat, partial, g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0, eps, momentum, mean, invstd, running_mean,
+                                stat, partial, mlp_fwd_pieces(), eps, momentum, mean, invstd, running_mean,
                                 running_var, num_batches_tracked, ymax, ymin, amax, amin, static_cast<hipStream_t>(stream));
 }
 
@@ -1127,7 +1129,7 @@ MVP_API int mvp_set_mlp_precision(int terms, int min_width) {
   g_mlp_min_width = min_width;
   return MVP_OK;
 }
-MVP_API int mvp_get_mlp_precision(void) { return g_mlp_terms; }
+MVP_API int mvp_get_mlp_precision(void) { return mlp_terms(); }
 // Split of the GRADIENT contractions (weight gradient, input gradient, one-kernel layer backward) when the forward precision is a
 // split one: terms = 3 (default) or 6.  Gradients through batch-statistics BatchNorm + max pooling carry ~1 % fp32 noise whatever the
 // contraction (profiles/r02_numerics_operating_point.txt); 2^-17 per product is invisible next to it and halves their MFMA + split work.
@@ -1136,7 +1138,17 @@ MVP_API int mvp_set_mlp_precision_backward(int terms) {
   g_mlp_terms_bwd = terms;
   return MVP_OK;
 }
-MVP_API int mvp_get_mlp_precision_backward(void) { return g_mlp_terms_bwd; }
+MVP_API int mvp_get_mlp_precision_backward(void) { return mlp_terms_bwd(); }
+// Thread-local override of the two settings for the calls THIS host thread makes (terms / terms_backward: -1 = keep the process default,
+// else as mvp_set_mlp_precision / _backward).  Returns the previous override packed as (terms + 1) * 16 + (terms_backward + 1): hand its
+// two halves back to restore.  Nothing process-wide is written.
+MVP_API int mvp_mlp_precision_scope(int terms, int terms_backward) {
+  if (!(terms == -1 || terms == 0 || terms == 3 || terms == 6) || !(terms_backward == -1 || terms_backward == 3 || terms_backward == 6)) return MVP_EINVAL;
+  const int old = (tl_mlp_terms + 1) * 16 + (tl_mlp_terms_bwd + 1);
+  tl_mlp_terms = terms;
+  tl_mlp_terms_bwd = terms_backward;
+  return old;
+}
 // Switch: 0 (default; measured 1.2 % faster on the bench step) routes every forward layer through the per-tile kernel (mlp_fwd_kernel), 1 lets long narrow layers
 // (>= 32768 rows, C_in and C_out <= 128, split-bf16) take the persistent streaming kernel (mlp_stream.hip).  Returns the old value.
 MVP_API int mvp_set_mlp_stream(int on) {

@@ -6,8 +6,16 @@ extern int g_mlp_terms;      // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (mvp_set_m
 extern int g_mlp_terms_bwd;  // split used by the GRADIENT contractions (dW, input gradient, layer backward) when g_mlp_terms != 0: 3 or 6
 extern int g_mlp_min_width;  // layers with max(Cin, Cout) below this stay on the fp32 MFMA
 
-// pieces per operand of the backward contractions: 0 (fp32 MFMA) when the forward runs fp32, else from g_mlp_terms_bwd
-static inline int mlp_bwd_pieces() { return g_mlp_terms == 0 ? 0 : (g_mlp_terms_bwd == 6 ? 3 : 2); }
+// The process-wide values above are DEFAULTS.  A host thread can override them for the calls it makes with mvp_mlp_precision_scope (a
+// thread-local pair, -1 = no override): several models / threads in one process then never see each other's choice, and nothing global is
+// flipped around a launch.  Every launch site reads the precision through these two functions.
+extern thread_local int tl_mlp_terms;      // -1, 0, 3 or 6
+extern thread_local int tl_mlp_terms_bwd;  // -1, 3 or 6
+static inline int mlp_terms() { return tl_mlp_terms >= 0 ? tl_mlp_terms : g_mlp_terms; }
+static inline int mlp_terms_bwd() { return tl_mlp_terms_bwd >= 0 ? tl_mlp_terms_bwd : g_mlp_terms_bwd; }
+static inline int mlp_fwd_pieces() { return mlp_terms() == 3 ? 2 : mlp_terms() == 6 ? 3 : 0; }
+// pieces per operand of the backward contractions: 0 (fp32 MFMA) when the forward runs fp32, else from the backward setting
+static inline int mlp_bwd_pieces() { return mlp_terms() == 0 ? 0 : (mlp_terms_bwd() == 6 ? 3 : 2); }
 
 namespace {
 

@@ -265,7 +265,7 @@ MVP_API int mvp_sa_fused_forward_f32(const float* zf, const float* xyz, const fl
   const float* bn[12] = {bn1_mean, bn1_invstd, bn1_gamma, bn1_beta, bn2_mean, bn2_invstd, bn2_gamma, bn2_beta, bn3_mean, bn3_invstd, bn3_gamma, bn3_beta};
   for (int i = 0; i < 12; ++i) MVP_NONNULL(bn[i]);
   MVP_REQUIRE(B >= 0 && N > 0 && M >= 0 && K > 0 && C1 > 0 && C2 > 0 && C3 > 0);
-  const int ns = g_mlp_terms == 3 ? 2 : g_mlp_terms == 6 ? 3 : 0;
+  const int ns = mlp_fwd_pieces();
   if (ns == 0 || K != 32 || C1 > 64 || C2 > 64 || C3 > 128 || C1 % 4 || C2 % 4 || C3 % 4 || C1 < 4) return MVP_EUNSUPPORTED;
   if (zf && ((uintptr_t)zf % 16) != 0) return MVP_EUNSUPPORTED;
   if (B == 0 || M == 0) return MVP_OK;

@@ -80,3 +80,23 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
                 assert 'mvp_oracle' not in text and 'c_oracle' not in text, f
+
+
+def test_thread_local_precision_scope():
+    """mvp_mlp_precision_scope: a thread-local override of the contraction precision (nothing process-wide is written): another thread
+    keeps seeing the process default while this one is inside a scope."""
+    import threading
+    from mvpnet_amd import _lib as L
+    lib = L.lib()
+    default = lib.mvp_get_mlp_precision()
+    seen = {}
+    with L.mlp_precision('fp32'):
+        assert lib.mvp_get_mlp_precision() == 0
+        t = threading.Thread(target=lambda: seen.setdefault('other', lib.mvp_get_mlp_precision()))
+        t.start()
+        t.join()
+        with L.mlp_precision('bf16x3', backward='bf16x6'):
+            assert lib.mvp_get_mlp_precision() == 3 and lib.mvp_get_mlp_precision_backward() == 6
+        assert lib.mvp_get_mlp_precision() == 0
+    assert seen['other'] == default and lib.mvp_get_mlp_precision() == default
+    assert lib.mvp_mlp_precision_scope(5, -1) == -1  # MVP_EINVAL
