@@ -260,7 +260,6 @@ def relaunch_under_torchrun(gpus, argv):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL between processes needs it on this driver
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(gpus, 1) // 2)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
@@ -360,6 +359,11 @@ def main():
     side = (args.extras == 'all' or (args.extras == 'auto' and world == 1)) and not args.train_only  # B = 1 latency, fp32-MFMA step, 2D network, dense config
     assert world == args.gpus, 'WORLD_SIZE ({}) != --gpus ({})'.format(world, args.gpus)
     local = int(os.environ.get('MVP_DEVICE', local))  # debugging aid: several ranks on one GPU (with MVP_DIST_BACKEND=gloo)
+    if world > 1 and 'MVP_DEVICE' in os.environ:
+        # Ranks that SHARE a GPU: keep each process on one HIP stream.  Two processes with three streams each time-slice the device
+        # pathologically (measured, round-2 and round-3 code alike: 0.9-2.1 s per step with the weight-gradient stream, 20 ms without).
+        from mvpnet_amd import rows as _rows
+        _rows.DW_SIDE_STREAM = False
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     torch.backends.cudnn.allow_tf32 = False
