@@ -193,6 +193,17 @@ __global__ __launch_bounds__(NT) void fps_kernel(const T* __restrict__ pts, int 
 //   * wave reduction on the value alone (6 DPP max steps), cross-wave on the packed (value : ~index) key.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// (v, v) as a register pair the compiler cannot see through.  Written as {v, v} the splat is folded into the packed op as a source
+// swizzle -- `v_pk_add_f32 d, a, b op_sel:[0,1]` when v happens to live in the odd register of a pair.  On MI355X that form (low lane of
+// src1 taken from the high register, src0 not swizzled) occasionally computes with the wrong half while a wave of the split-bf16 MLP
+// kernel is resident on the same SIMD (tools/exp/pkopsel reproduces it with one instruction); the same code is exact
+// when it runs alone.  The library therefore contains no op_sel'd packed fp32 arithmetic (tests/test_isa_cpu.py checks the binary).
+__device__ __forceinline__ f32x2 splat2(float v) {
+  f32x2 r = {v, v};
+  asm("" : "+v"(r));
+  return r;
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float fmax_dpp(float v) {
   const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ 
   if (LDS_PTS) __syncthreads();
 
   for (int it = 1; it < M; ++it) {
-    const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+    const f32x2 c2x = splat2(cx), c2y = splat2(cy), c2z = splat2(cz);
     float vmax = -3.f;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -323,6 +334,9 @@ __global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ 
 // first candidate that fails; the accepted picks are exactly the samples the one-at-a-time chain would have produced, in order.  All
 // waves then apply the accepted picks to their points in one pass.  Ties (lattices, duplicated points) make second-bests equal to
 // bests: the walk then accepts one pick per round and the kernel degrades to the per-sample scheme, never to a different result.
+#ifdef MVP_FPS_TRACE
+__device__ unsigned* g_fps_trace = nullptr;  // (tools/exp) [cloud][round][8] words written by the resolving wave
+#endif
 template <int D, int PPT, int NT>
 __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out, int dbg) {
   static_assert(PPT % 2 == 0, "points are processed in pairs");
@@ -332,12 +346,13 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
   static_assert(NR <= kWave, "one resolver lane per row");
   using K = Key<float>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [2][NR] row results (key hi, key lo, second-best value, pad), picked coordinates + count, output buffer, SoA copy of the cloud
+  // [2][NR] row results (key hi, key lo, second-best value, pad), picked coordinates + count, output buffer, SoA copy of the cloud.
+  // A pick is stored as (x, x, y, y, z, z, -, -): the lanes load ready-made register pairs for the packed update (see splat2).
   uint4* part = reinterpret_cast<uint4*>(smem);
-  float* cen = reinterpret_cast<float*>(smem + 2 * kWave * 16);      // [kMaxPick][4]
-  int* npick = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 16);  // [2]
-  int* sout = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 16 + 16);
-  float* sx = reinterpret_cast<float*>(smem + 2 * kWave * 16 + kMaxPick * 16 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15));
+  float* cen = reinterpret_cast<float*>(smem + 2 * kWave * 16);      // [kMaxPick][8]
+  int* npick = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 32);  // [2]
+  int* sout = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 32 + 16);
+  float* sx = reinterpret_cast<float*>(smem + 2 * kWave * 16 + kMaxPick * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15));
   float* sy = sx + N;
   float* sz = sy + N;
 
@@ -373,25 +388,34 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
   }
   if (tid == 0) {
     sout[0] = 0;
-    cen[0] = p[0];
-    cen[1] = p[1];
-    cen[2] = D == 3 ? p[2] : 0.f;
+    cen[0] = cen[1] = p[0];
+    cen[2] = cen[3] = p[1];
+    cen[4] = cen[5] = D == 3 ? p[2] : 0.f;
     npick[0] = 1;
+#ifdef MVP_FPS_TRACE
+    cen[6] = 0.f;
+    reinterpret_cast<unsigned*>(sz + N)[4096] = 0u;
+    reinterpret_cast<unsigned*>(sz + N)[4097] = 0u;
+#endif
   }
   __syncthreads();
 
   int it = 1;     // samples taken so far
   int par = 0;    // parity of the pick list / row results being consumed
   int rounds_done = 0;
+#ifdef MVP_FPS_VGPRS
+  asm volatile("v_mov_b32 v" MVP_FPS_VGPRS ", 0" ::: "v" MVP_FPS_VGPRS);  // (tools/exp) forces the wave's register allocation up
+#endif
   while (it < M) {
     ++rounds_done;
     // ---- A. apply the picks of the last round (sample 0 first) to this lane's points ----
     const int nc = npick[par];
-    const float4* cenv = reinterpret_cast<const float4*>(cen) + par * (kMaxPick / 2);
+    const f32x2* cenv = reinterpret_cast<const f32x2*>(cen) + par * (kMaxPick / 2) * 4;
     for (int c = 0; c < nc; ++c) {
-      const float4 cc = cenv[c];
-      const float cx = cc.x, cy = cc.y, cz = cc.z;
-      const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+      const f32x2 c2x = cenv[c * 4 + 0], c2y = cenv[c * 4 + 1], c2z = cenv[c * 4 + 2];
+#ifdef MVP_FPS_TRACE
+      if (__float_as_uint(cenv[c * 4 + 3][0]) != (unsigned)(rounds_done - 1)) atomicAdd(reinterpret_cast<unsigned*>(sz + N) + 4097, 1u);  // a pick of another round
+#endif
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const f32x2 dx = px[i] - c2x, dy = py[i] - c2y;
@@ -429,12 +453,19 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
     sec = fmax_dpp<kDppHalfMirror>(sec);
     sec = fmax_dpp<kDppMirror>(sec);
     uint4* cur = part + (par ^ 1) * kWave;
+#ifdef MVP_FPS_TRACE
+    if ((lane & 15) == 0) cur[tid >> 4] = make_uint4(k.hi, k.lo, __float_as_uint(sec), (unsigned)rounds_done);
+#else
     if ((lane & 15) == 0) cur[tid >> 4] = make_uint4(k.hi, k.lo, __float_as_uint(sec), 0u);
+#endif
     __syncthreads();
     // ---- D. one wave walks the row winners ----
     if (wave == 0) {
       uint4 e = make_uint4(0u, 0u, __float_as_uint(-3.f), 0u);
       if (lane < NR) e = cur[lane];
+#ifdef MVP_FPS_TRACE
+      if (lane < NR && e.w != (unsigned)rounds_done) atomicAdd(reinterpret_cast<unsigned*>(sz + N) + 4096, 1u);  // a row result of another round
+#endif
       const unsigned hi = e.x, lo = e.y;
       const float v = __uint_as_float(hi);
       const bool valid = (hi | lo) != 0u;
@@ -492,15 +523,21 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
       L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppHalfMirror, 0xF, 0xF, false));
       L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppMirror, 0xF, 0xF, false));
       L = min(min(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 16)), min(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 48)));
-      L = min(min(L, __popcll(em)), min(kMaxPick / 2, M - it));
+      L = min(min(L, (int)__popcll(em)), min(kMaxPick / 2, M - it));  // (int): min(int, unsigned) would resolve to the double overload
       if (elig && rank < L) {
-        float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + rank) * 4;
-        cdst[0] = x;
-        cdst[1] = y;
-        cdst[2] = z;
+        float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + rank) * 8;
+        *reinterpret_cast<float4*>(cdst) = make_float4(x, x, y, y);
+        *reinterpret_cast<f32x2*>(cdst + 4) = f32x2{z, z};
+#ifdef MVP_FPS_TRACE
+        cdst[6] = __uint_as_float((unsigned)rounds_done);
+#endif
         sout[it + rank] = cidx;
       }
       if (lane == 0) npick[par ^ 1] = L;
+#ifdef MVP_FPS_TRACE
+      if (lane == 0 && rounds_done <= 1024)
+        reinterpret_cast<uint4*>(sz + N)[rounds_done - 1] = make_uint4((unsigned)it | ((unsigned)L << 16), (unsigned)em, __float_as_uint(bound), __float_as_uint(vm));
+#endif
     }
     __syncthreads();
     par ^= 1;
@@ -508,14 +545,29 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
   }
   __syncthreads();
   for (int i = tid; i < M; i += NT) o[i] = sout[i];
+#ifdef MVP_FPS_TRACE
+  if (g_fps_trace)
+    for (int i = tid; i < 4096; i += NT)
+      g_fps_trace[(size_t)b * 4096 + i] = i >= 4092 ? reinterpret_cast<unsigned*>(sz + N)[4096 + (i & 1)] : i < 4 * min(rounds_done, 1023) ? reinterpret_cast<unsigned*>(sz + N)[i] : 0u;
+#endif
   if (dbg && tid == 0) o[0] = rounds_done;  // (tools/exp: rounds taken; the first sample is always 0)
 }
 
+#ifdef MVP_FPS_TRACE
+extern "C" __attribute__((visibility("default"))) int mvp_fps_exp_trace(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_trace), &buf, sizeof(buf));
+}
+#endif
 template <int D, int PPT, int NT>
 int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
-  const size_t head = 2 * kWave * 16 + 32 * 16 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
-  const size_t bytes = head + (size_t)N * 3 * sizeof(float);
+  const size_t head = 2 * kWave * 16 + 32 * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
+  size_t bytes = head + (size_t)N * 3 * sizeof(float);
   if (bytes > 150 * 1024) return MVP_EUNSUPPORTED;
+  static const int pad = []() { const char* e = getenv("MVP_FPS_LDS_PAD"); return e ? atoi(e) : 0; }();
+#ifdef MVP_FPS_TRACE
+  bytes += 16384 + 16;
+#endif
+  if (pad) bytes = 160 * 1024;  // (tools/exp) the workgroup takes the whole LDS of its CU: nothing else is co-resident
   auto k = fps_rounds_kernel<D, PPT, NT>;
   if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

@@ -143,3 +143,36 @@ def test_chain_forward_and_input_gradient_are_deterministic(dev, chain, K, R_):
         return out.detach(), xi.grad
 
     assert _all_equal(run, 12) == 0
+
+
+@pytest.mark.parametrize('N,M,shape', [(8192, 2048, None), (8192, 2048, 1), (2048, 512, None), (512, 128, None)])
+def test_sampling_beside_the_mlp_kernels_equals_the_oracle(dev, N, M, shape):
+    """The geometry of a step runs on a side stream while the MLP kernels run on the main one, so sampler workgroups share SIMDs with
+    MFMA waves.  Round 3 found the sampler returning wrong indices in exactly that situation (and only there): a packed-fp32 op with an
+    op_sel source swizzle misexecutes beside the split-bf16 MLP kernel (tests/test_isa_cpu.py).  Indices on a side
+    stream beside a train of MLP launches, several times, against the oracle (computed once) -- every run, every cloud."""
+    from oracle import c_oracle
+    from mvpnet_amd import ops, _lib as L
+    B = 32
+    rs = np.random.RandomState(N)
+    pts_h = rs.rand(B, N, 3).astype(np.float32)
+    pts = torch.from_numpy(pts_h).to(dev)
+    exp = torch.from_numpy(c_oracle.fps(pts_h[:4], M)).to(dev)
+    alone = ops.farthest_point_sample(pts, M, transpose=False, shape=shape).clone()
+    assert torch.equal(alone[:4], exp)
+    R = 786432
+    x = torch.randn(R, 64, device=dev)
+    w = torch.randn(64, 64, device=dev) * 0.1
+    y = torch.empty(R, 64, device=dev)
+    side = torch.cuda.Stream()
+    for prec in ('bf16x6', 'bf16x3', 'fp32'):
+        with L.mlp_precision(prec):
+            for _ in range(8):
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    idx = ops.farthest_point_sample(pts, M, transpose=False, shape=shape)
+                for _ in range(6):
+                    L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, 64, 64, L.ptr(w), 64, 64, None, None, None, None, None, L.ptr(y), None, None)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                assert torch.equal(idx, alone), 'sampling beside the %s MLP kernel differs from sampling alone' % prec

@@ -1,0 +1,61 @@
+#include <hip/hip_runtime.h>
+// tools/exp: single-instruction "aggressor" loops to run beside pk_opsel_kernel (which instruction of the split-bf16 MLP kernel disturbs
+// the op_sel'd packed-fp32 ops of a wave on the same SIMD?).  kind 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32,
+// 2: v_cvt_pk_bf16_f32, 3: v_perm_b32, 4: LDS b64 write + read, 5: v_mfma_f32_16x16x32_bf16, 6: v_pk_fma_f32 (plain), 7: v_mfma_f32_32x32x8_f16,
+// 8: v_pk_mov_b32 op_sel:[1,0], 9: v_pk_mov_b32, 10: v_pk_mul_f32, 11: v_mov_b64, 12: v_pk_mov_b32 op_sel:[0,1], 13: v_pk_mov_b32 op_sel_hi:[0,1]
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+extern "C" __global__ __launch_bounds__(256) void aggressor_kernel(float* out, int iters, int kind) {
+  __shared__ unsigned long long lds[256 * 2];
+  const int t = threadIdx.x;
+  f32x16 acc = {0};
+  f32x4 acc4 = {0};
+  bf16x8 a = {(short)(0x3f80 + t), 0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00, 0x3f80, 0x3e00}, b = a;
+  float x = t * 0.001f, y = 1.f;
+  unsigned u = t * 2654435761u, v = ~u, p = 0;
+  unsigned long long q = u;
+  f32x2 pk = {x, y}, pk2 = {1.f, 1.f};
+  for (int it = 0; it < iters; ++it) {
+    if (kind == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    else if (kind == 1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+    else if (kind == 2) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(x), "v"(y)); x += __uint_as_float((p & 0xff) | 0x3a000000u); }
+    else if (kind == 3) { asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(p) : "v"(u), "v"(v), "v"(0x07060302u)); u += p; }
+    else if (kind == 4) { lds[t] = q; __builtin_amdgcn_s_waitcnt(0xc07f); q += lds[t ^ 1] + 1; }
+    else if (kind == 5) acc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc4, 0, 0, 0);
+    else if (kind == 6) { asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(pk) : "v"(pk)); }
+    else if (kind == 8) { asm volatile("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(pk) : "v"(pk2)); }
+    else if (kind == 9) { asm volatile("v_pk_mov_b32 %0, %1, %0" : "+v"(pk) : "v"(pk2)); }
+    else if (kind == 10) { asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(pk) : "v"(pk2)); }
+    else if (kind == 11) { asm volatile("v_mov_b64 %0, %1" : "=v"(pk) : "v"(pk2)); }
+    else if (kind == 12) { asm volatile("v_pk_mov_b32 %0, %1, %0 op_sel:[0,1]" : "+v"(pk) : "v"(pk2)); }
+    else if (kind == 13) { asm volatile("v_pk_mov_b32 %0, %1, %0 op_sel_hi:[0,1]" : "+v"(pk) : "v"(pk2)); }
+    else if (kind >= 14 && kind <= 16) {
+      if ((t >> 6) & 1) {
+        if (kind == 14) asm volatile("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(pk) : "v"(pk2));
+        else if (kind == 15) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(pk) : "v"(pk2));
+        else { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(x), "v"(y)); x += __uint_as_float((p & 0xff) | 0x3a000000u); }
+      } else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    } else if (kind == 17) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      asm volatile("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]\n v_pk_mul_f32 %0, %1, %0\n v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]\n v_pk_mul_f32 %0, %1, %0" : "+v"(pk) : "v"(pk2));
+    } else if (kind == 18) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n v_cvt_pk_bf16_f32 %0, %2, %1" : "=v"(p) : "v"(x), "v"(y));
+      a[0] = (short)p;
+    } else if (kind == 19) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      lds[t] = q; __builtin_amdgcn_s_waitcnt(0xc07f); q += lds[t ^ 1] + 1;
+    }
+    else { f16x4 h = {(_Float16)1.f, (_Float16)0.5f, (_Float16)2.f, (_Float16)1.f}; acc = __builtin_amdgcn_mfma_f32_32x32x8f16(h, h, acc, 0, 0, 0); }
+  }
+  float s = x + y + __uint_as_float(u & 0x3fffffffu) + (float)(q & 0xff) + pk[0] + acc4[0];
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  if (s == 12345.678f) out[0] = s;
+}
+extern "C" __attribute__((visibility("default"))) int aggressor_launch(float* out, int blocks, int iters, int kind, void* stream) {
+  hipLaunchKernelGGL(aggressor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, kind);
+  return (int)hipGetLastError();
+}
