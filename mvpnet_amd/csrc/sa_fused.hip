@@ -101,13 +101,11 @@ __device__ __forceinline__ void layer_mfma(const float (&v)[KS][4][4], const uns
                                                                    __builtin_bit_cast(bf16x8, bfr[jj][SP::B[qd]]), acc[j0 + jj], 0, 0, 0);
       }
     }
-  // Nothing may be scheduled across the end of a layer's MFMA block.  Round 3 found the -O3 build of the narrow variants (one
-  // accumulator per layer: a chain of 12 dependent MFMAs) returning run-to-run different results on ~6 in a million balls
-  // (tools/exp/sa_fused_count.py: 30 corrupted balls in 60 launches of 65536; 0 in 600 with this barrier, as with -O1, with
-  // volatile tile accesses, or with either half of the tile exchange forced to 4-byte accesses -- i.e. whenever the instructions the
-  // scheduler otherwise interleaves with the tail of the chain stay behind it).  The hazard itself was not identified; the barrier
-  // costs nothing measurable (the chain's tail has no independent work worth overlapping).
-  __builtin_amdgcn_sched_barrier(0);
+  // (Round 3 found the -O3 build of the narrow variants returning run-to-run different results on a few in a million balls.  The cause
+  // was not this kernel's schedule but a packed fp32 op with an op_sel source swizzle -- the SLP vectoriser's pairing of the
+  // normalise / ReLU arithmetic -- misexecuting while other waves of the workgroup run MFMA on the same SIMD; see the Makefile, which
+  // builds this file without that vectoriser, tests/test_isa_cpu.py and DESIGN.md 4.10.  tools/exp/sa_fused_count.py: 10248 corrupted
+  // balls in 400 launches with the op_sel'd forms in the binary, 0 without them.)
 }
 
 template <int C1B, int C2B, int C3B, int NS>
@@ -204,14 +202,12 @@ __global__ __launch_bounds__(kFT) void sa_fused_fwd_kernel(SaArgs p) {
         const float a = ((acc2[jb][i] - m2[jb]) * i2[jb]) * g2[jb] + b2[jb];
         st[m * kFLd + li] = a > 0.f ? a : 0.f;
       }
-      __builtin_amdgcn_sched_barrier(0);  // (see layer_mfma: the tile exchange stays where it is written)
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const float4 a = *reinterpret_cast<const float4*>(st + li * kFLd + 8 * tt + 4 * lh);
         v2[jb][tt][0] = a.x; v2[jb][tt][1] = a.y; v2[jb][tt][2] = a.z; v2[jb][tt][3] = a.w;
       }
-      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_wave_barrier();
     }
     // ---- layer 3 + BatchNorm 3 + ReLU + max over the 32 neighbours (first arg-max: rows ascend with the register index)

@@ -11,7 +11,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 extern "C" __global__ __launch_bounds__(256) void aggressor_kernel(float* out, int iters, int kind) {
   __shared__ unsigned long long lds[256 * 2];
   const int t = threadIdx.x;
-  f32x16 acc = {0};
+  f32x16 acc = {0}, accb = {0};
   f32x4 acc4 = {0};
   bf16x8 a = {(short)(0x3f80 + t), 0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00, 0x3f80, 0x3e00}, b = a;
   float x = t * 0.001f, y = 1.f;
@@ -49,10 +49,22 @@ extern "C" __global__ __launch_bounds__(256) void aggressor_kernel(float* out, i
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
       lds[t] = q; __builtin_amdgcn_s_waitcnt(0xc07f); q += lds[t ^ 1] + 1;
     }
+    else if (kind == 20) {  // two independent accumulators: the MFMA pipe never waits for a result
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, accb, 0, 0, 0);
+    } else if (kind == 21) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, accb, 0, 0, 0);
+    } else if (kind == 22) {  // as the MLP kernel: operands re-split every iteration, two accumulators
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(x), "v"(y));
+      a[0] = (short)p; a[1] = (short)(p >> 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, accb, 0, 0, 0);
+    }
     else { f16x4 h = {(_Float16)1.f, (_Float16)0.5f, (_Float16)2.f, (_Float16)1.f}; acc = __builtin_amdgcn_mfma_f32_32x32x8f16(h, h, acc, 0, 0, 0); }
   }
   float s = x + y + __uint_as_float(u & 0x3fffffffu) + (float)(q & 0xff) + pk[0] + acc4[0];
-  for (int i = 0; i < 16; ++i) s += acc[i];
+  for (int i = 0; i < 16; ++i) s += acc[i] + accb[i];
   if (s == 12345.678f) out[0] = s;
 }
 extern "C" __attribute__((visibility("default"))) int aggressor_launch(float* out, int blocks, int iters, int kind, void* stream) {
