@@ -92,6 +92,17 @@ int mvp_group_points_backward_f32(const float* grad_out, const int64_t* index, i
                                   int64_t N2, int64_t K, float* grad_in, mvp_stream_t stream);
 int mvp_group_points_backward_f64(const double* grad_out, const int64_t* index, int64_t B, int64_t C, int64_t N1,
                                   int64_t N2, int64_t K, double* grad_in, mvp_stream_t stream);
+/* The same with a STRIDED feature operand, walked in place as the reference's TensorInfo path does (group_points_kernel.cu:131-133)
+ * instead of being copied: sb, sc, sn = element strides of input (B,C,N1); sb, sc, sm, sk = element strides of grad_out (B,C,N2,K).
+ * Any layout (a transposed channels-last view, a slice of a wider tensor); index and outputs stay contiguous. */
+int mvp_group_points_forward_strided_f32(const float* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index, int64_t B,
+                                         int64_t C, int64_t N1, int64_t N2, int64_t K, float* out, mvp_stream_t stream);
+int mvp_group_points_forward_strided_f64(const double* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index, int64_t B,
+                                         int64_t C, int64_t N1, int64_t N2, int64_t K, double* out, mvp_stream_t stream);
+int mvp_group_points_backward_strided_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sm, int64_t sk, const int64_t* index,
+                                          int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, float* grad_in, mvp_stream_t stream);
+int mvp_group_points_backward_strided_f64(const double* grad_out, int64_t sb, int64_t sc, int64_t sm, int64_t sk, const int64_t* index,
+                                          int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, double* grad_in, mvp_stream_t stream);
 
 /* ---- 3-NN with squared distances ------------------------------------------------------
  * replaces knn_distance_cuda.knn_distance (mvpnet/ops/cuda/knn_distance.cpp:8-15,
@@ -121,6 +132,18 @@ int mvp_interpolate_backward_f32(const float* grad_out, const int64_t* index, co
                                  int64_t C, int64_t N1, int64_t N2, float* grad_in, mvp_stream_t stream);
 int mvp_interpolate_backward_f64(const double* grad_out, const int64_t* index, const double* weight, int64_t B,
                                  int64_t C, int64_t N1, int64_t N2, double* grad_in, mvp_stream_t stream);
+/* Strided feature operand (interpolate_kernel.cu:108-111 walks TensorInfo): sb, sc, sn = element strides of input (B,C,N1) /
+ * grad_out (B,C,N2).  index, weight and the outputs stay contiguous. */
+int mvp_interpolate_forward_strided_f32(const float* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index, const float* weight,
+                                        int64_t B, int64_t C, int64_t N1, int64_t N2, float* out, mvp_stream_t stream);
+int mvp_interpolate_forward_strided_f64(const double* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index, const double* weight,
+                                        int64_t B, int64_t C, int64_t N1, int64_t N2, double* out, mvp_stream_t stream);
+int mvp_interpolate_backward_strided_f32(const float* grad_out, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,
+                                         const float* weight, int64_t B, int64_t C, int64_t N1, int64_t N2, float* grad_in,
+                                         mvp_stream_t stream);
+int mvp_interpolate_backward_strided_f64(const double* grad_out, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,
+                                         const double* weight, int64_t B, int64_t C, int64_t N1, int64_t N2, double* grad_in,
+                                         mvp_stream_t stream);
 
 /* ---- 2D -> 3D lifting (NEW on the device; the reference does this in dataloader workers) ----
  * un-projection: replaces depth2xyz + pose + masks of ScanNet2D3DChunks.get_rgbd_data

@@ -27,6 +27,14 @@ _SIGNATURES = {
     'mvp_ball_query_f64': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr],
     'mvp_ball_query_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],
     'mvp_ball_query_distance_f64': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],
+    'mvp_group_points_forward_strided_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_backward_strided_f32': [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_forward_strided_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_backward_strided_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_forward_strided_f64': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_backward_strided_f64': [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_forward_strided_f64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_backward_strided_f64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_forward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_forward_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],

@@ -15,7 +15,7 @@ constexpr int kGPThreads = 256;
 constexpr int kGPChanPerBlock = 8;
 
 template <typename T>
-__global__ __launch_bounds__(kGPThreads) void group_fwd_kernel(const T* __restrict__ in,
+__global__ __launch_bounds__(kGPThreads) void group_fwd_kernel(const T* __restrict__ in, int64_t sb, int64_t sc, int64_t sn,
                                                                const int64_t* __restrict__ idx, int C, int N1,
                                                                int64_t E /* N2*K */, T* __restrict__ out) {
   const int b = blockIdx.z;
@@ -25,9 +25,9 @@ __global__ __launch_bounds__(kGPThreads) void group_fwd_kernel(const T* __restri
   const bool ok = j >= 0 && j < N1;
   const int c0 = blockIdx.y * kGPChanPerBlock;
   const int c1 = min(C, c0 + kGPChanPerBlock);
-  const T* ip = in + ((size_t)b * C + c0) * N1;
+  const T* ip = in + (int64_t)b * sb + (int64_t)c0 * sc + (ok ? j * sn : 0);  // element strides of the (B,C,N1) input: any layout
   T* op = out + ((size_t)b * C + c0) * E + e;
-  for (int c = c0; c < c1; ++c, ip += N1, op += E) *op = ok ? ip[j] : T(0);
+  for (int c = c0; c < c1; ++c, ip += sc, op += E) *op = ok ? *ip : T(0);
 }
 
 constexpr int kGBThreads = 1024;
@@ -37,8 +37,8 @@ constexpr int kGBThreads = 1024;
 // channel-major layout makes every workgroup re-read the int64 index, which then dominates.  The
 // model pipeline uses the channels-last row kernels (rows.hip) instead.
 template <typename T>
-__global__ __launch_bounds__(kGBThreads) void group_bwd_lds_kernel(const T* __restrict__ gout,
-                                                                   const int64_t* __restrict__ idx, int C, int N1,
+__global__ __launch_bounds__(kGBThreads) void group_bwd_lds_kernel(const T* __restrict__ gout, int64_t sb, int64_t sc, int64_t sm,
+                                                                   int64_t sk, int K, const int64_t* __restrict__ idx, int C, int N1,
                                                                    int64_t E, int CH, T* __restrict__ gin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* acc = reinterpret_cast<T*>(smem);
@@ -49,11 +49,12 @@ __global__ __launch_bounds__(kGBThreads) void group_bwd_lds_kernel(const T* __re
   for (int i = tid; i < nc * N1; i += kGBThreads) acc[i] = T(0);
   __syncthreads();
   const int64_t* ix = idx + (size_t)b * E;
-  const T* gp = gout + ((size_t)b * C + c0) * E;
+  const T* gp = gout + (int64_t)b * sb + (int64_t)c0 * sc;
   for (int64_t e = tid; e < E; e += kGBThreads) {
     const int64_t j = ix[e];
     if (j < 0 || j >= N1) continue;
-    for (int c = 0; c < nc; ++c) atomicAdd(&acc[c * N1 + (int)j], gp[(size_t)c * E + e]);  // LDS atomic
+    const int64_t off = (e / K) * sm + (e % K) * sk;  // element strides of the (B,C,N2,K) gradient: any layout
+    for (int c = 0; c < nc; ++c) atomicAdd(&acc[c * N1 + (int)j], gp[(int64_t)c * sc + off]);  // LDS atomic
   }
   __syncthreads();
   T* op = gin + ((size_t)b * C + c0) * N1;
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(kGBThreads) void group_bwd_lds_kernel(const T* __re
 }
 
 template <typename T>
-__global__ __launch_bounds__(kGPThreads) void group_bwd_kernel(const T* __restrict__ gout,
-                                                               const int64_t* __restrict__ idx, int C, int N1,
+__global__ __launch_bounds__(kGPThreads) void group_bwd_kernel(const T* __restrict__ gout, int64_t sb, int64_t sc, int64_t sm,
+                                                               int64_t sk, int K, const int64_t* __restrict__ idx, int C, int N1,
                                                                int64_t E, T* __restrict__ gin) {
   const int b = blockIdx.z;
   const int64_t e = (int64_t)blockIdx.x * kGPThreads + threadIdx.x;
@@ -71,14 +72,14 @@ __global__ __launch_bounds__(kGPThreads) void group_bwd_kernel(const T* __restri
   if (j < 0 || j >= N1) return;
   const int c0 = blockIdx.y * kGPChanPerBlock;
   const int c1 = min(C, c0 + kGPChanPerBlock);
-  const T* gp = gout + ((size_t)b * C + c0) * E + e;
+  const T* gp = gout + (int64_t)b * sb + (int64_t)c0 * sc + (e / K) * sm + (e % K) * sk;
   T* ip = gin + ((size_t)b * C + c0) * N1 + j;
-  for (int c = c0; c < c1; ++c, gp += E, ip += N1) atomicAdd(ip, *gp);  // HW fp atomics (-munsafe-fp-atomics)
+  for (int c = c0; c < c1; ++c, gp += sc, ip += N1) atomicAdd(ip, *gp);  // HW fp atomics (-munsafe-fp-atomics)
 }
 
 template <typename T, bool BWD>
-int group_entry(const T* a, const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, T* o,
-                mvp_stream_t stream) {
+int group_entry(const T* a, const int64_t* st /* element strides of a: 3 (forward) or 4 (backward) */, const int64_t* index, int64_t B,
+                int64_t C, int64_t N1, int64_t N2, int64_t K, T* o, mvp_stream_t stream) {
   MVP_NONNULL(a);
   MVP_NONNULL(index);
   MVP_NONNULL(o);
@@ -99,7 +100,7 @@ int group_entry(const T* a, const int64_t* index, int64_t B, int64_t C, int64_t 
         if (e != hipSuccess) return (int)e;
       }
       dim3 grid((unsigned)cdiv(C, ch), (unsigned)B);
-      hipLaunchKernelGGL(k, grid, dim3(kGBThreads), bytes, s, a, index, (int)C, (int)N1, E, (int)ch, o);
+      hipLaunchKernelGGL(k, grid, dim3(kGBThreads), bytes, s, a, st[0], st[1], st[2], st[3], (int)K, index, (int)C, (int)N1, E, (int)ch, o);
       return mvp_launch_status();
     }
     hipError_t e = hipMemsetAsync(o, 0, sizeof(T) * (size_t)(B * C * N1), s);
@@ -108,27 +109,38 @@ int group_entry(const T* a, const int64_t* index, int64_t B, int64_t C, int64_t 
   if (E == 0) return MVP_OK;
   dim3 grid((unsigned)cdiv(E, kGPThreads), (unsigned)cdiv(C, kGPChanPerBlock), (unsigned)B);
   if (BWD)
-    hipLaunchKernelGGL(group_bwd_kernel<T>, grid, dim3(kGPThreads), 0, s, a, index, (int)C, (int)N1, E, o);
+    hipLaunchKernelGGL(group_bwd_kernel<T>, grid, dim3(kGPThreads), 0, s, a, st[0], st[1], st[2], st[3], (int)K, index, (int)C, (int)N1, E, o);
   else
-    hipLaunchKernelGGL(group_fwd_kernel<T>, grid, dim3(kGPThreads), 0, s, a, index, (int)C, (int)N1, E, o);
+    hipLaunchKernelGGL(group_fwd_kernel<T>, grid, dim3(kGPThreads), 0, s, a, st[0], st[1], st[2], index, (int)C, (int)N1, E, o);
   return mvp_launch_status();
 }
 
 }  // namespace
 
-MVP_API int mvp_group_points_forward_f32(const float* input, const int64_t* index, int64_t B, int64_t C, int64_t N1,
-                                         int64_t N2, int64_t K, float* out, mvp_stream_t stream) {
-  return group_entry<float, false>(input, index, B, C, N1, N2, K, out, stream);
-}
-MVP_API int mvp_group_points_forward_f64(const double* input, const int64_t* index, int64_t B, int64_t C, int64_t N1,
-                                         int64_t N2, int64_t K, double* out, mvp_stream_t stream) {
-  return group_entry<double, false>(input, index, B, C, N1, N2, K, out, stream);
-}
-MVP_API int mvp_group_points_backward_f32(const float* grad_out, const int64_t* index, int64_t B, int64_t C,
-                                          int64_t N1, int64_t N2, int64_t K, float* grad_in, mvp_stream_t stream) {
-  return group_entry<float, true>(grad_out, index, B, C, N1, N2, K, grad_in, stream);
-}
-MVP_API int mvp_group_points_backward_f64(const double* grad_out, const int64_t* index, int64_t B, int64_t C,
-                                          int64_t N1, int64_t N2, int64_t K, double* grad_in, mvp_stream_t stream) {
-  return group_entry<double, true>(grad_out, index, B, C, N1, N2, K, grad_in, stream);
-}
+// Contiguous operands: the natural strides.  *_strided_*: element strides of the feature operand as the caller's tensor has them
+// (the reference walks strided tensors through TensorInfo, group_points_kernel.cu:131-133, instead of copying them).
+#define MVP_GROUP_ENTRIES(SUF, T)                                                                                                          \
+  MVP_API int mvp_group_points_forward_##SUF(const T* input, const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, \
+                                             T* out, mvp_stream_t stream) {                                                               \
+    const int64_t st[4] = {C * N1, N1, 1, 0};                                                                                             \
+    return group_entry<T, false>(input, st, index, B, C, N1, N2, K, out, stream);                                                         \
+  }                                                                                                                                        \
+  MVP_API int mvp_group_points_forward_strided_##SUF(const T* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index, int64_t B,  \
+                                                     int64_t C, int64_t N1, int64_t N2, int64_t K, T* out, mvp_stream_t stream) {         \
+    const int64_t st[4] = {sb, sc, sn, 0};                                                                                                \
+    return group_entry<T, false>(input, st, index, B, C, N1, N2, K, out, stream);                                                         \
+  }                                                                                                                                        \
+  MVP_API int mvp_group_points_backward_##SUF(const T* grad_out, const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2,       \
+                                              int64_t K, T* grad_in, mvp_stream_t stream) {                                               \
+    const int64_t st[4] = {C * N2 * K, N2 * K, K, 1};                                                                                     \
+    return group_entry<T, true>(grad_out, st, index, B, C, N1, N2, K, grad_in, stream);                                                   \
+  }                                                                                                                                        \
+  MVP_API int mvp_group_points_backward_strided_##SUF(const T* grad_out, int64_t sb, int64_t sc, int64_t sm, int64_t sk,                   \
+                                                      const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K,      \
+                                                      T* grad_in, mvp_stream_t stream) {                                                  \
+    const int64_t st[4] = {sb, sc, sm, sk};                                                                                               \
+    return group_entry<T, true>(grad_out, st, index, B, C, N1, N2, K, grad_in, stream);                                                   \
+  }
+MVP_GROUP_ENTRIES(f32, float)
+MVP_GROUP_ENTRIES(f64, double)
+#undef MVP_GROUP_ENTRIES

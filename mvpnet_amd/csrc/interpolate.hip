@@ -14,7 +14,7 @@ constexpr int kIPThreads = 256;
 constexpr int kIPChanPerBlock = 16;
 
 template <typename T>
-__global__ __launch_bounds__(kIPThreads) void interp_fwd_kernel(const T* __restrict__ in,
+__global__ __launch_bounds__(kIPThreads) void interp_fwd_kernel(const T* __restrict__ in, int64_t sb, int64_t sc, int64_t sn,
                                                                 const int64_t* __restrict__ idx,
                                                                 const T* __restrict__ w, int C, int N1, int N2,
                                                                 T* __restrict__ out) {
@@ -28,16 +28,17 @@ __global__ __launch_bounds__(kIPThreads) void interp_fwd_kernel(const T* __restr
   const bool ok = i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1;
   const int c0 = blockIdx.y * kIPChanPerBlock;
   const int c1 = min(C, c0 + kIPChanPerBlock);
-  const T* fp = in + ((size_t)b * C + c0) * N1;
+  const T* fp = in + (int64_t)b * sb + (int64_t)c0 * sc;  // element strides of the (B,C,N1) input: any layout
+  const int64_t o0 = ok ? i0 * sn : 0, o1 = ok ? i1 * sn : 0, o2 = ok ? i2 * sn : 0;
   T* op = out + ((size_t)b * C + c0) * N2 + n;
-  for (int c = c0; c < c1; ++c, fp += N1, op += N2) *op = ok ? (fp[i0] * w0 + fp[i1] * w1) + fp[i2] * w2 : T(0);
+  for (int c = c0; c < c1; ++c, fp += sc, op += N2) *op = ok ? (fp[o0] * w0 + fp[o1] * w1) + fp[o2] * w2 : T(0);
 }
 
 constexpr int kIBThreads = 1024;
 
 // grad_in[b, c0:c0+CH, :] accumulated in LDS (ds_add), written once -- see group_points.hip.
 template <typename T>
-__global__ __launch_bounds__(kIBThreads) void interp_bwd_lds_kernel(const T* __restrict__ gout,
+__global__ __launch_bounds__(kIBThreads) void interp_bwd_lds_kernel(const T* __restrict__ gout, int64_t sb, int64_t sc, int64_t sn,
                                                                     const int64_t* __restrict__ idx,
                                                                     const T* __restrict__ w, int C, int N1, int N2,
                                                                     int CH, T* __restrict__ gin) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kIBThreads) void interp_bwd_lds_kernel(const T* __r
   const int tid = threadIdx.x;
   for (int i = tid; i < nc * N1; i += kIBThreads) acc[i] = T(0);
   __syncthreads();
-  const T* gp = gout + ((size_t)b * C + c0) * N2;
+  const T* gp = gout + (int64_t)b * sb + (int64_t)c0 * sc;  // element strides of the (B,C,N2) gradient: any layout
   for (int n = tid; n < N2; n += kIBThreads) {
     const int64_t* ip = idx + ((size_t)b * N2 + n) * 3;
     const T* wp = w + ((size_t)b * N2 + n) * 3;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(kIBThreads) void interp_bwd_lds_kernel(const T* __r
     const T w0 = wp[0], w1 = wp[1], w2 = wp[2];
     if (!(i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1)) continue;
     for (int c = 0; c < nc; ++c) {
-      const T g = gp[(size_t)c * N2 + n];
+      const T g = gp[(int64_t)c * sc + (int64_t)n * sn];
       atomicAdd(&acc[c * N1 + (int)i0], g * w0);
       atomicAdd(&acc[c * N1 + (int)i1], g * w1);
       atomicAdd(&acc[c * N1 + (int)i2], g * w2);
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kIBThreads) void interp_bwd_lds_kernel(const T* __r
 }
 
 template <typename T>
-__global__ __launch_bounds__(kIPThreads) void interp_bwd_kernel(const T* __restrict__ gout,
+__global__ __launch_bounds__(kIPThreads) void interp_bwd_kernel(const T* __restrict__ gout, int64_t sb, int64_t sc, int64_t sn,
                                                                 const int64_t* __restrict__ idx,
                                                                 const T* __restrict__ w, int C, int N1, int N2,
                                                                 T* __restrict__ gin) {
@@ -83,9 +84,9 @@ __global__ __launch_bounds__(kIPThreads) void interp_bwd_kernel(const T* __restr
   if (!(i0 >= 0 && i0 < N1 && i1 >= 0 && i1 < N1 && i2 >= 0 && i2 < N1)) return;
   const int c0 = blockIdx.y * kIPChanPerBlock;
   const int c1 = min(C, c0 + kIPChanPerBlock);
-  const T* gp = gout + ((size_t)b * C + c0) * N2 + n;
+  const T* gp = gout + (int64_t)b * sb + (int64_t)c0 * sc + (int64_t)n * sn;
   T* fp = gin + ((size_t)b * C + c0) * N1;
-  for (int c = c0; c < c1; ++c, gp += N2, fp += N1) {
+  for (int c = c0; c < c1; ++c, gp += sc, fp += N1) {
     const T g = *gp;
     atomicAdd(fp + i0, g * w0);
     atomicAdd(fp + i1, g * w1);
@@ -94,8 +95,8 @@ __global__ __launch_bounds__(kIPThreads) void interp_bwd_kernel(const T* __restr
 }
 
 template <typename T, bool BWD>
-int interp_entry(const T* a, const int64_t* index, const T* weight, int64_t B, int64_t C, int64_t N1, int64_t N2,
-                 T* o, mvp_stream_t stream) {
+int interp_entry(const T* a, const int64_t* st /* 3 element strides of a */, const int64_t* index, const T* weight, int64_t B, int64_t C,
+                 int64_t N1, int64_t N2, T* o, mvp_stream_t stream) {
   MVP_NONNULL(a);
   MVP_NONNULL(index);
   MVP_NONNULL(weight);
@@ -117,7 +118,7 @@ int interp_entry(const T* a, const int64_t* index, const T* weight, int64_t B, i
         if (e != hipSuccess) return (int)e;
       }
       dim3 grid((unsigned)cdiv(C, ch), (unsigned)B);
-      hipLaunchKernelGGL(k, grid, dim3(kIBThreads), bytes, s, a, index, weight, (int)C, (int)N1, (int)N2, (int)ch, o);
+      hipLaunchKernelGGL(k, grid, dim3(kIBThreads), bytes, s, a, st[0], st[1], st[2], index, weight, (int)C, (int)N1, (int)N2, (int)ch, o);
       return mvp_launch_status();
     }
     hipError_t e = hipMemsetAsync(o, 0, sizeof(T) * (size_t)(B * C * N1), s);
@@ -126,27 +127,39 @@ int interp_entry(const T* a, const int64_t* index, const T* weight, int64_t B, i
   if (N2 == 0) return MVP_OK;
   dim3 grid((unsigned)cdiv(N2, kIPThreads), (unsigned)cdiv(C, kIPChanPerBlock), (unsigned)B);
   if (BWD)
-    hipLaunchKernelGGL(interp_bwd_kernel<T>, grid, dim3(kIPThreads), 0, s, a, index, weight, (int)C, (int)N1, (int)N2, o);
+    hipLaunchKernelGGL(interp_bwd_kernel<T>, grid, dim3(kIPThreads), 0, s, a, st[0], st[1], st[2], index, weight, (int)C, (int)N1, (int)N2, o);
   else
-    hipLaunchKernelGGL(interp_fwd_kernel<T>, grid, dim3(kIPThreads), 0, s, a, index, weight, (int)C, (int)N1, (int)N2, o);
+    hipLaunchKernelGGL(interp_fwd_kernel<T>, grid, dim3(kIPThreads), 0, s, a, st[0], st[1], st[2], index, weight, (int)C, (int)N1, (int)N2, o);
   return mvp_launch_status();
 }
 
 }  // namespace
 
-MVP_API int mvp_interpolate_forward_f32(const float* input, const int64_t* index, const float* weight, int64_t B,
-                                        int64_t C, int64_t N1, int64_t N2, float* out, mvp_stream_t stream) {
-  return interp_entry<float, false>(input, index, weight, B, C, N1, N2, out, stream);
-}
-MVP_API int mvp_interpolate_forward_f64(const double* input, const int64_t* index, const double* weight, int64_t B,
-                                        int64_t C, int64_t N1, int64_t N2, double* out, mvp_stream_t stream) {
-  return interp_entry<double, false>(input, index, weight, B, C, N1, N2, out, stream);
-}
-MVP_API int mvp_interpolate_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B,
-                                         int64_t C, int64_t N1, int64_t N2, float* grad_in, mvp_stream_t stream) {
-  return interp_entry<float, true>(grad_out, index, weight, B, C, N1, N2, grad_in, stream);
-}
-MVP_API int mvp_interpolate_backward_f64(const double* grad_out, const int64_t* index, const double* weight, int64_t B,
-                                         int64_t C, int64_t N1, int64_t N2, double* grad_in, mvp_stream_t stream) {
-  return interp_entry<double, true>(grad_out, index, weight, B, C, N1, N2, grad_in, stream);
-}
+// Contiguous operands: the natural strides.  *_strided_*: element strides of the feature operand (input / grad_out) as the caller's tensor
+// has them (the reference walks strided tensors through TensorInfo, interpolate_kernel.cu:108-111, instead of copying them).
+#define MVP_INTERP_ENTRIES(SUF, T)                                                                                                          \
+  MVP_API int mvp_interpolate_forward_##SUF(const T* input, const int64_t* index, const T* weight, int64_t B, int64_t C, int64_t N1,        \
+                                            int64_t N2, T* out, mvp_stream_t stream) {                                                     \
+    const int64_t st[3] = {C * N1, N1, 1};                                                                                                 \
+    return interp_entry<T, false>(input, st, index, weight, B, C, N1, N2, out, stream);                                                    \
+  }                                                                                                                                         \
+  MVP_API int mvp_interpolate_forward_strided_##SUF(const T* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,               \
+                                                    const T* weight, int64_t B, int64_t C, int64_t N1, int64_t N2, T* out,                 \
+                                                    mvp_stream_t stream) {                                                                 \
+    const int64_t st[3] = {sb, sc, sn};                                                                                                    \
+    return interp_entry<T, false>(input, st, index, weight, B, C, N1, N2, out, stream);                                                    \
+  }                                                                                                                                         \
+  MVP_API int mvp_interpolate_backward_##SUF(const T* grad_out, const int64_t* index, const T* weight, int64_t B, int64_t C, int64_t N1,    \
+                                             int64_t N2, T* grad_in, mvp_stream_t stream) {                                                \
+    const int64_t st[3] = {C * N2, N2, 1};                                                                                                 \
+    return interp_entry<T, true>(grad_out, st, index, weight, B, C, N1, N2, grad_in, stream);                                              \
+  }                                                                                                                                         \
+  MVP_API int mvp_interpolate_backward_strided_##SUF(const T* grad_out, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,           \
+                                                     const T* weight, int64_t B, int64_t C, int64_t N1, int64_t N2, T* grad_in,            \
+                                                     mvp_stream_t stream) {                                                                \
+    const int64_t st[3] = {sb, sc, sn};                                                                                                    \
+    return interp_entry<T, true>(grad_out, st, index, weight, B, C, N1, N2, grad_in, stream);                                              \
+  }
+MVP_INTERP_ENTRIES(f32, float)
+MVP_INTERP_ENTRIES(f64, double)
+#undef MVP_INTERP_ENTRIES

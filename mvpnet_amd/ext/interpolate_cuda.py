@@ -14,22 +14,33 @@ def _check(x, index, weight):
 
 
 def interpolate_forward(input, index, weight):
-    """input (B,C,M), index (B,N,3), weight (B,N,3) -> (B,C,N)  (interpolate_kernel.cu:78-124)."""
+    """input (B,C,M), index (B,N,3), weight (B,N,3) -> (B,C,N)  (interpolate_kernel.cu:78-124).  A strided `input` is walked in place
+    (TensorInfo there, element strides here); the small index / weight tensors are made contiguous."""
     _check(input, index, weight)
-    input, index, weight = input.contiguous(), index.contiguous(), weight.contiguous()
+    index, weight = index.contiguous(), weight.contiguous()
     B, C, M = input.shape
     N = index.size(1)
     out = torch.empty((B, C, N), dtype=input.dtype, device=input.device)
-    L.call('mvp_interpolate_forward_' + L.suffix(input), input, L.ptr(input), L.ptr(index), L.ptr(weight), B, C, M, N, L.ptr(out))
+    if input.is_contiguous():
+        L.call('mvp_interpolate_forward_' + L.suffix(input), input, L.ptr(input), L.ptr(index), L.ptr(weight), B, C, M, N, L.ptr(out))
+    else:
+        sb, sc, sn = input.stride()
+        L.call('mvp_interpolate_forward_strided_' + L.suffix(input), input, L.ptr(input), sb, sc, sn, L.ptr(index), L.ptr(weight), B, C, M, N,
+               L.ptr(out))
     return out
 
 
 def interpolate_backward(grad_output, index, weight, num_inst):
-    """grad_output (B,C,N) -> grad_input (B,C,num_inst)  (interpolate_kernel.cu:184-230)."""
+    """grad_output (B,C,N) -> grad_input (B,C,num_inst)  (interpolate_kernel.cu:184-230); strided grad_output walked in place."""
     _check(grad_output, index, weight)
-    grad_output, index, weight = grad_output.contiguous(), index.contiguous(), weight.contiguous()
+    index, weight = index.contiguous(), weight.contiguous()
     B, C, N = grad_output.shape
     grad_input = torch.empty((B, C, int(num_inst)), dtype=grad_output.dtype, device=grad_output.device)
-    L.call('mvp_interpolate_backward_' + L.suffix(grad_output), grad_output, L.ptr(grad_output), L.ptr(index),
-           L.ptr(weight), B, C, int(num_inst), N, L.ptr(grad_input))
+    if grad_output.is_contiguous():
+        L.call('mvp_interpolate_backward_' + L.suffix(grad_output), grad_output, L.ptr(grad_output), L.ptr(index),
+               L.ptr(weight), B, C, int(num_inst), N, L.ptr(grad_input))
+    else:
+        sb, sc, sn = grad_output.stride()
+        L.call('mvp_interpolate_backward_strided_' + L.suffix(grad_output), grad_output, L.ptr(grad_output), sb, sc, sn, L.ptr(index),
+               L.ptr(weight), B, C, int(num_inst), N, L.ptr(grad_input))
     return grad_input

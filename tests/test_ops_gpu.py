@@ -1418,3 +1418,61 @@ def test_set_abstraction_against_float64_reference(dev, cin, widths, N, M, train
         for layer, w in zip(sa.mlp, ws):
             g = layer.conv.weight.grad.reshape(w.shape)
             assert rel(g, w.grad) <= 5e-3, (tuple(w.shape), rel(g, w.grad))
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64])
+def test_group_points_and_interpolate_walk_strided_operands_in_place(dev, dt):
+    """The reference hands strided tensors to its kernels through TensorInfo (group_points_kernel.cu:131-133, interpolate_kernel.cu:108-111)
+    instead of copying them.  Same here: a transposed channels-last view, a channel slice of a wider tensor, a strided gradient and an
+    expanded (stride 0) gradient go through the *_strided_* entry points -- no `.contiguous()` of the feature operand (checked by
+    intercepting the library calls) -- and give exactly what the contiguous copy gives, forward and backward, against the CPU oracle too."""
+    from mvpnet_amd import _lib as L
+    from mvpnet_amd.ops import group_points, feature_interpolate
+    torch.manual_seed(5)
+    B, C, N, M, K = 3, 37, 600, 129, 32
+    wide = torch.randn(B, N, C + 11, dtype=dt, device=dev)           # (B,N,Cw) channels-last, wider than needed
+    x = wide.transpose(1, 2)[:, 3:3 + C]                               # (B,C,N) view: strides (N*Cw, 1, Cw), offset 3
+    assert not x.is_contiguous()
+    idx = torch.randint(0, N, (B, M, K), device=dev)
+    seen = []
+    orig = L.call
+
+    def spy(name, t, *a):
+        seen.append(name)
+        return orig(name, t, *a)
+
+    L.call = spy
+    try:
+        out = group_points(x, idx)
+        xg = x.detach().requires_grad_(True)                           # a strided LEAF
+        y = group_points(xg, idx)
+        gout = torch.randn(B, M, K, C, dtype=dt, device=dev).permute(0, 3, 1, 2)   # strided gradient (B,C,M,K)
+        y.backward(gout)
+        g1 = xg.grad.clone()
+        xg.grad = None
+        group_points(xg, idx).backward(torch.ones(1, 1, 1, 1, dtype=dt, device=dev).expand(B, C, M, K))   # stride-0 gradient
+        g2 = xg.grad.clone()
+        # interpolation
+        idx3 = torch.randint(0, N, (B, 777, 3), device=dev)
+        w3 = torch.rand(B, 777, 3, dtype=dt, device=dev)
+        w3 = w3 / w3.sum(2, keepdim=True)
+        xi = x.detach().requires_grad_(True)
+        oi = feature_interpolate(xi, idx3, w3)
+        gi = torch.randn(B, 777, C, dtype=dt, device=dev).transpose(1, 2)
+        oi.backward(gi)
+    finally:
+        L.call = orig
+    suf = 'f32' if dt == torch.float32 else 'f64'
+    for name in ('mvp_group_points_forward_strided_', 'mvp_group_points_backward_strided_', 'mvp_interpolate_forward_strided_',
+                 'mvp_interpolate_backward_strided_'):
+        assert name + suf in seen, name
+    xc = x.contiguous()
+    assert torch.equal(out, group_points(xc, idx))
+    np.testing.assert_array_equal(out.cpu().numpy(), O().group_points_fwd(xc.cpu().numpy(), idx.cpu().numpy()))
+    tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(g1.cpu().numpy(), O().group_points_bwd(gout.contiguous().cpu().numpy(), idx.cpu().numpy(), N), **tol)
+    np.testing.assert_allclose(g2.cpu().numpy(), O().group_points_bwd(np.ones((B, C, M, K), g2.cpu().numpy().dtype), idx.cpu().numpy(), N), **tol)
+    oc = feature_interpolate(xc, idx3, w3)
+    assert torch.equal(oi.detach(), oc)
+    np.testing.assert_array_equal(oc.cpu().numpy(), O().interpolate_fwd(xc.cpu().numpy(), idx3.cpu().numpy(), w3.cpu().numpy()))
+    np.testing.assert_allclose(xi.grad.cpu().numpy(), O().interpolate_bwd(gi.contiguous().cpu().numpy(), idx3.cpu().numpy(), w3.cpu().numpy(), N), **tol)
