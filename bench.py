@@ -365,6 +365,8 @@ def main():
         from mvpnet_amd import rows as _rows
         _rows.DW_SIDE_STREAM = False
     torch.cuda.set_device(local)
+    if os.environ.get('MVP_MAIN_PRIORITY'):  # (tools/exp/prio_ab.sh) the whole step on a high-priority stream, side streams stay at 0
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ['MVP_MAIN_PRIORITY'])))
     dev = torch.device('cuda', local)
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False

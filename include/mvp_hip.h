@@ -263,7 +263,9 @@ int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float*
  * (group_points_kernel.cu:50-89, interpolate_kernel.cu:131-174: one atomicAdd per element) is a gather:
  *   grad_feature (B,N,C) = sum over the slots p of point j of weight[b,p] * grad_out[b, slot / S, :]
  * (weight NULL = 1; S = slots per grad_out row: 1 for the grouping with E = M*K rows, 3 for the 3-NN interpolation with E = 3*N2).
- * No atomics on the data, no zero fill, reproducible up to the order of the slots inside one point's list. */
+ * No atomics on the data, no zero fill.  While a chunk's N counters fit in LDS (N <= ~37 000) the build is one launch, one workgroup per
+ * chunk, and every list of up to 1024 slots is sorted ascending: the gradient is reproducible bit for bit; beyond that (whole-scene vote
+ * plans) three launches with global atomics, lists in arrival order. */
 int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots, int32_t* cursor,
                       mvp_stream_t stream);
 int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_t* offsets, const int32_t* slots, const float* weight,

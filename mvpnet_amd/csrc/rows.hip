@@ -373,6 +373,91 @@ __global__ __launch_bounds__(kRT) void csr_fill_kernel(const int64_t* __restrict
   if (j >= 0 && j < N) slots[(size_t)b * E + atomicAdd(cursor + (size_t)b * N + j, 1)] = (int)e;
 }
 
+// The whole build in ONE workgroup per chunk when a chunk's N counters fit in LDS (every level of the network: N <= 8192; the dense
+// configuration's 32768): count, scan and fill run on LDS atomics -- no zero fill of the offsets, no global atomics at all (the three
+// launches above are bound by them: ~0.5 % of their cycles issue instructions, and they run beside the backward pass of the step) -- and
+// every point's slot list (up to 1024 entries) is then sorted ascending, so the order of the gather's additions, and with it the gradient,
+// is the same in every run (the fill order of the atomics is not).
+__global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __restrict__ idx, int64_t E, int N, int* __restrict__ offsets,
+                                                             int* __restrict__ slots) {
+  extern __shared__ __attribute__((aligned(16))) char csr_smem[];
+  int* cnt = reinterpret_cast<int*>(csr_smem);  // [N]: counts, then running cursors
+  int* part = cnt + N;                          // [1024]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t* ix = idx + (size_t)b * E;
+  int* o = offsets + (size_t)b * (N + 1);
+  int* sl = slots + (size_t)b * E;
+  for (int i = tid; i < N; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  for (int64_t e = tid; e < E; e += 1024) {
+    const int64_t j = ix[e];
+    if (j >= 0 && j < N) atomicAdd(&cnt[j], 1);
+  }
+  __syncthreads();
+  // exclusive scan of cnt over contiguous runs of `per` points per thread
+  const int per = (N + 1023) / 1024;
+  const int j0 = tid * per;
+  int sum = 0;
+  for (int i = 0; i < per; ++i)
+    if (j0 + i < N) sum += cnt[j0 + i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele over the 1024 partial sums
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid ? part[tid - 1] : 0;
+  if (tid == 0) o[0] = 0;
+  for (int i = 0; i < per; ++i)
+    if (j0 + i < N) {
+      const int c = cnt[j0 + i];
+      cnt[j0 + i] = run;  // cursor = start of the list
+      run += c;
+      o[j0 + i + 1] = run;
+    }
+  __syncthreads();
+  for (int64_t e = tid; e < E; e += 1024) {
+    const int64_t j = ix[e];
+    if (j >= 0 && j < N) sl[atomicAdd(&cnt[j], 1)] = (int)e;
+  }
+  __syncthreads();  // (workgroup-scope: the slots written above are read back below by other lanes of THIS workgroup)
+  // ascending positions inside every list (insertion sort: 8 entries on average in the grouping, 3 in the interpolation)
+  for (int j = tid; j < N; j += 1024) {
+    const int p1 = cnt[j];                                   // the cursor ended at the list's end
+    const int p0 = j ? __hip_atomic_load(&cnt[j - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;  // = end of the previous list
+    const int n = p1 - p0;
+    if (n <= 1 || n > 1024) continue;  // (a degenerate cloud -- thousands of references to one point -- keeps the fill order: quadratic sort)
+    if (n <= 16) {  // the usual case, in registers: 16 independent loads, an odd-even transposition network, n stores
+      int v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = i < n ? sl[p0 + i] : 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int i = r & 1; i + 1 < 16; i += 2) {
+          const int lo = min(v[i], v[i + 1]), hi = max(v[i], v[i + 1]);
+          v[i] = lo;
+          v[i + 1] = hi;
+        }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < n) sl[p0 + i] = v[i];
+      continue;
+    }
+    for (int p = p0 + 1; p < p1; ++p) {
+      const int v = sl[p];
+      int q = p - 1;
+      while (q >= p0 && sl[q] > v) {
+        sl[q + 1] = sl[q];
+        --q;
+      }
+      sl[q + 1] = v;
+    }
+  }
+}
+
 // grad_feature[b,j,:] = sum over the slots p of point j of  w[p] * grad_out[b, slot / S, :]   (w == nullptr: 1; S = slots per row:
 // 1 for the grouping, 3 for the 3-NN interpolation).  One lane per (point, 4 channels).
 __global__ __launch_bounds__(kRT) void gather_bwd_csr_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
@@ -999,6 +1084,16 @@ MVP_API int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_
   MVP_REQUIRE(B >= 0 && E >= 0 && N > 0 && B < 65536 && E < (1ll << 31) && N < (1ll << 30));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B == 0) return MVP_OK;
+  const size_t lds = ((size_t)N + 1024) * sizeof(int);
+  static const bool use_lds = []() { const char* e = getenv("MVP_CSR_LDS"); return !(e && e[0] == '0'); }();  // (0: tools/exp A/B)
+  if (use_lds && lds <= 150 * 1024) {  // one workgroup per chunk, everything in LDS, sorted lists (csr_build_lds_kernel)
+    if (lds > 48 * 1024) {
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(csr_build_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e2 != hipSuccess) return (int)e2;
+    }
+    hipLaunchKernelGGL(csr_build_lds_kernel, dim3((unsigned)B), dim3(1024), lds, s, index, E, (int)N, offsets, slots);
+    return mvp_launch_status();
+  }
   hipError_t e = hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)(B * (N + 1)), s);
   if (e != hipSuccess) return (int)e;
   if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)cdiv(E, kRT), (unsigned)B), dim3(kRT), 0, s, index, E, (int)N, offsets);
