@@ -682,7 +682,11 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = co0 + wco + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+#ifdef MVP_EXP_DW_STORE  /* (tools/exp timing only: WRONG results) what the flush costs without the atomics */
+      if (co < Cout && ci < Cin) *(dW + (size_t)co * lddw + ci) = acc[i];
+#else
       if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * lddw + ci, acc[i]);
+#endif
     }
   }
 }
@@ -837,7 +841,11 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int co = co0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * g;
+#ifdef MVP_EXP_DW_STORE  /* (tools/exp timing only: WRONG results) what the flush costs without the atomics */
+          if (co < Cout && ci < Cin) *(dW + (size_t)co * lddw + ci) = acc[a][b][i];
+#else
           if (co < Cout && ci < Cin) atomicAdd(dW + (size_t)co * lddw + ci, acc[a][b][i]);
+#endif
         }
       }
   }

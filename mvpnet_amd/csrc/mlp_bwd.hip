@@ -449,7 +449,11 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int co = 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+#ifdef MVP_EXP_DW_STORE  /* (tools/exp timing only: WRONG results) what the flush costs without the atomics */
+          if (co < C && ci < Cp) *(p.dW + (size_t)co * p.lddw + ci0 + ci) = accw[a][b][i];
+#else
           if (co < C && ci < Cp) atomicAdd(p.dW + (size_t)co * p.lddw + ci0 + ci, accw[a][b][i]);
+#endif
         }
       }
   }
