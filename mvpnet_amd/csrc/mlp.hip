@@ -1045,7 +1045,8 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
     // g_mlp_min_width wide; Cin >= 8 (the 4-column coordinate operand of the first set-abstraction layer stays on fp32)
     const int ns = (std::max(Cin, Cout) >= g_mlp_min_width && Cin >= 8) ? mlp_bwd_pieces() : 0;
     if (ns != 0) {
-      int64_t splits = std::min<int64_t>(cdiv(1024, tiles), 512);
+      static const int64_t wg_target = []() { const char* e = getenv("MVP_DW_WORKGROUPS"); return e ? (int64_t)atoi(e) : (int64_t)1024; }();
+      int64_t splits = std::min<int64_t>(cdiv(wg_target, tiles), 512);
       int64_t rows_per_block = cdiv(cdiv(R, splits), 64) * 64;
       if (rows_per_block < 256) rows_per_block = 256;
       splits = cdiv(R, rows_per_block);
