@@ -433,11 +433,27 @@ int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mea
                                const float* W, int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
                                double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
                                const uint8_t* pool_arg, mvp_stream_t stream);
+/* The same with the weight gradient through a workspace + ordered reduction instead of fp32 atomics (see mvp_mlp_weight_grad_ws_f32;
+ * mvp_mlp_weight_grad_workspace_floats() floats are enough, a smaller / NULL workspace takes the atomics). */
+int mvp_mlp_layer_backward_ws_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                               const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx,
+                               const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                               const float* W, int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
+                               double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
+                               const uint8_t* pool_arg, float* workspace, int64_t workspace_floats, mvp_stream_t stream);
 /* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
  * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                             const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                             float* dW, int64_t lddw, mvp_stream_t stream);
+/* The same through a caller-provided workspace (contents irrelevant, not kept): the workgroups of the split-bf16 kernel leave their
+ * partial tiles there and a second launch adds them to dW in row-split order: no fp32 atomics (the flush of ~1000 workgroups queues up
+ * to 512 of them on every dW element) and the same dW bit for bit in every run.  mvp_mlp_weight_grad_workspace_floats() floats are
+ * always enough; a smaller or NULL workspace takes the atomics path above.  One workspace per stream. */
+int64_t mvp_mlp_weight_grad_workspace_floats(void);
+int mvp_mlp_weight_grad_ws_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                               const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                               float* dW, int64_t lddw, float* workspace, int64_t workspace_floats, mvp_stream_t stream);
 
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.

@@ -79,9 +79,12 @@ _SIGNATURES = {
     'mvp_bn_rows_backward_finish_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_bn_finalize_f32': [_ptr, _i64, _i64, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
+    'mvp_mlp_weight_grad_ws_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr],
     'mvp_mlp_input_grad_f32': [_ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_layer_backward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
                                    _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_mlp_layer_backward_ws_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
+                                   _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
     'mvp_mlp_forward_pool_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32,
                                  _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_pool_finalize_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr, _ptr],
@@ -100,7 +103,7 @@ _SIGNATURES = {
     'mvp_seg_loss_backward_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
-EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
+EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
            'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode'] + sorted(_SIGNATURES)
 
 
@@ -119,6 +122,8 @@ def lib():
         handle.mvp_lift_workspace_bytes.argtypes = [_i64, _i64, _i64, _i64, _i64]
         handle.mvp_group_lin_partial_count.restype = ctypes.c_int64
         handle.mvp_group_lin_partial_count.argtypes = [_i64, _i64, _i64, _i64]
+        handle.mvp_mlp_weight_grad_workspace_floats.restype = ctypes.c_int64
+        handle.mvp_mlp_weight_grad_workspace_floats.argtypes = []
         handle.mvp_colstats_partial_count.restype = ctypes.c_int64
         handle.mvp_colstats_partial_count.argtypes = [_i64, _i64]
         handle.mvp_set_mlp_precision.restype = ctypes.c_int
@@ -250,8 +255,38 @@ def _fn(name):
     return f
 
 
+# REPRODUCIBLE MODE (MVP_DETERMINISTIC=1 / set_deterministic(True)): the weight-gradient kernels flush their workgroups' partial tiles
+# through a workspace and an ordered reduction (mvp_mlp_weight_grad_ws_f32, mvp_mlp_layer_backward_ws_f32) instead of fp32 atomics -- the
+# last float32 atomics of a training step; with it every parameter after a step is the same bit for bit in every run
+# (tests/test_determinism_gpu.py).  Costs ~2 % of the step (the reductions are extra launches, five of them on the critical stream):
+# 8.20 -> 8.39 ms, so it is off by default; the atomics' run-to-run noise is ~1e-7 relative per gradient element.  One workspace per
+# (device, stream) -- a kernel and its reduction run in order on that stream --, handed out here to every caller of the two entry points.
+DW_WORKSPACE = os.environ.get('MVP_DETERMINISTIC', '0') == '1'
+
+
+def set_deterministic(flag):
+    """-> the previous setting."""
+    global DW_WORKSPACE
+    old, DW_WORKSPACE = DW_WORKSPACE, bool(flag)
+    return old
+
+
+_DW_WS = {}
+_DW_WS_NAMES = {'mvp_mlp_weight_grad_f32': 'mvp_mlp_weight_grad_ws_f32', 'mvp_mlp_layer_backward_f32': 'mvp_mlp_layer_backward_ws_f32'}
+
+
+def _with_dw_workspace(index, stream_handle, args):
+    ws = _DW_WS.get((index, stream_handle))
+    if ws is None:
+        ws = _DW_WS[(index, stream_handle)] = torch.empty(lib().mvp_mlp_weight_grad_workspace_floats(), dtype=torch.float32,
+                                                          device=torch.device('cuda', index))
+    return args + (ws.data_ptr(), ws.numel())
+
+
 def call_on(stream, name, *args):
     """Invoke `name(*args, stream)` on the given torch.cuda.Stream of the CURRENT device (no stream-context switch on the host)."""
+    if DW_WORKSPACE and name in _DW_WS_NAMES:
+        name, args = _DW_WS_NAMES[name], _with_dw_workspace(stream.device.index, stream.cuda_stream, args)
     code = _fn(name)(*args, stream.cuda_stream)
     if code != 0:
         check(code, name)
@@ -260,6 +295,9 @@ def call_on(stream, name, *args):
 def call(name, tensor_for_device, *args):
     """Invoke `name(*args, stream)` on the current stream of tensor_for_device's device."""
     index = tensor_for_device.device.index
+    if DW_WORKSPACE and name in _DW_WS_NAMES:
+        handle = _raw_stream(index) if _raw_stream is not None else torch.cuda.current_stream(tensor_for_device.device).cuda_stream
+        name, args = _DW_WS_NAMES[name], _with_dw_workspace(index, handle, args)
     if _raw_stream is not None and index == _raw_device():  # the usual case (one process per GPU): no device guard, no Stream object
         code = _fn(name)(*args, _raw_stream(index))
     elif index == torch.cuda.current_device():

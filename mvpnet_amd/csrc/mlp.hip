@@ -545,7 +545,7 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
 template <int TM, int TN, bool VEC>
 __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
                                                      int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
-                                                     float* __restrict__ dW, int lddw) {
+                                                     float* __restrict__ dW, int lddw, float* __restrict__ ws) {
   constexpr int NBLK = (TM / 32) * (TN / 32);  // output blocks of 32 x 32
   constexpr int RS = 4 / NBLK;                 // waves per output block = row split of the slab
   constexpr int BR = 32 * RS;                  // slab rows
@@ -677,7 +677,11 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
       }
     }
   }
-  if (rs == 0) {
+  if (rs == 0 && ws) {  // partial tile -> workspace (block, register, lane order: dw_reduce_kernel adds the row splits in order)
+    float* t = ws + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * (size_t)(NBLK * 1024);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(acc[i], t + (blk * 16 + i) * 64 + lane);
+  } else if (rs == 0) {
     const int ci = ci0 + wci + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
 template <int TMB, int TNB, int NS>
 __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
                                                         int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
-                                                        float* __restrict__ dW, int lddw) {
+                                                        float* __restrict__ dW, int lddw, float* __restrict__ ws) {
   using SP = SplitPairs<NS>;
   __shared__ float red[2][TMB * TNB * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -833,6 +837,16 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
   __syncthreads();
   if (wave == 0) {
     absorb(0);
+    if (ws) {  // the workgroup's tile as it lies in the accumulators, full-line stores: dw_reduce_kernel sums the row splits in order
+      float* t = ws + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * (size_t)(NBLK * 1024);
+#pragma unroll
+      for (int a = 0; a < TMB; ++a)
+#pragma unroll
+        for (int b = 0; b < TNB; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(acc[a][b][i], t + ((a * TNB + b) * 16 + i) * 64 + lane);
+      return;
+    }
 #pragma unroll
     for (int a = 0; a < TMB; ++a)
 #pragma unroll
@@ -1024,9 +1038,10 @@ MVP_API int mvp_mlp_forward_pool_f32(const float* X, int64_t R, int64_t Cin, int
 
 // dW (Cout,Cin; row stride lddw) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin])  (accumulated into dW: gradient-accumulation semantics).
 // lddw > Cin: dW is a column slice of a wider weight gradient (the linear-first factorisations split a conv weight by columns).
-MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
-                                    const float* act_mean, const float* act_invstd, const float* act_gamma,
-                                    const float* act_beta, float* dW, int64_t lddw, mvp_stream_t stream) {
+namespace {
+int weight_grad_impl(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, const float* act_mean,
+                     const float* act_invstd, const float* act_gamma, const float* act_beta, float* dW, int64_t lddw, float* ws, int64_t ws_floats,
+                     mvp_stream_t stream) {
   MVP_NONNULL(dY);
   MVP_NONNULL(X);
   MVP_NONNULL(dW);
@@ -1052,14 +1067,19 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
       splits = cdiv(R, rows_per_block);
       InAct act{act_mean, act_invstd, act_gamma, act_beta};
       dim3 grid((unsigned)cdiv(Cout, TM), (unsigned)cdiv(Cin, TN), (unsigned)splits);
+      // partial tiles through the caller's workspace + an ordered reduction when it is large enough, fp32 atomics otherwise
+      float* w = (ws && splits * tiles * (int64_t)(TM * TN) <= ws_floats && splits > 1) ? ws : nullptr;
 #define MVP_DWBF(A_, B_)                                                                                                           \
   do {                                                                                                                             \
     if (ns == 2)                                                                                                                   \
       hipLaunchKernelGGL((mlp_dw_bf_kernel<A_, B_, 2>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
-                         rows_per_block, dW, (int)lddw);                                                                           \
+                         rows_per_block, dW, (int)lddw, w);                                                                        \
     else                                                                                                                           \
       hipLaunchKernelGGL((mlp_dw_bf_kernel<A_, B_, 3>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
-                         rows_per_block, dW, (int)lddw);                                                                           \
+                         rows_per_block, dW, (int)lddw, w);                                                                        \
+    if (w)                                                                                                                         \
+      hipLaunchKernelGGL((dw_reduce_kernel<A_, B_>), dim3((unsigned)(tiles * (A_) * (B_) * 16)), dim3(256), 0, s, w, (int)splits,   \
+                         (int)grid.x, (int)grid.y, (int)Cout, (int)Cin, dW, (int)lddw);                                            \
   } while (0)
       if (TM == 32 && TN == 32) MVP_DWBF(1, 1);
       else if (TM == 32) MVP_DWBF(1, 2);
@@ -1078,14 +1098,18 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
   InAct act{act_mean, act_invstd, act_gamma, act_beta};
   dim3 grid((unsigned)cdiv(Cout, TM), (unsigned)cdiv(Cin, TN), (unsigned)splits);
   const bool vec = Cout % 4 == 0 && Cin % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dY) % 16 == 0 && ((uintptr_t)X) % 16 == 0;
+  float* w = (ws && splits * tiles * (int64_t)(TM * TN) <= ws_floats && splits > 1) ? ws : nullptr;  // as on the split-bf16 path
 #define MVP_DW_LAUNCH(M_, N_)                                                                                                      \
   do {                                                                                                                             \
     if (vec)                                                                                                                       \
       hipLaunchKernelGGL((mlp_dw_kernel<M_, N_, true>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
-                         rows_per_block, dW, (int)lddw);                                                                           \
+                         rows_per_block, dW, (int)lddw, w);                                                                        \
     else                                                                                                                           \
       hipLaunchKernelGGL((mlp_dw_kernel<M_, N_, false>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,        \
-                         rows_per_block, dW, (int)lddw);                                                                           \
+                         rows_per_block, dW, (int)lddw, w);                                                                        \
+    if (w)                                                                                                                         \
+      hipLaunchKernelGGL((dw_reduce_kernel<(M_) / 32, (N_) / 32>), dim3((unsigned)(tiles * ((M_) / 32) * ((N_) / 32) * 16)), dim3(256), 0, \
+                         s, w, (int)splits, (int)grid.x, (int)grid.y, (int)Cout, (int)Cin, dW, (int)lddw);                         \
   } while (0)
   if (TM == 32 && TN == 32) MVP_DW_LAUNCH(32, 32);
   else if (TM == 32) MVP_DW_LAUNCH(32, 64);
@@ -1093,6 +1117,24 @@ MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, 
   else MVP_DW_LAUNCH(64, 64);
 #undef MVP_DW_LAUNCH
   return mvp_launch_status();
+}
+}  // namespace
+
+MVP_API int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                                    const float* act_mean, const float* act_invstd, const float* act_gamma,
+                                    const float* act_beta, float* dW, int64_t lddw, mvp_stream_t stream) {
+  return weight_grad_impl(dY, X, R, Cout, Cin, ldx, act_mean, act_invstd, act_gamma, act_beta, dW, lddw, nullptr, 0, stream);
+}
+
+// The same with a caller-provided workspace of `workspace_floats` floats (contents irrelevant, not kept): the split-bf16 kernel leaves its
+// workgroups' partial tiles there and a second launch adds them to dW in row-split order -- no atomics, the same dW bit for bit in every
+// run.  mvp_mlp_weight_grad_workspace_floats() is always enough; a smaller (or NULL) workspace falls back to the atomics of
+// mvp_mlp_weight_grad_f32.  One workspace per stream (the two launches run in order on `stream`).
+MVP_API int64_t mvp_mlp_weight_grad_workspace_floats(void) { return (int64_t)1536 * 4096; }
+MVP_API int mvp_mlp_weight_grad_ws_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                                       const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                                       float* dW, int64_t lddw, float* workspace, int64_t workspace_floats, mvp_stream_t stream) {
+  return weight_grad_impl(dY, X, R, Cout, Cin, ldx, act_mean, act_invstd, act_gamma, act_beta, dW, lddw, workspace, workspace_floats, stream);
 }
 
 // d(input) of a layer, fused with the first half of the previous layer's BatchNorm+ReLU backward:

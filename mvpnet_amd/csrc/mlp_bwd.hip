@@ -46,6 +46,7 @@ struct BwdArgs {
   const float* W;        // (C, ldw) weight of layer i
   int ldw;
   float* dW;             // (C, lddw) accumulated into
+  float* ws;             // nullptr: one fp32 atomic per element and workgroup; else the workgroups' partial tiles go here (dw_reduce_kernel adds them in order)
   int lddw;
   float* dZ;             // (R, Cp) or nullptr
   double* partial;       // (workgroups, 2 Cp) column sums of dz_{i-1} and dz_{i-1} * xhat_{i-1}; nullptr without act
@@ -441,6 +442,15 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
   __syncthreads();
   if (wave == 0) {
     absorb(0);
+    if (p.ws) {  // (same layout as mlp_dw_bf_kernel: tile index (row split, 0, c_in slice), blocks in (a, b) order)
+      float* t = p.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)(CB * CPB * 1024);
+#pragma unroll
+      for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < CPB; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(accw[a][b][i], t + ((a * CPB + b) * 16 + i) * 64 + lane);
+    } else {
 #pragma unroll
     for (int a = 0; a < CB; ++a)
 #pragma unroll
@@ -456,6 +466,7 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
 #endif
         }
       }
+    }
   }
 }
 
@@ -479,12 +490,13 @@ MVP_API int64_t mvp_mlp_layer_backward_partial_count(int64_t R, int64_t Cp) {
 //   dgamma_i / dbeta_i (C, may be NULL): with Yi, the BatchNorm parameter gradients of layer i = stat_i[C + c] / stat_i[c] as float32.
 // Needs a split-bf16 precision (mvp_set_mlp_precision 3 or 6), C <= 128, Cp <= 128 and Cp % 4 == 0: MVP_EUNSUPPORTED otherwise
 // (callers then use the three separate entry points).
-MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
-                                       const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float* act_mean,
-                                       const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W,
-                                       int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
-                                       double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
-                                       const uint8_t* pool_arg, mvp_stream_t stream) {
+namespace {
+int layer_backward_impl(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                        const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float* act_mean,
+                        const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W,
+                        int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
+                        double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
+                        const uint8_t* pool_arg, float* ws, int64_t ws_floats, mvp_stream_t stream) {
   if (pool_dout) {  // POOL front end: y_i re-computed, dz_i from the pooled gradient (rows = groups of 32)
     MVP_NONNULL(pool_out);
     MVP_NONNULL(pool_arg);
@@ -538,6 +550,15 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   const int cb = C <= 32 ? 1 : C <= 64 ? 2 : 4;
   const int cpb = Cp <= 32 ? 1 : (Cp <= 64 || Cp > 96 || cb == 4) ? 2 : 3;
   const unsigned gy = (unsigned)cdiv(Cp, 32 * cpb);
+  const unsigned gyl = pool_dout ? 1u : gy;  // workgroup rows actually launched (the pooled variant covers Cp <= 32 cpb with one)
+  // dW through the caller's workspace + an ordered reduction (no atomics, reproducible) when it is large enough
+  a.ws = (ws && grid > 1 && grid * (int64_t)gyl * cb * cpb * 1024 <= ws_floats) ? ws : nullptr;
+#define MVP_DWRED(A_, B_)                                                                                                         \
+  do {                                                                                                                            \
+    if (a.ws)                                                                                                                     \
+      hipLaunchKernelGGL((dw_reduce_kernel<A_, B_>), dim3((unsigned)(gyl * (A_) * (B_) * 16)), dim3(256), 0, s, a.ws, (int)grid, 1,  \
+                         (int)gyl, (int)C, (int)Cp, dW, (int)lddw);                                                               \
+  } while (0)
 #define MVP_BWD1(A_, B_, PF_)                                                                                                  \
   do {                                                                                                                   \
     if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, false, PF_>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
@@ -555,11 +576,13 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   do {                                                                        \
     const bool pf = pf_mode > 0;                                                \
     if (pf) MVP_BWD1(A_, B_, true); else MVP_BWD1(A_, B_, false);              \
+    MVP_DWRED(A_, B_);                                                         \
   } while (0)
 #define MVP_BWD_POOL(A_, B_)                                                  \
   do {                                                                        \
     const bool pf = pf_mode > 0;                                               \
     if (pf) MVP_BWD_POOL1(A_, B_, true); else MVP_BWD_POOL1(A_, B_, false);    \
+    MVP_DWRED(A_, B_);                                                         \
   } while (0)
   if (pool_dout) {
     if (cb == 1 && cpb == 1) MVP_BWD_POOL(1, 1);
@@ -576,6 +599,7 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   else if (cpb == 1) MVP_BWD(4, 1);
   else if (cpb == 2) MVP_BWD(4, 2);
   else return MVP_EUNSUPPORTED;
+#undef MVP_DWRED
 #undef MVP_BWD_POOL
 #undef MVP_BWD_POOL1
 #undef MVP_BWD1
@@ -584,4 +608,27 @@ MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const fl
   if (rc != MVP_OK) return rc;
   if (a.partial) launch_stats_reduce(partial, grid, (int)(2 * Cp), stat_prev, s);
   return mvp_launch_status();
+}
+}  // namespace
+
+MVP_API int mvp_mlp_layer_backward_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                       const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float* act_mean,
+                                       const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W,
+                                       int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
+                                       double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
+                                       const uint8_t* pool_arg, mvp_stream_t stream) {
+  return layer_backward_impl(G, Yi, mean_i, invstd_i, gamma_i, stat_i, dgamma_i, dbeta_i, training, X, ldx, act_mean, act_invstd, act_gamma, act_beta,
+                             W, ldw, R, C, Cp, dW, lddw, dZ, stat_prev, partial, pool_dout, pool_out, pool_arg, nullptr, 0, stream);
+}
+
+// The same with the weight gradient through a caller-provided workspace (mvp_mlp_weight_grad_workspace_floats() floats, contents irrelevant)
+// and an ordered reduction instead of fp32 atomics: see mvp_mlp_weight_grad_ws_f32.
+MVP_API int mvp_mlp_layer_backward_ws_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                          const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx,
+                                          const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                                          const float* W, int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
+                                          double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
+                                          const uint8_t* pool_arg, float* workspace, int64_t workspace_floats, mvp_stream_t stream) {
+  return layer_backward_impl(G, Yi, mean_i, invstd_i, gamma_i, stat_i, dgamma_i, dbeta_i, training, X, ldx, act_mean, act_invstd, act_gamma, act_beta,
+                             W, ldw, R, C, Cp, dW, lddw, dZ, stat_prev, partial, pool_dout, pool_out, pool_arg, workspace, workspace_floats, stream);
 }

@@ -61,4 +61,40 @@ template <> struct SplitPairs<2> { static constexpr int N = 3; static constexpr 
 template <> struct SplitPairs<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
 
 
+// dW += the sum over the row splits of the partial tiles the weight-gradient kernels (mlp_dw_bf_kernel, mlp_bwd_layer_kernel) left in the workspace, in split order (wave w of a workgroup
+// takes the splits s = w, w + 4, ...; the four partial sums meet in LDS in wave order): no atomics -- the flush of ~1000 workgroups used
+// to queue up to 512 fp32 atomics on every dW element, beside the backward chain -- and the same additions in every run.
+// One thread quadruple per accumulator element (tile, block, register, lane); grid = tiles * NBLK * 16.
+template <int TMB, int TNB>
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ ws, int splits, int tiles_x, int tiles_y, int Cout, int Cin,
+                                                        float* __restrict__ dW, int lddw) {
+  constexpr int NBLK = TMB * TNB;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x;                    // (tile, block, register)
+  const int i = e & 15, ab = (e >> 4) % NBLK, tile = (e >> 4) / NBLK;
+  const int a = ab / TNB, b = ab % TNB;
+  const int tx = tile / tiles_y, ty = tile % tiles_y;
+  const size_t stride = (size_t)tiles_x * tiles_y * NBLK * 1024;  // floats between two splits
+  const float* p = ws + (size_t)tile * (NBLK * 1024) + (size_t)(ab * 16 + i) * 64 + lane;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int sI = wave;
+  for (; sI + 12 < splits; sI += 16) {  // four loads in flight
+    v0 += p[(size_t)sI * stride];
+    v1 += p[(size_t)(sI + 4) * stride];
+    v2 += p[(size_t)(sI + 8) * stride];
+    v3 += p[(size_t)(sI + 12) * stride];
+  }
+  for (; sI < splits; sI += 4) v0 += p[(size_t)sI * stride];
+  part[wave][lane] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (wave == 0) {
+    const float sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int co = tx * (32 * TMB) + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    const int ci = ty * (32 * TNB) + 32 * b + (lane & 31);
+    if (co < Cout && ci < Cin) dW[(size_t)co * lddw + ci] += sum;
+  }
+}
+
+
 }  // namespace

@@ -121,8 +121,9 @@ def test_eval_forward_of_the_whole_model_is_deterministic(dev):
 @pytest.mark.parametrize('chain,K,R_', [((32, (32, 64)), 32, 2097152), ((64, (64, 64, 64)), 3, 786432), ((64, (64, 128)), 32, 524288)])
 def test_chain_forward_and_input_gradient_are_deterministic(dev, chain, K, R_):
     """A whole shared-MLP chain in training mode (pooled last layer where it qualifies, one-kernel layer backward): the pooled output
-    and the gradient w.r.t. the chain's input are free of float atomics -> bit-identical over repeated forward + backward passes (the
-    weight gradients are not: their row splits meet in fp32 atomics)."""
+    and the gradient w.r.t. the chain's input are free of float atomics -> bit-identical over repeated forward + backward passes.  So
+    are the weight gradients since their row splits meet in a workspace and are added in order (mvp_mlp_weight_grad_ws_f32 /
+    mvp_mlp_layer_backward_ws_f32; the fp32 atomics they replace gave ~1e-7 of run-to-run noise) and the BatchNorm parameter gradients."""
     from mvpnet_amd import rows as R
     from mvpnet_amd.nn import SharedMLP
     torch.manual_seed(R_ % 997)
@@ -140,9 +141,14 @@ def test_chain_forward_and_input_gradient_are_deterministic(dev, chain, K, R_):
         xi = x.clone().requires_grad_(True)
         out = R.shared_mlp_rows(xi, mlp, K=K, reduce='sum' if K == 3 else 'max')
         out.backward(g)
-        return out.detach(), xi.grad
+        return (out.detach(), xi.grad) + tuple(p.grad for p in mlp.parameters())
 
-    assert _all_equal(run, 12) == 0
+    from mvpnet_amd import _lib as L
+    old = L.set_deterministic(True)  # weight gradients through the workspace: without it their row splits meet in fp32 atomics
+    try:
+        assert _all_equal(run, 12) == 0
+    finally:
+        L.set_deterministic(old)
 
 
 @pytest.mark.parametrize('N,M,shape', [(8192, 2048, None), (8192, 2048, 1), (2048, 512, None), (512, 128, None)])
@@ -176,3 +182,55 @@ def test_sampling_beside_the_mlp_kernels_equals_the_oracle(dev, N, M, shape):
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 assert torch.equal(idx, alone), 'sampling beside the %s MLP kernel differs from sampling alone' % prec
+
+
+def test_training_steps_are_reproducible(dev):
+    """REPRODUCIBLE MODE (_lib.set_deterministic / MVP_DETERMINISTIC=1).  Two runs of three full training steps (lifting, aggregation,
+    PN2SSG, loss, backward, Adam) from the same weights on the same batches, dropout included (its mask is a function of the seed): every parameter, every BatchNorm running statistic and the loss
+    are bit-identical.  What makes it so: index ops are exact, the gather backward adds through sorted transposed-index lists, the
+    weight gradients meet in a workspace in row-split order; the only float atomics left are the float64 statistics sums (their order
+    can move a sum by ~1e-16 relative, which would have to straddle an fp32 rounding boundary to show)."""
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss, train_step
+    from mvpnet_amd.synthetic import make_batch
+
+    class Net2D(torch.nn.Module):
+        feature = None
+
+        def forward(self, data):
+            return {'feature': self.feature}
+
+    B = 8
+    batches = []
+    for i in range(3):
+        bt = make_batch(70 + i, B, config=3)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        batches.append(({'images': torch.zeros(B, 3, 3, 120, 160, device=dev), 'points': t(bt['points'].transpose(0, 2, 1)),
+                         'seg_label': t(bt['seg_label']), 'depth': t(bt['depth_mm'].astype(np.int16)),
+                         'cam_matrix': t(np.repeat(bt['cam_matrix'][None, None, :3, :3], 3, 1).repeat(B, 0)), 'kinv': t(bt['kinv']),
+                         'pose': t(bt['pose']), 'pixel_box': t(bt['pixel_box']), 'k': 3},
+                        t(bt['feature_2d']).view(B * 3, 120, 160, 64).permute(0, 3, 1, 2)))
+
+    def run():
+        torch.manual_seed(4)
+        net2d = Net2D()
+        model = MVPNet3D(net2d, '', PN2SSG(64, 20), in_channels=64).to(dev).train()
+        opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+        loss_fn = SegLoss(weight=torch.linspace(0.5, 1.5, 20, device=dev))
+        losses = []
+        for i, (batch, feat) in enumerate(batches):
+            net2d.feature = feat
+            nxt = dict(batches[i + 1][0]) if i + 1 < len(batches) else None
+            loss, _ = train_step(model, loss_fn, opt, dict(batch), next_batch=nxt)
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in model.parameters()] + [b.clone() for b in model.buffers()] + losses
+
+    from mvpnet_amd import _lib as L
+    old = L.set_deterministic(True)
+    try:
+        a, b = run(), run()
+    finally:
+        L.set_deterministic(old)
+    bad = [i for i, (x, y) in enumerate(zip(a, b)) if not torch.equal(x, y)]
+    assert not bad, '{} of {} tensors differ between two runs of the same three steps'.format(len(bad), len(a))

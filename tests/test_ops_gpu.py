@@ -882,12 +882,15 @@ def test_knn3_weights_epilogue(dev, B, N1, N2):
 @pytest.mark.parametrize('R,C,Cp,ldx', [(5000, 32, 32, 32), (3333, 64, 32, 32), (4097, 64, 64, 64), (1000, 64, 68, 68), (70000, 32, 32, 32),
                                         (33, 20, 12, 12), (262144, 64, 64, 64), (9000, 128, 64, 64), (6001, 128, 128, 128), (777, 100, 96, 100),
                                         (2500, 32, 128, 128), (1200, 64, 72, 72)])
-@pytest.mark.parametrize('precision', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['bf16x6', 'bf16x3', 'bf16x3-ws'])
 def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
     """mvp_mlp_layer_backward_f32 (BatchNorm finish + weight gradient + input gradient with the previous layer's ReLU mask and column
     sums in ONE kernel) against a float64 evaluation of the three steps; all four combinations of {dz_i given / dy_i given} x
-    {previous activation / plain input}; rows not a multiple of 32, channels not a multiple of 32, no-dZ mode."""
+    {previous activation / plain input}; rows not a multiple of 32, channels not a multiple of 32, no-dZ mode.  '-ws': the reproducible
+    mode's entry point (weight gradient through the workspace + ordered reduction, mvp_mlp_layer_backward_ws_f32)."""
     from mvpnet_amd import _lib as L
+    det = L.set_deterministic(precision.endswith('-ws'))
+    precision = precision.replace('-ws', '')
     before = L.get_mlp_precision()
     L.set_mlp_precision(precision)
     L.set_mlp_precision_backward(precision)
@@ -944,6 +947,7 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
                             np.testing.assert_allclose(stat[:Cp].cpu().numpy(), ref_dz.sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
                             np.testing.assert_allclose(stat[Cp:].cpu().numpy(), (ref_dz * xh).sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
     finally:
+        L.set_deterministic(det)
         L.set_mlp_precision(before)
         L.set_mlp_precision_backward('bf16x3')
 
@@ -1490,3 +1494,51 @@ def test_group_points_and_interpolate_walk_strided_operands_in_place(dev, dt):
     assert torch.equal(oi.detach(), oc)
     np.testing.assert_array_equal(oc.cpu().numpy(), O().interpolate_fwd(xc.cpu().numpy(), idx3.cpu().numpy(), w3.cpu().numpy()))
     np.testing.assert_allclose(xi.grad.cpu().numpy(), O().interpolate_bwd(gi.contiguous().cpu().numpy(), idx3.cpu().numpy(), w3.cpu().numpy(), N), **tol)
+
+
+@pytest.mark.parametrize('R,Cout,Cin,lddw,use_act', [(262144, 128, 128, 128, True), (786432, 64, 64, 68, False), (2097152, 32, 32, 32, True),
+                                                      (65536, 256, 384, 384, False), (70001, 64, 100, 131, True), (5000, 32, 64, 64, False),
+                                                      (300, 64, 64, 64, True), (131072, 512, 256, 256, False)])
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16x6'])
+def test_weight_gradient_through_the_workspace_is_reproducible_and_equals_the_atomics_path(dev, R, Cout, Cin, lddw, use_act, prec):
+    """mvp_mlp_weight_grad_ws_f32: the workgroups' partial tiles go through a workspace and are added to dW in row-split order.  Against a
+    float64 product (same tolerance as the atomics path), against the atomics path itself (fp32 summation order is the only difference), added
+    INTO an existing dW (a column slice of a wider gradient: lddw > Cin, neighbours untouched) -- and bit-identical over repeated launches,
+    which the atomics path is not."""
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(R % 1000 + Cout)
+    dy = torch.randn(R, Cout, device=dev)
+    x = torch.randn(R, Cin, device=dev)
+    mean, invstd = torch.randn(Cin, device=dev) * 0.2, torch.rand(Cin, device=dev) + 0.5
+    gamma, beta = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.1
+    act = [mean, invstd, gamma, beta] if use_act else [None] * 4
+    a = torch.relu(((x - mean) * invstd) * gamma + beta) if use_act else x
+    ref = torch.zeros(Cout, Cin, dtype=torch.float64, device=dev)
+    for r0 in range(0, R, 262144):  # float64 reference in slabs (memory)
+        ref += dy[r0:r0 + 262144].double().t() @ a[r0:r0 + 262144].double()
+    ws = torch.full((L.lib().mvp_mlp_weight_grad_workspace_floats(),), float('nan'), device=dev)
+    base = torch.randn(Cout, lddw, device=dev)
+
+    def run(workspace):
+        dw = base.clone()
+        args = (L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, *[L.ptr(t) for t in act], L.ptr(dw), lddw)
+        with L.mlp_precision(prec, backward=prec):
+            if workspace is None:
+                L.lib()  # (the plain name would be re-routed to the workspace path by _lib.call)
+                code = L._fn('mvp_mlp_weight_grad_f32')(*args, torch.cuda.current_stream().cuda_stream)
+            else:
+                code = L._fn('mvp_mlp_weight_grad_ws_f32')(*args, L.ptr(workspace), workspace.numel(), torch.cuda.current_stream().cuda_stream)
+        assert code == 0
+        return dw
+
+    got = [run(ws) for _ in range(3)]
+    atom = run(None)
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2]), 'the workspace path gives the same dW in every run'
+    assert torch.equal(got[0][:, Cin:], base[:, Cin:]), 'columns outside the slice are untouched'
+    scale = max(1.0, float(ref.abs().max()))
+    tol = 3e-4 if prec == 'bf16x3' else 3e-5
+    np.testing.assert_allclose((got[0][:, :Cin] - base[:, :Cin]).double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * scale)
+    np.testing.assert_allclose(got[0].cpu().numpy(), atom.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    # a workspace that is too small falls back to the atomics path (same result up to the order of the additions)
+    small = run(torch.empty(1000, device=dev))
+    np.testing.assert_allclose(small.cpu().numpy(), atom.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
