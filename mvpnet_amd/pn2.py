@@ -8,6 +8,8 @@ reference's (B,C,M,K) tensors, its transposes and its separate conv / BN / ReLU 
 replaced by coalesced row gathers, one row-major GEMM per layer and fused BN+ReLU(+max) kernels.
 The public `forward` signatures still take and return the reference's channel-major tensors.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -16,6 +18,10 @@ from . import ops
 from . import rows as R
 from . import _lib as L
 
+
+# launch shape of the sampling kernels of a TRAINING step's prefetched geometry (1: one wave per SIMD -- beside the backward pass the
+# sampler leaves issue slots to the kernels it shares CUs with; 0: the fastest chain)
+TRAIN_FPS_SHAPE = int(os.environ.get('MVP_TRAIN_FPS_SHAPE', '1'))
 
 class QueryGrouper(nn.Module):
     """Ball query + grouping around centroids (modules.py:13-41)."""
@@ -324,7 +330,7 @@ class PN2SSG(nn.Module):
 
         # a training step's prefetched chain hides under forward + backward: sample with half the waves (passed per call, nothing
         # process-wide is touched)
-        fps_shape = (1 if (with_csr and stream is not None) else 0) if xyz.is_cuda else None
+        fps_shape = (TRAIN_FPS_SHAPE if (with_csr and stream is not None) else 0) if xyz.is_cuda else None
         with torch.cuda.stream(stream if stream is not None else cur):
             run = torch.cuda.current_stream(xyz.device)
             sa, xyzs = [], [xyz]
