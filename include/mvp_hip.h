@@ -350,8 +350,9 @@ int mvp_get_mlp_precision_backward(void);
  * never see each other's choice.  Returns the previous override packed as (terms + 1) * 16 + (terms_backward + 1), MVP_EINVAL for other
  * values.  The getters return what the calling thread's launches use. */
 int mvp_mlp_precision_scope(int terms, int terms_backward);
-/* Switch (returns the previous value): 1 = long narrow forward layers (>= 32768 rows, C_in, C_out <= 128) run on the persistent
- * streaming kernel with the weight matrix resident in LDS; 0 (default: measured 1.2 % faster on the bench step) = the per-tile kernel. */
+/* Switch (returns the previous value): 1 (default since round 3: 12-23 % faster alone at the step's shapes, 0.8 % on the step -- in round 2,
+ * beside the atomics-bound side-stream kernels of that time, it measured 1.2 % slower) = long narrow forward layers (>= 32768 rows, C_in,
+ * C_out <= 128) run on the persistent streaming kernel with the weight matrix resident in LDS; 0 = the per-tile kernel. */
 int mvp_set_mlp_stream(int on);
 
 /* Shared-MLP layer on rows with fp32 MFMA (mlp.hip): Y (R,Cout) = act(X (R,ldx)[:, :Cin]) . W (Cout,ldw)[:, :Cin]^T (+ bias).
