@@ -9,8 +9,9 @@
  *     0            success (kernel(s) enqueued on `stream`; nothing is synchronised)
  *     < 0          MVP_E* argument error, nothing was launched
  *     > 0          hipError_t reported by the launch
- * No entry point synchronises.  None allocates or keeps state either, with these exceptions: mvp_fps_* for clouds beyond 32768
- * points takes and returns a stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`); the mvp_set_* switches are
+ * No entry point synchronises.  None allocates or keeps state either, with these exceptions: mvp_fps_* for float32 clouds of 8193..65536
+ * points (a few KB per cloud: the exchange buffer of the workgroups that share a cloud) and for clouds beyond that (the running distances)
+ * takes and returns a stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`); the mvp_set_* switches are
  * process-wide DEFAULTS.  The kernels that let their last workgroup finalize keep their completion counter in caller memory (one extra
  * element behind `stat` / `acc`, zero on entry), so there is no device-side state shared between launches, streams, threads or graphs.
  * All tensors are dense row-major ("contiguous") in the stated shape.

@@ -578,6 +578,280 @@ int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* ou
   return mvp_launch_status();
 }
 
+// What the workgroups of one cloud exchange through: 64-bit relaxed atomics at device scope (single-copy atomic and coherent across the
+// XCDs by the memory model; 16-byte plain accesses with the sc1 bit turned out to tear: a reader saw the new half of an entry beside
+// the old one).  Every 64-bit unit carries the round stamp, so a reader knows each unit is of THIS round.
+typedef unsigned long long fps_u64;
+__device__ __forceinline__ void store_device(fps_u64* p, unsigned lo32, unsigned hi32) {
+  __hip_atomic_store(p, (fps_u64)lo32 | ((fps_u64)hi32 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ fps_u64 load_device(const fps_u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- rounds across several workgroups per cloud ---------------------------------------------------------------------------------
+// Clouds whose points do not fit one workgroup's registers at 8 points per lane (the dense configuration: 32768 points, 8192 samples)
+// used to take one sample per barrier with 32 points per lane: 4.6 us per sample, 37.8 ms per level.  Here W workgroups (one CU each)
+// share a cloud, each with the single-workgroup kernel's 8-16 points per lane, and run the SAME round protocol: every 16-lane row of
+// every workgroup publishes its best point (key, coordinates) and its second-best value to a global exchange buffer, stamped with the
+// round number; the resolving wave of EVERY workgroup reads all W x 64 row results, folds the W results of row l into one "super row"
+// (best key of the W; second best = the largest of their second-bests and of the losing bests) and walks the 64 super rows exactly as
+// fps_rounds_kernel does -- the same inputs and the same code in every workgroup, hence the same picks, no broadcast needed.  Any
+// partition of the points into rows gives the exact chain (see fps_rounds_kernel), so the result is the oracle's, ties included.
+// Exchange: five 64-bit device-scope atomic stores per row and round (one cache line per row result), every unit stamped with the
+// round; the readers spin until all units of an entry carry the stamp.  All W workgroups of a cloud must be resident together: the host launches at most 64 workgroups of 1024 threads (a quarter of
+// the CUs), and a reader that spins 2^22 times without seeing its partners sets an error flag and lets the kernel end (wrong samples,
+// no hang).
+template <int D, int PPT, int NT, int W>
+__global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out,
+                                                              fps_u64* __restrict__ xch /* [B][2][W][64][8] zero on entry */, int* __restrict__ err) {
+  static_assert(PPT % 2 == 0 && NT == 1024, "16 waves, points in pairs");
+  constexpr int NR = NT / 16;  // 64 rows per workgroup = one resolver lane per super row
+  constexpr int NP = PPT / 2;
+  constexpr int kMaxPick = 32;
+  using K = Key<float>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cen = reinterpret_cast<float*>(smem);                      // [kMaxPick][8]: (x,x,y,y,z,z,-,-) per pick, two halves
+  int* npick = reinterpret_cast<int*>(smem + kMaxPick * 32);        // [2] + dead flag
+  int* sout = reinterpret_cast<int*>(smem + kMaxPick * 32 + 16);    // [M] (workgroup 0 of the cloud writes it out)
+  const int b = blockIdx.x / W, w = blockIdx.x % W;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const float* p = pts + (size_t)b * N * D;
+  int64_t* o = out + (size_t)b * M;
+  fps_u64* xb = xch + (size_t)b * 2 * W * NR * 8;
+
+  const int pj = (tid & 15) * NR + (tid >> 4);  // as in fps_rounds_kernel: consecutive indices sit in different rows (and workgroups)
+  f32x2 px[NP], py[NP], pz[NP], md[NP];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int j = i * (W * NT) + pj * W + w;
+    float x = 0.f, y = 0.f, z = 0.f, m = -2.f;
+    if (j < N) {
+      x = p[(size_t)j * D + 0];
+      y = p[(size_t)j * D + 1];
+      z = D == 3 ? p[(size_t)j * D + 2] : 0.f;
+      m = INFINITY;
+    }
+    px[i >> 1][i & 1] = x;
+    py[i >> 1][i & 1] = y;
+    pz[i >> 1][i & 1] = z;
+    md[i >> 1][i & 1] = m;
+  }
+  if (tid == 0) {
+    sout[0] = 0;
+    cen[0] = cen[1] = p[0];
+    cen[2] = cen[3] = p[1];
+    cen[4] = cen[5] = D == 3 ? p[2] : 0.f;
+    npick[0] = 1;
+    npick[2] = 0;
+  }
+  __syncthreads();
+
+  int it = 1, par = 0, rounds_done = 0;
+  while (it < M) {
+    ++rounds_done;
+    // ---- A. apply the picks of the last round
+    const int nc = npick[par];
+    const f32x2* cenv = reinterpret_cast<const f32x2*>(cen) + par * (kMaxPick / 2) * 4;
+    for (int c = 0; c < nc; ++c) {
+      const f32x2 c2x = cenv[c * 4 + 0], c2y = cenv[c * 4 + 1], c2z = cenv[c * 4 + 2];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const f32x2 dx = px[i] - c2x, dy = py[i] - c2y;
+        f32x2 d = dx * dx + dy * dy;
+        if (D == 3) {
+          const f32x2 dz = pz[i] - c2z;
+          d = d + dz * dz;
+        }
+        f32x2 m = md[i];
+        m[0] = fminf(m[0], d[0]);
+        m[1] = fminf(m[1], d[1]);
+        md[i] = m;
+      }
+    }
+    // ---- B. this lane's best (value, first slot) and second-best value
+    float m1 = -3.f, m2 = -3.f;
+    int bi = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float x = md[i >> 1][i & 1];
+      m2 = __builtin_amdgcn_fmed3f(m1, m2, x);
+      if (x > m1) {
+        m1 = x;
+        bi = i;
+      }
+    }
+    // ---- C. row best key and second-best value; the row's winning lane publishes them with its point's coordinates
+    K k = m1 >= 0.f ? K::make(m1, bi * (W * NT) + pj * W + w) : K::none();
+    const K mine = k;
+    key_max_row<K, 16>(k);
+    const bool winner = (mine.hi == k.hi) && (mine.lo == k.lo) && (m1 >= 0.f);
+    float sec = winner ? m2 : m1;
+    sec = fmax_dpp<kDppXor1>(sec);
+    sec = fmax_dpp<kDppXor2>(sec);
+    sec = fmax_dpp<kDppHalfMirror>(sec);
+    sec = fmax_dpp<kDppMirror>(sec);
+    const unsigned stamp = (unsigned)rounds_done;
+    fps_u64* mine_x = xb + (((size_t)(rounds_done & 1) * W + w) * NR + (tid >> 4)) * 8;  // one 64-byte line per row result
+    const bool empty_row = k.hi == 0u && k.lo == 0u;  // no candidate in this row at all: its first lane publishes "none"
+    if (winner || (empty_row && (lane & 15) == 0)) {
+      float wx = 0.f, wy = 0.f, wz = 0.f;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i)
+        if (i == bi) {
+          wx = px[i >> 1][i & 1];
+          wy = py[i >> 1][i & 1];
+          wz = pz[i >> 1][i & 1];
+        }
+      // units: (value bits | ~index low 17 + stamp low 15), then (payload, stamp) x 4: indices fit 16 bits (N <= 65536), bit 16 of
+      // ~index is set for every real key and tells it from "none" even at value 0, index 65535
+      store_device(mine_x + 0, k.hi, (k.lo & 0x1ffffu) | (stamp << 17));
+      store_device(mine_x + 1, __float_as_uint(sec), stamp);
+      store_device(mine_x + 2, __float_as_uint(wx), stamp);
+      store_device(mine_x + 3, __float_as_uint(wy), stamp);
+      store_device(mine_x + 4, __float_as_uint(wz), stamp);
+    }
+    __syncthreads();  // (every lane's stores have been issued; the release below is the readers' spin on the stamps)
+    // ---- D. wave 0 of EVERY workgroup: read all W x NR row results, fold them into NR super rows, walk those
+    if (wave == 0) {
+      unsigned hi = 0u, lo = 0u;
+      float second = -3.f, x = 0.f, y = 0.f, z = 0.f;
+      bool dead = false;
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) {
+        const fps_u64* src = xb + (((size_t)(rounds_done & 1) * W + ww) * NR + lane) * 8;
+        fps_u64 u0, u1, u2, u3, u4;
+        int spin = 0;
+        bool ok;
+        do {
+          u0 = load_device(src + 0);
+          u1 = load_device(src + 1);
+          u2 = load_device(src + 2);
+          u3 = load_device(src + 3);
+          u4 = load_device(src + 4);
+          ok = (unsigned)(u0 >> 49) == (stamp & 0x7fffu) && (unsigned)(u1 >> 32) == stamp && (unsigned)(u2 >> 32) == stamp &&
+               (unsigned)(u3 >> 32) == stamp && (unsigned)(u4 >> 32) == stamp;
+        } while (!ok && ++spin < (1 << 22));
+        dead = dead || !ok;
+        const bool none = ((unsigned)(u0 >> 32) & 0x1ffffu) == 0u;  // K::none()
+        uint4 e0, e1;
+        e0.x = (unsigned)u0;
+        e0.y = none ? 0u : (0xffff0000u | ((unsigned)(u0 >> 32) & 0xffffu));  // ~index of an index below 65536
+        e0.z = (unsigned)u1;
+        e1.x = (unsigned)u2;
+        e1.y = (unsigned)u3;
+        e1.z = (unsigned)u4;
+        const float s2 = __uint_as_float(e0.z);
+        const bool better = e0.x > hi || (e0.x == hi && e0.y > lo);
+        // the loser of the two bests is one more "not a row winner" value
+        const float loser = better ? __uint_as_float(hi) : __uint_as_float(e0.x);
+        const bool loser_valid = better ? (hi | lo) != 0u : (e0.x | e0.y) != 0u;
+        second = fmaxf(second, s2);
+        if (loser_valid) second = fmaxf(second, loser);
+        if (better) {
+          hi = e0.x;
+          lo = e0.y;
+          x = __uint_as_float(e1.x);
+          y = __uint_as_float(e1.y);
+          z = __uint_as_float(e1.z);
+        }
+      }
+      if (__ballot(dead)) {
+        if (lane == 0) {
+          npick[2] = 1;
+          if (err) *err = 1;
+        }
+      }
+      const float v = __uint_as_float(hi);
+      const bool valid = (hi | lo) != 0u;
+      float bound = second;
+      bound = fmax_dpp<kDppXor1>(bound);
+      bound = fmax_dpp<kDppXor2>(bound);
+      bound = fmax_dpp<kDppHalfMirror>(bound);
+      bound = fmax_dpp<kDppMirror>(bound);
+      bound = fmax_dpp<kDppBcast15, 0xA>(bound);
+      bound = fmax_dpp<kDppBcast31, 0xC>(bound);
+      bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), 63));
+      float vm = valid ? v : -3.f;
+      vm = fmax_dpp<kDppXor1>(vm);
+      vm = fmax_dpp<kDppXor2>(vm);
+      vm = fmax_dpp<kDppHalfMirror>(vm);
+      vm = fmax_dpp<kDppMirror>(vm);
+      vm = fmax_dpp<kDppBcast15, 0xA>(vm);
+      vm = fmax_dpp<kDppBcast31, 0xC>(vm);
+      vm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vm), 63));
+      const unsigned long long tops = __ballot(valid && v == vm);
+      bool is_best = valid && v == vm;
+      if (tops & (tops - 1)) {
+        K g{hi, lo};
+        key_max_wave_to_lane63(g);
+        const K gbest = g.lane(63);
+        is_best = valid && hi == gbest.hi && lo == gbest.lo;
+      }
+      const bool elig = valid && (v > bound || is_best);
+      const unsigned long long em = __ballot(elig);
+      const int cidx = (int)~lo;
+      int rank = 0;
+      bool hit = false;
+      for (unsigned long long mm = em; mm != 0; mm &= mm - 1) {
+        const int j = __ffsll((long long)mm) - 1;
+        const unsigned jh = (unsigned)__builtin_amdgcn_readlane((int)hi, j), jl = (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+        const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j));
+        const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), j));
+        const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), j));
+        const bool before = jh > hi || (jh == hi && jl > lo);
+        const float d = D == 3 ? dist2_3(x, y, z, jx, jy, jz) : dist2_2(x, y, jx, jy);
+        rank += before ? 1 : 0;
+        hit = hit || (before && d < v);
+      }
+      int L = elig && hit ? rank : 0x7fffffff;
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor1, 0xF, 0xF, false));
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor2, 0xF, 0xF, false));
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppHalfMirror, 0xF, 0xF, false));
+      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppMirror, 0xF, 0xF, false));
+      L = min(min(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 16)), min(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 48)));
+      L = min(min(L, (int)__popcll(em)), min(kMaxPick / 2, M - it));
+      if (elig && rank < L) {
+        float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + rank) * 8;
+        *reinterpret_cast<float4*>(cdst) = make_float4(x, x, y, y);
+        *reinterpret_cast<f32x2*>(cdst + 4) = f32x2{z, z};
+        if (w == 0) sout[it + rank] = cidx;
+      }
+      if (lane == 0) npick[par ^ 1] = max(L, 1);
+    }
+    __syncthreads();
+    if (npick[2]) break;  // a partner workgroup never showed up (see above): end instead of hanging
+    par ^= 1;
+    it += npick[par];
+  }
+  __syncthreads();
+  if (w == 0)
+    for (int i = tid; i < M; i += NT) o[i] = sout[i];
+}
+
+template <int D, int PPT, int W>
+int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+  const size_t lds = 32 * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
+  if (lds > 150 * 1024 || B * W > 64) return MVP_EUNSUPPORTED;  // (64: two such launches on two streams still fit the chip together)
+  const size_t xbytes = (size_t)B * 2 * W * 64 * 8 * sizeof(fps_u64) + 16;
+  char* scratch = nullptr;  // stream-ordered scratch owned by this call (as launch_global): exchange buffer + error flag
+  if (hipMallocAsync(reinterpret_cast<void**>(&scratch), xbytes, s) != hipSuccess || !scratch) {
+    (void)hipGetLastError();
+    return MVP_EINVAL;
+  }
+  if (hipMemsetAsync(scratch, 0, xbytes, s) != hipSuccess) return MVP_EINVAL;
+  auto k = fps_rounds_multi_kernel<D, PPT, 1024, W>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)(B * W)), dim3(1024), lds, s, pts, (int)N, (int)M, out, reinterpret_cast<fps_u64*>(scratch),
+                     reinterpret_cast<int*>(scratch + xbytes - 16));
+  const int rc = mvp_launch_status();
+  (void)hipFreeAsync(scratch, s);
+  return rc;
+}
+
 template <typename T, int D, int PPT, int NT>
 int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
   const size_t part_bytes = 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15);  // keys + output buffer
@@ -719,6 +993,19 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int sh
     if (cfg == '2' || (cfg == '0' && shape == 1 && B >= 8)) return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s);
     if (cfg == '5') return launch_cfg<T, D, 16, 512>(pts, B, N, M, out, s);
     return launch_cfg<T, D, 8, 1024>(pts, B, N, M, out, s);
+  }
+  // 8193..65536 points: rounds across 4 workgroups per cloud (fps_rounds_multi_kernel) while all of them are resident together
+  // (B <= 16); MVP_FPS_MULTI=0 keeps the one-sample kernels
+  static const bool multi = []() { const char* e = getenv("MVP_FPS_MULTI"); return !(e && e[0] == '0'); }();
+  if constexpr (std::is_same<T, float>::value) {
+    if (rounds && multi && M > 1 && N <= 65536) {
+      int rc = MVP_EUNSUPPORTED;
+      static const int force16 = []() { const char* e = getenv("MVP_FPS_MULTI_PPT16"); return e ? atoi(e) : 0; }();  // (tools/exp)
+      if (N <= 16384 && !force16) rc = launch_rounds_multi<D, 4, 4>(pts, B, N, M, out, s);
+      else if (N <= 32768 && !force16) rc = launch_rounds_multi<D, 8, 4>(pts, B, N, M, out, s);
+      else rc = launch_rounds_multi<D, 16, 4>(pts, B, N, M, out, s);
+      if (rc != MVP_EUNSUPPORTED) return rc;
+    }
   }
   if (N <= 16384) return launch_cfg<T, D, 16, 1024>(pts, B, N, M, out, s);
   if (N <= 32768) return launch_cfg<T, D, 32, 1024>(pts, B, N, M, out, s);

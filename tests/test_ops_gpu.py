@@ -1542,3 +1542,33 @@ def test_weight_gradient_through_the_workspace_is_reproducible_and_equals_the_at
     # a workspace that is too small falls back to the atomics path (same result up to the order of the additions)
     small = run(torch.empty(1000, device=dev))
     np.testing.assert_allclose(small.cpu().numpy(), atom.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize('B,N,M,D', [(2, 32768, 8192, 3), (16, 9000, 700, 3), (5, 20000, 1000, 2), (1, 65536, 1500, 3), (3, 16384, 16384 // 8, 3)])
+def test_fps_rounds_across_workgroups(dev, B, N, M, D):
+    """Clouds of 8193..65536 points: four workgroups per cloud run the round protocol together and exchange their row results through
+    device-scope atomics (fps_rounds_multi_kernel) -- the dense configuration's 32768 -> 8192 level at full size among the cases.  Same
+    indices as the oracle; the same again while the split-bf16 MLP kernels keep the rest of the chip busy (the exchange must not
+    depend on when a partner workgroup gets to run); and as the one-sample kernels (MVP_FPS_MULTI=0 is the library's A/B switch, read
+    once per process, so that comparison lives in tools/exp/fps_multi_time.py)."""
+    from mvpnet_amd import ops, _lib as L
+    rs = np.random.RandomState(N + M)
+    pts_h = rs.rand(B, N, D).astype(np.float32)
+    pts_h[0, N // 3:N // 3 + 50] = pts_h[0, 7]  # duplicated points: ties at distance 0 late in the chain
+    pts = g(pts_h, dev)
+    exp = O().fps(pts_h[:2], M)
+    idx = ops.farthest_point_sample(pts, M, transpose=False)
+    np.testing.assert_array_equal(idx[:2].cpu().numpy(), exp)
+    x = torch.randn(786432, 64, device=dev)
+    w = torch.randn(64, 64, device=dev) * 0.1
+    y = torch.empty(786432, 64, device=dev)
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            again = ops.farthest_point_sample(pts, M, transpose=False)
+        for _ in range(12):
+            L.call('mvp_mlp_forward_f32', x, L.ptr(x), 786432, 64, 64, L.ptr(w), 64, 64, None, None, None, None, None, L.ptr(y), None, None)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(again, idx)
