@@ -175,10 +175,14 @@ class _SegLossFn(torch.autograd.Function):
         logit, label, weight, acc = ctx.saved_tensors
         B, C, N = logit.shape
         g = grad_out.contiguous().to(torch.float32)
-        grad = torch.empty((B, C, N), dtype=torch.float32, device=logit.device)
         sb, sc, sn = logit.stride()
+        # the gradient in the logits' own layout: PN2SSG hands out a transposed VIEW of its (B,N,classes) rows, and a gradient with the
+        # same strides flows back into the row kernels without a transposing copy (a (B,C,N)-contiguous logit gets a contiguous gradient)
+        dense = sorted((sb, sc, sn), reverse=True) in ([C * N, N, 1], [N * C, C, 1])
+        grad = torch.empty_strided((B, C, N), (sb, sc, sn) if dense else (C * N, N, 1), dtype=torch.float32, device=logit.device)
+        gb, gc, gn = grad.stride()
         L.call('mvp_seg_loss_backward_f32', logit, L.ptr(logit), B, C, N, sb, sc, sn, L.ptr(label), L.ptr(weight), ctx.ignore_index,
-               L.ptr(acc), L.ptr(g), L.ptr(grad), C * N, N, 1)
+               L.ptr(acc), L.ptr(g), L.ptr(grad), gb, gc, gn)
         return grad, None, None, None
 
 

@@ -406,7 +406,9 @@ class PN2SSG(nn.Module):
                     geometry=None if plan is None else plan['fp'][level])
         x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
         logit = R.linear_rows(x, self.seg_logit.weight, self.seg_logit.bias)  # (B*N, classes)
-        return {'seg_logit': logit.view(B, N, self.num_classes).transpose(1, 2).contiguous()}
+        # (B,classes,N) as the reference returns it -- as a transposed VIEW of the rows: the loss and the vote kernels take strided logits,
+        # the gradient comes back in the same layout (mvpnet3d._SegLossFn), so neither direction pays a transposing copy
+        return {'seg_logit': logit.view(B, N, self.num_classes).transpose(1, 2)}
 
     def reset_parameters(self):
         for m in self.modules():
