@@ -33,6 +33,11 @@ struct StreamArgs {
   const float* bias;
   float* Y;
   double* partial;  // (workgroups, 2, Cout) or nullptr
+  // the other way out for the statistics: every (persistent, so few) workgroup adds its sums to `stat` itself and the last one to finish
+  // (ticket = the extra element behind the 2*Cout sums, zero on entry and on exit) finalizes the BatchNorm: no launch behind the kernel
+  double* stat;
+  int finalize;
+  BnFinalize fin;
   int64_t tiles_per_wg;
   // POOL: every 32-row tile is one group (ball) of K = 32 neighbours; instead of Y the kernel leaves, per group and column, the
   // largest and the smallest PRE-BatchNorm value and the (first) row that attains each
@@ -250,6 +255,49 @@ __global__ __launch_bounds__(kST) void mlp_stream_fwd_kernel(StreamArgs p) {
         p.partial[((size_t)blockIdx.x * 2 + 0) * Cout + col] = sred[0][0][col] + sred[0][1][col] + sred[0][2][col] + sred[0][3][col];
         p.partial[((size_t)blockIdx.x * 2 + 1) * Cout + col] = sred[1][0][col] + sred[1][1][col] + sred[1][2][col] + sred[1][3][col];
       }
+  } else if (p.stat) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float s = ssum[j] + __shfl_xor(ssum[j], 32, kWave), q = qsum[j] + __shfl_xor(qsum[j], 32, kWave);
+      if (lane < 32) {
+        sred[0][wave][32 * j + li] = (double)s;
+        sred[1][wave][32 * j + li] = (double)q;
+      }
+    }
+    __syncthreads();
+    for (int col = tid; col < kCols; col += kST)
+      if (col < Cout) {
+        atomicAdd(p.stat + col, sred[0][0][col] + sred[0][1][col] + sred[0][2][col] + sred[0][3][col]);
+        atomicAdd(p.stat + Cout + col, sred[1][0][col] + sred[1][1][col] + sred[1][2][col] + sred[1][3][col]);
+      }
+    if (p.finalize) {  // as stats_reduce_finalize_kernel: completion wait, ticket, the last workgroup finalizes
+      __shared__ unsigned last;
+      wait_vm_complete();
+      __syncthreads();
+      unsigned* ticket = reinterpret_cast<unsigned*>(p.stat + 2 * Cout);
+      if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+      __syncthreads();
+      if (!last) return;
+      const BnFinalize& fin = p.fin;
+      for (int c = tid; c < Cout; c += kST) {
+        const double s1 = __hip_atomic_load(p.stat + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double s2 = __hip_atomic_load(p.stat + Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double m = s1 / (double)fin.rows;
+        double var = s2 / (double)fin.rows - m * m;
+        if (var < 0.0) var = 0.0;
+        fin.mean[c] = (float)m;
+        fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
+        if (fin.running_mean) {
+          const double unbiased = fin.rows > 1 ? var * ((double)fin.rows / (double)(fin.rows - 1)) : var;
+          fin.running_mean[c] = (float)((1.0 - fin.momentum) * (double)fin.running_mean[c] + fin.momentum * m);
+          fin.running_var[c] = (float)((1.0 - fin.momentum) * (double)fin.running_var[c] + fin.momentum * unbiased);
+        }
+      }
+      if (tid == 0) {
+        if (fin.num_batches_tracked) *fin.num_batches_tracked += 1;
+        *ticket = 0u;
+      }
+    }
   }
 }
 
@@ -280,7 +328,11 @@ int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const fl
   if (ns == 0 || Cin > 128 || Cout > 128 || Cin < 4 || Cout % 4 != 0 || R < 32768 || (stat && !partial)) return MVP_EUNSUPPORTED;
   if (ldx % 4 != 0 || Cin % 4 != 0 || ((uintptr_t)X % 16) != 0 || (!ymax && ((uintptr_t)Y % 16) != 0)) return MVP_EUNSUPPORTED;
   if (ymax && R % 32 != 0) return MVP_EUNSUPPORTED;
-  StreamArgs a{X, R, Cin, ldx, W, ldw, Cout, act, bias, Y, stat ? partial : nullptr, 0, ymax, ymin, amax, amin};
+  // statistics: added to `stat` by the (<= 1024) workgroups themselves, finalized by the last of them (default), or through the partial
+  // slots + a reduction launch (MVP_STREAM_TAIL=0)
+  static const bool tail = []() { const char* e = getenv("MVP_STREAM_TAIL"); return !(e && e[0] == '0'); }();
+  StreamArgs a{X, R, Cin, ldx, W, ldw, Cout, act, bias, Y, (stat && !tail) ? partial : nullptr, (stat && tail) ? stat : nullptr, bn_mean ? 1 : 0,
+               BnFinalize{R, bn_eps, bn_momentum, bn_mean, bn_invstd, bn_running_mean, bn_running_var, bn_num_batches}, 0, ymax, ymin, amax, amin};
   const int64_t ntiles = cdiv(R, 32);
   const int ks = (int)cdiv(Cin, 32), nb = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
   // persistent workgroups: enough to fill the chip at the occupancy the weight image allows, at least 16 tiles each
