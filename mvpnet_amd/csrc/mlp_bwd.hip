@@ -50,6 +50,7 @@ struct BwdArgs {
   int lddw;
   float* dZ;             // (R, Cp) or nullptr
   double* partial;       // (workgroups, 2 Cp) column sums of dz_{i-1} and dz_{i-1} * xhat_{i-1}; nullptr without act
+  double* stat_direct;   // or: the (<= 1024 x slices, persistent) workgroups add their sums to stat_prev themselves (fp64 atomics), no reduction launch
   int64_t R;
   int C, Cp;
   int64_t tiles_per_wg;
@@ -396,8 +397,8 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
     }
   }
 
-  // ---- column sums: lane halves -> waves -> this workgroup's slot
-  if (p.partial) {
+  // ---- column sums: lane halves -> waves -> this workgroup's slot (or straight into stat_prev)
+  if (p.partial || p.stat_direct) {
 #pragma unroll
     for (int b = 0; b < CPB; ++b) {
       const float s = ssum[b] + __shfl_xor(ssum[b], 32, kWave), tq = tsum[b] + __shfl_xor(tsum[b], 32, kWave);
@@ -413,6 +414,12 @@ __global__ __launch_bounds__(kBT) void mlp_bwd_layer_kernel(BwdArgs p) {
       if (col < Cp) {
         p.partial[((size_t)blockIdx.x * 2 + 0) * p.Cp + ci0 + col] = sred[0][0][col] + sred[0][1][col] + sred[0][2][col] + sred[0][3][col];
         p.partial[((size_t)blockIdx.x * 2 + 1) * p.Cp + ci0 + col] = sred[1][0][col] + sred[1][1][col] + sred[1][2][col] + sred[1][3][col];
+      }
+  } else if (p.stat_direct) {
+    for (int col = tid; col < CPB * 32; col += kBT)
+      if (col < Cp) {
+        atomicAdd(p.stat_direct + ci0 + col, sred[0][0][col] + sred[0][1][col] + sred[0][2][col] + sred[0][3][col]);
+        atomicAdd(p.stat_direct + p.Cp + ci0 + col, sred[1][0][col] + sred[1][1][col] + sred[1][2][col] + sred[1][3][col]);
       }
   }
   // ---- dW: 4 partial tiles -> 1 (two rounds through LDS), one atomic per element and workgroup
@@ -539,7 +546,9 @@ int layer_backward_impl(const float* G, const float* Yi, const float* mean_i, co
   a.X = X; a.ldx = (int)ldx;
   a.act = InAct{act_mean, act_invstd, act_gamma, act_beta};
   a.W = W; a.ldw = (int)ldw; a.dW = dW; a.lddw = (int)lddw; a.dZ = dZ;
-  a.partial = (dZ && act_mean) ? partial : nullptr;
+  static const bool direct = []() { const char* e = getenv("MVP_STREAM_TAIL"); return !(e && e[0] == '0'); }();  // (same A/B switch as mlp_stream.hip)
+  a.partial = (dZ && act_mean && !direct) ? partial : nullptr;
+  a.stat_direct = (dZ && act_mean && direct) ? stat_prev : nullptr;
   a.R = R; a.C = (int)C; a.Cp = (int)Cp;
   a.pool_dout = pool_dout; a.pool_out = pool_out; a.pool_arg = pool_arg;
   const int64_t ntiles = cdiv(R, 32);
