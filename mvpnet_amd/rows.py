@@ -21,6 +21,9 @@ from . import _lib as L
 # variants run at one wave per SIMD and re-read dy_i per c_in slice -- tuning knob, default from the measurements.
 FUSE_BWD_MAX_COUT = int(os.environ.get('MVP_BWD_FUSE_MAXC', '64'))
 FUSE_BWD_MAX_CIN = int(os.environ.get('MVP_BWD_FUSE_MAXCIN', '96'))
+# Column statistics of the tile kernels: below this many rows (R / 128 workgroups) the workgroups add into `stat` with fp64 atomics, from it on
+# through per-tile slots + a reduction launch (atomics queue per address: ~10 ns each)
+PARTIAL_MIN_ROWS = int(os.environ.get('MVP_PARTIAL_MIN_ROWS', '65536'))
 # Set-abstraction levels (K = 32 neighbours, max pooling): run the LAST shared-MLP layer without ever storing its (B*M*32, C) output --
 # forward leaves per-ball max / min of the pre-BN values (mvp_mlp_forward_pool_f32), backward re-computes the layer from its input inside
 # the one-kernel layer backward (POOL front end).  Needs C_out, C_in <= 64 and >= 32768 rows (levels 1 and, with 64-wide MLPs, 2).
@@ -649,7 +652,7 @@ def bn_act_rows(y, bn, relu=True, K=1):
 
 def _partial(R, cols, device):
     """Scratch for the atomics-free statistics reduction of the MFMA kernels (ceil(R/128) x 2 x cols float64)."""
-    if R < 65536:
+    if R < PARTIAL_MIN_ROWS:
         return None  # few workgroups: fp64 atomics are cheaper than a second launch
     return torch.empty(((R + 127) // 128) * 2 * cols, dtype=torch.float64, device=device)
 
