@@ -222,10 +222,11 @@ def contraction_info():
     default the products run on the bf16 matrix pipe as a split of each fp32 operand into bf16 pieces."""
     from mvpnet_amd import _lib
     fwd = _lib.get_mlp_precision()
-    bwd = {0: 'fp32', 3: 'bf16x3', 6: 'bf16x6'}.get(_lib.lib().mvp_get_mlp_precision_backward(), '?') if fwd != 'fp32' else 'fp32'
+    bwd = {0: 'fp32', 1: 'bf16', 3: 'bf16x3', 6: 'bf16x6'}.get(_lib.lib().mvp_get_mlp_precision_backward(), '?') if fwd != 'fp32' else 'fp32'
     note = {'fp32': 'fp32 MFMA (v_mfma_f32_32x32x2_f32)',
             'bf16x6': '3 bf16 pieces per fp32 operand, 6 products of order <= 2 on v_mfma_f32_32x32x16_bf16: dropped terms <= 2^-25 |ab| (fp32-equivalent)',
-            'bf16x3': '2 bf16 pieces per operand, 3 products: ~2^-17 relative per product (NARROWER than fp32)'}
+            'bf16x3': '2 bf16 pieces per operand, 3 products: ~2^-17 relative per product (NARROWER than fp32)',
+            'bf16': 'operands rounded to bf16 once, 1 product: ~2^-9 relative per product (bf16-autocast accuracy; OUTSIDE the fp32 parity bar)'}
     return {'storage': 'f32', 'accumulate': 'f32', 'forward': fwd, 'backward': bwd, 'forward_note': note[fwd], 'backward_note': note[bwd]}
 
 
@@ -582,6 +583,29 @@ def main():
             fp32_mfma = {'chunks_per_s_per_gpu': round(args.batch / (ms4 * 1e-3), 1), 'ms_per_step': round(ms4, 3)}
         finally:
             _lib.set_mlp_precision(before)
+    # ... and with PLAIN bf16 operands (one piece, one product: the "bf16" that BASELINE.json's configs[2] names; accuracy of a bf16 autocast with
+    # fp32 accumulation and storage).  OUTSIDE the fp32 parity bar, therefore a side number and never `value`.
+    bf16_contraction = None
+    if side:
+        before = _lib.get_mlp_precision()
+        before_bwd = {1: 'bf16', 3: 'bf16x3', 6: 'bf16x6'}[_lib.lib().mvp_get_mlp_precision_backward()]
+        _lib.set_mlp_precision('bf16')
+        _lib.set_mlp_precision_backward('bf16')
+        try:
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for _ in range(8):
+                eager_step()
+            torch.cuda.synchronize()
+            ms5 = (time.perf_counter() - t5) / 8 * 1e3
+            bf16_contraction = {'chunks_per_s_per_gpu': round(args.batch / (ms5 * 1e-3), 1), 'ms_per_step': round(ms5, 3),
+                                'note': 'MVP_MLP_PRECISION=bf16 MVP_MLP_PRECISION_BWD=bf16: operands of the shared-MLP contractions rounded to bf16 once '
+                                        '(~2^-9 per product), fp32 accumulation and storage; outside the 1e-4 parity bar (opt-in)'}
+        finally:
+            _lib.set_mlp_precision(before)
+            _lib.set_mlp_precision_backward(before_bwd)
     dense = dense_extra(dev) if side else None
 
     if rank == 0:
@@ -600,6 +624,7 @@ def main():
                        'contraction': contraction_info()},
             'parity': parity_info(),
             'fp32_mfma': fp32_mfma,
+            'bf16_contraction': bf16_contraction,
             'dense': dense,
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
             'with_2d_network': e2e,

@@ -104,6 +104,17 @@ int mvp_group_points_backward_strided_f32(const float* grad_out, int64_t sb, int
                                           int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, float* grad_in, mvp_stream_t stream);
 int mvp_group_points_backward_strided_f64(const double* grad_out, int64_t sb, int64_t sc, int64_t sm, int64_t sk, const int64_t* index,
                                           int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, double* grad_in, mvp_stream_t stream);
+/* bfloat16 VALUES (uint16_t = the bf16 bit pattern; SURVEY 8b: "+bf16 for gather/interp/MLP values"): the gather is a copy (bit-exact);
+ * the backward accumulates in fp32 and rounds ONCE to bf16 when the sums are written (clouds whose fp32 sums do not fit the LDS of a
+ * workgroup, N1 > 30720, go through stream-ordered fp32 scratch). */
+int mvp_group_points_forward_bf16(const uint16_t* input, const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K,
+                                  uint16_t* out, mvp_stream_t stream);
+int mvp_group_points_backward_bf16(const uint16_t* grad_out, const int64_t* index, int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K,
+                                   uint16_t* grad_in, mvp_stream_t stream);
+int mvp_group_points_forward_strided_bf16(const uint16_t* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index, int64_t B,
+                                          int64_t C, int64_t N1, int64_t N2, int64_t K, uint16_t* out, mvp_stream_t stream);
+int mvp_group_points_backward_strided_bf16(const uint16_t* grad_out, int64_t sb, int64_t sc, int64_t sm, int64_t sk, const int64_t* index,
+                                           int64_t B, int64_t C, int64_t N1, int64_t N2, int64_t K, uint16_t* grad_in, mvp_stream_t stream);
 
 /* ---- 3-NN with squared distances ------------------------------------------------------
  * replaces knn_distance_cuda.knn_distance (mvpnet/ops/cuda/knn_distance.cpp:8-15,
@@ -145,6 +156,18 @@ int mvp_interpolate_backward_strided_f32(const float* grad_out, int64_t sb, int6
 int mvp_interpolate_backward_strided_f64(const double* grad_out, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,
                                          const double* weight, int64_t B, int64_t C, int64_t N1, int64_t N2, double* grad_in,
                                          mvp_stream_t stream);
+/* bfloat16 VALUES (uint16_t = the bf16 bit pattern), fp32 weights: the fp32 kernel's arithmetic on the widened values,
+ * out = bf16_rn((f0 w0 + f1 w1) + f2 w2); the backward adds g w_k in fp32 and rounds ONCE to bf16 when the sums are written. */
+int mvp_interpolate_forward_bf16(const uint16_t* input, const int64_t* index, const float* weight, int64_t B, int64_t C, int64_t N1,
+                                 int64_t N2, uint16_t* out, mvp_stream_t stream);
+int mvp_interpolate_backward_bf16(const uint16_t* grad_out, const int64_t* index, const float* weight, int64_t B, int64_t C, int64_t N1,
+                                  int64_t N2, uint16_t* grad_in, mvp_stream_t stream);
+int mvp_interpolate_forward_strided_bf16(const uint16_t* input, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,
+                                         const float* weight, int64_t B, int64_t C, int64_t N1, int64_t N2, uint16_t* out,
+                                         mvp_stream_t stream);
+int mvp_interpolate_backward_strided_bf16(const uint16_t* grad_out, int64_t sb, int64_t sc, int64_t sn, const int64_t* index,
+                                          const float* weight, int64_t B, int64_t C, int64_t N1, int64_t N2, uint16_t* grad_in,
+                                          mvp_stream_t stream);
 
 /* ---- 2D -> 3D lifting (NEW on the device; the reference does this in dataloader workers) ----
  * un-projection: replaces depth2xyz + pose + masks of ScanNet2D3DChunks.get_rgbd_data
@@ -338,12 +361,15 @@ int mvp_sa_fused_forward_f32(const float* zf, const float* xyz, const float* cen
  *   terms = 0  fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain);
  *   terms = 6  (the default) split-bf16: every fp32 operand as 3 bf16 pieces, the 6 products of order <= 2 on v_mfma_f32_32x32x16_bf16 with fp32
  *              accumulation -- fp32-level accuracy at 2.67x the fp32-MFMA rate;
- *   terms = 3  2 pieces, 3 products: ~2^-17 relative error per product, 5.3x the rate.
+ *   terms = 3  2 pieces, 3 products: ~2^-17 relative error per product, 5.3x the rate;
+ *   terms = 1  plain bf16 operands (each fp32 operand rounded to bf16 ONCE, one product, fp32 accumulation, fp32 storage): ~2^-9 per
+ *              product -- the accuracy of a bf16 autocast of the convolution; opt-in, OUTSIDE the fp32 parity bar (BASELINE.json's
+ *              configs[2] names bf16; the default stays the fp32-equivalent split).
  * Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Returns MVP_EINVAL for other values. */
 int mvp_set_mlp_precision(int terms, int min_width);
 int mvp_get_mlp_precision(void);
 /* Split of the gradient contractions (dW, input gradient, mvp_mlp_layer_backward_f32) while the forward precision is a split one:
- * terms = 3 (default) or 6. */
+ * terms = 3 (default), 6 or 1. */
 int mvp_set_mlp_precision_backward(int terms);
 int mvp_get_mlp_precision_backward(void);
 /* The two settings above are process-wide DEFAULTS.  mvp_mlp_precision_scope overrides them for the calls the CALLING host thread makes

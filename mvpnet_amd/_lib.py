@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MVP_LIBRARY') or os.path.join(_HERE, 'libmvp_hip.so')  # MVP_LIBRARY: an experiment build of the same ABI (tools/exp)
 _lib = None
-MLP_PRECISIONS = {'fp32': 0, 'bf16x3': 3, 'bf16x6': 6}
+MLP_PRECISIONS = {'fp32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
 
 _i64 = ctypes.c_int64
 _ptr = ctypes.c_void_p
@@ -32,20 +32,28 @@ _SIGNATURES = {
     'mvp_interpolate_forward_strided_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_backward_strided_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_forward_strided_f64': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_forward_strided_bf16': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_backward_strided_f64': [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_backward_strided_bf16': [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_forward_strided_f64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_forward_strided_bf16': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_backward_strided_f64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_backward_strided_bf16': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_forward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_forward_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_forward_bf16': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_backward_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_group_points_backward_bf16': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_knn_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_knn_distance_f64': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_knn3_weights_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr, _ptr, _ptr, _ptr],
     'mvp_interpolate_forward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_forward_f64': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_forward_bf16': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_backward_f64': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_interpolate_backward_bf16': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_unproject_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_unproject_u16': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_pixel_knn_bruteforce_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
@@ -161,8 +169,9 @@ def lib():
 
 def set_mlp_precision(name, min_width=0):
     """Contraction precision of the shared-MLP kernels (mvp_set_mlp_precision): 'fp32' (fp32 MFMA), 'bf16x6' (split-bf16,
-    3 pieces / 6 products, fp32-level accuracy), 'bf16x3' (2 pieces / 3 products, ~2^-17 per product).  Layers narrower than
-    `min_width` channels stay on the fp32 MFMA.  Also settable through MVP_MLP_PRECISION / MVP_MLP_MIN_WIDTH."""
+    3 pieces / 6 products, fp32-level accuracy), 'bf16x3' (2 pieces / 3 products, ~2^-17 per product), 'bf16' (operands rounded to
+    bf16 once, 1 product, ~2^-9 per product: the accuracy of a bf16 autocast with fp32 accumulation and storage -- opt-in, outside the
+    fp32 parity bar).  Layers narrower than `min_width` channels stay on the fp32 MFMA.  Also settable through MVP_MLP_PRECISION / MVP_MLP_MIN_WIDTH."""
     if name not in MLP_PRECISIONS:
         raise ValueError('mlp precision must be one of {}'.format(sorted(MLP_PRECISIONS)))
     check(lib().mvp_set_mlp_precision(MLP_PRECISIONS[name], int(min_width)), 'mvp_set_mlp_precision')
@@ -170,9 +179,9 @@ def set_mlp_precision(name, min_width=0):
 
 def set_mlp_precision_backward(name):
     """Split of the gradient contractions (weight / input gradient, one-kernel layer backward) while the forward runs a split
-    precision: 'bf16x3' (default: 2^-17 per product, invisible next to the ~1 % fp32 noise of these gradients) or 'bf16x6'."""
-    if name not in ('bf16x3', 'bf16x6'):
-        raise ValueError("backward mlp precision must be 'bf16x3' or 'bf16x6'")
+    precision: 'bf16x3' (default: 2^-17 per product, invisible next to the ~1 % fp32 noise of these gradients), 'bf16x6' or 'bf16'."""
+    if name not in ('bf16', 'bf16x3', 'bf16x6'):
+        raise ValueError("backward mlp precision must be 'bf16', 'bf16x3' or 'bf16x6'")
     check(lib().mvp_set_mlp_precision_backward(MLP_PRECISIONS[name]), 'mvp_set_mlp_precision_backward')
 
 
@@ -186,7 +195,7 @@ class mlp_precision:
         self.terms = -1 if forward is None else MLP_PRECISIONS[forward]
         self.bwd = -1 if backward is None else MLP_PRECISIONS[backward]
         if self.bwd == 0:
-            raise ValueError("backward mlp precision must be 'bf16x3' or 'bf16x6'")
+            raise ValueError("backward mlp precision must be 'bf16', 'bf16x3' or 'bf16x6'")
 
     def __enter__(self):
         old = lib().mvp_mlp_precision_scope(self.terms, self.bwd)
@@ -241,6 +250,11 @@ def suffix(t):
     if t.dtype == torch.float64:
         return 'f64'
     raise RuntimeError('expected a float32 or float64 tensor, got {}'.format(t.dtype))
+
+
+def value_suffix(t):
+    """Entry-point suffix of the ops that also exist for bfloat16 VALUES (group_points, interpolate)."""
+    return 'bf16' if t.dtype == torch.bfloat16 else suffix(t)
 
 
 _FN = {}  # entry point name -> bound ctypes function (one dict lookup per launch instead of a getattr on the CDLL)

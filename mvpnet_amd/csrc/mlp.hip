@@ -894,6 +894,7 @@ void launch_mlp(const float* X, int64_t R, int K, int ldx, const float* W, int l
 #define MVP_MLP_BY_NS(BN)                                                                                                          \
   do {                                                                                                                             \
     if (!vec) MVP_MLP_LAUNCH(BN, false, 0);                                                                                        \
+    else if (ns == 1) MVP_MLP_LAUNCH(BN, true, 1);                                                                                 \
     else if (ns == 2) MVP_MLP_LAUNCH(BN, true, 2);                                                                                 \
     else if (ns == 3) MVP_MLP_LAUNCH(BN, true, 3);                                                                                 \
     else MVP_MLP_LAUNCH(BN, true, 0);                                                                                              \
@@ -1071,7 +1072,10 @@ int weight_grad_impl(const float* dY, const float* X, int64_t R, int64_t Cout, i
       float* w = (ws && splits * tiles * (int64_t)(TM * TN) <= ws_floats && splits > 1) ? ws : nullptr;
 #define MVP_DWBF(A_, B_)                                                                                                           \
   do {                                                                                                                             \
-    if (ns == 2)                                                                                                                   \
+    if (ns == 1)                                                                                                                   \
+      hipLaunchKernelGGL((mlp_dw_bf_kernel<A_, B_, 1>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
+                         rows_per_block, dW, (int)lddw, w);                                                                        \
+    else if (ns == 2)                                                                                                              \
       hipLaunchKernelGGL((mlp_dw_bf_kernel<A_, B_, 2>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act,         \
                          rows_per_block, dW, (int)lddw, w);                                                                        \
     else                                                                                                                           \
@@ -1171,10 +1175,11 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
 // Contraction precision of the shared-MLP kernels (forward, input gradient, weight gradient):
 //   terms = 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain);
 //   terms = 6: split-bf16 with 3 pieces per operand and 6 products on v_mfma_f32_32x32x16_bf16 (fp32-level accuracy, 2.67x the rate);
-//   terms = 3: 2 pieces, 3 products (~2^-17 relative per product, 5.3x the rate).
+//   terms = 3: 2 pieces, 3 products (~2^-17 relative per product, 5.3x the rate);
+//   terms = 1: plain bf16 operands, 1 product (~2^-9 per product: bf16-autocast accuracy with fp32 accumulation and storage; opt-in).
 // Layers with max(Cin, Cout) < min_width keep the fp32 MFMA.  Process-wide, not thread-safe against concurrent launches.
 MVP_API int mvp_set_mlp_precision(int terms, int min_width) {
-  MVP_REQUIRE(terms == 0 || terms == 3 || terms == 6);
+  MVP_REQUIRE(terms == 0 || terms == 1 || terms == 3 || terms == 6);
   MVP_REQUIRE(min_width >= 0);
   g_mlp_terms = terms;
   g_mlp_min_width = min_width;
@@ -1185,7 +1190,7 @@ MVP_API int mvp_get_mlp_precision(void) { return mlp_terms(); }
 // split one: terms = 3 (default) or 6.  Gradients through batch-statistics BatchNorm + max pooling carry ~1 % fp32 noise whatever the
 // contraction (profiles/r02_numerics_operating_point.txt); 2^-17 per product is invisible next to it and halves their MFMA + split work.
 MVP_API int mvp_set_mlp_precision_backward(int terms) {
-  MVP_REQUIRE(terms == 3 || terms == 6);
+  MVP_REQUIRE(terms == 1 || terms == 3 || terms == 6);
   g_mlp_terms_bwd = terms;
   return MVP_OK;
 }
@@ -1194,7 +1199,9 @@ MVP_API int mvp_get_mlp_precision_backward(void) { return mlp_terms_bwd(); }
 // else as mvp_set_mlp_precision / _backward).  Returns the previous override packed as (terms + 1) * 16 + (terms_backward + 1): hand its
 // two halves back to restore.  Nothing process-wide is written.
 MVP_API int mvp_mlp_precision_scope(int terms, int terms_backward) {
-  if (!(terms == -1 || terms == 0 || terms == 3 || terms == 6) || !(terms_backward == -1 || terms_backward == 3 || terms_backward == 6)) return MVP_EINVAL;
+  if (!(terms == -1 || terms == 0 || terms == 1 || terms == 3 || terms == 6) ||
+      !(terms_backward == -1 || terms_backward == 1 || terms_backward == 3 || terms_backward == 6))
+    return MVP_EINVAL;
   const int old = (tl_mlp_terms + 1) * 16 + (tl_mlp_terms_bwd + 1);
   tl_mlp_terms = terms;
   tl_mlp_terms_bwd = terms_backward;

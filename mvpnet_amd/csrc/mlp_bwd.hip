@@ -570,12 +570,14 @@ int layer_backward_impl(const float* G, const float* Yi, const float* mean_i, co
   } while (0)
 #define MVP_BWD1(A_, B_, PF_)                                                                                                  \
   do {                                                                                                                   \
-    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, false, PF_>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
+    if (ns == 1) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 1, false, PF_>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
+    else if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, false, PF_>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a); \
     else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, false, PF_>), dim3((unsigned)grid, gy), dim3(kBT), 0, s, a);        \
   } while (0)
 #define MVP_BWD_POOL1(A_, B_, PF_)                                                                                            \
   do {                                                                                                                  \
-    if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a); \
+    if (ns == 1) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 1, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a); \
+    else if (ns == 2) hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 2, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a); \
     else hipLaunchKernelGGL((mlp_bwd_layer_kernel<A_, B_, 3, true, PF_>), dim3((unsigned)grid, 1), dim3(kBT), 0, s, a);        \
   } while (0)
   // cross-tile prefetch costs registers and measured slower on the step (8.77 vs 8.72 ms, tools/exp/README.md): only with

@@ -2,20 +2,20 @@
 #pragma once
 #include "common.h"
 
-extern int g_mlp_terms;      // 0 = fp32 MFMA, 3 = bf16x3, 6 = bf16x6 (mvp_set_mlp_precision, defined in mlp.hip)
-extern int g_mlp_terms_bwd;  // split used by the GRADIENT contractions (dW, input gradient, layer backward) when g_mlp_terms != 0: 3 or 6
+extern int g_mlp_terms;      // 0 = fp32 MFMA, 1 = bf16 (one piece), 3 = bf16x3, 6 = bf16x6 (mvp_set_mlp_precision, defined in mlp.hip)
+extern int g_mlp_terms_bwd;  // split used by the GRADIENT contractions (dW, input gradient, layer backward) when g_mlp_terms != 0: 1, 3 or 6
 extern int g_mlp_min_width;  // layers with max(Cin, Cout) below this stay on the fp32 MFMA
 
 // The process-wide values above are DEFAULTS.  A host thread can override them for the calls it makes with mvp_mlp_precision_scope (a
 // thread-local pair, -1 = no override): several models / threads in one process then never see each other's choice, and nothing global is
 // flipped around a launch.  Every launch site reads the precision through these two functions.
-extern thread_local int tl_mlp_terms;      // -1, 0, 3 or 6
-extern thread_local int tl_mlp_terms_bwd;  // -1, 3 or 6
+extern thread_local int tl_mlp_terms;      // -1, 0, 1, 3 or 6
+extern thread_local int tl_mlp_terms_bwd;  // -1, 1, 3 or 6
 static inline int mlp_terms() { return tl_mlp_terms >= 0 ? tl_mlp_terms : g_mlp_terms; }
 static inline int mlp_terms_bwd() { return tl_mlp_terms_bwd >= 0 ? tl_mlp_terms_bwd : g_mlp_terms_bwd; }
-static inline int mlp_fwd_pieces() { return mlp_terms() == 3 ? 2 : mlp_terms() == 6 ? 3 : 0; }
+static inline int mlp_fwd_pieces() { return mlp_terms() == 1 ? 1 : mlp_terms() == 3 ? 2 : mlp_terms() == 6 ? 3 : 0; }
 // pieces per operand of the backward contractions: 0 (fp32 MFMA) when the forward runs fp32, else from the backward setting
-static inline int mlp_bwd_pieces() { return mlp_terms() == 0 ? 0 : (mlp_terms_bwd() == 6 ? 3 : 2); }
+static inline int mlp_bwd_pieces() { return mlp_terms() == 0 ? 0 : (mlp_terms_bwd() == 6 ? 3 : mlp_terms_bwd() == 1 ? 1 : 2); }
 
 namespace {
 
@@ -37,7 +37,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //   x = x0 + x1 (+ x2),  x0 = bf16_rn(x), x1 = bf16_rn(x - x0), x2 = bf16_rn(x - x0 - x1)   (the residuals are exact in fp32)
 //   NS = 3 pieces (24 significant bits: x is represented EXACTLY up to ~2^-26) and the six products of total order <= 2
 //        a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 -> dropped terms <= 2^-25 |ab|: the error of one fp32 rounding ("bf16x6", 2.67x);
-//   NS = 2 pieces and the three products a0b0 + a0b1 + a1b0 -> relative error ~2^-17 per product, unbiased ("bf16x3", 5.3x).
+//   NS = 2 pieces and the three products a0b0 + a0b1 + a1b0 -> relative error ~2^-17 per product, unbiased ("bf16x3", 5.3x);
+//   NS = 1: no split -- each operand rounded to bf16 once, the one product a0b0 (~2^-9 per product: what a bf16 autocast of the conv
+//        computes, with fp32 accumulation and fp32 storage kept; "bf16", opt-in, 16x the fp32-MFMA rate and no split arithmetic).
 // Products of bf16 pairs are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; small terms are accumulated first.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned pack_bf16(float x, float y) {  // v_cvt_pk_bf16_f32: low half = rn(x), high half = rn(y)
@@ -47,6 +49,7 @@ __device__ __forceinline__ unsigned pack_bf16(float x, float y) {  // v_cvt_pk_b
 template <int NS>
 __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NS]) {
   pc[0] = pack_bf16(x, y);
+  if constexpr (NS == 1) return;
   float rx = x - __uint_as_float(pc[0] << 16), ry = y - __uint_as_float(pc[0] & 0xffff0000u);
   pc[1] = pack_bf16(rx, ry);
   if constexpr (NS == 3) {
@@ -57,6 +60,7 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pc)[NS])
 }
 // the products to accumulate, smallest first: (piece of A, piece of B)
 template <int NS> struct SplitPairs;
+template <> struct SplitPairs<1> { static constexpr int N = 1; static constexpr int A[1] = {0}; static constexpr int B[1] = {0}; };
 template <> struct SplitPairs<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
 template <> struct SplitPairs<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
 

@@ -345,7 +345,8 @@ int mvp_mlp_stream_forward(const float* X, int64_t R, int Cin, int ldx, const fl
   const bool has_act = act.mean != nullptr;
 #define MVP_STREAM(KS_, NB_)                                                      \
   do {                                                                            \
-    if (ns == 2) launch_stream<KS_, NB_, 2>(a, grid, has_act, s);                  \
+    if (ns == 1) launch_stream<KS_, NB_, 1>(a, grid, has_act, s);                  \
+    else if (ns == 2) launch_stream<KS_, NB_, 2>(a, grid, has_act, s);             \
     else launch_stream<KS_, NB_, 3>(a, grid, has_act, s);                          \
   } while (0)
 #define MVP_STREAM_NB(KS_)                       \

@@ -282,7 +282,8 @@ MVP_API int mvp_sa_fused_forward_f32(const float* zf, const float* xyz, const fl
   const int A = up(c1b), Bk = up(c2b), Ck = up(c3b);
 #define MVP_SA(A_, B_, C_)                                                                                       \
   do {                                                                                                           \
-    if (ns == 2) hipLaunchKernelGGL((sa_fused_fwd_kernel<A_, B_, C_, 2>), dim3(grid), dim3(kFT), 0, s, a);         \
+    if (ns == 1) hipLaunchKernelGGL((sa_fused_fwd_kernel<A_, B_, C_, 1>), dim3(grid), dim3(kFT), 0, s, a);         \
+    else if (ns == 2) hipLaunchKernelGGL((sa_fused_fwd_kernel<A_, B_, C_, 2>), dim3(grid), dim3(kFT), 0, s, a);    \
     else hipLaunchKernelGGL((sa_fused_fwd_kernel<A_, B_, C_, 3>), dim3(grid), dim3(kFT), 0, s, a);                 \
   } while (0)
   const int key = A * 100 + Bk * 10 + Ck;

@@ -100,3 +100,6 @@ def test_thread_local_precision_scope():
         assert lib.mvp_get_mlp_precision() == 0
     assert seen['other'] == default and lib.mvp_get_mlp_precision() == default
     assert lib.mvp_mlp_precision_scope(5, -1) == -1  # MVP_EINVAL
+    with L.mlp_precision('bf16', backward='bf16'):  # plain bf16 operands, one product (opt-in)
+        assert lib.mvp_get_mlp_precision() == 1 and lib.mvp_get_mlp_precision_backward() == 1
+    assert lib.mvp_get_mlp_precision() == default

@@ -650,9 +650,10 @@ def test_bn_act_rows_vs_torch(dev, K, relu, train, C):
 
 
 # ------------------------------------------------------------------ fp32-MFMA shared-MLP kernels
-@pytest.fixture(params=['fp32', 'bf16x6', 'bf16x3'])
+@pytest.fixture(params=['fp32', 'bf16x6', 'bf16x3', 'bf16'])
 def mlp_precision(request):
-    """fp32 MFMA / split-bf16 with 6 products (fp32-level accuracy) / split-bf16 with 3 products (mvp_set_mlp_precision)"""
+    """fp32 MFMA / split-bf16 with 6 products (fp32-level accuracy) / split-bf16 with 3 products / plain bf16 operands, 1 product
+    (mvp_set_mlp_precision)"""
     from mvpnet_amd import _lib as L
     before = L.get_mlp_precision()
     L.set_mlp_precision(request.param)
@@ -670,9 +671,10 @@ def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout, mlp_precision):
     """mvp_mlp_forward / weight_grad / input_grad vs a float64 torch matmul on awkward shapes -- rows not a multiple of 128, K not a
     multiple of 32, padded leading dimension, Cout not a multiple of 32 -- and on shapes large enough for the 128-column tiles,
     many row tiles, the scratch-slot statistics and the row-split weight gradient; in all three contraction precisions.
-    bf16x6 is held to the SAME tolerance as the fp32 MFMA (it is an fp32-accurate contraction), bf16x3 to 2^-17 per product."""
+    bf16x6 is held to the SAME tolerance as the fp32 MFMA (it is an fp32-accurate contraction), bf16x3 to 2^-17 per product, the opt-in
+    plain-bf16 mode to 2^-9 per product (its exact semantics: test_plain_bf16_contraction_is_the_product_of_the_rounded_operands)."""
     from mvpnet_amd import _lib as L
-    loose = 16.0 if mlp_precision == 'bf16x3' else 1.0
+    loose = {'bf16x3': 16.0, 'bf16': 4096.0}.get(mlp_precision, 1.0)
     torch.manual_seed(R + Cin)
     x = torch.randn(R, ldx, device=dev)
     x[:, Cin:] = 7.0  # padding columns must be ignored
@@ -882,7 +884,7 @@ def test_knn3_weights_epilogue(dev, B, N1, N2):
 @pytest.mark.parametrize('R,C,Cp,ldx', [(5000, 32, 32, 32), (3333, 64, 32, 32), (4097, 64, 64, 64), (1000, 64, 68, 68), (70000, 32, 32, 32),
                                         (33, 20, 12, 12), (262144, 64, 64, 64), (9000, 128, 64, 64), (6001, 128, 128, 128), (777, 100, 96, 100),
                                         (2500, 32, 128, 128), (1200, 64, 72, 72)])
-@pytest.mark.parametrize('precision', ['bf16x6', 'bf16x3', 'bf16x3-ws'])
+@pytest.mark.parametrize('precision', ['bf16x6', 'bf16x3', 'bf16x3-ws', 'bf16'])
 def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
     """mvp_mlp_layer_backward_f32 (BatchNorm finish + weight gradient + input gradient with the previous layer's ReLU mask and column
     sums in ONE kernel) against a float64 evaluation of the three steps; all four combinations of {dz_i given / dy_i given} x
@@ -894,7 +896,7 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
     before = L.get_mlp_precision()
     L.set_mlp_precision(precision)
     L.set_mlp_precision_backward(precision)
-    loose = 16.0 if precision == 'bf16x3' else 1.0
+    loose = {'bf16x3': 16.0, 'bf16': 4096.0}.get(precision, 1.0)
     hi = torch.float64
     torch.manual_seed(R + C)
     try:
@@ -1496,6 +1498,72 @@ def test_group_points_and_interpolate_walk_strided_operands_in_place(dev, dt):
     np.testing.assert_allclose(xi.grad.cpu().numpy(), O().interpolate_bwd(gi.contiguous().cpu().numpy(), idx3.cpu().numpy(), w3.cpu().numpy(), N), **tol)
 
 
+def test_group_points_and_interpolate_on_bfloat16_values(dev):
+    """the gather / interpolation entry points also exist for bfloat16 VALUES (`*_bf16`; the reference dispatches float32 / float64
+    only, group_points_kernel.cu:33, interpolate_kernel.cu:103).  Contract: the gather is a copy (bit-exact); interpolation computes the fp32
+    kernel's arithmetic on the widened values with fp32 weights and rounds once (bit-exact against the rounded fp32 oracle); both backward
+    passes add in fp32 and round once (within one bf16 unit of the float64 oracle, >= 99 % of the elements equal to its rounding).  Contiguous,
+    strided, and clouds beyond the LDS accumulator (fp32 scratch path)."""
+    from mvpnet_amd import _lib as L
+    from mvpnet_amd.ops import group_points, feature_interpolate
+    bf = torch.bfloat16
+    torch.manual_seed(11)
+
+    def close_to_rounded(got, ref64):
+        got, ref = got.float().cpu(), torch.from_numpy(np.asarray(ref64, np.float64))
+        assert bool(((got.double() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-5).all()), float((got.double() - ref).abs().max())
+        assert float((got == ref.float().to(bf).float()).float().mean()) >= 0.99
+
+    seen = []
+    orig = L.call
+
+    def spy(name, t, *a):
+        seen.append(name)
+        return orig(name, t, *a)
+
+    L.call = spy
+    try:
+        for (B, C, N, M, K) in [(3, 37, 600, 129, 32), (2, 5, 40000, 300, 8)]:       # the second: N1 beyond the LDS accumulator
+            x = torch.randn(B, C, N, device=dev).to(bf)
+            idx = torch.randint(0, N, (B, M, K), device=dev)
+            out = group_points(x, idx)
+            assert out.dtype == bf
+            np.testing.assert_array_equal(out.float().cpu().numpy(), O().group_points_fwd(x.float().cpu().numpy(), idx.cpu().numpy()))
+            xs = torch.randn(B, N, C + 3, device=dev).to(bf).transpose(1, 2)[:, 1:1 + C]   # strided values
+            assert torch.equal(group_points(xs, idx), group_points(xs.contiguous(), idx))
+            xg = x.detach().requires_grad_(True)
+            gout = torch.randn(B, C, M, K, device=dev).to(bf)
+            group_points(xg, idx).backward(gout)
+            assert xg.grad.dtype == bf
+            close_to_rounded(xg.grad, O().group_points_bwd(gout.double().cpu().numpy(), idx.cpu().numpy(), N))
+            gs = torch.randn(B, M, K, C, device=dev).to(bf).permute(0, 3, 1, 2)             # strided gradient
+            xg.grad = None
+            group_points(xg, idx).backward(gs)
+            close_to_rounded(xg.grad, O().group_points_bwd(gs.double().contiguous().cpu().numpy(), idx.cpu().numpy(), N))
+            # interpolation: fp32 weights (a bfloat16 weight tensor widens exactly)
+            Q = 777
+            idx3 = torch.randint(0, N, (B, Q, 3), device=dev)
+            w3 = torch.rand(B, Q, 3, device=dev)
+            w3 = w3 / w3.sum(2, keepdim=True)
+            xi = x.detach().requires_grad_(True)
+            oi = feature_interpolate(xi, idx3, w3)
+            assert oi.dtype == bf
+            ref = O().interpolate_fwd(x.float().cpu().numpy(), idx3.cpu().numpy(), w3.cpu().numpy())          # fp32 oracle = the fp32 kernel's arithmetic
+            assert torch.equal(oi.detach().cpu(), torch.from_numpy(ref).to(bf))
+            assert torch.equal(feature_interpolate(xs, idx3, w3), feature_interpolate(xs.contiguous(), idx3, w3))
+            wb = w3.to(bf)
+            assert torch.equal(feature_interpolate(x, idx3, wb), feature_interpolate(x, idx3, wb.float()))
+            gi = torch.randn(B, Q, C, device=dev).to(bf).transpose(1, 2)                                        # strided gradient
+            oi.backward(gi)
+            close_to_rounded(xi.grad, O().interpolate_bwd(gi.double().contiguous().cpu().numpy(), idx3.cpu().numpy(), w3.double().cpu().numpy(), N))
+    finally:
+        L.call = orig
+    for name in ('mvp_group_points_forward_bf16', 'mvp_group_points_forward_strided_bf16', 'mvp_group_points_backward_bf16',
+                 'mvp_group_points_backward_strided_bf16', 'mvp_interpolate_forward_bf16', 'mvp_interpolate_forward_strided_bf16',
+                 'mvp_interpolate_backward_strided_bf16'):
+        assert name in seen, name
+
+
 @pytest.mark.parametrize('R,Cout,Cin,lddw,use_act', [(262144, 128, 128, 128, True), (786432, 64, 64, 68, False), (2097152, 32, 32, 32, True),
                                                       (65536, 256, 384, 384, False), (70001, 64, 100, 131, True), (5000, 32, 64, 64, False),
                                                       (300, 64, 64, 64, True), (131072, 512, 256, 256, False)])
@@ -1542,6 +1610,47 @@ def test_weight_gradient_through_the_workspace_is_reproducible_and_equals_the_at
     # a workspace that is too small falls back to the atomics path (same result up to the order of the additions)
     small = run(torch.empty(1000, device=dev))
     np.testing.assert_allclose(small.cpu().numpy(), atom.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize('R,Cin,Cout', [(5000, 64, 64), (70001, 64, 128), (140000, 32, 64), (33000, 128, 256), (1000, 68, 32), (262144, 128, 128)])
+def test_plain_bf16_contraction_is_the_product_of_the_rounded_operands(dev, R, Cin, Cout):
+    """The opt-in 'bf16' precision (mvp_set_mlp_precision(1): the "bf16" BASELINE.json's configs[2] names) rounds each operand of the
+    shared-MLP contractions to bfloat16 ONCE and accumulates the exact products in fp32; storage stays fp32.  With operands that ARE
+    bfloat16 values nothing is rounded, so forward (tile and streaming kernels), weight gradient and input gradient must agree with the
+    float64 product at the tolerance of the fp32 MFMA path; with general fp32 operands they must agree with the product of the ROUNDED
+    operands at that same tolerance."""
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(R + Cout)
+    hi = torch.float64
+    rnd = lambda t: t.to(torch.bfloat16).float()
+    x32, w32, dy32 = torch.randn(R, Cin, device=dev), torch.randn(Cout, Cin, device=dev) * 0.2, torch.randn(R, Cout, device=dev)
+    bias = torch.randn(Cout, device=dev)
+    with L.mlp_precision('bf16', backward='bf16'):
+        assert L.lib().mvp_get_mlp_precision() == 1 and L.lib().mvp_get_mlp_precision_backward() == 1
+        for exact_operands in (True, False):
+            x, w, dy = (rnd(x32), rnd(w32), rnd(dy32)) if exact_operands else (x32, w32, dy32)
+            xr, wr, dyr = rnd(x).to(hi), rnd(w).to(hi), rnd(dy).to(hi)
+            for stream in (1, 0):
+                old = L.lib().mvp_set_mlp_stream(stream)
+                try:
+                    y = torch.empty(R, Cout, device=dev)
+                    stat = torch.zeros(2 * Cout, dtype=hi, device=dev)
+                    L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, Cin, Cin, L.ptr(w), Cin, Cout, None, None, None, None, L.ptr(bias), L.ptr(y), L.ptr(stat),
+                           L.ptr(torch.empty(((R + 127) // 128) * 2 * Cout, dtype=hi, device=dev)))
+                finally:
+                    L.lib().mvp_set_mlp_stream(old)
+                ref = xr @ wr.t() + bias.to(hi)
+                np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(ref.abs().max())))
+                np.testing.assert_allclose(stat[:Cout].cpu().numpy(), y.double().sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+            dw = torch.zeros(Cout, Cin, device=dev)
+            L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, None, None, None, None, L.ptr(dw), Cin)
+            refw = dyr.t() @ xr
+            np.testing.assert_allclose(dw.cpu().numpy(), refw.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(refw.abs().max())))
+            dz = torch.empty(R, Cin, device=dev)
+            L.call('mvp_mlp_input_grad_f32', dy, L.ptr(dy), R, Cout, L.ptr(w), Cin, None, None, None, None, None, L.ptr(dz), None, None)
+            refx = dyr @ wr
+            np.testing.assert_allclose(dz.cpu().numpy(), refx.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(refx.abs().max())))
+    assert L.lib().mvp_get_mlp_precision() != 1
 
 
 @pytest.mark.parametrize('B,N,M,D', [(2, 32768, 8192, 3), (16, 9000, 700, 3), (5, 20000, 1000, 2), (1, 65536, 1500, 3), (3, 16384, 16384 // 8, 3)])
