@@ -288,10 +288,13 @@ int mvp_interp_rows_f32(const float* feature, const int64_t* index, const float*
  *   grad_feature (B,N,C) = sum over the slots p of point j of weight[b,p] * grad_out[b, slot / S, :]
  * (weight NULL = 1; S = slots per grad_out row: 1 for the grouping with E = M*K rows, 3 for the 3-NN interpolation with E = 3*N2).
  * No atomics on the data, no zero fill.  While a chunk's N counters fit in LDS (N <= ~37 000) the build is one launch, one workgroup per
- * chunk, and every list of up to 1024 slots is sorted ascending: the gradient is reproducible bit for bit; beyond that (whole-scene vote
- * plans) three launches with global atomics, lists in arrival order. */
+ * chunk; beyond that (whole-scene vote plans) three launches with global atomics.  The entries of a list are in arrival order (differs
+ * from run to run).  mvp_csr_build_sorted_i64: on the one-launch path every list of up to 1024 slots is also sorted ascending, so the
+ * gather backward adds in the same order in every run -- the reproducible training mode's build (the sort is 40-55 % of the kernel). */
 int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots, int32_t* cursor,
                       mvp_stream_t stream);
+int mvp_csr_build_sorted_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots, int32_t* cursor,
+                             mvp_stream_t stream);
 int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_t* offsets, const int32_t* slots, const float* weight,
                                      int64_t B, int64_t N, int64_t C, int64_t E, int64_t S, int64_t ld, float* grad_feature,
                                      mvp_stream_t stream);

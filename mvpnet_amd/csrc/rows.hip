@@ -375,11 +375,12 @@ __global__ __launch_bounds__(kRT) void csr_fill_kernel(const int64_t* __restrict
 
 // The whole build in ONE workgroup per chunk when a chunk's N counters fit in LDS (every level of the network: N <= 8192; the dense
 // configuration's 32768): count, scan and fill run on LDS atomics -- no zero fill of the offsets, no global atomics at all (the three
-// launches above are bound by them: ~0.5 % of their cycles issue instructions, and they run beside the backward pass of the step) -- and
-// every point's slot list (up to 1024 entries) is then sorted ascending, so the order of the gather's additions, and with it the gradient,
-// is the same in every run (the fill order of the atomics is not).
+// launches above are bound by them: ~0.5 % of their cycles issue instructions, and they run beside the backward pass of the step).
+// sorted != 0 (mvp_csr_build_sorted_i64, the reproducible mode): every point's slot list (up to 1024 entries) is then sorted ascending, so
+// the order of the gather's additions, and with it the gradient, is the same in every run (the fill order of the atomics is not); the
+// sort is 40-55 % of the kernel (112 -> 64 us for the 8192-point level, B = 32) and 0.07 ms of the training step it runs beside.
 __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __restrict__ idx, int64_t E, int N, int* __restrict__ offsets,
-                                                             int* __restrict__ slots) {
+                                                             int* __restrict__ slots, int sorted) {
   extern __shared__ __attribute__((aligned(16))) char csr_smem[];
   int* cnt = reinterpret_cast<int*>(csr_smem);  // [N]: counts, then running cursors
   int* part = cnt + N;                          // [1024]
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __re
     const int64_t j = ix[e];
     if (j >= 0 && j < N) sl[atomicAdd(&cnt[j], 1)] = (int)e;
   }
+  if (!sorted) return;
   __syncthreads();  // (workgroup-scope: the slots written above are read back below by other lanes of THIS workgroup)
   // ascending positions inside every list (insertion sort: 8 entries on average in the grouping, 3 in the interpolation)
   for (int j = tid; j < N; j += 1024) {
@@ -1075,8 +1077,8 @@ MVP_API int mvp_group_rows_backward_f32(const float* grad_out, const int64_t* in
   return mvp_launch_status();
 }
 
-MVP_API int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots,
-                              int32_t* cursor, mvp_stream_t stream) {
+static int csr_build(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots, int32_t* cursor, int sorted,
+                     mvp_stream_t stream) {
   MVP_NONNULL(index);
   MVP_NONNULL(offsets);
   MVP_NONNULL(slots);
@@ -1091,7 +1093,7 @@ MVP_API int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_
       hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(csr_build_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e2 != hipSuccess) return (int)e2;
     }
-    hipLaunchKernelGGL(csr_build_lds_kernel, dim3((unsigned)B), dim3(1024), lds, s, index, E, (int)N, offsets, slots);
+    hipLaunchKernelGGL(csr_build_lds_kernel, dim3((unsigned)B), dim3(1024), lds, s, index, E, (int)N, offsets, slots, sorted);
     return mvp_launch_status();
   }
   hipError_t e = hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)(B * (N + 1)), s);
@@ -1100,6 +1102,17 @@ MVP_API int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_
   hipLaunchKernelGGL(csr_scan_kernel, dim3((unsigned)B), dim3(1024), 0, s, offsets, cursor, (int)N);
   if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)cdiv(E, kRT), (unsigned)B), dim3(kRT), 0, s, index, E, (int)N, cursor, slots);
   return mvp_launch_status();
+}
+
+MVP_API int mvp_csr_build_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots, int32_t* cursor,
+                              mvp_stream_t stream) {
+  return csr_build(index, B, E, N, offsets, slots, cursor, 0, stream);
+}
+
+// The same with every list (of up to 1024 slots) sorted ascending while a chunk's N counters fit in LDS: the reproducible mode's build.
+MVP_API int mvp_csr_build_sorted_i64(const int64_t* index, int64_t B, int64_t E, int64_t N, int32_t* offsets, int32_t* slots,
+                                     int32_t* cursor, mvp_stream_t stream) {
+  return csr_build(index, B, E, N, offsets, slots, cursor, 1, stream);
 }
 
 MVP_API int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_t* offsets, const int32_t* slots, const float* weight,

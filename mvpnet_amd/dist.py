@@ -137,7 +137,7 @@ def _vote_plan(chunk_inds, n_pts, dev):
         offs = [0]
         for n in lens:
             offs.append(offs[-1] + n)
-        pt_offsets, pt_slots = R.build_csr(flat.view(1, -1), n_pts)
+        pt_offsets, pt_slots = R.build_csr(flat.view(1, -1), n_pts, sorted=True)  # built once per scene: the vote adds in a fixed order
         plan = {'chunk_offsets': torch.tensor(offs, dtype=torch.int64).to(dev), 'pt_offsets': pt_offsets, 'pt_slots': pt_slots,
                 'max_len': max(lens), 'keep': list(chunk_inds)}  # (the index tensors stay alive: their addresses are the key)
         _VOTE_PLANS.clear()  # one scene at a time

@@ -381,9 +381,11 @@ class EvalInvStd:
 eval_invstd = EvalInvStd()
 
 
-def build_csr(index, N):
+def build_csr(index, N, sorted=None):
     """index (B, ...) int64 positions into N points -> (offsets (B,N+1) int32, slots (B,E) int32): for every point the list of
-    flattened positions that read it (mvp_csr_build_i64).  Turns the scatter-add backward of a gather into a gather."""
+    flattened positions that read it (mvp_csr_build_i64).  Turns the scatter-add backward of a gather into a gather.
+    sorted (default: the reproducible mode, _lib.DW_WORKSPACE): every list ascending (mvp_csr_build_sorted_i64) -- the gather then adds in
+    the same order in every run; unsorted the build is ~45 % shorter."""
     B = index.size(0)
     flat = index.reshape(B, -1)
     E = flat.size(1)
@@ -391,7 +393,8 @@ def build_csr(index, N):
     offsets = torch.empty((B, N + 1), dtype=torch.int32, device=dev)
     slots = torch.empty((B, E), dtype=torch.int32, device=dev)
     cursor = torch.empty((B, N), dtype=torch.int32, device=dev)
-    L.call('mvp_csr_build_i64', flat, L.ptr(flat), B, E, N, L.ptr(offsets), L.ptr(slots), L.ptr(cursor))
+    name = 'mvp_csr_build_sorted_i64' if (L.DW_WORKSPACE if sorted is None else sorted) else 'mvp_csr_build_i64'
+    L.call(name, flat, L.ptr(flat), B, E, N, L.ptr(offsets), L.ptr(slots), L.ptr(cursor))
     return offsets, slots
 
 

@@ -829,24 +829,26 @@ def test_interp_add_rows_vs_torch(dev, B, N1, N2, C, with_add):
         assert torch.equal(add.grad, cot)
 
 
+@pytest.mark.parametrize('want_sorted', [True, False])
 @pytest.mark.parametrize('B,E,N', [(3, 5000, 700), (32, 65536, 8192), (2, 3 * 8192, 2048), (2, 70000, 32768), (1, 50000, 60000), (2, 100, 5)])
-def test_csr_build(dev, B, E, N):
-    """mvp_csr_build_i64: every position appears exactly once in the list of the point it reads; negative / out-of-range
-    entries are dropped; empty lists for unreferenced points.  While N counters fit in LDS (all but the 60000-point case, which takes
-    the three-launch path with global atomics) the lists come out SORTED -- the gather backward then adds in the same order in every
-    run -- and two builds are identical."""
+def test_csr_build(dev, B, E, N, want_sorted):
+    """mvp_csr_build_i64 / mvp_csr_build_sorted_i64: every position appears exactly once in the list of the point it reads; negative /
+    out-of-range entries are dropped; empty lists for unreferenced points.  The sorted build (the reproducible mode's), while N counters
+    fit in LDS (all but the 60000-point case, which takes the three-launch path with global atomics): the lists come out SORTED -- the
+    gather backward then adds in the same order in every run -- and two builds are identical."""
     from mvpnet_amd import rows as R
     rs = np.random.RandomState(3)
     idx = rs.randint(-2, N + 2, (B, E)).astype(np.int64)
     if N == 5:
         idx[0, :] = 2  # one list holds everything (shorter than the 1024-entry sorting bound)
-    offsets, slots = R.build_csr(g(idx, dev), N)
-    o2, s2 = R.build_csr(g(idx, dev), N)
-    if N < 37000:
+    offsets, slots = R.build_csr(g(idx, dev), N, sorted=want_sorted)
+    o2, s2 = R.build_csr(g(idx, dev), N, sorted=want_sorted)
+    assert torch.equal(offsets, o2)
+    if N < 37000 and want_sorted:
         assert torch.equal(offsets, o2) and torch.equal(slots[:, :int(offsets[:, N].min())], s2[:, :int(offsets[:, N].min())])
     offsets, slots = offsets.cpu().numpy(), slots.cpu().numpy()
     for b in range(min(B, 4)):
-        if N < 37000:
+        if N < 37000 and want_sorted:
             used = slots[b, :offsets[b, N]]
             starts = offsets[b, :-1]
             asc = np.ones(len(used), bool)
