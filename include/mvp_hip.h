@@ -380,6 +380,17 @@ int mvp_get_mlp_precision_backward(void);
  * never see each other's choice.  Returns the previous override packed as (terms + 1) * 16 + (terms_backward + 1), MVP_EINVAL for other
  * values.  The getters return what the calling thread's launches use. */
 int mvp_mlp_precision_scope(int terms, int terms_backward);
+/* Shared-MLP layer on bfloat16 VALUES (mlp_bf16.hip; SURVEY 8b "+bf16 for gather/interp/MLP values"; uint16_t = bf16 bit patterns):
+ *   Y (R, ldy)[:, :Cout] = act((X (R, ldx)[:, :Cin] . bf16_rn(W (Cout, ldw)[:, :Cin])^T + bias) * scale + shift)
+ * -- the reference's conv -> BatchNorm -> ReLU layer (common/nn/modules/conv.py:41-51) in inference with the running-statistics
+ * BatchNorm folded into scale / shift by the caller; bias, scale, shift (Cout floats) may be NULL, relu != 0 clamps at zero.  Native
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation, every fp32 step rounded once (no fused multiply-add), one rounding to bf16 on the way
+ * out.  Not part of the fp32 parity path.  MVP_EUNSUPPORTED unless Cin % 16 == 0, Cout % 8 == 0, ldx % 8 == 0, ldy % 8 == 0 and X, Y
+ * are 16-byte aligned. */
+int mvp_mlp_forward_bf16(const uint16_t* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+                         const float* bias, const float* scale, const float* shift, int relu, uint16_t* Y, int64_t ldy,
+                         mvp_stream_t stream);
+
 /* Switch (returns the previous value): 1 (default since round 3: 12-23 % faster alone at the step's shapes, 0.8 % on the step -- in round 2,
  * beside the atomics-bound side-stream kernels of that time, it measured 1.2 % slower) = long narrow forward layers (>= 32768 rows, C_in,
  * C_out <= 128) run on the persistent streaming kernel with the weight matrix resident in LDS; 0 = the per-tile kernel. */

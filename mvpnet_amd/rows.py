@@ -1051,6 +1051,28 @@ def linear_rows(x, weight, bias=None, cols=None, sink=None):
     return LinearRows.apply(x.contiguous(), weight, bias, c0, c1, sink)
 
 
+def linear_rows_bf16(x, weight, bias=None, scale=None, shift=None, relu=False):
+    """x (R, C_in) bfloat16 rows (row stride a multiple of 8), weight (C_out, C_in[,1[,1]]) float32 master weights -> (R, C_out) bfloat16:
+    act((x . bf16(weight)^T + bias) * scale + shift) with fp32 accumulation (mvp_mlp_forward_bf16, csrc/mlp_bf16.hip) -- the reference's
+    conv -> BatchNorm -> ReLU layer (common/nn/modules/conv.py:41-51) on bfloat16 activations in inference, the running-statistics
+    BatchNorm folded into scale / shift by the caller.  No autograd, not part of the fp32 parity path."""
+    if not (x.is_cuda and weight.is_cuda):
+        raise RuntimeError('mvpnet_amd ops run on the GPU only; there is no CPU fallback')
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or x.stride(1) != 1:
+        raise RuntimeError('linear_rows_bf16: x must be a (R, C_in) bfloat16 tensor with unit column stride')
+    w = weight.detach().reshape(weight.size(0), -1)
+    if w.dtype != torch.float32 or not w.is_contiguous() or w.size(1) != x.size(1):
+        raise RuntimeError('linear_rows_bf16: weight must be contiguous float32 (C_out, C_in)')
+    R, cin = x.shape
+    cout = w.size(0)
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    bias, scale, shift = f(bias), f(scale), f(shift)
+    y = torch.empty((R, cout), dtype=torch.bfloat16, device=x.device)
+    L.call('mvp_mlp_forward_bf16', x, L.ptr(x), R, cin, x.stride(0), L.ptr(w), cin, cout, L.ptr(bias), L.ptr(scale), L.ptr(shift), int(bool(relu)),
+           L.ptr(y), cout)
+    return y
+
+
 SA_FUSED_EVAL = os.environ.get('MVP_SA_FUSED', '1') != '0'
 
 

@@ -1655,6 +1655,41 @@ def test_plain_bf16_contraction_is_the_product_of_the_rounded_operands(dev, R, C
     assert L.lib().mvp_get_mlp_precision() != 1
 
 
+@pytest.mark.parametrize('R,Cin,Cout,ldx', [(1000, 64, 64, 64), (70001, 64, 128, 72), (4096, 128, 256, 128), (333, 768, 256, 768), (129, 16, 8, 16),
+                                             (262144, 32, 64, 32), (5000, 272, 40, 280), (1, 128, 128, 128)])
+def test_mlp_layer_on_bfloat16_values(dev, R, Cin, Cout, ldx):
+    """mvp_mlp_forward_bf16 (bf16 value variant of the shared-MLP layer; conv -> folded BatchNorm -> ReLU of
+    common/nn/modules/conv.py:41-51 in inference): bfloat16 rows in and out, fp32 master weights rounded to bf16 once, exact products,
+    fp32 accumulation, bias / scale / shift / ReLU in fp32 (each step rounded once), ONE rounding to bf16.  Against the float64 value of the
+    same expression on the rounded operands: within one bf16 unit everywhere, >= 98 % of the outputs equal to its rounding; rows not a
+    multiple of 128, padded rows (ldx > Cin), k chunks beyond 128, partial column blocks."""
+    from mvpnet_amd import rows as RW
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(R + Cout)
+    bf, hi = torch.bfloat16, torch.float64
+    xs = torch.randn(R, ldx, device=dev).to(bf)
+    x = xs[:, :Cin]
+    w = torch.randn(Cout, Cin, device=dev) * 0.2
+    bias, scale, shift = torch.randn(Cout, device=dev), torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.3
+    prod = x.to(hi) @ w.to(bf).to(hi).t()
+    for use_bias, use_affine, relu in ((False, False, False), (True, False, False), (True, True, True), (False, True, False)):
+        y = RW.linear_rows_bf16(x, w, bias if use_bias else None, scale if use_affine else None, shift if use_affine else None, relu)
+        assert y.dtype == bf and y.shape == (R, Cout)
+        ref = prod + (bias.to(hi) if use_bias else 0.0)
+        if use_affine:
+            ref = ref * scale.to(hi) + shift.to(hi)
+        if relu:
+            ref = torch.relu(ref)
+        err = (y.to(hi) - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-3 * 2.0 ** -8 + 2e-5 * float(prod.abs().max())).all()), float(err.max())
+        assert float((y == ref.float().to(bf)).float().mean()) >= 0.98
+    # what the entry point refuses (no silent fallback)
+    y = torch.empty(R, Cout, dtype=bf, device=dev)
+    code = L._fn('mvp_mlp_forward_bf16')(L.ptr(xs), R, Cin - 8, ldx, L.ptr(w), Cin, Cout, None, None, None, 0, L.ptr(y), Cout,
+                                         torch.cuda.current_stream().cuda_stream)
+    assert code == -2  # MVP_EUNSUPPORTED: C_in not a multiple of 16
+
+
 @pytest.mark.parametrize('B,N,M,D', [(2, 32768, 8192, 3), (16, 9000, 700, 3), (5, 20000, 1000, 2), (1, 65536, 1500, 3), (3, 16384, 16384 // 8, 3)])
 def test_fps_rounds_across_workgroups(dev, B, N, M, D):
     """Clouds of 8193..65536 points: four workgroups per cloud run the round protocol together and exchange their row results through
