@@ -381,8 +381,11 @@ class PN2SSG(nn.Module):
         per cloud for ~2.8 ms whatever the batch size, so planning ALL chunks of a scene in one call and slicing per batch costs
         one FPS chain per scene instead of one per batch (scene.infer_scene)."""
         cut = lambda g: None if g is None else tuple(t[lo:hi] for t in g)
-        return {'sa': [cut(g) for g in plan['sa']], 'fp': [cut(g) for g in plan['fp']], 'event': plan['event'],
-                'stream': plan['stream'], 'xyz': plan['xyz']}
+        out = {'sa': [cut(g) for g in plan['sa']], 'fp': [cut(g) for g in plan['fp']], 'event': plan['event'],
+               'stream': plan['stream'], 'xyz': plan['xyz']}
+        if 'level_events' in plan:  # the per-level events of the whole plan hold for every slice of it
+            out['level_events'] = plan['level_events']
+        return out
 
     def _second_stream(self, device):
         if getattr(self, '_geo_stream2', None) is None or self._geo_stream2.device != device:

@@ -395,6 +395,15 @@ def test_geometry_of_several_batches_in_one_plan(dev):
         model.net_2d.feature = fc
         got_c = model(c2)['seg_logit'].clone()
     assert torch.equal(got_a, ref[0]) and torch.equal(got_b, ref[1]) and torch.equal(got_c, ref[2])
+    # Inference plans carry one event pair per level (a set-abstraction level starts when ITS geometry exists, the deeper levels are
+    # still being sampled); waiting for the single end-of-plan event instead gives the same logits
+    from mvpnet_amd.mvpnet3d import prefetch_geometry
+    with torch.no_grad():
+        a3, a4 = prefetch_geometry(model, dict(a)), prefetch_geometry(model, dict(a))
+        assert len(a3['geometry_plan']['level_events']) == 4 and 'level_events' in a2['geometry_plan']
+        a4['geometry_plan'].pop('level_events')
+        model.net_2d.feature = fa
+        assert torch.equal(model(a3)['seg_logit'], ref[0]) and torch.equal(model(a4)['seg_logit'], ref[0])
 
 
 def _load_case(module, g, prefix, seed):
