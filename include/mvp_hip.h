@@ -380,6 +380,14 @@ int mvp_get_mlp_precision_backward(void);
  * never see each other's choice.  Returns the previous override packed as (terms + 1) * 16 + (terms_backward + 1), MVP_EINVAL for other
  * values.  The getters return what the calling thread's launches use. */
 int mvp_mlp_precision_scope(int terms, int terms_backward);
+/* One Adam step of n float32 tensors in one launch (adam.hip; replaces, on the GPU, torch.optim.Adam.step of the reference's training loop:
+ * common/solver/build.py:7-22, train_mvpnet_3d.py:176).  params / grads / exp_avg / exp_avg_sq: HOST arrays of n device pointers, numel
+ * their element counts (< 2^31 each); torch.optim.Adam semantics (L2 weight decay added to the gradient, no amsgrad, minimising):
+ *   g' = g + weight_decay p;  m += (g' - m)(1 - beta1);  v = beta2 v + (1 - beta2) g'^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * step >= 1 is the number of THIS update; fp32 arithmetic, the bias corrections in double on the host.  96 tensors per launch. */
+int mvp_adam_step_f32(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
+                      int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, double step, mvp_stream_t stream);
+
 /* Shared-MLP layer on bfloat16 VALUES (mlp_bf16.hip; SURVEY 8b "+bf16 for gather/interp/MLP values"; uint16_t = bf16 bit patterns):
  *   Y (R, ldy)[:, :Cout] = act((X (R, ldx)[:, :Cin] . bf16_rn(W (Cout, ldw)[:, :Cin])^T + bias) * scale + shift)
  * -- the reference's conv -> BatchNorm -> ReLU layer (common/nn/modules/conv.py:41-51) in inference with the running-statistics

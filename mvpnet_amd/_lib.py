@@ -73,6 +73,7 @@ _SIGNATURES = {
     'mvp_relation_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interp_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_mlp_forward_bf16': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _i64, _ptr],
+    'mvp_adam_step_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64] + [ctypes.c_double] * 6 + [_ptr],
     'mvp_csr_build_i64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_csr_build_sorted_i64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_gather_rows_backward_csr_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],

@@ -203,8 +203,11 @@ def build_optimizer(cfg, model):
         return None
     kwargs = dict(cfg.OPTIMIZER.get(name, {}))
     params = [p for p in model.parameters()]
+    if name == 'Adam' and not kwargs.get('amsgrad') and 'fused' not in kwargs and params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        from .optim import FusedAdam  # a torch.optim.Adam (same state, same checkpoints) whose step is ONE launch for all parameter tensors
+        return FusedAdam(params, lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY, **kwargs)
     if name in ('Adam', 'AdamW') and 'fused' not in kwargs and params and all(p.is_cuda for p in params):
-        kwargs['fused'] = True  # same update rule in ONE kernel for all ~90 parameter tensors instead of ~10 multi-tensor launches
+        kwargs['fused'] = True  # ATen's multi-tensor kernel (three launches for ~80 tensors)
     return getattr(torch.optim, name)(params, lr=cfg.OPTIMIZER.BASE_LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY, **kwargs)
 
 

@@ -83,6 +83,7 @@ def gpu_step(sdn, bt, B, class_weight, dev, mode='eager'):
     (its first step falls back to torch.zeros), the second -- the one reported -- runs with the arenas live."""
     from mvpnet_amd.pn2 import PN2SSG
     from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss, train_step, prefetch_geometry
+    from mvpnet_amd.optim import FusedAdam
     t = lambda a, dt=None: (torch.from_numpy(np.ascontiguousarray(a)) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dt)).to(dev)
     nv = bt['depth_mm'].shape[1]
     h, w, c = bt['feature_2d'].shape[2:]
@@ -102,7 +103,7 @@ def gpu_step(sdn, bt, B, class_weight, dev, mode='eager'):
     out = None
     for it in range(2):
         model.load_state_dict(init)
-        opt = torch.optim.Adam(model.parameters(), lr=2e-3, fused=True)
+        opt = FusedAdam(model.parameters(), lr=2e-3)  # what config.build_optimizer gives the bench
         cur = prefetch_geometry(model, fresh())
         nxt = fresh()
         before = {k: v.detach().clone() for k, v in model.named_parameters()}
