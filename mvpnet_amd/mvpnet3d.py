@@ -83,6 +83,23 @@ class FeatureAggregation(nn.Module):
         return self.reduction(self.mlp(x), 3)
 
 
+def points_rows(data_batch, points=None):
+    """(B,N,3) rows of the batch's (B,3,N) `points` (or of another (B,3,N) tensor of the batch, e.g. the rotated points), transposed ONCE
+    per batch: lifting, aggregation, the geometry plan and the 3D network all read the same copy (four transposing launches per training
+    step before).  Cached in the batch dict under a private key, per source tensor and its version counter (an in-place refill of a
+    loader's static buffer gives a new copy)."""
+    points = data_batch['points'] if points is None else points
+    cache = data_batch.get('_points_rows')
+    if cache is None:
+        cache = data_batch['_points_rows'] = {}
+    hit = cache.get(id(points))
+    if hit is not None and hit[0] is points and hit[1] == points._version:
+        return hit[2]
+    rows = points.transpose(1, 2).contiguous()
+    cache[id(points)] = (points, points._version, rows)
+    return rows
+
+
 def net3d_points(data_batch):
     """(B,3,N) points as the 3D network sees them: the loader's points, or -- when the batch carries a device-side z rotation
     ('z_rot' (B,3,3) float64 from mvpnet_amd.augment, lifting still to be done on the device) -- those points rotated
@@ -91,7 +108,7 @@ def net3d_points(data_batch):
     if 'z_rot' not in data_batch or 'knn_indices' in data_batch:
         return points
     if '_points_rot' not in data_batch:
-        data_batch['_points_rot'] = ops.rotate_rows(points.transpose(1, 2).contiguous(), data_batch['z_rot']).transpose(1, 2).contiguous()
+        data_batch['_points_rot'] = ops.rotate_rows(points_rows(data_batch), data_batch['z_rot']).transpose(1, 2).contiguous()
     return data_batch['_points_rot']
 
 
@@ -111,7 +128,7 @@ class MVPNet3D(nn.Module):
         (h,w)), pose (B,nv,4,4) [, kinv, pixel_box (B,4), k]: gathered feature, gathered xyz, knn_indices."""
         cam = data_batch['cam_matrix']
         kinv = data_batch['kinv'] if 'kinv' in data_batch else torch.linalg.inv(cam)
-        points_nc = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3), un-rotated: the search precedes the rotation
+        points_nc = points_rows(data_batch)  # (B,N,3), un-rotated: the search precedes the rotation
         return ops.lift(feature_cl, data_batch['depth'], kinv, cam, data_batch['pose'], points_nc,
                         k=int(data_batch.get('k', 3)), box=data_batch.get('pixel_box'), flip=data_batch.get('flip'),
                         rot=data_batch.get('z_rot'))
@@ -131,7 +148,7 @@ class MVPNet3D(nn.Module):
         plan = data_batch.get('geometry_plan')
         points = net3d_points(data_batch)  # what the 3D network sees (rotated when the batch carries a device-side z rotation)
         if plan is None and hasattr(self.net_3d, 'plan_geometry') and points.is_cuda:
-            pts_rows = points.transpose(1, 2).contiguous()
+            pts_rows = points_rows(data_batch, points)
             plan = self.net_3d.plan_geometry(pts_rows, stream=self._side_stream(pts_rows.device))
         images = data_batch['images']  # (B,nv,3,h,w)
         b, nv, _, h, w = images.shape
@@ -146,8 +163,9 @@ class MVPNet3D(nn.Module):
         nxt = data_batch.get('prefetch_next')
         if nxt is not None:  # start the NEXT batch's FPS / ball query / 3-NN now: runs under this batch's MLPs
             prefetch_geometry(self, nxt)
-        feature_2d3d = self.feat_aggreg(gxyz, points.transpose(1, 2).contiguous(), gfeat, rows=True)  # (B,N,C) rows
-        return self.net_3d({'points': points, 'feature_rows': feature_2d3d, 'geometry_plan': plan})
+        rows = points_rows(data_batch, points)
+        feature_2d3d = self.feat_aggreg(gxyz, rows, gfeat, rows=True)  # (B,N,C) rows
+        return self.net_3d({'points': points, 'points_rows': rows, 'feature_rows': feature_2d3d, 'geometry_plan': plan})
 
 
 class _SegLossFn(torch.autograd.Function):
@@ -221,7 +239,7 @@ def prefetch_geometry(model, data_batch):
         return prefetch_geometry_many(model, data_batch)
     net = model.module if hasattr(model, 'module') else model
     if 'geometry_plan' not in data_batch and hasattr(net, 'net_3d') and data_batch['points'].is_cuda:
-        pts_rows = net3d_points(data_batch).transpose(1, 2).contiguous()
+        pts_rows = points_rows(data_batch, net3d_points(data_batch))
         data_batch['geometry_plan'] = net.net_3d.plan_geometry(pts_rows, stream=net._side_stream(pts_rows.device))
     return data_batch
 

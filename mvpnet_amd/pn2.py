@@ -393,13 +393,13 @@ class PN2SSG(nn.Module):
         return self._geo_stream2
 
     def forward(self, data_batch):
-        """data_batch: 'points' (B,3,N) [+ 'feature' (B,C,N), or 'feature_rows' (B,N,C) channels-last]
+        """data_batch: 'points' (B,3,N) [+ 'points_rows' (B,N,3): the same, already transposed] [+ 'feature' (B,C,N), or 'feature_rows' (B,N,C) channels-last]
         [+ 'geometry_plan' from plan_geometry()] -> {'seg_logit': (B,num_classes,N)}."""
         with R.zero_pool.step(data_batch['points'].device), R.eval_invstd.scope(self):  # one zero fill per step / one invstd pass per eval forward
             return self._forward(data_batch)
 
     def _forward(self, data_batch):
-        xyz = data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
+        xyz = data_batch['points_rows'] if 'points_rows' in data_batch else data_batch['points'].transpose(1, 2).contiguous()  # (B,N,3)
         plan = data_batch.get('geometry_plan')
         level_events = None if plan is None else plan.get('level_events')
         if plan is not None and plan.get('event') is not None and level_events is None:
