@@ -20,7 +20,7 @@ def main():
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     # a step ends with the fused Adam launches: split there
-    marks = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name']]
+    marks = [i for i, r in enumerate(rows) if 'adam_multi_kernel' in r['Kernel_Name'] or 'FusedAdam' in r['Kernel_Name']]
     ends = [m for j, m in enumerate(marks) if j + 1 == len(marks) or marks[j + 1] - m > 8]
     a, b = ends[-back - 1] + 1, ends[-back] + 1
     step = rows[a:b]
