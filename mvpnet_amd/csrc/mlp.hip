@@ -423,6 +423,23 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
       __builtin_amdgcn_wave_barrier();
     }
   }
+  // y_prev tiles of ALL column blocks: their loads are issued together, ahead of the per-block epilogue below -- one exposed load latency
+  // per row tile instead of one per column block (the K loop's operand registers are dead here: no extra register pressure)
+  f32x4 ypv[VEC ? NB : 1][4];
+  if constexpr (VEC) {
+    if (epi.y) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const int row = pp * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+          const int64_t r = row0 + wave * 32 + row;
+          const int cc = col0 + j * 32 + c4;
+          ypv[j][pp] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (r < R && cc < Cout) ypv[j][pp] = *reinterpret_cast<const f32x4*>(epi.y + (size_t)r * Cout + cc);
+        }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int co = col0 + j * 32 + cl;
@@ -439,16 +456,12 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
     if (has_rel && co < Cout) wr = *reinterpret_cast<const f32x4*>(epi.wrel + (size_t)co * 4);
     float yst[16];
     if constexpr (VEC) {
-      if (epi.y) {  // y_prev tile: 16-byte row loads into the wave's LDS tile, read back in the accumulator layout below
+      if (epi.y) {  // y_prev tile: 16-byte row loads (issued above) into the wave's LDS tile, read back in the accumulator layout below
         float* st = Ss[wave];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
           const int row = pp * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-          const int64_t r = row0 + wave * 32 + row;
-          const int cc = col0 + j * 32 + c4;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (r < R && cc < Cout) v = *reinterpret_cast<const f32x4*>(epi.y + (size_t)r * Cout + cc);
-          *reinterpret_cast<f32x4*>(st + row * kLdS + c4) = v;
+          *reinterpret_cast<f32x4*>(st + row * kLdS + c4) = ypv[j][pp];
         }
         __builtin_amdgcn_wave_barrier();
       }
