@@ -1034,6 +1034,26 @@ def test_pooled_last_layer_without_its_output_tensor(dev, chain):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=2e-4 * float(a.abs().max()))
     for a, b in zip(b0, b1):
         np.testing.assert_allclose(b.float().cpu().numpy(), a.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # ... and both against the chain written out in plain float64 torch with autograd (conv.py:41-51 in training mode: 1x1 conv ->
+    # BatchNorm with batch statistics -> ReLU; modules.py:100-108: max over the K neighbours): pooled output, input and parameter gradients
+    hi = torch.float64
+    xr = x0.to(hi).requires_grad_(True)
+    params, h = [], xr
+    for layer in base:
+        w = layer.conv.weight.detach().reshape(layer.conv.weight.size(0), -1).to(hi).requires_grad_(True)
+        g, bt = layer.bn.weight.detach().to(hi).requires_grad_(True), layer.bn.bias.detach().to(hi).requires_grad_(True)
+        params += [w, g, bt]
+        y = h @ w.t()
+        h = torch.relu((y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + layer.bn.eps) * g + bt)
+    ref = h.view(G, K, -1).max(dim=1)[0]
+    (ref * wgt.to(hi)).sum().backward()
+    for o, gx, gp in ((o0, gx0, gp0), (o1, gx1, gp1)):
+        np.testing.assert_allclose(o.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.detach().abs().max()))
+        rel = lambda a, r: float((a.to(hi).reshape(r.shape) - r).norm() / r.norm())
+        assert rel(gx, xr.grad) <= 5e-3, rel(gx, xr.grad)      # (gradient contractions: 2 bf16 pieces, ~2^-17 per product)
+        assert len(gp) == len(params)
+        for a, r in zip(gp, params):
+            assert rel(a, r.grad) <= 5e-3, (tuple(r.shape), rel(a, r.grad))
 
 
 @pytest.mark.parametrize('cin,widths,N,M', [(64, (32, 32, 64), 2048, 512), (64, (64, 64, 128), 1024, 256), (0, (32, 32, 64), 1500, 300),
@@ -1068,6 +1088,24 @@ def test_sa_fused_inference_kernel(dev, cin, widths, N, M):
     (x0, f0), (x1, f1) = res
     assert torch.equal(x0, x1) and f0.shape == f1.shape == (B, M, widths[-1])
     np.testing.assert_allclose(f1.cpu().numpy(), f0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # ... and both against the level written out in plain float64 torch (modules.py:74-109 with conv.py:41-51 in eval mode): gather,
+    # [feature | xyz - centre], three x (1x1 conv -> BatchNorm with running statistics -> ReLU), max over the 32 neighbours
+    hi = torch.float64
+    new_xyz, ball = sa.geometry(xyz)[:2]
+    assert torch.equal(new_xyz, x0)
+    bi = torch.arange(B, device=dev)[:, None, None]
+    x = (xyz[bi, ball] - new_xyz[:, :, None]).to(hi)
+    if cin:
+        x = torch.cat([feat[bi, ball].to(hi), x], dim=-1)
+    for layer in sa.mlp:
+        w = layer.conv.weight.detach().reshape(layer.conv.weight.size(0), -1).to(hi)
+        bn = layer.bn
+        x = x @ w.t()
+        x = torch.relu((x - bn.running_mean.to(hi)) / torch.sqrt(bn.running_var.to(hi) + bn.eps) * bn.weight.detach().to(hi) + bn.bias.detach().to(hi))
+    ref = x.max(dim=2)[0]
+    scale = float(ref.abs().max())
+    for got in (f0, f1):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
     # a ball query with empty slots (index -1): zero rows, exactly like the unfused gather
     geo = list(sa.geometry(xyz))
     geo[1] = geo[1].clone()
