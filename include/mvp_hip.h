@@ -273,6 +273,13 @@ int64_t mvp_group_lin_partial_count(int64_t B, int64_t C, int64_t M, int64_t K);
 int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
                            int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat,
                            double* partial, mvp_stream_t stream);
+/* The same with the BatchNorm finalize of the layer (batch statistics over the B*M*K rows: mean, invstd (C floats out), running
+ * statistics and num_batches_tracked updated when not NULL -- the arithmetic of mvp_bn_finalize_f32) carried by the last workgroup
+ * of the statistics reduction: no finalize launch behind it.  stat: 2*C + 1 float64, ZERO on entry (sums + completion counter). */
+int mvp_group_lin_rows_bn_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index, int64_t B,
+                              int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat, double* partial, float eps,
+                              float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, mvp_stream_t stream);
 /* stat (2*C float64) += column sums of y and y^2 over the R rows of y (R,C); accumulated: the caller provides zeros */
 int mvp_colstats_f32(const float* y, int64_t R, int64_t C, double* stat, double* partial, mvp_stream_t stream);
 /* `partial` of mvp_colstats_f32 / mvp_bn_rows_forward_f32 / mvp_bn_rows_backward_f32: optional scratch of
@@ -304,6 +311,10 @@ int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_t* offse
  * stat (2*C float64, accumulated into) / partial (mvp_group_lin_partial_count(B,C,N2,1) float64) as in mvp_group_lin_rows_f32. */
 int mvp_interp_add_rows_f32(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B, int64_t N1,
                             int64_t C, int64_t N2, float* out, double* stat, double* partial, mvp_stream_t stream);
+/* ... with the BatchNorm finalize over the B*N2 rows carried by the reduction, as mvp_group_lin_rows_bn_f32 (stat: 2*C + 1, zero). */
+int mvp_interp_add_rows_bn_f32(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B, int64_t N1,
+                               int64_t C, int64_t N2, float* out, double* stat, double* partial, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
 int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B, int64_t N1,
                                  int64_t C, int64_t N2, int64_t ld, float* grad_feature, mvp_stream_t stream);
 /* BatchNorm (+ReLU) (+max over K consecutive rows) on a row matrix y (G*K, C): replaces the BN / ReLU /

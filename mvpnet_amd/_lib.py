@@ -69,6 +69,7 @@ _SIGNATURES = {
     'mvp_group_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_rows_backward_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_lin_rows_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_group_lin_rows_bn_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_colstats_f32': [_ptr, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_relation_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interp_rows_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
@@ -78,6 +79,7 @@ _SIGNATURES = {
     'mvp_csr_build_sorted_i64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_gather_rows_backward_csr_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interp_add_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
+    'mvp_interp_add_rows_bn_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_interp_rows_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_bn_rows_forward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, ctypes.c_int, _f32, _f32, ctypes.c_int, _ptr, _ptr, _ptr, _ptr,
                                 _ptr, _ptr, _ptr, _ptr, _ptr],

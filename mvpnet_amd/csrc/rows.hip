@@ -1143,9 +1143,8 @@ MVP_API int mvp_interp_rows_f32(const float* feature, const int64_t* index, cons
   return mvp_launch_status();
 }
 
-MVP_API int mvp_interp_add_rows_f32(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B,
-                                    int64_t N1, int64_t C, int64_t N2, float* out, double* stat, double* partial,
-                                    mvp_stream_t stream) {
+static int interp_add_rows(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B, int64_t N1,
+                           int64_t C, int64_t N2, float* out, double* stat, double* partial, const BnFinalize* fin, mvp_stream_t stream) {
   MVP_NONNULL(feature);
   MVP_NONNULL(index);
   MVP_NONNULL(weight);
@@ -1157,8 +1156,29 @@ MVP_API int mvp_interp_add_rows_f32(const float* feature, const int64_t* index, 
   const int64_t gx = cdiv(N2, (int64_t)kGLIter * (kRT / (C / 4)));
   hipLaunchKernelGGL(interp_add_rows_kernel, dim3((unsigned)gx, (unsigned)B), dim3(kRT), 0, s, feature, index, weight, add, (int)N1,
                      (int)C, (int)N2, out, stat ? partial : nullptr);
-  if (stat) launch_stats_reduce(partial, gx * B, (int)(2 * C), stat, s);
+  if (stat && fin) launch_stats_reduce_finalize(partial, gx * B, (int)(2 * C), stat, *fin, s);
+  else if (stat) launch_stats_reduce(partial, gx * B, (int)(2 * C), stat, s);
   return mvp_launch_status();
+}
+
+MVP_API int mvp_interp_add_rows_f32(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B,
+                                    int64_t N1, int64_t C, int64_t N2, float* out, double* stat, double* partial,
+                                    mvp_stream_t stream) {
+  return interp_add_rows(feature, index, weight, add, B, N1, C, N2, out, stat, partial, nullptr, stream);
+}
+
+// The same with the BatchNorm finalize of the layer this output feeds (batch statistics over the B*N2 rows: mean, invstd, running
+// statistics) riding on the last workgroup of the statistics reduction -- no bn_finalize launch behind it.  stat: 2*C + 1 float64,
+// ZERO on entry (sums + the completion counter, left zero again).
+MVP_API int mvp_interp_add_rows_bn_f32(const float* feature, const int64_t* index, const float* weight, const float* add, int64_t B,
+                                       int64_t N1, int64_t C, int64_t N2, float* out, double* stat, double* partial, float eps,
+                                       float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, mvp_stream_t stream) {
+  MVP_NONNULL(stat);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  const BnFinalize fin{B * N2, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
+  return interp_add_rows(feature, index, weight, add, B, N1, C, N2, out, stat, partial, &fin, stream);
 }
 
 MVP_API int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* index, const float* weight, int64_t B,
@@ -1398,9 +1418,9 @@ MVP_API int64_t mvp_group_lin_partial_count(int64_t B, int64_t C, int64_t M, int
   return B * cdiv(M * K, (int64_t)kGLIter * (kRT / (C / 4))) * 2 * C;
 }
 
-MVP_API int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
-                                   int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat,
-                                   double* partial, mvp_stream_t stream) {
+static int group_lin_rows(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index, int64_t B,
+                          int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat, double* partial,
+                          const BnFinalize* fin, mvp_stream_t stream) {
   MVP_NONNULL(xyz);
   MVP_NONNULL(centre);
   MVP_NONNULL(wxyz);
@@ -1414,8 +1434,28 @@ MVP_API int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const floa
   dim3 grid((unsigned)gx, (unsigned)B);
   hipLaunchKernelGGL(group_lin_rows_kernel, grid, dim3(kRT), 0, s, zf, xyz, centre, wxyz, index, (int)N, (int)C, (int)M, (int)K, out,
                      diff, stat ? partial : nullptr);
-  if (stat) launch_stats_reduce(partial, gx * B, (int)(2 * C), stat, s);
+  if (stat && fin) launch_stats_reduce_finalize(partial, gx * B, (int)(2 * C), stat, *fin, s);
+  else if (stat) launch_stats_reduce(partial, gx * B, (int)(2 * C), stat, s);
   return mvp_launch_status();
+}
+
+MVP_API int mvp_group_lin_rows_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
+                                   int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat,
+                                   double* partial, mvp_stream_t stream) {
+  return group_lin_rows(zf, xyz, centre, wxyz, index, B, N, C, M, K, out, diff, stat, partial, nullptr, stream);
+}
+
+// The same with the BatchNorm finalize of the layer (batch statistics over the B*M*K rows) carried by the statistics reduction, as
+// mvp_interp_add_rows_bn_f32.  stat: 2*C + 1 float64, ZERO on entry.
+MVP_API int mvp_group_lin_rows_bn_f32(const float* zf, const float* xyz, const float* centre, const float* wxyz, const int64_t* index,
+                                      int64_t B, int64_t N, int64_t C, int64_t M, int64_t K, float* out, float* diff, double* stat,
+                                      double* partial, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream) {
+  MVP_NONNULL(stat);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  const BnFinalize fin{B * M * K, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
+  return group_lin_rows(zf, xyz, centre, wxyz, index, B, N, C, M, K, out, diff, stat, partial, &fin, stream);
 }
 
 // stat (2*C float64, accumulated into) += column sums of y and y*y over R rows

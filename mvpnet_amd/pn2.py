@@ -132,10 +132,11 @@ class SetAbstraction(nn.Module):
                 fused = R.sa_fused_eval(zf, xyz, new_xyz, ball, self.mlp)
                 if fused is not None:
                     return new_xyz, fused
-            y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=bn_training, csr=csr, sink=sink)  # (B,M,K,C_1): conv output of layer 1
+            # (B,M,K,C_1): conv output of layer 1; in training also its batch statistics AND the BatchNorm finalize, from the same call
+            y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=l0.bn if bn_training else False, csr=csr, sink=sink)
             stat1 = None
             if bn_training:
-                y1, stat1 = y1
+                y1, stat1 = y1[0], (y1[1], y1[2])
             new_feature = R.shared_mlp_rows(y1.view(B * M * K, c1), self.mlp, K=K, first_done=True, first_stat=stat1)
             return new_xyz, new_feature.view(B, M, -1)
         if use_feature and feature.size(2) % 4:
@@ -253,10 +254,10 @@ class FeaturePropagation(nn.Module):
                 if dense_feature is not None:
                     zs = R.linear_rows(dense_feature.reshape(B * N, -1), l0.conv.weight, cols=(c2, w1.size(1)), sink=sink).view(B, N, c1)
                 bn_training = l0.bn.training
-                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=bn_training, csr=csr)
+                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=l0.bn if bn_training else False, csr=csr)
                 stat1 = None
                 if bn_training:
-                    y1, stat1 = y1
+                    y1, stat1 = y1[0], (y1[1], y1[2])
                 return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1).view(B, N, -1)
             new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)
         return R.shared_mlp_rows(new_feature.reshape(B * N, -1), self.mlp).view(B, N, -1)

@@ -439,18 +439,30 @@ class GroupLinRows(torch.autograd.Function):
         dev = xyz.device
         out = torch.empty((B, M, K, C), dtype=torch.float32, device=dev)
         diff = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_w else None
-        stat = zero_pool.zeros(2 * C, torch.float64, dev) if want_stat else None
+        # want_stat: False / True / the layer's BatchNorm module (training): its finalize (mean | invstd, running statistics) then rides
+        # on the statistics reduction of this call and the result carries a third tensor (2C floats: mean | invstd)
+        bn = want_stat if isinstance(want_stat, torch.nn.Module) else None
+        stat = zero_pool.zeros(2 * C + (1 if bn is not None else 0), torch.float64, dev) if want_stat else None
         partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, M, K), dtype=torch.float64, device=dev) if want_stat else None
-        L.call('mvp_group_lin_rows_f32', xyz, L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(wxyz), L.ptr(index), B, N, C, M, K,
-               L.ptr(out), L.ptr(diff), L.ptr(stat), L.ptr(partial))
+        mi = torch.empty(2 * C, dtype=torch.float32, device=dev) if bn is not None else None
+        if bn is not None:
+            L.call('mvp_group_lin_rows_bn_f32', xyz, L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(wxyz), L.ptr(index), B, N, C, M, K,
+                   L.ptr(out), L.ptr(diff), L.ptr(stat), L.ptr(partial), float(bn.eps), 0.1 if bn.momentum is None else float(bn.momentum),
+                   L.ptr(mi), L.ptr_at(mi, C), L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked))
+        else:
+            L.call('mvp_group_lin_rows_f32', xyz, L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(wxyz), L.ptr(index), B, N, C, M, K,
+                   L.ptr(out), L.ptr(diff), L.ptr(stat), L.ptr(partial))
         ctx.has_zf = zf is not None
         if offsets is None and ctx.has_zf and zf.requires_grad:  # not supplied by the geometry plan: build it here
             offsets, slots = build_csr(index, N)
         ctx.save_for_backward(index, diff, offsets, slots)
         ctx.dims = (B, N, C, M, K)
         if want_stat:
-            ctx.mark_non_differentiable(stat)
             ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
+            if mi is not None:
+                ctx.mark_non_differentiable(stat, mi)
+                return out, stat, mi
+            ctx.mark_non_differentiable(stat)
             return out, stat
         return out
 
@@ -494,11 +506,12 @@ class GroupLinRows(torch.autograd.Function):
 
 def group_lin_rows(zf, xyz, centre, wxyz, index, want_stat=False, csr=None, sink=None):
     """zf (B,N,C) or None, xyz (B,N,3), centre (B,M,3), wxyz (C,3) -- or the whole conv weight (C, C_in+3[,1,1]) whose last
-    three columns are used --, index (B,M,K) -> (B,M,K,C) [, stat (2C) float64].
+    three columns are used --, index (B,M,K) -> (B,M,K,C) [, stat (2C) float64].  want_stat = the layer's BatchNorm module (training):
+    its finalize runs on the same call's reduction and a third tensor (2C floats: mean | invstd) is returned.
     csr: (offsets, slots) of build_csr(index, N) when the geometry plan already holds it."""
     offsets, slots = csr if csr is not None else (None, None)
     return GroupLinRows.apply(None if zf is None else zf.contiguous(), xyz.contiguous(), centre.contiguous(), wxyz,
-                              index.contiguous(), bool(want_stat), offsets, slots, sink)
+                              index.contiguous(), want_stat if isinstance(want_stat, torch.nn.Module) else bool(want_stat), offsets, slots, sink)
 
 
 class InterpRows(torch.autograd.Function):
@@ -541,18 +554,28 @@ class InterpAddRows(torch.autograd.Function):
         N2 = index.size(1)
         dev = feature.device
         out = torch.empty((B, N2, C), dtype=torch.float32, device=dev)
-        stat = zero_pool.zeros(2 * C, torch.float64, dev) if want_stat else None
+        bn = want_stat if isinstance(want_stat, torch.nn.Module) else None  # as GroupLinRows: the BatchNorm finalize rides on the reduction
+        stat = zero_pool.zeros(2 * C + (1 if bn is not None else 0), torch.float64, dev) if want_stat else None
         partial = torch.empty(L.lib().mvp_group_lin_partial_count(B, C, N2, 1), dtype=torch.float64, device=dev) if want_stat else None
-        L.call('mvp_interp_add_rows_f32', feature, L.ptr(feature), L.ptr(index), L.ptr(weight), L.ptr(add), B, N1, C, N2, L.ptr(out),
-               L.ptr(stat), L.ptr(partial))
+        mi = torch.empty(2 * C, dtype=torch.float32, device=dev) if bn is not None else None
+        if bn is not None:
+            L.call('mvp_interp_add_rows_bn_f32', feature, L.ptr(feature), L.ptr(index), L.ptr(weight), L.ptr(add), B, N1, C, N2, L.ptr(out),
+                   L.ptr(stat), L.ptr(partial), float(bn.eps), 0.1 if bn.momentum is None else float(bn.momentum), L.ptr(mi), L.ptr_at(mi, C),
+                   L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked))
+        else:
+            L.call('mvp_interp_add_rows_f32', feature, L.ptr(feature), L.ptr(index), L.ptr(weight), L.ptr(add), B, N1, C, N2, L.ptr(out),
+                   L.ptr(stat), L.ptr(partial))
         if offsets is None and feature.requires_grad:
             offsets, slots = build_csr(index, N1)
         ctx.save_for_backward(index, weight, offsets, slots)
         ctx.dims = (B, N1, C, N2)
         ctx.has_add = add is not None
         if want_stat:
-            ctx.mark_non_differentiable(stat)
             ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
+            if mi is not None:
+                ctx.mark_non_differentiable(stat, mi)
+                return out, stat, mi
+            ctx.mark_non_differentiable(stat)
             return out, stat
         return out
 
@@ -580,7 +603,7 @@ def interp_add_rows(feature, index, weight, add=None, want_stat=False, csr=None)
         raise RuntimeError('interp_add_rows: float32 feature with C % 4 == 0 expected')
     offsets, slots = csr if csr is not None else (None, None)
     return InterpAddRows.apply(feature.contiguous(), index.contiguous(), weight.contiguous(), None if add is None else add.contiguous(),
-                               bool(want_stat), offsets, slots)
+                               want_stat if isinstance(want_stat, torch.nn.Module) else bool(want_stat), offsets, slots)
 
 
 class BNActRows(torch.autograd.Function):
@@ -730,6 +753,14 @@ class MLPChainRows(torch.autograd.Function):
                 assert i == 0
                 cout = x0.size(1)
                 y = x0
+                if training and isinstance(first_stat, tuple):  # ... and finalized the BatchNorm on its reduction: (stat, mean | invstd)
+                    first_mi = first_stat[1]
+                    ys.append(y)
+                    means.append(first_mi[:cout])
+                    invstds.append(first_mi[cout:])
+                    act = (means[-1], invstds[-1], gamma, beta)
+                    x = y
+                    continue
                 if training and first_stat is not None:
                     stat = first_stat  # the grouping kernel already summed the columns
                 elif training:

@@ -803,6 +803,31 @@ def test_group_lin_rows_vs_torch(dev, B, N, M, K, C, with_zf):
     if with_zf:
         refz = torch.zeros(B, N, C, device=dev).index_put_((bi.expand(B, M, K).reshape(-1), idx.reshape(-1)), cot.reshape(-1, C), accumulate=True)
         np.testing.assert_allclose(zf.grad.cpu().numpy(), refz.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    out2 = _check_bn_on_the_reduction(dev, lambda bn: R.group_lin_rows(None if zf is None else zf.detach(), xyz, centre, w.detach(), idx, want_stat=bn), flat, C)
+    assert torch.equal(out2, out.detach())
+
+
+def _check_bn_on_the_reduction(dev, call, flat, C):
+    """want_stat = a BatchNorm module (training): the same call also finalizes it -- mean | invstd in a third tensor, running statistics
+    and num_batches_tracked moved exactly as torch's own BatchNorm moves them on the same rows."""
+    bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.2).to(dev).train()
+    ref_bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.2).to(dev).train()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        ref_bn.running_mean.copy_(bn.running_mean)
+        ref_bn.running_var.copy_(bn.running_var)
+    out, stat, mi = call(bn)
+    assert stat.numel() == 2 * C + 1 and float(stat[2 * C]) == 0.0  # the completion counter is zero again
+    np.testing.assert_allclose(stat[:C].cpu().numpy(), flat.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    np.testing.assert_allclose(mi[:C].cpu().numpy(), mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mi[C:].cpu().numpy(), (1.0 / torch.sqrt(var + 1e-3)).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    ref_bn(flat.float())
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref_bn.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref_bn.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    return out
 
 
 @pytest.mark.parametrize('B,N1,N2,C,with_add', [(2, 40, 300, 32, True), (3, 128, 1000, 128, False), (1, 4, 17, 256, True)])
@@ -827,6 +852,8 @@ def test_interp_add_rows_vs_torch(dev, B, N1, N2, C, with_add):
     np.testing.assert_allclose(f.grad.cpu().numpy(), reff.cpu().numpy(), rtol=1e-4, atol=1e-4)
     if with_add:
         assert torch.equal(add.grad, cot)
+    out2 = _check_bn_on_the_reduction(dev, lambda bn: R.interp_add_rows(f.detach(), idx, wt, None if add is None else add.detach(), want_stat=bn), flat, C)
+    assert torch.equal(out2, out.detach())
 
 
 @pytest.mark.parametrize('want_sorted', [True, False])
