@@ -495,7 +495,7 @@ def main():
         fwd_ms = (time.perf_counter() - t1) / 10 * 1e3 if not args.train_only else float('nan')
         # configs[1] at B = 1: the LATENCY of one chunk -- nothing to prefetch behind, the forward waits for its own
         # geometry (the FPS chain is a serial dependency of ~2700 steps), synchronised after every chunk
-        b1_ms = float('nan')
+        b1_ms = b1_graph_ms = float('nan')
         if side:
             one = {k: (v[:1] if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == args.batch else v) for k, v in batch.items()}
             net2d.feature = feature[:one['depth'].size(1)]
@@ -507,6 +507,18 @@ def main():
                 model(fresh(one))
                 torch.cuda.synchronize()
             b1_ms = (time.perf_counter() - t1) / 20 * 1e3
+            # ... and the same chunk replayed from ONE HIP graph (mvpnet3d.GraphedForward: inputs copied into the static buffers per call)
+            from mvpnet_amd.mvpnet3d import GraphedForward
+            gf = GraphedForward(model, fresh(one))
+            for _ in range(3):
+                gf(one)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                gf(one)
+                torch.cuda.synchronize()
+            b1_graph_ms = (time.perf_counter() - t1) / 20 * 1e3
+            del gf
             net2d.feature = feature
     # configs[3]: whole-scene inference -- 64 chunks of one synthetic scene sharded over the ranks, ONE all-gather of the per-chunk
     # logits, vote on the device (mvpnet_amd/scene.py).  Extra field; the chunk inputs are the resident batch, tiled.
@@ -630,9 +642,9 @@ def main():
             'with_2d_network': e2e,
             'scene_inference': scene,
             'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),
-                         'latency_ms_B1': round(b1_ms, 3),
+                         'latency_ms_B1': round(b1_ms, 3), 'latency_ms_B1_graph': round(b1_graph_ms, 3),
                          'note': 'configs[1]: lifting + aggregation + PN2SSG forward, eval mode, same batch, geometry of the next batches prefetched two batches per plan; '
-                                 'latency_ms_B1 = one chunk alone, synchronised per chunk (bounded by the serial FPS chain)'},
+                                 'latency_ms_B1 = one chunk alone, synchronised per chunk (bounded by the serial FPS chain); _graph = the same forward replayed from one HIP graph (GraphedForward)'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': lift_traffic(args.batch), 'traffic_source': 'profiles/r03_step_traffic.json (committed rocprofv3 PMC passes of this step at B=32, not read live)', 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},

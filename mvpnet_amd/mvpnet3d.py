@@ -303,6 +303,45 @@ def _plan_tensors(plan):
     return [t for g in plan['sa'] + plan['fp'] if g is not None for t in g]
 
 
+class GraphedForward:
+    """The eval-mode forward of one batch shape (geometry plan on the side stream + 2D network + lifting + aggregation + PN2SSG) replayed
+    from ONE HIP graph.  A single chunk issued eagerly sits behind ~100 launches and the serial FPS chain (2.33 ms, of which the chain is
+    1.55); replayed, the host submits one graph and the levels' kernels follow their per-level events at dispatch speed: 2.25 ms on an idle
+    host (bench field `latency_ms_B1_graph`) -- the chain, not the launches, is what bounds one chunk; under host load the replay is immune.
+    `batch`: a data dict as MVPNet3D.forward takes it (its tensors become the static inputs; keys starting with '_' are ignored);
+    calling the object with another batch of the same shapes copies its tensors in and replays; returns the model's output dict (static
+    tensors: clone what must outlive the next call).  The reference has no counterpart (test_mvpnet_3d.py:142-174 feeds chunk by chunk)."""
+
+    COPY_KEYS = ('images', 'points', 'depth', 'cam_matrix', 'kinv', 'pose', 'pixel_box', 'image_xyz', 'knn_indices', 'flip', 'z_rot', 'feature')
+
+    def __init__(self, model, batch, warmup=2):
+        self.model = model
+        net = model.module if hasattr(model, 'module') else model
+        assert not net.training, 'GraphedForward captures the eval-mode forward (model.eval() first)'
+        self.static = {k: (v.clone() if torch.is_tensor(v) and k in self.COPY_KEYS else v) for k, v in batch.items()
+                       if k not in ('geometry_plan', 'prefetch_next') and not k.startswith('_')}
+        dev = self.static['points'].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():  # eager warm-up off the default stream (allocator, lazy module state, kernel attributes)
+            for _ in range(warmup):
+                model(dict(self.static))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        R.weight_slices.refresh(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.preds = model(dict(self.static))
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            for k, v in batch.items():
+                if k in self.COPY_KEYS and torch.is_tensor(v) and v.data_ptr() != self.static[k].data_ptr():
+                    self.static[k].copy_(v)
+        self.graph.replay()
+        return self.preds
+
+
 class GraphedTrainStep:
     """The training iteration of `train_step` with forward + loss + backward captured ONCE in a HIP graph
     (torch.cuda.CUDAGraph): ~400 kernel launches per step become one graph launch, so the step no longer depends on the

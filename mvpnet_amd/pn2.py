@@ -332,10 +332,10 @@ class PN2SSG(nn.Module):
         # a training step's prefetched chain hides under forward + backward: sample with half the waves (passed per call, nothing
         # process-wide is touched)
         fps_shape = (TRAIN_FPS_SHAPE if (with_csr and stream is not None) else 0) if xyz.is_cuda else None
-        # Inference on two side streams also records one event pair per level: forward() then starts set-abstraction level l as soon as
-        # ITS centroids and neighbours exist instead of after the whole chain (a single chunk: the levels' MLPs run under the rest of the
-        # FPS chain, 2.40 -> ~2.1 ms).
-        level_events = [] if two else None
+        # Inference plans on a side stream also record one event (pair) per level: forward() then starts set-abstraction level l as soon
+        # as ITS centroids and neighbours exist instead of after the whole chain (a single chunk: the levels' MLPs run under the rest of
+        # the FPS chain).  Inside a graph capture (one side stream) the events become edges of the graph.
+        level_events = [] if (stream is not None and not with_csr) else None
         with torch.cuda.stream(stream if stream is not None else cur):
             run = torch.cuda.current_stream(xyz.device)
             sa, xyzs = [], [xyz]
@@ -353,9 +353,10 @@ class PN2SSG(nn.Module):
                 if fpm.interpolator is not None:
                     fp_by_level[level] = on_second(run, lambda i=fpm.interpolator, a=xyzs[-2], b=xyzs[-1]: i.geometry(a, b, with_csr=with_csr))
                 if level_events is not None:
-                    ev_run, ev_s2 = torch.cuda.Event(), torch.cuda.Event()
-                    ev_run.record(run)   # this level's centroids (the FPS chain so far)
-                    ev_s2.record(s2)     # its ball query, and the 3-NN of every level up to here
+                    ev_run, ev_s2 = torch.cuda.Event(), (torch.cuda.Event() if two else None)
+                    ev_run.record(run)   # this level's centroids (the FPS chain so far; with ONE side stream also its neighbours)
+                    if two:
+                        ev_s2.record(s2)  # its ball query, and the 3-NN of every level up to here
                     level_events.append((ev_run, ev_s2))
             fp = [fp_by_level.get(len(self.sa_modules) - 1 - k) for k in range(len(self.fp_modules))]
             if two:
@@ -416,7 +417,10 @@ class PN2SSG(nn.Module):
             if level_events is not None:  # this level's geometry only (the deeper levels are still being sampled)
                 cur = torch.cuda.current_stream(xyz.device)
                 for ev in level_events[level]:
-                    cur.wait_event(ev)
+                    if ev is not None:
+                        cur.wait_event(ev)
+                if level + 1 == len(self.sa_modules) and plan.get('event') is not None:
+                    cur.wait_event(plan['event'])  # the plan's own end (nothing is left to run: this joins the side stream, as a capture needs)
             xyz, feature = sa(xyz, feature, rows=True, geometry=None if plan is None else plan['sa'][level])
             xyzs.append(xyz)
             feats.append(feature)

@@ -406,6 +406,39 @@ def test_geometry_of_several_batches_in_one_plan(dev):
         assert torch.equal(model(a3)['seg_logit'], ref[0]) and torch.equal(model(a4)['seg_logit'], ref[0])
 
 
+def test_graphed_forward_replays_the_eager_logits(dev):
+    """mvpnet3d.GraphedForward: the eval-mode forward (geometry plan on the side stream with per-level events as graph edges, lifting,
+    aggregation, PN2SSG) captured once and replayed for other inputs of the same shape gives the eager forward's logits bit for bit."""
+    from mvpnet_amd.pn2 import PN2SSG
+    from mvpnet_amd.mvpnet3d import MVPNet3D, GraphedForward
+    torch.manual_seed(33)
+    model = MVPNet3D(StubNet2D(), '', PN2SSG(16, 20, dropout_prob=0.0, **CFG), in_channels=16, mlp_channels=(16, 16, 16)).to(dev).eval()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def batch_of(ids):
+        cs = [make_chunk(900 + i, nb_pts=1024, nv=2, h=30, w=40, channels=16) for i in ids]
+        st = lambda k: np.stack([c[k] for c in cs])
+        b = {'images': torch.zeros(len(ids), 2, 3, 30, 40, device=dev), 'points': t(st('points').transpose(0, 2, 1)),
+             'depth': t(st('depth_mm').astype(np.int16)), 'cam_matrix': t(np.stack([np.repeat(c['cam_matrix'][None, :3, :3], 2, 0) for c in cs])),
+             'kinv': t(st('kinv')), 'pose': t(st('pose')), 'pixel_box': t(st('pixel_box')), 'k': 3}
+        return b, t(st('feature_2d')).view(len(ids) * 2, 30, 40, 16).permute(0, 3, 1, 2).contiguous()
+
+    (a, fa), (b, fb) = batch_of([0, 1]), batch_of([2, 3])
+    feat = fa.clone()          # the stub 2D network hands out this tensor: static memory, refilled per batch
+    model.net_2d.feature = feat
+    with torch.no_grad():
+        ref_a = model(dict(a))['seg_logit'].clone()
+        feat.copy_(fb)
+        ref_b = model(dict(b))['seg_logit'].clone()
+    feat.copy_(fa)
+    gf = GraphedForward(model, dict(a))
+    assert torch.equal(gf()['seg_logit'], ref_a)
+    feat.copy_(fb)
+    assert torch.equal(gf(b)['seg_logit'], ref_b)
+    feat.copy_(fa)
+    assert torch.equal(gf(a)['seg_logit'], ref_a)
+
+
 def _load_case(module, g, prefix, seed):
     ref_keys = [(k, tuple(sh)) for k, sh in json.loads(str(g[prefix + '_state_keys']))]
     assert [(k, tuple(v.shape)) for k, v in module.state_dict().items()] == ref_keys, 'state_dict keys/shapes differ from the reference'
