@@ -349,15 +349,17 @@ class PN2SSG(nn.Module):
                     csr = with_csr and (level > 0 or self.in_channels > 0)
                     sa.append((new_xyz,) + on_second(run, lambda m=m, a=new_xyz, b=xyzs[-1], c=csr: m.neighbours(a, b, c)))
                     xyzs.append(new_xyz)
-                fpm = self.fp_modules[len(self.sa_modules) - 1 - level]  # propagates level + 1 -> level
-                if fpm.interpolator is not None:
-                    fp_by_level[level] = on_second(run, lambda i=fpm.interpolator, a=xyzs[-2], b=xyzs[-1]: i.geometry(a, b, with_csr=with_csr))
                 if level_events is not None:
+                    # recorded BEFORE this level's 3-NN search is queued: set abstraction does not need it (one chunk: 180 us on the
+                    # second stream); feature propagation waits for the plan's end event, which covers every 3-NN
                     ev_run, ev_s2 = torch.cuda.Event(), (torch.cuda.Event() if two else None)
                     ev_run.record(run)   # this level's centroids (the FPS chain so far; with ONE side stream also its neighbours)
                     if two:
-                        ev_s2.record(s2)  # its ball query, and the 3-NN of every level up to here
+                        ev_s2.record(s2)  # its ball query
                     level_events.append((ev_run, ev_s2))
+                fpm = self.fp_modules[len(self.sa_modules) - 1 - level]  # propagates level + 1 -> level
+                if fpm.interpolator is not None:
+                    fp_by_level[level] = on_second(run, lambda i=fpm.interpolator, a=xyzs[-2], b=xyzs[-1]: i.geometry(a, b, with_csr=with_csr))
             fp = [fp_by_level.get(len(self.sa_modules) - 1 - k) for k in range(len(self.fp_modules))]
             if two:
                 run.wait_stream(s2)
