@@ -15,7 +15,7 @@ from mvpnet_amd.mvpnet3d import MVPNet3D  # noqa: E402
 from tests.operating_point import SuppliedFeature2D  # noqa: E402
 
 dev = torch.device('cuda:0')
-B = 1
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 bt = make_batch(7000, B, config=3)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 nv = bt['depth_mm'].shape[1]
