@@ -35,8 +35,18 @@ constexpr int kRegC = 32;
 __device__ __forceinline__ float row_lse(const float* __restrict__ p, int64_t ld_c, int C, float* mx_out, float* x /* kRegC */) {
   float mx, se = 0.f;
   if (C <= kRegC) {
+    if (ld_c == 1 && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      // channels-last rows (the layout PN2SSG hands out): the point's C logits are C / 4 16-byte loads instead of 32 4-byte ones whose
+      // lanes sit 4 C bytes apart (34 -> ~12 us for the 262144 x 20 batch); same values, same arithmetic
 #pragma unroll
-    for (int c = 0; c < kRegC; ++c) x[c] = p[(int64_t)min(c, C - 1) * ld_c];
+      for (int q = 0; q < kRegC / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * min(q, C / 4 - 1));  // quads >= C / 4 repeat the last one
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < kRegC; ++c) x[c] = p[(int64_t)min(c, C - 1) * ld_c];
+    }
     mx = x[0];
 #pragma unroll
     for (int c = 1; c < kRegC; ++c) mx = fmaxf(mx, x[c]);  // entries >= C repeat the last class
@@ -101,8 +111,12 @@ __global__ __launch_bounds__(kST) void seg_loss_bwd_kernel(const float* __restri
   const int64_t b = r / N, n = r - b * N;
   float* g = grad + b * gld_b + n * gld_n;
   const int64_t y = label[r];
+  const bool gvec = gld_c == 1 && (C & 3) == 0 && C <= kRegC && (reinterpret_cast<uintptr_t>(g) & 15) == 0;  // rows layout: 16-byte stores
   if (y == ignore_index || y < 0 || y >= C) {
-    for (int c = 0; c < C; ++c) g[(int64_t)c * gld_c] = 0.f;
+    if (gvec)
+      for (int q = 0; q < C / 4; ++q) *reinterpret_cast<float4*>(g + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else
+      for (int c = 0; c < C; ++c) g[(int64_t)c * gld_c] = 0.f;
     return;
   }
   const float* p = logit + b * ld_b + n * ld_n;
@@ -110,9 +124,18 @@ __global__ __launch_bounds__(kST) void seg_loss_bwd_kernel(const float* __restri
   const float lse = row_lse(p, ld_c, C, &mx, x);
   const float scale = (float)((double)(*grad_out) * (double)(weight ? weight[y] : 1.f) / acc[1]);
   if (C <= kRegC) {
+    float gv[kRegC];
 #pragma unroll
-    for (int c = 0; c < kRegC; ++c)
-      if (c < C) g[(int64_t)c * gld_c] = scale * (expf((x[c] - mx) - lse) - (c == y ? 1.f : 0.f));
+    for (int c = 0; c < kRegC; ++c) gv[c] = c < C ? scale * (expf((x[c] - mx) - lse) - (c == y ? 1.f : 0.f)) : 0.f;
+    if (gvec) {
+#pragma unroll
+      for (int q = 0; q < kRegC / 4; ++q)
+        if (4 * q < C) *reinterpret_cast<float4*>(g + 4 * q) = make_float4(gv[4 * q], gv[4 * q + 1], gv[4 * q + 2], gv[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < kRegC; ++c)
+        if (c < C) g[(int64_t)c * gld_c] = gv[c];
+    }
   } else {
     for (int c = 0; c < C; ++c) {
       const float sm = expf((p[(int64_t)c * ld_c] - mx) - lse);
