@@ -96,6 +96,8 @@ def points_rows(data_batch, points=None):
     if hit is not None and hit[0] is points and hit[1] == points._version:
         return hit[2]
     rows = points.transpose(1, 2).contiguous()
+    if len(cache) >= 2:  # a batch has at most two sources (the loader's points, the rotated ones): a dict that is REUSED with new
+        cache.clear()    # point tensors must not collect their copies
     cache[id(points)] = (points, points._version, rows)
     return rows
 
