@@ -211,7 +211,9 @@ MVP_API int mvp_seg_loss_f32(const float* logit, int64_t B, int64_t C, int64_t N
   MVP_NONNULL(acc);
   MVP_NONNULL(loss);
   const int64_t R = B * N;
-  const unsigned blocks = (unsigned)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(R, kST)));
+  // at most 256 workgroups: each ends in three fp64 atomics on ONE cache line (sums + ticket), which queue (262144 points: 23.7 us with
+  // 256, 28.7 with 512, 45.5 with 1024, 24.5 with 128 workgroups -- tools/exp/seg_loss_time.py)
+  const unsigned blocks = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, cdiv(R, kST)));
   hipLaunchKernelGGL(seg_loss_kernel, dim3(blocks), dim3(kST), 0, static_cast<hipStream_t>(stream), logit, B, (int)C, N, ld_b, ld_c, ld_n,
                      label, weight, ignore_index, acc, loss);
   return mvp_launch_status();
