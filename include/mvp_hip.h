@@ -61,6 +61,24 @@ int mvp_fps_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M
 /* the same with the launch shape (0 / 1, see mvp_set_fps_mode) as an argument: nothing process-wide is read */
 int mvp_fps_shape_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, mvp_stream_t stream);
 int mvp_fps_shape_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, mvp_stream_t stream);
+/* the same with a caller-provided DEVICE status word (may be NULL).  float32 clouds of 8193..65536 points are sampled by four workgroups
+ * per cloud that wait for each other's row results; a workgroup that polls 2^22 times without seeing its partners (they were not resident
+ * together: other streams held the CUs) gives up, leaves -1 in its rows and sets *status = 1 (sticky: the library never clears it).  The
+ * one-workgroup kernel is queued right behind with the flag as its guard and re-samples the call's clouds when -- and only when -- the flag
+ * is set, so `index` holds the exact chain in either case (reference contract: a failed launch is an error, never wrong indices --
+ * fps_kernel.cu:177 THCudaCheck).  mvp_fps_debug_spin_limit(polls) sets the poll bound (<= 0: the default 2^22) and returns the old one:
+ * a test hook that forces the time-out path. */
+int mvp_fps_checked_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, int* status,
+                        mvp_stream_t stream);
+int mvp_fps_debug_spin_limit(int polls);
+/* Centroids of a CHAIN of sampling levels from the first level's indices (mvpnet/models/pn2/modules.py:74-87 applied level after level,
+ * pn2ssg.py:92-99): outs[l][b, m, :] = points[b, index[b, m], :] for m < counts[l], counts[0] = M >= counts[1] >= ... (host arrays of
+ * `levels` <= 8 entries; outs[l] = device pointer to (B, counts[l], D)).  Farthest point sampling of a cloud that is itself the output of
+ * a sampling run, in sampling order, returns 0, 1, 2, ...: the running distances of the second chain are the first chain's, its maxima are
+ * attained by the same points, and every tie is won by the lowest index; when all remaining distances are 0 both chains return point 0,
+ * whose coordinates the prefix holds as well -- so the deeper levels' centroid coordinates are the PREFIXES of the first level's. */
+int mvp_fps_centroid_levels_f32(const float* points, const int64_t* index, int64_t B, int64_t N, int64_t D, int64_t M, int64_t levels,
+                                const int64_t* counts, float* const* outs, mvp_stream_t stream);
 
 /* ---- ball query ---------------------------------------------------------------------
  * replaces ball_query_cuda.ball_query (mvpnet/ops/cuda/ball_query.cpp:7-15,
@@ -515,6 +533,54 @@ int64_t mvp_mlp_weight_grad_workspace_floats(void);
 int mvp_mlp_weight_grad_ws_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                                const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                                float* dW, int64_t lddw, float* workspace, int64_t workspace_floats, mvp_stream_t stream);
+
+/* ---- the shared-MLP entry points with the contraction precision as ARGUMENTS (csrc/mlp_prec.hip) -----------------------------------
+ * mvp_<name>_p_f32 = mvp_<name>_f32 with two more parameters in front of the stream:
+ *     precision           contraction of this call: 0 = fp32 MFMA, 1 = bf16, 3 = bf16x3, 6 = bf16x6, -1 = the default
+ *     precision_backward  split of a gradient contraction made by this call: 1, 3, 6, -1 = the default
+ * With both >= 0 nothing process-wide is read: mvp_set_mlp_precision[_backward] only provide the defaults that -1 selects (SURVEY 8b:
+ * stateless, re-entrant -- the reference's ops take everything they depend on as arguments: the pybind signatures under mvpnet/ops/cuda).  The host code hands
+ * the precision a forward ran with to the node's backward calls, which autograd issues from another thread.  MVP_EINVAL for other values. */
+int mvp_mlp_forward_p_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout, const
+    float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, const float* bias, float* Y,
+    double* stat, double* partial, int precision, int precision_backward, mvp_stream_t stream);
+int mvp_mlp_forward_bn_p_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+    const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* Y, double* stat,
+    double* partial, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, int64_t*
+    num_batches_tracked, int precision, int precision_backward, mvp_stream_t stream);
+int mvp_mlp_forward_rel_bn_p_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+    const float* rel, const float* wrel, float* Y, double* stat, double* partial, float eps, float momentum, float* mean, float*
+    invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int precision, int precision_backward,
+    mvp_stream_t stream);
+int mvp_mlp_forward_pool_p_f32(const float* X, int64_t R, int64_t Cin, int64_t ldx, const float* W, int64_t ldw, int64_t Cout,
+    const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* ymax, float* ymin,
+    uint8_t* amax, uint8_t* amin, double* stat, double* partial, float eps, float momentum, float* mean, float* invstd, float*
+    running_mean, float* running_var, int64_t* num_batches_tracked, int precision, int precision_backward, mvp_stream_t stream);
+int mvp_mlp_input_grad_p_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev, const
+    float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ, double* stat, double* partial, int
+    precision, int precision_backward, mvp_stream_t stream);
+int mvp_mlp_weight_grad_p_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, const float*
+    act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* dW, int64_t lddw, int precision,
+    int precision_backward, mvp_stream_t stream);
+int mvp_mlp_weight_grad_ws_p_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, const
+    float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* dW, int64_t lddw, float*
+    workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
+int mvp_mlp_layer_backward_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float*
+    gamma_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float*
+    act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw, int64_t R,
+    int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, double* partial, const float* pool_dout, const
+    float* pool_out, const uint8_t* pool_arg, int precision, int precision_backward, mvp_stream_t stream);
+int mvp_mlp_layer_backward_ws_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float*
+    gamma_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx, const float*
+    act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw, int64_t R,
+    int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, double* partial, const float* pool_dout, const
+    float* pool_out, const uint8_t* pool_arg, float* workspace, int64_t workspace_floats, int precision, int precision_backward,
+    mvp_stream_t stream);
+int mvp_sa_fused_forward_p_f32(const float* zf, const float* xyz, const float* centre, const int64_t* index, const float* wxyz,
+    int64_t B, int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd, const float*
+    bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean, const float* bn2_invstd, const float*
+    bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3, const float* bn3_mean, const float* bn3_invstd, const float*
+    bn3_gamma, const float* bn3_beta, float* out, uint8_t* arg, int precision, int precision_backward, mvp_stream_t stream);
 
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.

@@ -23,6 +23,8 @@ _SIGNATURES = {
     'mvp_fps_f64': [_ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_fps_shape_f32': [_ptr, _i64, _i64, _i64, _i64, _ptr, ctypes.c_int, _ptr],
     'mvp_fps_shape_f64': [_ptr, _i64, _i64, _i64, _i64, _ptr, ctypes.c_int, _ptr],
+    'mvp_fps_checked_f32': [_ptr, _i64, _i64, _i64, _i64, _ptr, ctypes.c_int, _ptr, _ptr],
+    'mvp_fps_centroid_levels_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_ball_query_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr],
     'mvp_ball_query_f64': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr],
     'mvp_ball_query_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],
@@ -116,8 +118,13 @@ _SIGNATURES = {
     'mvp_seg_loss_backward_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
+# the shared-MLP entry points with the precision as arguments (csrc/mlp_prec.hip): base parameters + (precision, precision_backward)
+for _n in ['mvp_mlp_forward_f32', 'mvp_mlp_forward_bn_f32', 'mvp_mlp_forward_rel_bn_f32', 'mvp_mlp_forward_pool_f32', 'mvp_mlp_input_grad_f32',
+           'mvp_mlp_weight_grad_f32', 'mvp_mlp_weight_grad_ws_f32', 'mvp_mlp_layer_backward_f32', 'mvp_mlp_layer_backward_ws_f32',
+           'mvp_sa_fused_forward_f32']:
+    _SIGNATURES[_n[:-4] + '_p_f32'] = _SIGNATURES[_n][:-1] + [ctypes.c_int, ctypes.c_int, _ptr]
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
-           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode'] + sorted(_SIGNATURES)
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode', 'mvp_fps_debug_spin_limit'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -154,6 +161,8 @@ def lib():
         handle.mvp_set_mlp_stream.argtypes = [ctypes.c_int]
         handle.mvp_set_fps_mode.restype = ctypes.c_int
         handle.mvp_set_fps_mode.argtypes = [ctypes.c_int]
+        handle.mvp_fps_debug_spin_limit.restype = ctypes.c_int
+        handle.mvp_fps_debug_spin_limit.argtypes = [ctypes.c_int]
         if os.environ.get('MVP_MLP_STREAM') is not None:
             handle.mvp_set_mlp_stream(int(os.environ['MVP_MLP_STREAM']))
         handle.mvp_set_mlp_precision_backward.restype = ctypes.c_int
@@ -193,8 +202,9 @@ def set_mlp_precision_backward(name):
 class mlp_precision:
     """`with mlp_precision('fp32'): ...` / `with mlp_precision('bf16x6', backward='bf16x6'): ...` -- the contraction precision of the
     shared-MLP launches made by THIS thread inside the block (mvp_mlp_precision_scope: a thread-local override, the process-wide defaults
-    of set_mlp_precision[_backward] are not touched).  Note that autograd runs backward functions on its own thread: wrap a training
-    step's backward in a scope entered from a backward hook, or use the process defaults, when the backward precision matters."""
+    of set_mlp_precision[_backward] are not touched).  An autograd node built inside the block records the pair and hands it to its
+    backward launches as arguments (the `_p_f32` entry points), so `loss.backward()` may run outside the block and on autograd's own
+    thread: forward and backward of a node always agree."""
 
     def __init__(self, forward=None, backward=None):
         self.terms = -1 if forward is None else MLP_PRECISIONS[forward]
@@ -213,9 +223,42 @@ class mlp_precision:
         lib().mvp_mlp_precision_scope(*self.old)
 
 
+def current_precision():
+    """(forward terms, backward terms) the CALLING thread's shared-MLP launches use right now (thread-local scope, else the process
+    defaults): what an autograd node records in forward and hands to its backward calls (`prec=` of call / call_on), which autograd
+    issues from its own thread."""
+    h = lib()
+    return (h.mvp_get_mlp_precision(), h.mvp_get_mlp_precision_backward())
+
+
 def get_mlp_precision():
     terms = lib().mvp_get_mlp_precision()
     return {v: k for k, v in MLP_PRECISIONS.items()}[terms]
+
+
+_FPS_STATUS = {}
+
+
+def fps_status(device):
+    """The per-device status word the sampling calls of this process hand to mvp_fps_checked_f32 (int32, sticky: 1 once a
+    multi-workgroup launch timed out and was repaired by the one-workgroup kernel)."""
+    t = _FPS_STATUS.get(device)
+    if t is None:
+        t = _FPS_STATUS[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def fps_timed_out(device=None, reset=False):
+    """True when a multi-workgroup sampling launch on `device` gave up waiting for its partner workgroups since the last reset (its
+    result was re-computed by the one-workgroup kernel: the indices were right, the launch took ~5x longer).  Synchronises."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    t = _FPS_STATUS.get(device)
+    if t is None:
+        return False
+    hit = bool(int(t.item()))
+    if reset:
+        t.zero_()
+    return hit
 
 
 def check(code, what):
@@ -302,21 +345,27 @@ def _with_dw_workspace(index, stream_handle, args):
     return args + (ws.data_ptr(), ws.numel())
 
 
-def call_on(stream, name, *args):
-    """Invoke `name(*args, stream)` on the given torch.cuda.Stream of the CURRENT device (no stream-context switch on the host)."""
+def call_on(stream, name, *args, prec=None):
+    """Invoke `name(*args, stream)` on the given torch.cuda.Stream of the CURRENT device (no stream-context switch on the host).
+    prec = (precision, precision_backward): the `_p_f32` variant of a shared-MLP entry point, precision as arguments."""
     if DW_WORKSPACE and name in _DW_WS_NAMES:
         name, args = _DW_WS_NAMES[name], _with_dw_workspace(stream.device.index, stream.cuda_stream, args)
+    if prec is not None:
+        name, args = name[:-4] + '_p_f32', args + prec
     code = _fn(name)(*args, stream.cuda_stream)
     if code != 0:
         check(code, name)
 
 
-def call(name, tensor_for_device, *args):
-    """Invoke `name(*args, stream)` on the current stream of tensor_for_device's device."""
+def call(name, tensor_for_device, *args, prec=None):
+    """Invoke `name(*args, stream)` on the current stream of tensor_for_device's device.
+    prec = (precision, precision_backward): the `_p_f32` variant of a shared-MLP entry point, precision as arguments."""
     index = tensor_for_device.device.index
     if DW_WORKSPACE and name in _DW_WS_NAMES:
         handle = _raw_stream(index) if _raw_stream is not None else torch.cuda.current_stream(tensor_for_device.device).cuda_stream
         name, args = _DW_WS_NAMES[name], _with_dw_workspace(index, handle, args)
+    if prec is not None:
+        name, args = name[:-4] + '_p_f32', args + prec
     if _raw_stream is not None and index == _raw_device():  # the usual case (one process per GPU): no device guard, no Stream object
         code = _fn(name)(*args, _raw_stream(index))
     elif index == torch.cuda.current_device():

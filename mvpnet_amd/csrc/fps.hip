@@ -99,7 +99,8 @@ __device__ __forceinline__ void key_max_wave_to_lane63(K& k) {
 
 template <typename T, int D, int PPT, int NT, bool LDS_PTS>
 __global__ __launch_bounds__(NT) void fps_kernel(const T* __restrict__ pts, int N, int M,
-                                                 int64_t* __restrict__ out) {
+                                                 int64_t* __restrict__ out, const int* __restrict__ guard) {
+  if (guard && *guard == 0) return;  // repair launch behind the multi-workgroup sampler: runs only when that one gave up
   constexpr int NW = NT / kWave;
   using K = Key<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,8 +213,9 @@ __device__ __forceinline__ float fmax_dpp(float v) {
 
 template <int D, int PPT, int NT, bool LDS_PTS>
 __global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ pts, int N, int M,
-                                                      int64_t* __restrict__ out) {
+                                                      int64_t* __restrict__ out, const int* __restrict__ guard) {
   static_assert(PPT % 2 == 0, "points are processed in pairs");
+  if (guard && *guard == 0) return;  // repair launch behind the multi-workgroup sampler: runs only when that one gave up
   constexpr int NW = NT / kWave;
   constexpr int NP = PPT / 2;
   using K = Key<float>;
@@ -604,7 +606,8 @@ __device__ __forceinline__ fps_u64 load_device(const fps_u64* p) {
 // no hang).
 template <int D, int PPT, int NT, int W>
 __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out,
-                                                              fps_u64* __restrict__ xch /* [B][2][W][64][8] zero on entry */, int* __restrict__ err) {
+                                                              fps_u64* __restrict__ xch /* [B][2][W][64][8] zero on entry */, int* __restrict__ err,
+                                                              int spin_limit) {
   static_assert(PPT % 2 == 0 && NT == 1024, "16 waves, points in pairs");
   constexpr int NR = NT / 16;  // 64 rows per workgroup = one resolver lane per super row
   constexpr int NP = PPT / 2;
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __res
           u4 = load_device(src + 4);
           ok = (unsigned)(u0 >> 49) == (stamp & 0x7fffu) && (unsigned)(u1 >> 32) == stamp && (unsigned)(u2 >> 32) == stamp &&
                (unsigned)(u3 >> 32) == stamp && (unsigned)(u4 >> 32) == stamp;
-        } while (!ok && ++spin < (1 << 22));
+        } while (!ok && ++spin < spin_limit);
         dead = dead || !ok;
         const bool none = ((unsigned)(u0 >> 32) & 0x1ffffu) == 0u;  // K::none()
         uint4 e0, e1;
@@ -825,12 +828,29 @@ __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __res
     it += npick[par];
   }
   __syncthreads();
+  // a workgroup that gave up leaves -1 in every slot it owns: together with *err the caller can never mistake the row for samples
+  // (the host side then repairs the launch with the one-workgroup kernel, see launch_rounds_multi)
   if (w == 0)
-    for (int i = tid; i < M; i += NT) o[i] = sout[i];
+    for (int i = tid; i < M; i += NT) o[i] = npick[2] ? -1 : sout[i];
 }
 
+int g_fps_spin_limit = 1 << 22;  // polls of a partner's stamp before a workgroup gives up (mvp_fps_debug_spin_limit: tests force the time-out)
+
 template <int D, int PPT, int W>
-int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int* status, hipStream_t s);
+
+template <typename T, int D, int PPT, int NT>
+int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s, const int* guard);
+template <typename T, int D>
+int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s, const int* guard);
+
+// The W workgroups of a cloud wait for each other, and an ordinary launch does not promise that they are resident together (the launch is
+// capped at 64 workgroups, but other streams may hold the CUs).  A workgroup that polls `g_fps_spin_limit` times in vain sets the flag
+// (`status` when the caller gave one -- sticky, never cleared here -- else a word of the call's scratch) and leaves -1 in its rows; the
+// ONE-workgroup kernel is queued right behind with the flag as its guard: it returns at once when the flag is 0 and re-samples every cloud
+// of the call when it is not.  The indices a caller reads are therefore the exact chain in either case, and the flag tells that it happened.
+template <int D, int PPT, int W>
+int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int* status, hipStream_t s) {
   const size_t lds = 32 * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
   if (lds > 150 * 1024 || B * W > 64) return MVP_EUNSUPPORTED;  // (64: two such launches on two streams still fit the chip together)
   const size_t xbytes = (size_t)B * 2 * W * 64 * 8 * sizeof(fps_u64) + 16;
@@ -839,21 +859,33 @@ int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64
     (void)hipGetLastError();
     return MVP_EINVAL;
   }
-  if (hipMemsetAsync(scratch, 0, xbytes, s) != hipSuccess) return MVP_EINVAL;
-  auto k = fps_rounds_multi_kernel<D, PPT, 1024, W>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+  int rc = MVP_OK;
+  if (hipMemsetAsync(scratch, 0, xbytes, s) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = MVP_EINVAL;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)(B * W)), dim3(1024), lds, s, pts, (int)N, (int)M, out, reinterpret_cast<fps_u64*>(scratch),
-                     reinterpret_cast<int*>(scratch + xbytes - 16));
-  const int rc = mvp_launch_status();
-  (void)hipFreeAsync(scratch, s);
+  int* err = status ? status : reinterpret_cast<int*>(scratch + xbytes - 16);
+  if (rc == MVP_OK) {
+    auto k = fps_rounds_multi_kernel<D, PPT, 1024, W>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) rc = (int)e;
+    }
+    if (rc == MVP_OK) {
+      hipLaunchKernelGGL(k, dim3((unsigned)(B * W)), dim3(1024), lds, s, pts, (int)N, (int)M, out, reinterpret_cast<fps_u64*>(scratch), err,
+                         g_fps_spin_limit);
+      rc = mvp_launch_status();
+    }
+    if (rc == MVP_OK)  // the repair launch (a no-op unless the flag is set)
+      rc = N <= 16384 ? launch_cfg<float, D, 16, 1024>(pts, B, N, M, out, s, err) : N <= 32768 ? launch_cfg<float, D, 32, 1024>(pts, B, N, M, out, s, err)
+                                                                                                 : launch_global<float, D>(pts, B, N, M, out, s, err);
+  }
+  (void)hipFreeAsync(scratch, s);  // (on every path: the early returns used to leak it)
   return rc;
 }
 
 template <typename T, int D, int PPT, int NT>
-int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s, const int* guard) {
   const size_t part_bytes = 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15);  // keys + output buffer
   const size_t pts_bytes = (size_t)N * 3 * sizeof(T);
   const bool lds = pts_bytes + part_bytes <= 150 * 1024;
@@ -865,14 +897,14 @@ int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return (int)e;
       }
-      hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out);
+      hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out, guard);
     } else {
       auto k = fps_fast_kernel<D, PPT, NT, false>;
       if (part_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_bytes);
         if (e != hipSuccess) return (int)e;
       }
-      hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), part_bytes, s, pts, (int)N, (int)M, out);
+      hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), part_bytes, s, pts, (int)N, (int)M, out, guard);
     }
     return mvp_launch_status();
   }
@@ -883,14 +915,14 @@ int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipS
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out);
+    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out, guard);
   } else {
     auto k = fps_kernel<T, D, PPT, NT, false>;
     if (part_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_bytes);
       if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), part_bytes, s, pts, (int)N, (int)M, out);
+    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), part_bytes, s, pts, (int)N, (int)M, out, guard);
   }
   return mvp_launch_status();
 }
@@ -902,7 +934,8 @@ int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipS
 // results as the reference kernel (fps_kernel.cu:60-135: first maximum = lowest index); slower per point, but complete.
 template <typename T, int D, int NT>
 __global__ __launch_bounds__(NT) void fps_global_kernel(const T* __restrict__ pts, int N, int M, T* __restrict__ mind,
-                                                        int64_t* __restrict__ out) {
+                                                        int64_t* __restrict__ out, const int* __restrict__ guard) {
+  if (guard && *guard == 0) return;
   constexpr int NW = NT / kWave;
   using K = Key<T>;
   __shared__ K part[2][16];
@@ -943,14 +976,14 @@ __global__ __launch_bounds__(NT) void fps_global_kernel(const T* __restrict__ pt
 }
 
 template <typename T, int D>
-int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s, const int* guard) {
   if (N >= (1ll << 31) / 4) return MVP_EUNSUPPORTED;
   T* mind = nullptr;  // stream-ordered scratch owned by this call
   if (hipMallocAsync(reinterpret_cast<void**>(&mind), sizeof(T) * (size_t)B * (size_t)N, s) != hipSuccess || !mind) {
     (void)hipGetLastError();
     return MVP_EINVAL;
   }
-  hipLaunchKernelGGL((fps_global_kernel<T, D, 1024>), dim3((unsigned)B), dim3(1024), 0, s, pts, (int)N, (int)M, mind, out);
+  hipLaunchKernelGGL((fps_global_kernel<T, D, 1024>), dim3((unsigned)B), dim3(1024), 0, s, pts, (int)N, (int)M, mind, out, guard);
   const int rc = mvp_launch_status();
   (void)hipFreeAsync(mind, s);
   return rc;
@@ -959,13 +992,13 @@ int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, h
 int g_fps_mode = 0;  // mvp_set_fps_mode: the launch shape mvp_fps_f32 / _f64 use (a process default; mvp_fps_shape_* take it per call)
 
 template <typename T, int D>
-int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int shape, hipStream_t s) {
+int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int shape, int* status, hipStream_t s) {
   // (threads, points/thread): one wave per SIMD (256 threads) keeps the per-iteration barrier
   // cheap while 4 SIMDs share the distance updates; small clouds shrink to a single wave.
-  if (N <= 64) return launch_cfg<T, D, 1, 64>(pts, B, N, M, out, s);
-  if (N <= 128) return launch_cfg<T, D, 2, 64>(pts, B, N, M, out, s);
-  if (N <= 256) return launch_cfg<T, D, 1, 256>(pts, B, N, M, out, s);
-  if (N <= 512) return launch_cfg<T, D, 2, 256>(pts, B, N, M, out, s);
+  if (N <= 64) return launch_cfg<T, D, 1, 64>(pts, B, N, M, out, s, nullptr);
+  if (N <= 128) return launch_cfg<T, D, 2, 64>(pts, B, N, M, out, s, nullptr);
+  if (N <= 256) return launch_cfg<T, D, 1, 256>(pts, B, N, M, out, s, nullptr);
+  if (N <= 512) return launch_cfg<T, D, 2, 256>(pts, B, N, M, out, s, nullptr);
   // fp32 clouds of 257..8192 points: several exact samples per synchronisation (fps_rounds_kernel).  MVP_FPS_ROUNDS=0 keeps the
   // one-sample-per-barrier kernels (A/B switch).
   static const bool rounds = []() { const char* e = getenv("MVP_FPS_ROUNDS"); return !(e && e[0] == '0'); }();
@@ -980,9 +1013,9 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int sh
       if (rc != MVP_EUNSUPPORTED) return rc;
     }
   }
-  if (N <= 1024) return launch_cfg<T, D, 4, 256>(pts, B, N, M, out, s);
-  if (N <= 2048) return launch_cfg<T, D, 8, 256>(pts, B, N, M, out, s);
-  if (N <= 4096) return launch_cfg<T, D, 8, 512>(pts, B, N, M, out, s);
+  if (N <= 1024) return launch_cfg<T, D, 4, 256>(pts, B, N, M, out, s, nullptr);
+  if (N <= 2048) return launch_cfg<T, D, 8, 256>(pts, B, N, M, out, s, nullptr);
+  if (N <= 4096) return launch_cfg<T, D, 8, 512>(pts, B, N, M, out, s, nullptr);
   if (N <= 8192) {
     // Threads per cloud for 4096 < N <= 8192.  16 waves (1024 threads) give the shortest chain: 2.44 ms for 2048 samples of 8192
     // points -- the choice when the chain is what one waits for (inference, a single chunk).  One wave per SIMD (256 threads, 32
@@ -990,9 +1023,9 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int sh
     // anyway (mvp_set_fps_mode(1): the training step's prefetched geometry, 9.16 -> 9.03 ms per step; exposed chains lose:
     // whole-scene inference 7.7 -> 8.2 ms).  MVP_FPS_CFG = 1 / 2 / 5 forces 1024 / 256 / 512 threads.
     static const char cfg = []() { const char* e = getenv("MVP_FPS_CFG"); return e ? e[0] : '0'; }();
-    if (cfg == '2' || (cfg == '0' && shape == 1 && B >= 8)) return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s);
-    if (cfg == '5') return launch_cfg<T, D, 16, 512>(pts, B, N, M, out, s);
-    return launch_cfg<T, D, 8, 1024>(pts, B, N, M, out, s);
+    if (cfg == '2' || (cfg == '0' && shape == 1 && B >= 8)) return launch_cfg<T, D, 32, 256>(pts, B, N, M, out, s, nullptr);
+    if (cfg == '5') return launch_cfg<T, D, 16, 512>(pts, B, N, M, out, s, nullptr);
+    return launch_cfg<T, D, 8, 1024>(pts, B, N, M, out, s, nullptr);
   }
   // 8193..65536 points: rounds across 4 workgroups per cloud (fps_rounds_multi_kernel) while all of them are resident together
   // (B <= 16); MVP_FPS_MULTI=0 keeps the one-sample kernels
@@ -1001,19 +1034,19 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int sh
     if (rounds && multi && M > 1 && N <= 65536) {
       int rc = MVP_EUNSUPPORTED;
       static const int force16 = []() { const char* e = getenv("MVP_FPS_MULTI_PPT16"); return e ? atoi(e) : 0; }();  // (tools/exp)
-      if (N <= 16384 && !force16) rc = launch_rounds_multi<D, 4, 4>(pts, B, N, M, out, s);
-      else if (N <= 32768 && !force16) rc = launch_rounds_multi<D, 8, 4>(pts, B, N, M, out, s);
-      else rc = launch_rounds_multi<D, 16, 4>(pts, B, N, M, out, s);
+      if (N <= 16384 && !force16) rc = launch_rounds_multi<D, 4, 4>(pts, B, N, M, out, status, s);
+      else if (N <= 32768 && !force16) rc = launch_rounds_multi<D, 8, 4>(pts, B, N, M, out, status, s);
+      else rc = launch_rounds_multi<D, 16, 4>(pts, B, N, M, out, status, s);
       if (rc != MVP_EUNSUPPORTED) return rc;
     }
   }
-  if (N <= 16384) return launch_cfg<T, D, 16, 1024>(pts, B, N, M, out, s);
-  if (N <= 32768) return launch_cfg<T, D, 32, 1024>(pts, B, N, M, out, s);
-  return launch_global<T, D>(pts, B, N, M, out, s);  // > 32768 points per cloud: running distances in global memory
+  if (N <= 16384) return launch_cfg<T, D, 16, 1024>(pts, B, N, M, out, s, nullptr);
+  if (N <= 32768) return launch_cfg<T, D, 32, 1024>(pts, B, N, M, out, s, nullptr);
+  return launch_global<T, D>(pts, B, N, M, out, s, nullptr);  // > 32768 points per cloud: running distances in global memory
 }
 
 template <typename T>
-int fps_entry(const T* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, mvp_stream_t stream) {
+int fps_entry(const T* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, int* status, mvp_stream_t stream) {
   MVP_NONNULL(points);
   MVP_NONNULL(index);
   MVP_REQUIRE(B >= 0 && (D == 2 || D == 3));
@@ -1021,7 +1054,7 @@ int fps_entry(const T* points, int64_t B, int64_t N, int64_t D, int64_t M, int64
   if (B == 0) return MVP_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   MVP_REQUIRE(shape == 0 || shape == 1);
-  return D == 3 ? dispatch<T, 3>(points, B, N, M, index, shape, s) : dispatch<T, 2>(points, B, N, M, index, shape, s);
+  return D == 3 ? dispatch<T, 3>(points, B, N, M, index, shape, status, s) : dispatch<T, 2>(points, B, N, M, index, shape, status, s);
 }
 
 }  // namespace
@@ -1034,17 +1067,76 @@ MVP_API int mvp_set_fps_mode(int mode) {
 
 MVP_API int mvp_fps_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index,
                         mvp_stream_t stream) {
-  return fps_entry<float>(points, B, N, D, M, index, g_fps_mode, stream);
+  return fps_entry<float>(points, B, N, D, M, index, g_fps_mode, nullptr, stream);
 }
 MVP_API int mvp_fps_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index,
                         mvp_stream_t stream) {
-  return fps_entry<double>(points, B, N, D, M, index, g_fps_mode, stream);
+  return fps_entry<double>(points, B, N, D, M, index, g_fps_mode, nullptr, stream);
 }
 MVP_API int mvp_fps_shape_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape,
                               mvp_stream_t stream) {
-  return fps_entry<float>(points, B, N, D, M, index, shape, stream);
+  return fps_entry<float>(points, B, N, D, M, index, shape, nullptr, stream);
 }
 MVP_API int mvp_fps_shape_f64(const double* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape,
                               mvp_stream_t stream) {
-  return fps_entry<double>(points, B, N, D, M, index, shape, stream);
+  return fps_entry<double>(points, B, N, D, M, index, shape, nullptr, stream);
+}
+
+MVP_API int mvp_fps_checked_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, int* status,
+                                mvp_stream_t stream) {
+  return fps_entry<float>(points, B, N, D, M, index, shape, status, stream);
+}
+MVP_API int mvp_fps_debug_spin_limit(int polls) {
+  const int old = g_fps_spin_limit;
+  g_fps_spin_limit = polls > 0 ? polls : (1 << 22);
+  return old;
+}
+
+namespace {
+struct CentroidLevels {
+  float* out[8];
+  int count[8];
+  int n;
+};
+// centroids of a CHAIN of sampling levels from the first level's indices: out[l][b, m, :] = points[b, index[b, m], :] for m < count[l]
+__global__ __launch_bounds__(256) void fps_centroid_levels_kernel(const float* __restrict__ pts, const int64_t* __restrict__ index, int N, int M, int D,
+                                                                  int64_t total, CentroidLevels lv) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t b = t / M;
+  const int m = (int)(t - b * M);
+  int64_t j = index[t];
+  j = j < 0 ? 0 : (j >= N ? N - 1 : j);
+  const float* p = pts + ((size_t)b * N + j) * D;
+  const float x = p[0], y = p[1], z = D == 3 ? p[2] : 0.f;
+  for (int l = 0; l < lv.n; ++l)
+    if (m < lv.count[l]) {
+      float* o = lv.out[l] + ((size_t)b * lv.count[l] + m) * D;
+      o[0] = x;
+      o[1] = y;
+      if (D == 3) o[2] = z;
+    }
+}
+}  // namespace
+
+MVP_API int mvp_fps_centroid_levels_f32(const float* points, const int64_t* index, int64_t B, int64_t N, int64_t D, int64_t M, int64_t levels,
+                                        const int64_t* counts, float* const* outs, mvp_stream_t stream) {
+  MVP_NONNULL(points);
+  MVP_NONNULL(index);
+  MVP_NONNULL(counts);
+  MVP_NONNULL(outs);
+  MVP_REQUIRE(B >= 0 && N > 0 && M > 0 && (D == 2 || D == 3) && levels >= 1 && levels <= 8);
+  CentroidLevels lv;
+  lv.n = (int)levels;
+  for (int l = 0; l < lv.n; ++l) {
+    MVP_NONNULL(outs[l]);
+    MVP_REQUIRE(counts[l] > 0 && counts[l] <= M && (l == 0 || counts[l] <= counts[l - 1]));
+    lv.out[l] = outs[l];
+    lv.count[l] = (int)counts[l];
+  }
+  if (B == 0) return MVP_OK;
+  const int64_t total = B * M;
+  hipLaunchKernelGGL(fps_centroid_levels_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), points, index,
+                     (int)N, (int)M, (int)D, total, lv);
+  return mvp_launch_status();
 }

@@ -137,7 +137,7 @@ def _vote_plan(chunk_inds, n_pts, dev):
         offs = [0]
         for n in lens:
             offs.append(offs[-1] + n)
-        pt_offsets, pt_slots = R.build_csr(flat.view(1, -1), n_pts, sorted=True)  # built once per scene: the vote adds in a fixed order
+        pt_offsets, pt_slots = R.build_csr(flat.view(1, -1), n_pts)  # built once per scene; the gather kernel orders each point's slots itself (ascending = chunk order)
         plan = {'chunk_offsets': torch.tensor(offs, dtype=torch.int64).to(dev), 'pt_offsets': pt_offsets, 'pt_slots': pt_slots,
                 'max_len': max(lens), 'keep': list(chunk_inds)}  # (the index tensors stay alive: their addresses are the key)
         _VOTE_PLANS.clear()  # one scene at a time
@@ -157,6 +157,8 @@ def vote_scene(logits, chunk_inds, n_pts):
     # atomics and adding in chunk order (bit-identical on every rank): every scene point gathers through the transposed index of the
     # concatenated chunk lists.  That index depends on the scene only and is kept for the next call on the same lists.
     if len(chunk_inds):
+        if len(chunk_inds) > logits.size(0):  # (the per-chunk loop this launch replaced raised IndexError on the host here)
+            raise RuntimeError('vote_scene: {} chunk index lists but logits of {} chunks'.format(len(chunk_inds), logits.size(0)))
         plan = _vote_plan(chunk_inds, n_pts, logits.device)
         if plan['max_len'] > logits.size(2):
             raise RuntimeError('vote_scene: a chunk lists {} points but its logits have {} columns'.format(plan['max_len'], logits.size(2)))

@@ -18,7 +18,12 @@ def farthest_point_sample(points, num_centroids, shape=None):
     if not (num_centroids > 0 and N >= num_centroids):
         raise RuntimeError('Expected 0 < num_centroids <= num_points, got {} and {}'.format(num_centroids, N))
     index = torch.empty((B, num_centroids), dtype=torch.int64, device=points.device)
-    if shape is None:
+    if points.dtype == torch.float32 and 8192 < N <= 65536:
+        # sampled by four workgroups per cloud that wait for each other: the status word makes a time-out visible (_lib.fps_timed_out);
+        # the library repairs the result itself (include/mvp_hip.h: mvp_fps_checked_f32)
+        L.call('mvp_fps_checked_f32', points, L.ptr(points), B, N, D, num_centroids, L.ptr(index), 0 if shape is None else int(shape),
+               L.ptr(L.fps_status(points.device)))
+    elif shape is None:
         L.call('mvp_fps_' + L.suffix(points), points, L.ptr(points), B, N, D, num_centroids, L.ptr(index))
     else:
         L.call('mvp_fps_shape_' + L.suffix(points), points, L.ptr(points), B, N, D, num_centroids, L.ptr(index), int(shape))

@@ -65,7 +65,7 @@ class FusedAdam(torch.optim.Adam):
                     t = st['step'] = torch.tensor(float(t), dtype=torch.float32)
                 steps.append(t)
             torch._foreach_add_(steps, 1)
-            count = float(steps[0])
+            counts = [float(t) for t in steps]
             plan = self._plan(gi, plist)
             grads = []
             g_arr = plan['g']
@@ -79,11 +79,24 @@ class FusedAdam(torch.optim.Adam):
             dev = plist[0].device
             if any(p.device != dev for p in plist):
                 raise RuntimeError('FusedAdam: the parameters of a group must live on one device')
+            # The bias corrections depend on the parameter's OWN step count (torch.optim.Adam keeps one per parameter): parameters that
+            # skipped an iteration (grad None), were added later or came from a checkpoint with unequal counts get their own launch --
+            # one launch per DISTINCT count, i.e. one launch in the usual case.
+            if all(c == counts[0] for c in counts):
+                buckets = [(counts[0], plan['p'], g_arr, plan['m'], plan['v'], plan['numel'], len(plist))]
+            else:
+                buckets = []
+                for c in sorted(set(counts)):
+                    ids = [i for i, ci in enumerate(counts) if ci == c]
+                    sub = lambda arr, typ: (typ * len(ids))(*[arr[i] for i in ids])
+                    buckets.append((c, sub(plan['p'], ctypes.c_void_p), sub(g_arr, ctypes.c_void_p), sub(plan['m'], ctypes.c_void_p),
+                                    sub(plan['v'], ctypes.c_void_p), sub(plan['numel'], ctypes.c_int64), len(ids)))
             with torch.cuda.device(dev):
-                code = L._fn('mvp_adam_step_f32')(plan['p'], g_arr, plan['m'], plan['v'], plan['numel'], len(plist), float(group['lr']), float(beta1),
-                                                  float(beta2), float(group['eps']), float(group['weight_decay']), count,
-                                                  torch.cuda.current_stream(dev).cuda_stream)
-            if code != 0:
-                L.check(code, 'mvp_adam_step_f32')
+                for count, p_arr, gg_arr, m_arr, v_arr, n_arr, n in buckets:
+                    code = L._fn('mvp_adam_step_f32')(p_arr, gg_arr, m_arr, v_arr, n_arr, n, float(group['lr']), float(beta1), float(beta2),
+                                                      float(group['eps']), float(group['weight_decay']), count,
+                                                      torch.cuda.current_stream(dev).cuda_stream)
+                    if code != 0:
+                        L.check(code, 'mvp_adam_step_f32')
             del grads
         return loss

@@ -22,6 +22,27 @@ from . import _lib as L
 # launch shape of the sampling kernels of a TRAINING step's prefetched geometry (1: one wave per SIMD -- beside the backward pass the
 # sampler leaves issue slots to the kernels it shares CUs with; 0: the fastest chain)
 TRAIN_FPS_SHAPE = int(os.environ.get('MVP_TRAIN_FPS_SHAPE', '1'))
+# Sampling a cloud that is itself a sampling result, in sampling order, returns 0, 1, 2, ... (PN2SSG._centroid_run): the deeper levels'
+# centroids are prefixes of the first level's.  0 = sample every level (A/B switch; same coordinates either way).
+FPS_PREFIX = os.environ.get('MVP_FPS_PREFIX', '1') != '0'
+
+
+def centroid_levels(xyz, index, counts):
+    """xyz (B,N,D), index (B,M) int64 = farthest_point_sample(xyz, M), counts[0] = M >= counts[1] >= ... -> [xyz[b, index[b, :c]] for c in
+    counts], each (B,c,D) contiguous: the centroids of a chain of sampling levels from ONE gather launch (mvp_fps_centroid_levels_f32)."""
+    B, N, D = xyz.shape
+    M = index.size(1)
+    assert counts[0] == M and all(0 < b <= a for a, b in zip(counts, counts[1:])) and len(counts) <= 8
+    if xyz.is_cuda and xyz.dtype == torch.float32:
+        import ctypes
+        xyz, index = xyz.contiguous(), index.contiguous()
+        outs = [torch.empty((B, c, D), dtype=torch.float32, device=xyz.device) for c in counts]
+        L.call('mvp_fps_centroid_levels_f32', xyz, L.ptr(xyz), L.ptr(index), B, N, D, M, len(counts), (ctypes.c_int64 * len(counts))(*counts),
+               (ctypes.c_void_p * len(counts))(*[o.data_ptr() for o in outs]))
+        return outs
+    g = torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, D))
+    return [g if c == M else g[:, :c].contiguous() for c in counts]
+
 
 class QueryGrouper(nn.Module):
     """Ball query + grouping around centroids (modules.py:13-41)."""
@@ -300,6 +321,31 @@ class PN2SSG(nn.Module):
         self.seg_logit = nn.Conv1d(seg_channels[-1], num_classes, 1, bias=True)
         self.reset_parameters()
 
+    def _centroid_run(self, level, xyz, fps_shape=None):
+        """Centroids of set-abstraction level `level` (input cloud xyz (B,N,3)) AND of the levels behind it that sample its output:
+        {level: new_xyz, level + 1: ..., ...}.  The reference samples level after level (modules.py:74-87, pn2ssg.py:92-99); level l + 1
+        then samples a cloud that IS level l's sampling result in sampling order, and farthest point sampling of such a cloud returns
+        0, 1, 2, ...: by induction the second chain's running distances are the first chain's (same centroids so far, same arithmetic),
+        the point the first chain took next attains the maximum over the superset and hence over the subset, points taken earlier sit
+        at distance 0, and any tied point has a higher index -- so the first maximum is index i.  When the maximum is 0 (fewer distinct
+        points than samples) both chains return point 0, whose coordinates the prefix repeats.  Either way the centroid COORDINATES of
+        level l + 1 are the first M_{l+1} rows of level l's: one sampling launch and one gather per run of levels instead of one each per
+        level (tests/test_model_gpu.py::test_centroid_prefix_equals_the_chained_sampling).  MVP_FPS_PREFIX=0 samples every level."""
+        mods = self.sa_modules
+        m = mods[level]
+        assert m.num_centroids != 0
+        if m.num_centroids == -1:
+            return {level: xyz}
+        run, counts = [level], [m.num_centroids]
+        j = level + 1
+        while FPS_PREFIX and j < len(mods) and len(run) < 8 and (mods[j].num_centroids == -1 or 0 < mods[j].num_centroids <= counts[-1]):
+            counts.append(counts[-1] if mods[j].num_centroids == -1 else mods[j].num_centroids)
+            run.append(j)
+            j += 1
+        with torch.no_grad():
+            index = ops.farthest_point_sample(xyz, m.num_centroids, transpose=False, shape=fps_shape)
+            return dict(zip(run, centroid_levels(xyz, index, counts)))
+
     def plan_geometry(self, xyz, stream=None, with_csr=None):
         """All coordinate-only work of the network -- 4 x (FPS, ball query) and 4 x (3-NN + weights) -- as a
         plan that forward() consumes.  FPS is a chain of ~2700 dependent steps that occupies only B CUs; with
@@ -340,12 +386,15 @@ class PN2SSG(nn.Module):
             run = torch.cuda.current_stream(xyz.device)
             sa, xyzs = [], [xyz]
             fp_by_level = {}
+            cents = {}
             for level, m in enumerate(self.sa_modules):
                 if m.num_centroids == 0:
                     sa.append(None)
                     xyzs.append(xyz.new_zeros([xyz.size(0), 1, 3]))
                 else:
-                    new_xyz = m.centroids(xyzs[-1], fps_shape)
+                    if level not in cents:  # one sampling launch for this level and every level that samples its output
+                        cents.update(self._centroid_run(level, xyzs[-1], fps_shape))
+                    new_xyz = cents[level]
                     csr = with_csr and (level > 0 or self.in_channels > 0)
                     sa.append((new_xyz,) + on_second(run, lambda m=m, a=new_xyz, b=xyzs[-1], c=csr: m.neighbours(a, b, c)))
                     xyzs.append(new_xyz)
@@ -415,7 +464,13 @@ class PN2SSG(nn.Module):
             feature = None if feature is None else feature.transpose(1, 2).contiguous()
         B, N, _ = xyz.shape
         xyzs, feats = [xyz], [None]
+        cents = {}
         for level, sa in enumerate(self.sa_modules):
+            geometry = None if plan is None else plan['sa'][level]
+            if plan is None and sa.num_centroids != 0 and xyz.is_cuda:  # no plan: still ONE sampling launch per run of levels
+                if level not in cents:
+                    cents.update(self._centroid_run(level, xyz))
+                geometry = (cents[level],) + sa.neighbours(cents[level], xyz)
             if level_events is not None:  # this level's geometry only (the deeper levels are still being sampled)
                 cur = torch.cuda.current_stream(xyz.device)
                 for ev in level_events[level]:
@@ -423,7 +478,7 @@ class PN2SSG(nn.Module):
                         cur.wait_event(ev)
                 if level + 1 == len(self.sa_modules) and plan.get('event') is not None:
                     cur.wait_event(plan['event'])  # the plan's own end (nothing is left to run: this joins the side stream, as a capture needs)
-            xyz, feature = sa(xyz, feature, rows=True, geometry=None if plan is None else plan['sa'][level])
+            xyz, feature = sa(xyz, feature, rows=True, geometry=geometry)
             xyzs.append(xyz)
             feats.append(feature)
         up = feats[-1]

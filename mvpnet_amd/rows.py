@@ -269,9 +269,10 @@ class SideStream:
         self.open.clear()
         self.keep.clear()  # freed behind the join on the calling stream: the allocator hands the blocks to later work of that stream only
 
-    def run(self, dev, name, args, tensors):
+    def run(self, dev, name, args, tensors, prec=None):
         """Library entry point `name(*args, stream)` on the side stream, after everything queued so far on the current one;
-        `tensors` = what it touches.  Only inside an autograd backward pass (the join is queued as its final callback)."""
+        `tensors` = what it touches.  Only inside an autograd backward pass (the join is queued as its final callback).
+        prec: (precision, precision_backward) as arguments of the call (_lib.call)."""
         st = self.streams.get(dev)
         if st is None:
             st = self.streams[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Event())
@@ -286,10 +287,10 @@ class SideStream:
         fork.record(torch.cuda.current_stream(dev))
         side.wait_event(fork)
         if dev.index == torch.cuda.current_device():
-            L.call_on(side, name, *args)
+            L.call_on(side, name, *args, prec=prec)
         else:
             with torch.cuda.stream(side):
-                L.call(name, tensors[0], *args)
+                L.call(name, tensors[0], *args, prec=prec)
         self.keep.extend(tensors)
 
 
@@ -316,13 +317,13 @@ class WeightGradSink:
             self.buf = zero_pool.zeros(self.numel + 4, torch.float32, dev)  # + 4: slack for the 4-column coordinate operand
         return self.buf
 
-    def run(self, dev, name, args, tensors):
+    def run(self, dev, name, args, tensors, prec=None):
         if self.aside is None:
             self.aside = bool(DW_SIDE_STREAM and self.use is not None and self.use.aside_ok())
         if self.aside:
-            side_stream.run(dev, name, args, [self.buf] + list(tensors))
+            side_stream.run(dev, name, args, [self.buf] + list(tensors), prec=prec)
         else:
-            L.call(name, tensors[0], *args)
+            L.call(name, tensors[0], *args, prec=prec)
 
     def done(self):
         """-> the gradient when this was the last user, else None."""
@@ -421,6 +422,7 @@ class GroupLinRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, zf, xyz, centre, wxyz, index, want_stat, offsets=None, slots=None, sink=None):
         ctx.sink = sink
+        ctx.prec = L.current_precision()  # backward runs on autograd's thread: it gets the forward's precision as arguments
         # wxyz: a weight whose LAST three columns multiply the coordinates -- a (C,3) matrix, or the layer's whole conv weight
         # (C, C_in + 3 [,1,1]): the slice is taken here and its gradient written into the full-size gradient below, so autograd
         # sees no slicing (which costs a zero fill and a strided copy per slice in backward).
@@ -490,16 +492,16 @@ class GroupLinRows(torch.autograd.Function):
             if sink is not None:  # the weight's other slices add their columns into the same buffer (WeightGradSink)
                 buf = sink.buffer(g.device)
                 sink.run(g.device, 'mvp_mlp_weight_grad_f32', (L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None,
-                                                               L.ptr_at(buf, ctot - 3), ctot), (g, diff))
+                                                               L.ptr_at(buf, ctot - 3), ctot), (g, diff), prec=ctx.prec)
                 gw = sink.done()
             elif ctot >= 4:
                 buf = zero_pool.zeros(numel + 4, torch.float32, g.device)
                 gw = buf[:numel].view(ctx.w_shape)
                 L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None,
-                       L.ptr_at(buf, ctot - 3), ctot)
+                       L.ptr_at(buf, ctot - 3), ctot, prec=ctx.prec)
             else:  # the weight IS the (C,3) coordinate part (no input feature)
                 gw4 = zero_pool.zeros((C, 4), torch.float32, g.device)
-                L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4), 4)
+                L.call('mvp_mlp_weight_grad_f32', g, L.ptr(g), L.ptr(diff), B * M * K, C, 4, 4, None, None, None, None, L.ptr(gw4), 4, prec=ctx.prec)
                 gw = gw4[:, :3].contiguous().view(ctx.w_shape)
         return gz, None, None, gw, None, None, None, None, None
 
@@ -721,6 +723,10 @@ class MLPChainRows(torch.autograd.Function):
         nl = len(params) // 3
         R = x0.size(0)
         dev = x0.device
+        # the contraction precision of THIS node: what the calling thread's scope / the process default says now, passed to every launch
+        # as arguments -- also to the backward's, which autograd issues from its own thread (a forward under
+        # _lib.mlp_precision(...) used to get the process default in backward)
+        prec = ctx.prec = L.current_precision()
         # pool_sum: plain bool, or a dict of options {'sum', 'drop_p', 'drop_seed' (dropout behind the last layer, K = 1: SharedMLPDO),
         # 'use' (WeightUse: the weight gradients may run on the side stream, see SideStream)}
         opts = pool_sum if isinstance(pool_sum, dict) else {'sum': bool(pool_sum)}
@@ -741,7 +747,7 @@ class MLPChainRows(torch.autograd.Function):
         arena = zero_pool.zeros(2 * sum(couts) + nl, torch.float64, dev) if training else None
         wl = params[3 * (nl - 1)]
         pooled = bool(POOL_WITHOUT_Y and training and K == 32 and not pool_sum and nl >= 2 and wl is not None and R % 32 == 0 and R >= 32768 and
-                      L.get_mlp_precision() != 'fp32' and wl.size(0) <= min(64, FUSE_BWD_MAX_COUT) and wl.size(1) <= 64 and
+                      prec[0] != 0 and wl.size(0) <= min(64, FUSE_BWD_MAX_COUT) and wl.size(1) <= 64 and
                       wl.size(0) % 4 == 0 and wl.size(1) % 4 == 0)
         off = 0
         for i in range(nl):
@@ -778,10 +784,10 @@ class MLPChainRows(torch.autograd.Function):
                         invstd = torch.empty(cout, dtype=torch.float32, device=dev)
                         L.call('mvp_mlp_forward_rel_bn_f32', x, L.ptr(x), R, cin_f, cin_f, L.ptr(w), cin, cout, L.ptr(rel), L.ptr(wrel), L.ptr(y),
                                L.ptr(stat), L.ptr(_partial(R, cout, dev)), float(eps), float(mom), L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv),
-                               L.ptr(nbt))
+                               L.ptr(nbt), prec=prec)
                     else:
                         L.call('mvp_mlp_forward_rel_bn_f32', x, L.ptr(x), R, cin_f, cin_f, L.ptr(w), cin, cout, L.ptr(rel), L.ptr(wrel), L.ptr(y),
-                               None, None, 0.0, 0.0, None, None, None, None, None)
+                               None, None, 0.0, 0.0, None, None, None, None, None, prec=prec)
                         mean, invstd = rm, eval_invstd.get(rv, eps)
                     ys.append(y)
                     means.append(mean)
@@ -802,7 +808,7 @@ class MLPChainRows(torch.autograd.Function):
                     L.call('mvp_mlp_forward_pool_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
                            L.ptr(act[2]), L.ptr(act[3]), L.ptr(ymax), L.ptr(ymin), L.ptr(amax), L.ptr(amin), L.ptr(stat),
                            L.ptr(torch.empty(((R + 127) // 128) * 2 * cout, dtype=torch.float64, device=dev)), float(eps), float(mom),
-                           L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.ptr(nbt))
+                           L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.ptr(nbt), prec=prec)
                     out = torch.empty((G, cout), dtype=torch.float32, device=dev)
                     arg = torch.empty((G, cout), dtype=torch.uint8, device=dev)
                     ysel = torch.empty((G, cout), dtype=torch.float32, device=dev)
@@ -821,7 +827,7 @@ class MLPChainRows(torch.autograd.Function):
                     invstd = torch.empty(cout, dtype=torch.float32, device=dev)
                     L.call('mvp_mlp_forward_bn_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
                            L.ptr(act[2]), L.ptr(act[3]), L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev)), float(eps), float(mom),
-                           L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.ptr(nbt))
+                           L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.ptr(nbt), prec=prec)
                     ys.append(y)
                     means.append(mean)
                     invstds.append(invstd)
@@ -829,7 +835,7 @@ class MLPChainRows(torch.autograd.Function):
                     x = y
                     continue
                 L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, cin, x.size(1), L.ptr(w), cin, cout, L.ptr(act[0]), L.ptr(act[1]),
-                       L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None))
+                       L.ptr(act[2]), L.ptr(act[3]), None, L.ptr(y), L.ptr(stat), L.ptr(_partial(R, cout, dev) if training else None), prec=prec)
             rm, rv, nbt = bn_buffers[i]
             if training:
                 mean = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -903,7 +909,7 @@ class MLPChainRows(torch.autograd.Function):
         st_arena = zero_pool.zeros(2 * sum(params[3 * i].size(1) for i in range(1, nl)), torch.float64, g.device)
         dw_off, st_off = 0, 0
         dev = g.device
-        split = L.get_mlp_precision() != 'fp32'   # the one-kernel layer backward (mvp_mlp_layer_backward_f32) contracts in split-bf16 only
+        split = ctx.prec[0] != 0   # the one-kernel layer backward (mvp_mlp_layer_backward_f32) contracts in split-bf16 only
         # State while walking the layers backwards: `gcur` is either dy_i itself (pending is None) or dz_i = the gradient w.r.t.
         # layer i's ACTIVATION already masked by its ReLU, with `pending` = its two BatchNorm-backward column sums: the "finish"
         # step (dz_i -> dy_i) then happens INSIDE the fused layer kernel, or as its own pass when the layer cannot be fused.
@@ -950,12 +956,12 @@ class MLPChainRows(torch.autograd.Function):
                 for xs, ncol, c0 in ((src, cin_f, 0), (rel, 4, cin_f)):
                     wg_args = (L.ptr(gcur), L.ptr(xs), R, cout, ncol, ncol, None, None, None, None, L.ptr_at(dw, c0), cin)
                     if dw_aside:
-                        side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, xs, dw))
+                        side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, xs, dw), prec=ctx.prec)
                     else:
-                        L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args)
+                        L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args, prec=ctx.prec)
                 if need_dz:
                     wf = weight_slices.get(w0_param, 0, cin_f, cin_f)
-                    L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(wf), cin_f, None, None, None, None, None, L.ptr(dz), None, None)
+                    L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(wf), cin_f, None, None, None, None, None, L.ptr(dz), None, None, prec=ctx.prec)
                     dx0 = dz
                 break
             if fuse:
@@ -966,7 +972,7 @@ class MLPChainRows(torch.autograd.Function):
                        L.ptr(params[3 * i + 1]) if pending is not None else None, L.ptr(pending), L.ptr(None if dgb is None else dgb[0]),
                        L.ptr(None if dgb is None else dgb[1]), int(training), L.ptr(src), src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]),
                        L.ptr(act[3]), L.ptr(w), cin, R, cout, cin, L.ptr(dw), cin, L.ptr(dz), L.ptr(stat), L.ptr(part),
-                       L.ptr(pool[0]) if pool_here else None, L.ptr(pool[1]) if pool_here else None, L.ptr(pool[2]) if pool_here else None)
+                       L.ptr(pool[0]) if pool_here else None, L.ptr(pool[1]) if pool_here else None, L.ptr(pool[2]) if pool_here else None, prec=ctx.prec)
                 if pending is not None:
                     grads[3 * i + 1], grads[3 * i + 2] = dgb[0], dgb[1]
             else:
@@ -975,16 +981,16 @@ class MLPChainRows(torch.autograd.Function):
                 if _EXP_SKIP_DW:
                     pass  # (timing experiment only: tools/exp/README.md, "what the graph step would cost with the weight gradients for free")
                 elif dw_aside:
-                    side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, src, dw) + tuple(t for t in act if t is not None))
+                    side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, src, dw) + tuple(t for t in act if t is not None), prec=ctx.prec)
                 else:
-                    L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args)
+                    L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args, prec=ctx.prec)
                 if need_dz and i > 0:
                     # d(input) = dy . W with the previous layer's ReLU mask and BN-backward column sums in the epilogue
                     pm, pi, pg, pb = act
                     L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(w), cin, L.ptr(ys[i - 1]), L.ptr(pm), L.ptr(pi),
-                           L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat), L.ptr(_partial(R, cin, dev)))
+                           L.ptr(pg), L.ptr(pb), L.ptr(dz), L.ptr(stat), L.ptr(_partial(R, cin, dev)), prec=ctx.prec)
                 elif need_dz:
-                    L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(dz), None, None)
+                    L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(dz), None, None, prec=ctx.prec)
             if i > 0:
                 gcur, pending = dz, stat
             elif need_dz:
@@ -1023,6 +1029,7 @@ class LinearRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_full, bias, c0=0, c1=None, sink=None):
         ctx.sink = sink
+        prec = ctx.prec = L.current_precision()
         # w_full (C_out, C_tot[,1[,1]]); columns [c0, c1) multiply x (R, >= c1 - c0 columns; extra columns are zero padding).
         # The slice is copied here (one small kernel) and its gradient is written straight into a full-size zeroed gradient
         # (lddw), so autograd sees no slicing: that costs a zero fill and a strided copy per slice in backward.
@@ -1040,7 +1047,7 @@ class LinearRows(torch.autograd.Function):
         L.require_gpu(x, w, bias)
         cout = w.size(0)
         y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
-        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, ldx, ldx, L.ptr(w), ldx, cout, None, None, None, None, L.ptr(bias), L.ptr(y), None, None)
+        L.call('mvp_mlp_forward_f32', x, L.ptr(x), R, ldx, ldx, L.ptr(w), ldx, cout, None, None, None, None, L.ptr(bias), L.ptr(y), None, None, prec=prec)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.slice = (c0, cin, tuple(w_full.shape))
@@ -1056,20 +1063,20 @@ class LinearRows(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None)
+            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None, prec=ctx.prec)
         if ctx.needs_input_grad[1]:
             c0, ncol, shape = ctx.slice
             sink = ctx.sink
             if sink is not None:  # the weight's other slices add their columns into the same buffer (WeightGradSink)
                 buf = sink.buffer(gy.device)
                 sink.run(gy.device, 'mvp_mlp_weight_grad_f32', (L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None,
-                                                                L.ptr_at(buf, c0), sink.numel // cout), (gy, x))
+                                                                L.ptr_at(buf, c0), sink.numel // cout), (gy, x), prec=ctx.prec)
                 gw = sink.done()
             else:
                 # (on the calling stream: without a sink, autograd adds the gradients of a weight's several slices straight away)
                 gw = zero_pool.zeros(shape, torch.float32, w.device)  # accumulated into; columns outside the slice stay zero
                 L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None, L.ptr_at(gw, c0),
-                       gw.numel() // cout)
+                       gw.numel() // cout, prec=ctx.prec)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         return gx, gw, gb, None, None, None
@@ -1135,7 +1142,7 @@ def sa_fused_eval(zf, xyz, centre, index, mlp):
     zfc = None if zf is None else zf.contiguous()
     L.call('mvp_sa_fused_forward_f32', xyz, L.ptr(zfc), L.ptr(xyz.contiguous()), L.ptr(centre.contiguous()), L.ptr(index.contiguous()), L.ptr(wxyz),
            B, N, M, 32, c1, *[L.ptr(t.detach().contiguous()) for t in bn[0:4]], L.ptr(w2), c2, *[L.ptr(t.detach().contiguous()) for t in bn[4:8]],
-           L.ptr(w3), c3, *[L.ptr(t.detach().contiguous()) for t in bn[8:12]], L.ptr(out), None)
+           L.ptr(w3), c3, *[L.ptr(t.detach().contiguous()) for t in bn[8:12]], L.ptr(out), None, prec=L.current_precision())
     return out
 
 

@@ -112,6 +112,7 @@ class UNetResNet34(nn.Module):
         """Undo frozen_inference(): drop the folded runtime copy, parameters trainable again, train() works normally."""
         self.__dict__.pop('_fast', None)
         self.__dict__.pop('_fast_dtype', None)
+        self.__dict__['_frozen'] = False  # the load_state_dict hook stays registered but no longer re-creates the folded copy
         for p in self.parameters():
             p.requires_grad_(True)
         return self
@@ -169,9 +170,11 @@ class UNetResNet34(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         self.__dict__['_fast_dtype'] = compute_dtype
+        self.__dict__['_frozen'] = True
         self._refold()
         if not self.__dict__.get('_refold_hooked'):
-            self.register_load_state_dict_post_hook(lambda module, incompatible: module._refold())
+            # (only while frozen: after unfreeze() a load_state_dict must not quietly freeze the module again)
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module._refold() if module.__dict__.get('_frozen') else None)
             self.__dict__['_refold_hooked'] = True
         return self
 
@@ -181,6 +184,7 @@ class UNetResNet34(nn.Module):
         self.__dict__.pop('_fast', None)
         fast = copy.deepcopy(self)
         fast.__dict__.pop('_refold_hooked', None)
+        fast.__dict__.pop('_frozen', None)
         fast.__dict__.pop('_fast_dtype', None)
         fast._load_state_dict_post_hooks.clear()
         fast._fold_in_place()

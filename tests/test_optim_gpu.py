@@ -103,3 +103,27 @@ def test_build_optimizer_gives_the_fused_adam_on_the_gpu(dev):
     model = torch.nn.Linear(8, 8).to(dev)
     opt = C.build_optimizer(cfg, model)
     assert isinstance(opt, FusedAdam) and opt.defaults['lr'] == cfg.OPTIMIZER.BASE_LR
+
+
+def test_fused_adam_keeps_one_step_count_per_parameter(dev):
+    """torch.optim.Adam applies each parameter's OWN 'step' in the bias corrections; a parameter whose gradient was None on
+    some iterations (or one that joined later) has a smaller count than the others.  FusedAdam launches once per distinct count."""
+    from mvpnet_amd.optim import FusedAdam
+    pa, pb = _params(dev, 11, False), _params(dev, 11, False)
+    oa = FusedAdam(pa, lr=2e-3, weight_decay=1e-3)
+    ob = torch.optim.Adam(pb, lr=2e-3, weight_decay=1e-3)
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    for it in range(5):
+        for k, (a, b) in enumerate(zip(pa[:-1], pb[:-1])):
+            if (k == 2 and it in (1, 3)) or (k == 5 and it < 2):  # these two skip iterations: grad None
+                a.grad, b.grad = None, None
+                continue
+            gr = torch.randn(a.shape, generator=gen).to(dev)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    assert float(oa.state[pa[2]]['step']) == float(ob.state[pb[2]]['step']) == 3.0
+    assert float(oa.state[pa[5]]['step']) == float(ob.state[pb[5]]['step']) == 3.0
+    assert float(oa.state[pa[0]]['step']) == 5.0
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)

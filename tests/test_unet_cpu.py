@@ -69,6 +69,16 @@ def test_frozen_unet_survives_model_train():
     model.unfreeze()
     outer.train()
     assert model.training and all(p.requires_grad for p in model.parameters())
+    # a load_state_dict after unfreeze() must not quietly freeze the module again (the refold hook stays registered)
+    model.load_state_dict(model.state_dict())
+    outer.train()
+    assert model.__dict__.get('_fast') is None and model.training
+    y = model(x)['feature']
+    assert y.requires_grad  # the real parameters are in the graph again
+    # ... and a module that is frozen again refolds on load as before
+    model.frozen_inference()
+    model.load_state_dict(model.state_dict())
+    assert model.__dict__.get('_fast') is not None and not model.training
 
 
 def test_resnet34_encoder_against_the_torchvision_definition():
