@@ -91,9 +91,9 @@ class TimedLifting:
         orig_call = L.call
         timer = self
 
-        def call(name, tensor_for_device, *args):
+        def call(name, tensor_for_device, *args, **kw):
             if name != 'mvp_lift_f32' or not timer.enabled:
-                return orig_call(name, tensor_for_device, *args)
+                return orig_call(name, tensor_for_device, *args, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             orig_call(name, tensor_for_device, *args)

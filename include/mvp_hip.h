@@ -534,6 +534,52 @@ int mvp_mlp_weight_grad_ws_f32(const float* dY, const float* X, int64_t R, int64
                                const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                                float* dW, int64_t lddw, float* workspace, int64_t workspace_floats, mvp_stream_t stream);
 
+/* ---- a set-abstraction level in TRAINING mode without its (B*M*32, C) tensors (csrc/sa_train.hip) ---------------------------------------
+ * replaces, forward and backward, QueryGrouper + SharedMLP(ndim=2, bn=True) + torch.max of mvpnet/models/pn2/modules.py:20-37,100-108
+ * (common/nn/modules/conv.py:41-51 with BATCH statistics).  Batch statistics force one pass over the level per layer; each pass
+ * RE-CREATES the ball's rows from the per-point tensor zf (B,N,C1) = first-layer feature columns applied per point, the coordinates and
+ * the ball index instead of loading stored activations:
+ *   plan      mvp_sa_geom_sums_f32: per point the sum of the centred coordinates of the rows that gathered it and their count (dsum (B,N,4)),
+ *             and the batch-wide first and second moments of the centred coordinates (gsum: 16 float64, zero on entry) -- coordinates only
+ *   forward   pass 1: mvp_sa_train_stats1_f32: statistics of y_1 + BatchNorm-1 finalize from per-POINT sums (y_1 is affine in per-point data),
+ *                     + zsum (C1,3) for the backward  (or mvp_group_lin_rows_bn_f32 with out == NULL: the same statistics row by row)
+ *             pass 2: mvp_sa_train_forward_f32(stage 2): statistics of y_2 + BatchNorm-2 finalize (mean, invstd, running statistics)
+ *             pass 3: mvp_sa_train_forward_f32(stage 3): statistics of y_3 + finalize, and per ball and column the largest / smallest pre-BN
+ *                     y_3 with the first row attaining each (ymax, ymin, amax, amin: (B*M, C3)) -> mvp_pool_finalize_f32 pools exactly
+ *   backward  mvp_pool_backward_stats_f32, then
+ *             mvp_sa_train_backward_f32(layer 3): dW3 +=, dz_2 (B*M*32, C2) stored, its two column sums += stat_prev, dgamma3 / dbeta3
+ *             mvp_sa_train_backward_f32(layer 2): dz_2 read, dW2 +=, dz_1 (B*M*32, C1) stored, column sums, dgamma2 / dbeta2
+ *             mvp_sa_train_backward1_f32: per POINT: a plain gather of dz_1 through the transposed ball index (mvp_csr_build_i64) + the
+ *                     closed-form BatchNorm-backward terms -> gradient of zf; gradient of the first layer's coordinate columns from tsum
+ *                     (accumulated by the layer-2 pass), zsum, gsum; dgamma1 / dbeta1
+ * Only dz_2 and dz_1 ever have the shape (B*M*32, C) in memory.  stat: 2*C + 1 float64, ALL zero on entry (sums of y, of y^2, completion
+ * counter: zero again on exit); stat_prev: 2*Cp float64 accumulated into.  training = 0 drops the batch terms of the BatchNorm backward.
+ * Needs K == 32, C1, C2 <= 64, C3 <= 64 (C3 <= 128 when C1, C2 > 32: level 2 of the reference network), multiples of 4, zf 16-byte aligned, a
+ * split-bf16 precision: MVP_EUNSUPPORTED otherwise (callers then take the per-layer entry points). */
+int mvp_sa_train_forward_f32(int stage, const float* zf, const float* xyz, const float* centre, const int64_t* index, const float* wxyz,
+                             int64_t B, int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd,
+                             const float* bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean,
+                             const float* bn2_invstd, const float* bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3,
+                             double* stat, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                             float* running_var, int64_t* num_batches_tracked, float* ymax, float* ymin, uint8_t* amax, uint8_t* amin,
+                             mvp_stream_t stream);
+int mvp_sa_train_backward_f32(int layer, const float* zf, const float* xyz, const float* centre, const int64_t* index, const float* wxyz,
+                              int64_t B, int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd,
+                              const float* bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean,
+                              const float* bn2_invstd, const float* bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3,
+                              const float* mean_i, const float* invstd_i, const float* gamma_i, const double* stat_i, float* dgamma_i,
+                              float* dbeta_i, int training, const float* G, const float* pool_dout, const float* pool_out,
+                              const uint8_t* pool_arg, float* dW, int64_t lddw, float* dZ, double* stat_prev, float* tsum, mvp_stream_t stream);
+int mvp_sa_train_backward1_f32(const float* dz1, const int32_t* offsets, const int32_t* slots, const float* zf, const float* dsum,
+                               const float* wxyz, const float* tsum, const double* zsum, const double* gsum, int64_t B, int64_t N, int64_t M,
+                               int64_t K, int64_t C1, const float* mean, const float* invstd, const float* gamma, const double* stat,
+                               int training, float* dgamma, float* dbeta, float* gz, float* dWxyz, int64_t lddw, mvp_stream_t stream);
+int mvp_sa_geom_sums_f32(const int32_t* offsets, const int32_t* slots, const float* xyz, const float* centre, int64_t B, int64_t N, int64_t M,
+                         int64_t K, float* dsum, double* gsum, mvp_stream_t stream);
+int mvp_sa_train_stats1_f32(const float* zf, const float* dsum, const float* wxyz, const double* gsum, int64_t B, int64_t N, int64_t M, int64_t K,
+                            int64_t C1, double* stat, double* zsum, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                            float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
+
 /* ---- the shared-MLP entry points with the contraction precision as ARGUMENTS (csrc/mlp_prec.hip) -----------------------------------
  * mvp_<name>_p_f32 = mvp_<name>_f32 with two more parameters in front of the stream:
  *     precision           contraction of this call: 0 = fp32 MFMA, 1 = bf16, 3 = bf16x3, 6 = bf16x6, -1 = the default
@@ -581,6 +627,20 @@ int mvp_sa_fused_forward_p_f32(const float* zf, const float* xyz, const float* c
     bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean, const float* bn2_invstd, const float*
     bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3, const float* bn3_mean, const float* bn3_invstd, const float*
     bn3_gamma, const float* bn3_beta, float* out, uint8_t* arg, int precision, int precision_backward, mvp_stream_t stream);
+
+int mvp_sa_train_forward_p_f32(int stage, const float* zf, const float* xyz, const float* centre, const int64_t* index, const
+    float* wxyz, int64_t B, int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd, const
+    float* bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean, const float* bn2_invstd, const
+    float* bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3, double* stat, float eps, float momentum, float* mean,
+    float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* ymax, float* ymin, uint8_t*
+    amax, uint8_t* amin, int precision, int precision_backward, mvp_stream_t stream);
+int mvp_sa_train_backward_p_f32(int layer, const float* zf, const float* xyz, const float* centre, const int64_t* index, const
+    float* wxyz, int64_t B, int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd, const
+    float* bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean, const float* bn2_invstd, const
+    float* bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3, const float* mean_i, const float* invstd_i, const
+    float* gamma_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* G, const float* pool_dout,
+    const float* pool_out, const uint8_t* pool_arg, float* dW, int64_t lddw, float* dZ, double* stat_prev, float* tsum, int precision, int
+    precision_backward, mvp_stream_t stream);
 
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.

@@ -106,6 +106,15 @@ _SIGNATURES = {
     'mvp_pool_backward_stats_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, ctypes.c_int, _ptr, _ptr, _ptr],
     'mvp_sa_fused_forward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr,
                                  _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_sa_train_forward_f32': [ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr,
+                                 _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_sa_train_backward_f32': [ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr,
+                                  _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr,
+                                  _ptr, _ptr],
+    'mvp_sa_train_backward1_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr,
+                                   ctypes.c_int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
+    'mvp_sa_geom_sums_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
+    'mvp_sa_train_stats1_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_forward_bn_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr,
                                _ptr, _ptr, _ptr],
     'mvp_mlp_forward_rel_bn_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -121,7 +130,7 @@ _SIGNATURES = {
 # the shared-MLP entry points with the precision as arguments (csrc/mlp_prec.hip): base parameters + (precision, precision_backward)
 for _n in ['mvp_mlp_forward_f32', 'mvp_mlp_forward_bn_f32', 'mvp_mlp_forward_rel_bn_f32', 'mvp_mlp_forward_pool_f32', 'mvp_mlp_input_grad_f32',
            'mvp_mlp_weight_grad_f32', 'mvp_mlp_weight_grad_ws_f32', 'mvp_mlp_layer_backward_f32', 'mvp_mlp_layer_backward_ws_f32',
-           'mvp_sa_fused_forward_f32']:
+           'mvp_sa_fused_forward_f32', 'mvp_sa_train_forward_f32', 'mvp_sa_train_backward_f32']:
     _SIGNATURES[_n[:-4] + '_p_f32'] = _SIGNATURES[_n][:-1] + [ctypes.c_int, ctypes.c_int, _ptr]
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
            'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode', 'mvp_fps_debug_spin_limit'] + sorted(_SIGNATURES)

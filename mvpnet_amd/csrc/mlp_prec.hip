@@ -83,7 +83,8 @@ MVP_API int mvp_mlp_layer_backward_p_f32(const float* G, const float* Yi, const 
                                          double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
                                          const uint8_t* pool_arg, int precision, int precision_backward, mvp_stream_t stream) {
   MVP_WITH_PRECISION(mvp_mlp_layer_backward_f32(G, Yi, mean_i, invstd_i, gamma_i, stat_i, dgamma_i, dbeta_i, training, X, ldx, act_mean, act_invstd,
-                                                act_gamma, act_beta, W, ldw, R, C, Cp, dW, lddw, dZ, stat_prev, partial, pool_dout, pool_out, pool_arg,
+                                                act_gamma, act_beta, W, ldw, R, C, Cp, dW, lddw, dZ, stat_prev, partial, pool_dout,
+                                                    pool_out, pool_arg,
                                                 stream));
 }
 MVP_API int mvp_mlp_layer_backward_ws_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
@@ -93,7 +94,8 @@ MVP_API int mvp_mlp_layer_backward_ws_p_f32(const float* G, const float* Yi, con
                                             double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
                                             const uint8_t* pool_arg, float* workspace, int64_t workspace_floats, int precision,
                                             int precision_backward, mvp_stream_t stream) {
-  MVP_WITH_PRECISION(mvp_mlp_layer_backward_ws_f32(G, Yi, mean_i, invstd_i, gamma_i, stat_i, dgamma_i, dbeta_i, training, X, ldx, act_mean, act_invstd,
+  MVP_WITH_PRECISION(mvp_mlp_layer_backward_ws_f32(G, Yi, mean_i, invstd_i, gamma_i, stat_i, dgamma_i, dbeta_i, training, X, ldx, act_mean,
+      act_invstd,
                                                    act_gamma, act_beta, W, ldw, R, C, Cp, dW, lddw, dZ, stat_prev, partial, pool_dout, pool_out,
                                                    pool_arg, workspace, workspace_floats, stream));
 }
@@ -103,6 +105,28 @@ MVP_API int mvp_sa_fused_forward_p_f32(const float* zf, const float* xyz, const 
                                        const float* bn2_invstd, const float* bn2_gamma, const float* bn2_beta, const float* W3, int64_t C3,
                                        const float* bn3_mean, const float* bn3_invstd, const float* bn3_gamma, const float* bn3_beta,
                                        float* out, uint8_t* arg, int precision, int precision_backward, mvp_stream_t stream) {
-  MVP_WITH_PRECISION(mvp_sa_fused_forward_f32(zf, xyz, centre, index, wxyz, B, N, M, K, C1, bn1_mean, bn1_invstd, bn1_gamma, bn1_beta, W2, C2, bn2_mean,
+  MVP_WITH_PRECISION(mvp_sa_fused_forward_f32(zf, xyz, centre, index, wxyz, B, N, M, K, C1, bn1_mean, bn1_invstd, bn1_gamma, bn1_beta, W2,
+      C2, bn2_mean,
                                               bn2_invstd, bn2_gamma, bn2_beta, W3, C3, bn3_mean, bn3_invstd, bn3_gamma, bn3_beta, out, arg, stream));
+}
+MVP_API int mvp_sa_train_forward_p_f32(int stage, const float* zf, const float* xyz, const float* centre, const int64_t* index, const float*
+    wxyz, int64_t B, int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd, const float* bn1_gamma,
+    const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean, const float* bn2_invstd, const float* bn2_gamma, const float*
+    bn2_beta, const float* W3, int64_t C3, double* stat, float eps, float momentum, float* mean, float* invstd, float* running_mean, float*
+    running_var, int64_t* num_batches_tracked, float* ymax, float* ymin, uint8_t* amax, uint8_t* amin, int precision, int
+    precision_backward, mvp_stream_t stream) {
+  MVP_WITH_PRECISION(mvp_sa_train_forward_f32(stage, zf, xyz, centre, index, wxyz, B, N, M, K, C1, bn1_mean, bn1_invstd, bn1_gamma,
+      bn1_beta, W2, C2, bn2_mean, bn2_invstd, bn2_gamma, bn2_beta, W3, C3, stat, eps, momentum, mean, invstd, running_mean, running_var,
+      num_batches_tracked, ymax, ymin, amax, amin, stream));
+}
+
+MVP_API int mvp_sa_train_backward_p_f32(int layer, const float* zf, const float* xyz, const float* centre, const int64_t* index, const
+    float* wxyz, int64_t B, int64_t N, int64_t M, int64_t K, int64_t C1, const float* bn1_mean, const float* bn1_invstd, const float*
+    bn1_gamma, const float* bn1_beta, const float* W2, int64_t C2, const float* bn2_mean, const float* bn2_invstd, const float* bn2_gamma,
+    const float* bn2_beta, const float* W3, int64_t C3, const float* mean_i, const float* invstd_i, const float* gamma_i, const double*
+    stat_i, float* dgamma_i, float* dbeta_i, int training, const float* G, const float* pool_dout, const float* pool_out, const uint8_t*
+    pool_arg, float* dW, int64_t lddw, float* dZ, double* stat_prev, float* tsum, int precision, int precision_backward, mvp_stream_t stream) {
+  MVP_WITH_PRECISION(mvp_sa_train_backward_f32(layer, zf, xyz, centre, index, wxyz, B, N, M, K, C1, bn1_mean, bn1_invstd, bn1_gamma,
+      bn1_beta, W2, C2, bn2_mean, bn2_invstd, bn2_gamma, bn2_beta, W3, C3, mean_i, invstd_i, gamma_i, stat_i, dgamma_i, dbeta_i, training,
+      G, pool_dout, pool_out, pool_arg, dW, lddw, dZ, stat_prev, tsum, stream));
 }

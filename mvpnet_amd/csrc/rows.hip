@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kRT) void group_lin_rows_kernel(const float* __rest
         v = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
       }
     }
-    st4(out + ((size_t)b * E + e) * C + c, v);
+    if (out != nullptr) st4(out + ((size_t)b * E + e) * C + c, v);  // (null: statistics only -- the training-mode fused level, sa_train.hip)
     if (diff != nullptr && c == 0) st4(diff + ((size_t)b * E + e) * 4, make_float4(dx, dy, dz, 0.f));
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
@@ -1425,7 +1425,7 @@ static int group_lin_rows(const float* zf, const float* xyz, const float* centre
   MVP_NONNULL(centre);
   MVP_NONNULL(wxyz);
   MVP_NONNULL(index);
-  MVP_NONNULL(out);
+  if (!stat) MVP_NONNULL(out);  // out == NULL with stat: the layer's batch statistics alone, nothing of shape (B,M,K,C) is stored
   if (stat) MVP_NONNULL(partial);
   MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && C <= 1024 && (kRT % (C / 4)) == 0 && M >= 0 && K > 0 && B < 65536);
   if (B == 0 || M == 0) return MVP_OK;

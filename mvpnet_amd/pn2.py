@@ -99,11 +99,16 @@ class SetAbstraction(nn.Module):
             return torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, 3))
 
     def neighbours(self, new_xyz, xyz, with_csr=False):
-        """Ball query [+ with_csr: the transposed index (offsets, slots) the backward of the grouping gathers through]."""
+        """Ball query [+ with_csr: the transposed index (offsets, slots) the backward of the grouping gathers through, and -- for levels the
+        training-mode fused path can take (K = 32, fp32) -- the geometry-only sums of its per-point first-layer passes (R.geom_sums)]."""
         with torch.no_grad():
             ball = ops.ball_query(new_xyz, xyz, self.radius, self.max_neighbors, transpose=False)
             if with_csr:
-                return (ball,) + R.build_csr(ball, xyz.size(1))
+                csr = R.build_csr(ball, xyz.size(1))
+                if R.SA_TRAIN_FUSED and self.max_neighbors == 32 and xyz.dtype == torch.float32 and len(self.mlp) == 3 and \
+                        R.sa_level_train_widths_ok(*(l.conv.weight.size(0) for l in self.mlp)):
+                    csr = csr + R.geom_sums(csr[0], csr[1], xyz.contiguous(), new_xyz.contiguous(), 32)
+                return (ball,) + csr
         return (ball,)
 
     def geometry(self, xyz, with_csr=False):
@@ -127,6 +132,7 @@ class SetAbstraction(nn.Module):
         geometry = self.geometry(xyz) if geometry is None else geometry
         new_xyz, ball = geometry[0], geometry[1]
         csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
+        csr_geo = tuple(geometry[2:6]) if len(geometry) >= 6 else csr   # (+ the geometry sums of the fused training path)
         M, K = new_xyz.size(1), self.max_neighbors
         l0 = self.mlp[0]
         c1 = l0.conv.weight.size(0)
@@ -153,6 +159,9 @@ class SetAbstraction(nn.Module):
                 fused = R.sa_fused_eval(zf, xyz, new_xyz, ball, self.mlp)
                 if fused is not None:
                     return new_xyz, fused
+            if bn_training and R.sa_level_train_ok(zf, self.mlp, K):
+                # training: the whole level without any (B,M,K,C) tensor -- every pass re-creates the ball's rows from zf (csrc/sa_train.hip)
+                return new_xyz, R.sa_level_train(zf, xyz, new_xyz, ball, self.mlp, csr=csr_geo, sink=sink)
             # (B,M,K,C_1): conv output of layer 1; in training also its batch statistics AND the BatchNorm finalize, from the same call
             y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=l0.bn if bn_training else False, csr=csr, sink=sink)
             stat1 = None
@@ -433,7 +442,7 @@ class PN2SSG(nn.Module):
         """The geometry plan of clouds lo..hi-1 of a plan made for a larger batch (views, no copies).  FPS runs one workgroup
         per cloud for ~2.8 ms whatever the batch size, so planning ALL chunks of a scene in one call and slicing per batch costs
         one FPS chain per scene instead of one per batch (scene.infer_scene)."""
-        cut = lambda g: None if g is None else tuple(t[lo:hi] for t in g)
+        cut = lambda g: None if g is None else tuple(t[lo:hi] for t in g[:4])  # (the geometry sums behind the transposed index are batch-wide: dropped)
         out = {'sa': [cut(g) for g in plan['sa']], 'fp': [cut(g) for g in plan['fp']], 'event': plan['event'],
                'stream': plan['stream'], 'xyz': plan['xyz']}
         if 'level_events' in plan:  # the per-level events of the whole plan hold for every slice of it

@@ -399,6 +399,19 @@ def build_csr(index, N, sorted=None):
     return offsets, slots
 
 
+def geom_sums(offsets, slots, xyz, centre, K):
+    """Geometry-only sums of a set-abstraction level for the per-point first-layer passes (mvp_sa_geom_sums_f32, csrc/sa_train.hip):
+    offsets (B,N+1), slots (B,M*K) = build_csr(ball index, N), xyz (B,N,3), centre (B,M,3) -> dsum (B,N,4) float32 = per point (sum of the
+    centred coordinates of the rows that gathered it, their count), gsum (16) float64 = first and second moments of the centred
+    coordinates over all rows.  Coordinates only: part of the geometry plan."""
+    L.require_gpu(offsets, slots, xyz, centre)
+    B, N, _ = xyz.shape
+    dsum = torch.empty((B, N, 4), dtype=torch.float32, device=xyz.device)
+    gsum = torch.zeros(16, dtype=torch.float64, device=xyz.device)
+    L.call('mvp_sa_geom_sums_f32', xyz, L.ptr(offsets), L.ptr(slots), L.ptr(xyz), L.ptr(centre), B, N, centre.size(1), K, L.ptr(dsum), L.ptr(gsum))
+    return dsum, gsum
+
+
 def knn3_weights(query, key, eps=1e-10):
     """query (B,N1,3), key (B,N2,3) float32 -> index (B,N1,3) int64, weight (B,N1,3): the 3 nearest keys and FeatureInterpolator's
     inverse-squared-distance weights (modules.py:135-140) from one launch (mvp_knn3_weights_f32)."""
@@ -1109,6 +1122,143 @@ def linear_rows_bf16(x, weight, bias=None, scale=None, shift=None, relu=False):
     L.call('mvp_mlp_forward_bf16', x, L.ptr(x), R, cin, x.stride(0), L.ptr(w), cin, cout, L.ptr(bias), L.ptr(scale), L.ptr(shift), int(bool(relu)),
            L.ptr(y), cout)
     return y
+
+
+# Training-mode set-abstraction levels without their (B*M*32, C) tensors (csrc/sa_train.hip): every pass re-creates the ball's rows from
+# the per-point tensor zf instead of loading stored activations.  MVP_SA_TRAIN=0: the per-layer path (A/B switch).
+SA_TRAIN_FUSED = os.environ.get('MVP_SA_TRAIN', '1') != '0'
+
+
+def sa_level_train_widths_ok(c1, c2, c3):
+    """Widths csrc/sa_train.hip instantiates: C1, C2 <= 64 with C3 <= 64, or the (33..64, 33..64, 65..128) shape of the reference network's level 2."""
+    return c1 >= 4 and max(c1, c2) <= 64 and (c3 <= 64 or (c3 <= 128 and min(c1, c2) > 32))
+
+
+def sa_level_train_ok(zf, mlp, K):
+    """True when a level (zf (B,N,C1) per-point first-layer output, 3-layer SharedMLP `mlp` in training mode, K neighbours) runs as
+    SALevelTrain: K = 32, widths sa_level_train_widths_ok and multiples of 4, BatchNorm + ReLU everywhere, a split-bf16 contraction."""
+    if not (SA_TRAIN_FUSED and zf is not None and zf.is_cuda and zf.dtype == torch.float32 and len(mlp) == 3 and K == 32 and mlp_chain_is_fused(mlp)):
+        return False
+    if L.DW_WORKSPACE:  # the reproducible mode keeps the per-layer path: its weight gradients go through a workspace + ordered reduction,
+        return False    # the fused passes flush theirs (and the coordinate-column sums) with fp32 atomics
+    c1, c2, c3 = (l.conv.weight.size(0) for l in mlp)
+    return sa_level_train_widths_ok(c1, c2, c3) and all(l.bn.training for l in mlp) and L.current_precision()[0] != 0 and \
+        all(l.conv.weight.is_contiguous() for l in mlp)
+
+
+class SALevelTrain(torch.autograd.Function):
+    """One set-abstraction level in training mode (QueryGrouper + SharedMLP(ndim=2) + max over the neighbours: mvpnet/models/pn2/modules.py:
+    20-37,100-108, conv.py:41-51 with batch statistics) WITHOUT any (B*M*32, C) activation tensor: three forward passes (statistics of
+    y_1; of y_2; of y_3 + per-ball max / min) and three backward passes (layer 3; layer 2; per point through the transposed index) that
+    each re-create the ball's rows from zf, the coordinates and the ball index (csrc/sa_train.hip).  Only dz_2 and dz_1 are stored.
+    Gradients: zf, the first layer's coordinate columns (into the weight's gradient sink), W2, W3, the three BatchNorms' parameters."""
+
+    @staticmethod
+    def forward(ctx, zf, xyz, centre, index, offsets, slots, dsum, gsum, w1_full, sink, bns, W2, W3, g1, b1, g2, b2, g3, b3):
+        L.require_gpu(zf, xyz, centre, index, W2, W3)
+        prec = ctx.prec = L.current_precision()
+        ctx.sink = sink
+        B, N, C1 = zf.shape
+        M, K = index.size(1), index.size(2)
+        C2, C3 = W2.size(0), W3.size(0)
+        dev = zf.device
+        ctot = w1_full.numel() // w1_full.size(0)
+        ctx.w_shape = tuple(w1_full.shape)
+        wxyz = weight_slices.get(w1_full, ctot - 3, ctot, 3)
+        arena = zero_pool.zeros(2 * (C1 + C2 + C3) + 3 + 3 * C1, torch.float64, dev)
+        stat1, stat2, stat3 = arena[:2 * C1 + 1], arena[2 * C1 + 1:2 * (C1 + C2) + 2], arena[2 * (C1 + C2) + 2:2 * (C1 + C2 + C3) + 3]
+        zsum = arena[2 * (C1 + C2 + C3) + 3:]
+        mi = torch.empty(2 * (C1 + C2 + C3), dtype=torch.float32, device=dev)
+        m1, i1 = mi[:C1], mi[C1:2 * C1]
+        m2, i2 = mi[2 * C1:2 * C1 + C2], mi[2 * C1 + C2:2 * (C1 + C2)]
+        m3, i3 = mi[2 * (C1 + C2):2 * (C1 + C2) + C3], mi[2 * (C1 + C2) + C3:]
+        (rm1, rv1, nb1, e1, mo1), (rm2, rv2, nb2, e2, mo2), (rm3, rv3, nb3, e3, mo3) = bns
+        if offsets is None:
+            offsets, slots = build_csr(index, N)
+        if dsum is None:  # (not supplied by the geometry plan)
+            dsum, gsum = geom_sums(offsets, slots, xyz, centre, K)
+        # pass 1: statistics of y_1 (+ BatchNorm-1 finalize) per POINT: y_1 is affine in per-point data (csrc/sa_train.hip)
+        L.call('mvp_sa_train_stats1_f32', zf, L.ptr(zf), L.ptr(dsum), L.ptr(wxyz), L.ptr(gsum), B, N, M, K, C1, L.ptr(stat1), L.ptr(zsum), float(e1),
+               float(mo1), L.ptr(m1), L.ptr(i1), L.ptr(rm1), L.ptr(rv1), L.ptr(nb1))
+        level = (L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(index), L.ptr(wxyz), B, N, M, K, C1, L.ptr(m1), L.ptr(i1), L.ptr(g1), L.ptr(b1), L.ptr(W2), C2)
+        # pass 2: statistics of y_2
+        L.call('mvp_sa_train_forward_f32', xyz, 2, *level, None, None, None, None, None, 0, L.ptr(stat2), float(e2), float(mo2), L.ptr(m2), L.ptr(i2),
+               L.ptr(rm2), L.ptr(rv2), L.ptr(nb2), None, None, None, None, prec=prec)
+        # pass 3: statistics of y_3 + per ball max / min of the pre-BN values
+        G = B * M
+        ymax = torch.empty((G, C3), dtype=torch.float32, device=dev)
+        ymin = torch.empty((G, C3), dtype=torch.float32, device=dev)
+        amax = torch.empty((G, C3), dtype=torch.uint8, device=dev)
+        amin = torch.empty((G, C3), dtype=torch.uint8, device=dev)
+        L.call('mvp_sa_train_forward_f32', xyz, 3, *level, L.ptr(m2), L.ptr(i2), L.ptr(g2), L.ptr(b2), L.ptr(W3), C3, L.ptr(stat3), float(e3), float(mo3),
+               L.ptr(m3), L.ptr(i3), L.ptr(rm3), L.ptr(rv3), L.ptr(nb3), L.ptr(ymax), L.ptr(ymin), L.ptr(amax), L.ptr(amin), prec=prec)
+        out = torch.empty((G, C3), dtype=torch.float32, device=dev)
+        arg = torch.empty((G, C3), dtype=torch.uint8, device=dev)
+        ysel = torch.empty((G, C3), dtype=torch.float32, device=dev)
+        L.call('mvp_pool_finalize_f32', ymax, L.ptr(ymax), L.ptr(ymin), L.ptr(amax), L.ptr(amin), L.ptr(m3), L.ptr(i3), L.ptr(g3), L.ptr(b3), G, C3, 1,
+               L.ptr(out), L.ptr(arg), L.ptr(ysel))
+        ctx.save_for_backward(zf, xyz, centre, index, offsets, slots, dsum, gsum, zsum, wxyz, mi, g1, b1, g2, b2, g3, W2, W3, out, arg, ysel)
+        ctx.dims = (B, N, M, K, C1, C2, C3)
+        return out.view(B, M, C3)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        zf, xyz, centre, index, offsets, slots, dsum, gsum, zsum, wxyz, mi, g1, b1, g2, b2, g3, W2, W3, out, arg, ysel = ctx.saved_tensors
+        B, N, M, K, C1, C2, C3 = ctx.dims
+        prec = ctx.prec
+        dev = zf.device
+        G, R = B * M, B * M * K
+        g = grad_out.contiguous().view(G, C3)
+        m1, i1 = mi[:C1], mi[C1:2 * C1]
+        m2, i2 = mi[2 * C1:2 * C1 + C2], mi[2 * C1 + C2:2 * (C1 + C2)]
+        m3, i3 = mi[2 * (C1 + C2):2 * (C1 + C2) + C3], mi[2 * (C1 + C2) + C3:]
+        stat3 = torch.empty(2 * C3, dtype=torch.float64, device=dev)
+        L.call('mvp_pool_backward_stats_f32', g, L.ptr(g), L.ptr(out), L.ptr(ysel), L.ptr(m3), L.ptr(i3), G, C3, 1, L.ptr(stat3),
+               L.ptr(_cs_partial(G, C3, dev)))
+        st = zero_pool.zeros(2 * (C2 + C1), torch.float64, dev)
+        stat2, stat1 = st[:2 * C2], st[2 * C2:]
+        dw = zero_pool.zeros(C3 * C2 + C2 * C1 + 16 * 4 * C1, torch.float32, dev)
+        dW3, dW2, tsum = dw[:C3 * C2].view(C3, C2), dw[C3 * C2:C3 * C2 + C2 * C1].view(C2, C1), dw[C3 * C2 + C2 * C1:]
+        dgb = torch.empty(2 * (C1 + C2 + C3), dtype=torch.float32, device=dev)
+        dg1, db1 = dgb[:C1], dgb[C1:2 * C1]
+        dg2, db2 = dgb[2 * C1:2 * C1 + C2], dgb[2 * C1 + C2:2 * (C1 + C2)]
+        dg3, db3 = dgb[2 * (C1 + C2):2 * (C1 + C2) + C3], dgb[2 * (C1 + C2) + C3:]
+        level = (L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(index), L.ptr(wxyz), B, N, M, K, C1, L.ptr(m1), L.ptr(i1), L.ptr(g1), L.ptr(b1), L.ptr(W2), C2,
+                 L.ptr(m2), L.ptr(i2), L.ptr(g2), L.ptr(b2))
+        dz2 = torch.empty((R, C2), dtype=torch.float32, device=dev)
+        L.call('mvp_sa_train_backward_f32', zf, 3, *level, L.ptr(W3), C3, L.ptr(m3), L.ptr(i3), L.ptr(g3), L.ptr(stat3), L.ptr(dg3), L.ptr(db3), 1, None,
+               L.ptr(g), L.ptr(out), L.ptr(arg), L.ptr(dW3), C2, L.ptr(dz2), L.ptr(stat2), None, prec=prec)
+        dz1 = torch.empty((R, C1), dtype=torch.float32, device=dev)
+        L.call('mvp_sa_train_backward_f32', zf, 2, *level, None, 0, L.ptr(m2), L.ptr(i2), L.ptr(g2), L.ptr(stat2), L.ptr(dg2), L.ptr(db2), 1, L.ptr(dz2),
+               None, None, None, L.ptr(dW2), C1, L.ptr(dz1), L.ptr(stat1), L.ptr(tsum), prec=prec)
+        del dz2
+        # pass 1: per point through the transposed index; the coordinate columns' gradient goes straight into the weight's full-size gradient
+        numel = 1
+        for d in ctx.w_shape:
+            numel *= d
+        ctot = numel // C1
+        sink = ctx.sink
+        buf = sink.buffer(dev) if sink is not None else zero_pool.zeros(numel + 4, torch.float32, dev)
+        gz = torch.empty((B, N, C1), dtype=torch.float32, device=dev)
+        L.call('mvp_sa_train_backward1_f32', zf, L.ptr(dz1), L.ptr(offsets), L.ptr(slots), L.ptr(zf), L.ptr(dsum), L.ptr(wxyz), L.ptr(tsum), L.ptr(zsum),
+               L.ptr(gsum), B, N, M, K, C1, L.ptr(m1), L.ptr(i1), L.ptr(g1), L.ptr(stat1), 1, L.ptr(dg1), L.ptr(db1), L.ptr(gz), L.ptr_at(buf, ctot - 3), ctot)
+        gw1 = sink.done() if sink is not None else buf[:numel].view(ctx.w_shape)
+        return (gz if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None, gw1, None, None, dW2, dW3, dg1, db1, dg2, db2, dg3, db3)
+
+
+def sa_level_train(zf, xyz, centre, index, mlp, csr=None, sink=None):
+    """zf (B,N,C1) = the level's first-layer feature columns applied per point, xyz (B,N,3), centre (B,M,3), index (B,M,32) int64,
+    mlp = the level's 3-layer SharedMLP in training mode (sa_level_train_ok) -> pooled feature (B,M,C3).  csr = (offsets, slots[, dsum, gsum])
+    of build_csr(index, N) [and geom_sums] when the geometry plan holds them; sink = the WeightGradSink of the first layer's weight."""
+    offsets, slots = (csr[0], csr[1]) if csr is not None else (None, None)
+    dsum, gsum = (csr[2], csr[3]) if csr is not None and len(csr) >= 4 else (None, None)
+    l1, l2, l3 = mlp
+    bns = [(l.bn.running_mean, l.bn.running_var, l.bn.num_batches_tracked, l.bn.eps, 0.1 if l.bn.momentum is None else l.bn.momentum) for l in mlp]
+    W2 = l2.conv.weight.reshape(l2.conv.weight.size(0), -1)
+    W3 = l3.conv.weight.reshape(l3.conv.weight.size(0), -1)
+    return SALevelTrain.apply(zf.contiguous(), xyz.contiguous(), centre.contiguous(), index.contiguous(), offsets, slots, dsum, gsum, l1.conv.weight, sink, bns,
+                              W2, W3, l1.bn.weight, l1.bn.bias, l2.bn.weight, l2.bn.bias, l3.bn.weight, l3.bn.bias)
 
 
 SA_FUSED_EVAL = os.environ.get('MVP_SA_FUSED', '1') != '0'

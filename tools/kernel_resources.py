@@ -7,7 +7,7 @@ import sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
 cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-munsafe-fp-atomics',
-       '-fvisibility=hidden', '-c', src, '-o', '/dev/null', '-Rpass-analysis=kernel-resource-usage']
+       '-fvisibility=hidden', '-fno-slp-vectorize', '-c', src, '-o', '/dev/null', '-Rpass-analysis=kernel-resource-usage']
 txt = subprocess.run(cmd, capture_output=True, text=True).stderr
 OCC, LDS = r'Occupancy \[waves/SIMD\]', r'LDS Size \[bytes/block\]'
 for b in re.split(r'Function Name: ', txt)[1:]:
