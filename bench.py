@@ -211,10 +211,35 @@ def dense_extra(dev, chunks=2):
             model(dict(batch))
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t0) / 5 * 1e3
+    # (c) the full training step of the same configuration (lifting + aggregation + PN2SSG + SegLoss + backward + Adam), eager, the
+    # geometry of the next step prefetched beside the backward pass as in the headline step
+    from mvpnet_amd.mvpnet3d import SegLoss, train_step, prefetch_geometry
+    from mvpnet_amd.optim import FusedAdam
+    model.train()
+    loss_fn = SegLoss()
+    opt = FusedAdam(model.parameters(), lr=2e-3)
+    tbatch = dict(batch, seg_label=t(bt['seg_label']))
+    fresh = lambda: dict(tbatch)
+    nxt = prefetch_geometry(model, fresh())
+    for _ in range(3):
+        cur, nxt = nxt, fresh()
+        train_step(model, loss_fn, opt, cur, next_batch=nxt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        cur, nxt = nxt, fresh()
+        train_step(model, loss_fn, opt, cur, next_batch=nxt)
+    torch.cuda.synchronize()
+    train_ms = (time.perf_counter() - t0) / 5 * 1e3
+    from mvpnet_amd import _lib
+    timed_out = bool(_lib.fps_timed_out(dev))
     return {'workload': 'configs[4]: 5 views of 320x240, 32768 points per chunk, k = 5, centroids (8192, 2048, 512, 128); {} chunks on this GPU'.format(chunks),
             'lift': {'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': DENSE_LIFT_BYTES_PER_CHUNK * chunks,
                      'achieved_GBps': round(achieved, 1), 'frac_of_hbm_peak': round(achieved / HBM_PEAK_GBS, 4)},
-            'fwd_only': {'chunks_per_s_per_gpu': round(chunks / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3)}}
+            'fwd_only': {'chunks_per_s_per_gpu': round(chunks / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3)},
+            'train_step': {'chunks_per_s_per_gpu': round(chunks / (train_ms * 1e-3), 1), 'ms_per_step': round(train_ms, 3),
+                           'note': 'fwd + loss + bwd + Adam, eager; parity: tests/test_dense_gpu.py::test_dense_train_step'},
+            'fps_multi_workgroup_timed_out': timed_out}
 
 
 def contraction_info():

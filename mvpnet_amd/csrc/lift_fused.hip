@@ -175,7 +175,7 @@ __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, in
 // cooperative form costs one round trip and ~100 instructions per such lane.  Candidates, arithmetic and the (distance, id)
 // order are those of the per-lane form (pixel_knn_core.h), so results are identical.
 // All 64 lanes of the wave must call this (`active` = the lane has a query).
-template <int K>
+template <int K, int T>
 __device__ __forceinline__ void filtered_search(const float4* __restrict__ crec, const uint16_t* __restrict__ cplane,
                                                 const ViewParam* __restrict__ vp, int nv, int h, int w, int pitch, bool active,
                                                 float qx, float qy, float qz, unsigned long long (&kk)[K],
@@ -196,7 +196,12 @@ __device__ __forceinline__ void filtered_search(const float4* __restrict__ crec,
 #endif
     // views per group: the window rows of a whole group are in flight together.  Measured: 1 (118 VGPRs) = 2 capped at 128 VGPRs; 3
     // (156 VGPRs, three workgroups per CU) is 8 % slower -- the launch is bound by its HBM window, not by these round trips
-    constexpr int G = MVP_PROBE_GROUP;
+    // One-wave workgroups (T == 64) are the launches with about one wave per SIMD (a few dense chunks, one chunk's latency): nothing but the
+    // wave's own loads hides a round trip there, so all views' window rows go out together (MVP_PROBE_GROUP_SMALL, registers are free)
+#ifndef MVP_PROBE_GROUP_SMALL
+#define MVP_PROBE_GROUP_SMALL 5
+#endif
+    constexpr int G = T == 64 ? MVP_PROBE_GROUP_SMALL : MVP_PROBE_GROUP;
     for (int v0 = 0; v0 < nv; v0 += G) {
       ProbeGeom geo[G];
       u32x3a rowv[G][5];
@@ -260,7 +265,7 @@ __device__ __forceinline__ void filtered_search(const float4* __restrict__ crec,
           const int i = __ffs((int)m) - 1;
           m &= m - 1;
           const int a = (i * 13) >> 6;  // i / 5 for 0 <= i < 25
-          slist[cnt * kLFThreads + tid] = base + a * w + (i - 5 * a);
+          slist[cnt * T + tid] = base + a * w + (i - 5 * a);
           ++cnt;
         }
       }
@@ -273,7 +278,7 @@ __device__ __forceinline__ void filtered_search(const float4* __restrict__ crec,
     for (int s0 = 0; __any(s0 < cnt); s0 += SF) {
       unsigned long long key[SF];
 #pragma unroll
-      for (int j = 0; j < SF; ++j) key[j] = (s0 + j < cnt) ? exact_key(crec, slist[(s0 + j) * kLFThreads + tid], qx, qy, qz) : ~0ull;
+      for (int j = 0; j < SF; ++j) key[j] = (s0 + j < cnt) ? exact_key(crec, slist[(s0 + j) * T + tid], qx, qy, qz) : ~0ull;
 #pragma unroll
       for (int j = 0; j < SF; ++j) key_insert<K>(kk, key[j]);
     }
@@ -355,6 +360,69 @@ __device__ __forceinline__ void filtered_search(const float4* __restrict__ crec,
     const unsigned long long tasks = __ballot(has);
     if (tasks == 0) break;
     const int owner = __ffsll((long long)tasks) - 1;
+    // ---- several owners per round trip.  A task whose rectangle is at most 16 x 16 pixels (a 5x5 window, rings up to half-width 7)
+    // is ONE step of the tiling below: 16 columns x 4 rows of lanes x 4 loads.  Tasks of different owners are independent, so up to
+    // kOwners of them put their loads in flight together and are resolved one after the other -- the wave then pays one memory round
+    // trip per kOwners tasks instead of one per task (two dense 5-view chunks: ~130 such tasks per wave with one wave per SIMD,
+    // 190 of the kernel's 200 us).  Same candidates, same arithmetic, same (distance, id) order per owner: identical results.
+    constexpr int kOwners = T == 64 ? 8 : 4;  // (one-wave workgroups run at ~1 wave per SIMD: registers are free, round trips are not)
+    {
+      const bool small = has && (t_uhi - t_ulo) < 16 && (t_vhi - t_vlo) < 16;
+      unsigned long long sm = __ballot(small);
+      if (__popcll(sm) >= 2) {
+        int own[kOwners];
+#pragma unroll
+        for (int o = 0; o < kOwners; ++o) {
+          own[o] = sm != 0 ? __ffsll((long long)sm) - 1 : -1;
+          sm &= sm - 1;  // (0 stays 0)
+        }
+        const int lc = lane & 15, lr = lane >> 4;
+        unsigned long long key[kOwners][4];
+        unsigned long long okth[kOwners];
+#pragma unroll
+        for (int o = 0; o < kOwners; ++o) {
+          const int ow = own[o] < 0 ? 0 : own[o];
+          const int o_vi = bcast_i(t_vi, ow), o_ulo = bcast_i(t_ulo, ow), o_uhi = bcast_i(t_uhi, ow);
+          const int o_vlo = bcast_i(t_vlo, ow), o_vhi = bcast_i(t_vhi, ow);
+          const int o_iu0 = bcast_i(t_iu0, ow), o_iu1 = bcast_i(t_iu1, ow), o_iv0 = bcast_i(t_iv0, ow), o_iv1 = bcast_i(t_iv1, ow);
+          const float oqx = bcast_f(qx, ow), oqy = bcast_f(qy, ow), oqz = bcast_f(qz, ow);
+          okth[o] = bcast_u64(kk[K - 1], ow);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int vv = o_vlo + j * 4 + lr, uu = o_ulo + lc;
+            const bool take = own[o] >= 0 && vv <= o_vhi && uu <= o_uhi && !(vv >= o_iv0 && vv <= o_iv1 && uu >= o_iu0 && uu <= o_iu1);
+            key[o][j] = take ? exact_key(crec, o_vi * hw + vv * w + uu, oqx, oqy, oqz) : ~0ull;
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < kOwners; ++o) {
+          if (own[o] < 0) continue;  // (wave-uniform)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned long long pm = __ballot(key[o][j] < okth[o]);
+            while (pm != 0) {
+              const int l = __ffsll((long long)pm) - 1;
+              const unsigned long long kx = bcast_u64(key[o][j], l);
+              if (lane == own[o]) key_insert<K>(kk, kx);
+              okth[o] = bcast_u64(kk[K - 1], own[o]);
+              pm &= pm - 1;
+              pm &= __ballot(key[o][j] < okth[o]);
+            }
+          }
+          if (lane == own[o]) {  // the owner's bookkeeping (as below)
+            if (t_pend) {
+              pend &= pend - 1;
+            } else if (t_wr < 0) {
+              ++rv;
+              wdone = 2;
+            } else {
+              wdone = t_wr;
+            }
+          }
+        }
+        continue;
+      }
+    }
     // the owner's task and query, wave-uniform
     const int o_vi = bcast_i(t_vi, owner), o_ulo = bcast_i(t_ulo, owner), o_uhi = bcast_i(t_uhi, owner);
     const int o_vlo = bcast_i(t_vlo, owner), o_vhi = bcast_i(t_vhi, owner);
@@ -411,8 +479,11 @@ __device__ unsigned long long g_lift_ts[4 * 8192];  // per workgroup: start, sea
 #ifndef MVP_LIFT_WAVES
 #define MVP_LIFT_WAVES 1
 #endif
-template <int K>
-__global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_LIFT_WAVES))) void lift_knn_gather_kernel(const float4* __restrict__ rec,
+// T = points (threads) per workgroup: 256, or 64 (one wave) for launches of fewer than ~4 workgroups of 256 per CU -- two dense chunks are
+// 256 such workgroups, ONE per CU, whose search and gather phases then run in lock step with nothing to overlap (0.105 of the HBM peak);
+// as 1024 one-wave workgroups every CU holds four at different points of their search / gather sequence.
+template <int K, int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MVP_LIFT_WAVES))) void lift_knn_gather_kernel(const float4* __restrict__ rec,
                                                                      const uint16_t* __restrict__ plane, int pitch,
                                                                      const float* __restrict__ points,
                                                                      const float* __restrict__ cam,
@@ -426,8 +497,8 @@ __global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_
                                                                      const double* __restrict__ rot,
                                                                      float* __restrict__ points_out, int sched) {
   __shared__ ViewParam vp[kMaxViews];
-  __shared__ int sidx[kLFThreads * K];
-  __shared__ int slist[kLFThreads * kSurvCap];
+  __shared__ int sidx[T * K];
+  __shared__ int slist[T * kSurvCap];
   // XCD-aware chunk placement: L % 8 = XCD; chunks b with b % 8 == xcd live on that XCD.
   const int L = blockIdx.x;
   int b, blk;
@@ -450,7 +521,7 @@ __global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_
   const int hw = h * w;
   const int P = nv * hw;
   const float4* crec = rec + (size_t)b * P;
-  const int n = blk * kLFThreads + tid;
+  const int n = blk * T + tid;
   const bool active = n < N;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (active) {
@@ -458,7 +529,7 @@ __global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_
     qx = q[0]; qy = q[1]; qz = q[2];
   }
   unsigned long long kk[K];
-  filtered_search<K>(crec, plane + (size_t)b * nv * plane_rows(h) * pitch, vp, nv, h, w, pitch, active, qx, qy, qz, kk, slist, tid);
+  filtered_search<K, T>(crec, plane + (size_t)b * nv * plane_rows(h) * pitch, vp, nv, h, w, pitch, active, qx, qy, qz, kk, slist, tid);
 #ifdef MVP_LIFT_EXP
   if ((tid & 63) == 0 && L < 8192) g_lift_ts[4 * L + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -514,12 +585,12 @@ __global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_
   if (tid == 0 && L < 8192) g_lift_ts[4 * L + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
   // ---- gather: rows (n0 .. n0+255) x K of C floats, contiguous in the output ----
-  const int rows = min(kLFThreads, N - blk * kLFThreads) * K;
+  const int rows = min(T, N - blk * T) * K;
   const int C4 = C >> 2;               // C % 4 == 0 checked by the host entry
-  const int rpp = kLFThreads / C4;     // rows per pass (16 for C = 64)
+  const int rpp = T / C4;     // rows per pass (16 for C = 64 and 256 threads)
   const int c4 = tid % C4, r0 = tid / C4;
   const float4* fb = reinterpret_cast<const float4*>(feature + (size_t)b * P * C);
-  float4* ob = reinterpret_cast<float4*>(gfeat + ((size_t)b * N + (size_t)blk * kLFThreads) * K * C);
+  float4* ob = reinterpret_cast<float4*>(gfeat + ((size_t)b * N + (size_t)blk * T) * K * C);
   // Output rows are written once and never re-read by this kernel: non-temporal stores keep them
   // from displacing the records / feature rows in L2 (measured 70 -> 57 us on the gather alone).
 #ifndef MVP_GATHER_U
@@ -556,20 +627,33 @@ __global__ __launch_bounds__(kLFThreads) __attribute__((amdgpu_waves_per_eu(MVP_
 #endif
 }
 
-template <int K>
-int launch_lift(const float4* rec, const uint16_t* plane, int pitch, const float* points, const float* cam, const float* pose, const float* feature,
-                int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N, int64_t C, int64_t* knn_index, float* gfeat,
-                float* gxyz, const uint8_t* flip, const double* rot, float* points_out, hipStream_t s) {
-  const int bpc = (int)cdiv(N, kLFThreads);
+template <int K, int T>
+int launch_lift_t(const float4* rec, const uint16_t* plane, int pitch, const float* points, const float* cam, const float* pose, const float* feature,
+                  int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N, int64_t C, int64_t* knn_index, float* gfeat,
+                  float* gxyz, const uint8_t* flip, const double* rot, float* points_out, hipStream_t s) {
+  const int bpc = (int)cdiv(N, T);
   const int64_t groups = cdiv(B, kXcds);  // chunks per XCD (rounded up; surplus workgroups exit at once)
   dim3 grid((unsigned)(B >= kXcds ? kXcds * groups * bpc : B * bpc));
   int sched = 0;
 #ifdef MVP_LIFT_EXP
   if (const char* e = getenv("MVP_LIFT_SCHED")) sched = atoi(e);
 #endif
-  hipLaunchKernelGGL((lift_knn_gather_kernel<K>), grid, dim3(kLFThreads), 0, s, rec, plane, pitch, points, cam, pose, feature,
+  hipLaunchKernelGGL((lift_knn_gather_kernel<K, T>), grid, dim3(T), 0, s, rec, plane, pitch, points, cam, pose, feature,
                      (int)B, (int)nv, (int)h, (int)w, (int)N, (int)C, bpc, knn_index, gfeat, gxyz, flip, rot, points_out, sched);
   return mvp_launch_status();
+}
+
+template <int K>
+int launch_lift(const float4* rec, const uint16_t* plane, int pitch, const float* points, const float* cam, const float* pose, const float* feature,
+                int64_t B, int64_t nv, int64_t h, int64_t w, int64_t N, int64_t C, int64_t* knn_index, float* gfeat,
+                float* gxyz, const uint8_t* flip, const double* rot, float* points_out, hipStream_t s) {
+  // one-wave workgroups while the launch has fewer than 4 workgroups of 256 points per CU (a few dense chunks, a single chunk's latency);
+  // MVP_LIFT_WG = 64 / 256 forces one shape (A/B switch).  The gather needs T % (C / 4) == 0.
+  static const int force = []() { const char* e = getenv("MVP_LIFT_WG"); return e ? atoi(e) : 0; }();
+  const bool small = force == 64 || (force != 256 && B * cdiv(N, kLFThreads) < 4 * 256);
+  if (small && (C == 0 || (C % 4 == 0 && 64 % (C / 4) == 0)))
+    return launch_lift_t<K, 64>(rec, plane, pitch, points, cam, pose, feature, B, nv, h, w, N, C, knn_index, gfeat, gxyz, flip, rot, points_out, s);
+  return launch_lift_t<K, kLFThreads>(rec, plane, pitch, points, cam, pose, feature, B, nv, h, w, N, C, knn_index, gfeat, gxyz, flip, rot, points_out, s);
 }
 
 }  // namespace
