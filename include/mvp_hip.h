@@ -642,6 +642,24 @@ int mvp_sa_train_backward_p_f32(int layer, const float* zf, const float* xyz, co
     const float* pool_out, const uint8_t* pool_arg, float* dW, int64_t lddw, float* dZ, double* stat_prev, float* tsum, int precision, int
     precision_backward, mvp_stream_t stream);
 
+/* ---- the coordinate-only work of a PointNet++ (SSG) network in ONE call (csrc/plan.hip) -----------------------------------------------
+ * replaces the geometry half of SetAbstraction / FeatureInterpolator called level after level from Python (mvpnet/models/pn2/modules.py:
+ * 74-87,122-140, pn2ssg.py:92-115): one sampling launch + the centroid prefixes of all levels (mvp_fps_centroid_levels_f32), a ball query per
+ * level, 3-NN + interpolation weights per propagation level, optionally (flags bit 0) the transposed index of every ball / 3-NN index
+ * (bit 2: the sorted build) and (bit 1) mvp_sa_geom_sums_f32 for the levels with geom[l] != 0 -- the same launches in the same order on
+ * `stream`, from one table of caller-allocated buffers instead of ~25 calls (0.65 ms of host time per plan from Python).
+ * xyz (B,N,3); centroids / radius / neighbours: host arrays of `levels` <= 8 entries, centroids non-increasing and <= N.
+ * buffers (host array of n_buffers device pointers, all non-NULL, in this order; N_l = N for l = 0, else centroids[l-1]):
+ *   fps_index (B,centroids[0]) i64;
+ *   per level l = 0 ..: new_xyz (B,M_l,3) f32, ball (B,M_l,K_l) i64 [, offsets (B,N_l+1) i32, slots (B,M_l*K_l) i32, cursor (B,N_l) i32
+ *                       [, dsum (B,N_l,4) f32, gsum (16) f64 zeroed by the caller]];
+ *   per propagation level l = levels-1 .. 0: index (B,N_l,3) i64, weight (B,N_l,3) f32 [, offsets (B,M_l+1) i32, slots (B,3*N_l) i32, cursor (B,M_l) i32].
+ * events: NULL or `levels` hipEvent_t handles, events[l] recorded once level l's centroids + ball index (+ transposed index, sums) are queued.
+ * fps_status: see mvp_fps_checked_f32 (may be NULL).  MVP_EINVAL when n_buffers does not match the flags. */
+int mvp_pn2_plan_f32(const float* xyz, int64_t B, int64_t N, int64_t levels, const int64_t* centroids, const float* radius,
+                     const int64_t* neighbours, const int32_t* geom, int fps_shape, int flags, float knn_eps, void* const* buffers,
+                     int64_t n_buffers, void* const* events, int* fps_status, mvp_stream_t stream);
+
 /* ---- chunk -> scene vote ----------------------------------------------------------------
  * replaces the NumPy accumulation of mvpnet/test_mvpnet_3d.py:137-138,160-174.
  * accumulate: logit (n,C) rows of one chunk (row stride ld, so a (C,n) tensor can be passed

@@ -25,6 +25,8 @@ TRAIN_FPS_SHAPE = int(os.environ.get('MVP_TRAIN_FPS_SHAPE', '1'))
 # Sampling a cloud that is itself a sampling result, in sampling order, returns 0, 1, 2, ... (PN2SSG._centroid_run): the deeper levels'
 # centroids are prefixes of the first level's.  0 = sample every level (A/B switch; same coordinates either way).
 FPS_PREFIX = os.environ.get('MVP_FPS_PREFIX', '1') != '0'
+# The whole geometry plan of a network in ONE library call (mvp_pn2_plan_f32) where its shape allows; 0 = level by level from Python (A/B switch)
+NATIVE_PLAN = os.environ.get('MVP_NATIVE_PLAN', '1') != '0'
 
 
 def centroid_levels(xyz, index, counts):
@@ -364,6 +366,8 @@ class PN2SSG(nn.Module):
         the grouping and of the interpolation gathers instead of scattering with atomics."""
         if with_csr is None:
             with_csr = self.training and torch.is_grad_enabled()
+        if NATIVE_PLAN and self._native_plan_ok(xyz):
+            return self._plan_geometry_native(xyz, stream, with_csr)
         cur = torch.cuda.current_stream(xyz.device)
         if stream is not None:
             stream.wait_stream(cur)
@@ -435,6 +439,89 @@ class PN2SSG(nn.Module):
                 if g is not None:
                     for t in g:
                         t.record_stream(cur)
+        return plan
+
+    def _native_plan_ok(self, xyz):
+        """The whole plan in ONE library call (mvp_pn2_plan_f32) needs: float32 clouds on the GPU, every level sampling the level above
+        (so one sampling launch + prefixes give all centroids), 3-NN interpolation at every propagation level, the 4-level default wiring."""
+        ms = [m.num_centroids for m in self.sa_modules]
+        return (xyz.is_cuda and xyz.dtype == torch.float32 and FPS_PREFIX and len(ms) <= 8 and len(self.fp_modules) == len(ms) and
+                all(m > 0 for m in ms) and ms[0] <= xyz.size(1) and all(b <= a for a, b in zip(ms, ms[1:])) and
+                all(f.interpolator is not None and f.interpolator.num_neighbors == 3 for f in self.fp_modules) and min(ms) >= 3)
+
+    def _plan_geometry_native(self, xyz, stream, with_csr):
+        """plan_geometry through mvp_pn2_plan_f32 (csrc/plan.hip): the same launches in the same order on ONE stream, from one table of
+        buffers allocated here -- ~0.1 ms of host time instead of ~0.65 (25 calls + allocations), which in a training step sits between
+        the forward and the backward pass and in inference in front of a single chunk's latency.  Inference plans on a side stream carry
+        one event per level (recorded by the library call) so forward() starts level l as soon as its own geometry is queued."""
+        import ctypes
+        dev = xyz.device
+        B, N, _ = xyz.shape
+        mods = self.sa_modules
+        nl = len(mods)
+        ms = [m.num_centroids for m in mods]
+        ks = [m.max_neighbors for m in mods]
+        cur = torch.cuda.current_stream(dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if stream is not None:
+            stream.wait_stream(cur)
+        run = stream if stream is not None else cur
+        fps_shape = (TRAIN_FPS_SHAPE if (with_csr and stream is not None) else 0)
+        i32, i64, f32 = torch.int32, torch.int64, torch.float32
+        with torch.cuda.stream(run):
+            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+            fps_index = e((B, ms[0]), i64)
+            table = [fps_index]
+            sa, fp = [], []
+            geom = []
+            for l, m in enumerate(mods):
+                nin = N if l == 0 else ms[l - 1]
+                csr_l = with_csr and (l > 0 or self.in_channels > 0)
+                g = (e((B, ms[l], 3), f32), e((B, ms[l], ks[l]), i64))
+                scratch = ()
+                want_geo = False
+                if with_csr:  # (the library builds every level's transposed index when asked for any: level 0 without an input feature keeps none)
+                    g += (e((B, nin + 1), i32), e((B, ms[l] * ks[l]), i32))
+                    scratch = (e((B, nin), i32),)
+                    want_geo = bool(csr_l and R.SA_TRAIN_FUSED and ks[l] == 32 and len(m.mlp) == 3 and
+                                    R.sa_level_train_widths_ok(*(x.conv.weight.size(0) for x in m.mlp)))
+                    if want_geo:
+                        g += (e((B, nin, 4), f32), torch.zeros(16, dtype=torch.float64, device=dev))
+                geom.append(1 if want_geo else 0)
+                table += list(g[:4]) + list(scratch) + list(g[4:])
+                sa.append(g if (csr_l or not with_csr) else g[:2])
+            for l in range(nl - 1, -1, -1):
+                nq = N if l == 0 else ms[l - 1]
+                g = (e((B, nq, 3), i64), e((B, nq, 3), f32))
+                scratch = ()
+                if with_csr:
+                    g += (e((B, ms[l] + 1), i32), e((B, 3 * nq), i32))
+                    scratch = (e((B, ms[l]), i32),)
+                table += list(g) + list(scratch)
+                fp.append(g)
+            level_events = None
+            ev_arr = None
+            if stream is not None and not with_csr:
+                level_events = []
+                for _ in range(nl):
+                    ev = torch.cuda.Event()
+                    ev.record(run)  # (creates the handle; the library call records it again, later in stream order)
+                    level_events.append((ev, None))
+                ev_arr = (ctypes.c_void_p * nl)(*[ev.cuda_event for ev, _ in level_events])
+            flags = (1 if with_csr else 0) | (2 if (with_csr and any(geom)) else 0) | (4 if (with_csr and L.DW_WORKSPACE) else 0)
+            radius = (ctypes.c_float * nl)(*[float(m.radius) for m in mods])
+            L.call('mvp_pn2_plan_f32', xyz, L.ptr(xyz), B, N, nl, (ctypes.c_int64 * nl)(*ms), radius, (ctypes.c_int64 * nl)(*ks),
+                   (ctypes.c_int32 * nl)(*geom), int(fps_shape), flags, float(self.fp_modules[0].interpolator._eps),
+                   (ctypes.c_void_p * len(table))(*[t.data_ptr() for t in table]), len(table), ev_arr, L.ptr(L.fps_status(dev)))
+            event = torch.cuda.Event()
+            event.record()
+        plan = {'sa': sa, 'fp': fp, 'event': event, 'stream': stream, 'xyz': xyz}
+        if level_events is not None:
+            plan['level_events'] = level_events
+        if stream is not None and not capturing:
+            xyz.record_stream(stream)
+            for t in table:
+                t.record_stream(cur)
         return plan
 
     @staticmethod

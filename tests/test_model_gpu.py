@@ -544,3 +544,45 @@ def test_mvpnet2d_against_reference_fixture(dev):
         bref = model(dict(images=batch['images'], knn_indices=knn))['seg_logit']
     assert torch.equal(a, bref)
 
+
+
+@pytest.mark.parametrize('with_csr', [False, True])
+def test_geometry_plan_in_one_library_call_equals_the_level_by_level_plan(dev, with_csr):
+    """The whole coordinate-only plan of PN2SSG from ONE library call (mvp_pn2_plan_f32, csrc/plan.hip: one sampling launch + centroid
+    prefixes, ball queries, 3-NN + weights, transposed indices, geometry sums of the fused training levels) against the plan issued level
+    by level from Python (MVP_NATIVE_PLAN=0): centroids, ball and 3-NN indices, weights and list offsets bit-equal; the lists themselves
+    equal as sets per point (their order is arrival order); the geometry sums equal to rounding of the addition order."""
+    from mvpnet_amd import pn2
+    from mvpnet_amd.synthetic import make_batch
+    model = pn2.PN2SSG(64, 20).to(dev).train(with_csr)
+    pts = torch.from_numpy(make_batch(4300, 3, config=3)['points'].astype(np.float32)).to(dev)
+    side = torch.cuda.Stream()
+    plans = []
+    old = pn2.NATIVE_PLAN
+    try:
+        for flag in (False, True):
+            pn2.NATIVE_PLAN = flag
+            plan = model.plan_geometry(pts, stream=side, with_csr=with_csr)
+            torch.cuda.current_stream().wait_event(plan['event'])
+            torch.cuda.synchronize()
+            plans.append(plan)
+    finally:
+        pn2.NATIVE_PLAN = old
+    a, b = plans
+    assert ('level_events' in b) == (not with_csr)
+    for key in ('sa', 'fp'):
+        for level, (ga, gb) in enumerate(zip(a[key], b[key])):
+            assert len(ga) == len(gb), (key, level, len(ga), len(gb))
+            for i, (ta, tb) in enumerate(zip(ga, gb)):
+                if i in (0, 1) or (i == 2 and with_csr):      # centroids / index, ball / weight, list offsets
+                    assert torch.equal(ta, tb), (key, level, i)
+                elif i == 3:                                   # the lists: same members per point
+                    off = ga[2].long()
+                    seg = torch.repeat_interleave(torch.arange(off.size(1) - 1, device=dev).repeat(off.size(0), 1).flatten(),
+                                                  (off[:, 1:] - off[:, :-1]).flatten())
+                    n_tot = seg.numel() // ta.size(0) if ta.size(0) else 0
+                    ka = (seg.view(ta.size(0), -1) * ta.size(1) + ta[:, :n_tot].long()).sort(1).values
+                    kb = (seg.view(tb.size(0), -1) * tb.size(1) + tb[:, :n_tot].long()).sort(1).values
+                    assert torch.equal(ka, kb), (key, level)
+                else:                                          # geometry sums
+                    np.testing.assert_allclose(tb.double().cpu().numpy(), ta.double().cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ta.abs().max()))
