@@ -348,6 +348,38 @@ def dry_run(args):
         torch.distributed.destroy_process_group()
 
 
+def peer_run(args):
+    """A HOST-ONLY peer rank of a real multi-rank job (MVP_REAL_RANKS=r: ranks >= r run this): the same model on the CPU, the same
+    parameter broadcast, one dist.GradSync all-reduce per step, the same barriers and the closing MAX all-reduce as a real rank -- so a
+    box with ONE GPU can run `bench.py --gpus 8` as one real rank + seven peers and measure what the launcher, eight Python processes
+    and the gloo collectives cost the real rank (tools/multi_rank_host.sh).  The real ranks must run with
+    MVP_DIST_BACKEND=gloo, --train-only and --extras none.  Nothing here is a measurement of its own."""
+    from mvpnet_amd import dist as D
+    from mvpnet_amd import config as C
+    import yaml
+    rank, world, _ = D.init_from_env(backend='gloo')
+    with open(os.path.join(ROOT, 'tests', 'golden', 'configs.json')) as f:
+        cfg = C.load_cfg(text=yaml.safe_dump(json.load(f)['mvpnet_3d_unet_resnet34_pn2ssg']))
+    torch.manual_seed(0)
+    model = C.build_model_mvpnet_3d(cfg, SuppliedFeature2D(), load_2d_ckpt=False)
+    D.broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    sync = D.GradSync(model.parameters())
+    n = args.warmup + args.steps + (5 if args.graph else 0)
+    for it in range(n):
+        if it == args.warmup or it == args.warmup + args.steps:  # before the timed steps; (--graph: + behind them, before the 5 eager steps)
+            torch.distributed.barrier()
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        sync(weight_sum=torch.tensor(1.0))
+    if not args.graph:
+        torch.distributed.barrier()
+    tmax = torch.zeros(1, dtype=torch.float64)
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -373,6 +405,8 @@ def main():
         sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
     if args.dry:
         return dry_run(args)
+    if int(os.environ.get('RANK', '0')) >= int(os.environ.get('MVP_REAL_RANKS', '1000000')):
+        return peer_run(args)
 
     from mvpnet_amd import dist as D
     from mvpnet_amd import _lib
@@ -430,6 +464,7 @@ def main():
     def fresh(b):
         nb = dict(b)
         nb.pop('geometry_plan', None)
+        nb.pop('_feature_2d', None)
         return nb
 
     state = {'cur': prefetch_geometry(model, fresh(batch))}
@@ -585,21 +620,29 @@ def main():
         opt2 = C.build_optimizer(cfg, model2)
         b2 = dict(batch, images=torch.randn(args.batch, 3, 3, 120, 160, device=dev))
         e2e = {}
-        for tag, ctx in (('fp32', None), ('bf16_2d_net', torch.bfloat16)):
+        import mvpnet_amd.mvpnet3d as _m3
+        for tag, ctx, overlap in (('fp32', None, True), ('bf16_2d_net', torch.bfloat16, True), ('fp32_in_line', None, False), ('bf16_2d_net_in_line', torch.bfloat16, False)):
             model2.net_2d.__dict__['_fast_dtype'] = ctx  # frozen_inference(compute_dtype=...): autocast only around the frozen 2D network
-            cur2 = prefetch_geometry(model2, fresh(b2))
-            for i in range(7):
-                if i == 2:
-                    torch.cuda.synchronize()
-                    t3 = time.perf_counter()
-                nxt2 = fresh(b2)
-                train_step(model2, loss_fn, opt2, cur2, next_batch=nxt2)
-                cur2 = nxt2
-            torch.cuda.synchronize()
+            keep = _m3.prefetch_features_2d
+            if not overlap:  # the image branch in front of the 3D forward, on the training stream (what the reference's loop does)
+                _m3.prefetch_features_2d = lambda m, b: b
+            try:
+                cur2 = prefetch_geometry(model2, fresh(b2))
+                for i in range(7):
+                    if i == 2:
+                        torch.cuda.synchronize()
+                        t3 = time.perf_counter()
+                    nxt2 = fresh(b2)
+                    train_step(model2, loss_fn, opt2, cur2, next_batch=nxt2)
+                    cur2 = nxt2
+                torch.cuda.synchronize()
+            finally:
+                _m3.prefetch_features_2d = keep
             ms2 = (time.perf_counter() - t3) / 5 * 1e3
             e2e[tag] = {'chunks_per_s_per_gpu': round(args.batch / (ms2 * 1e-3), 1), 'ms_per_step': round(ms2, 3)}
         model2.net_2d.__dict__['_fast_dtype'] = None
-        e2e['note'] = 'full train step INCLUDING the frozen UNetResNet34 forward on 3x160x120 images (mvpnet_amd/unet_resnet34.py)'
+        e2e['note'] = ('full train step INCLUDING the frozen UNetResNet34 forward on 3x160x120 images (mvpnet_amd/unet_resnet34.py); fp32 / bf16_2d_net: the image '
+                       'branch of batch i+1 on its own stream beside the backward pass of batch i (mvpnet3d.prefetch_features_2d); *_in_line: in front of the 3D forward')
         del model2, opt2
     model.train()
     # The same train step with the shared-MLP contractions on the fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the split-bf16 default:

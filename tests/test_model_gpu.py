@@ -586,3 +586,65 @@ def test_geometry_plan_in_one_library_call_equals_the_level_by_level_plan(dev, w
                     assert torch.equal(ka, kb), (key, level)
                 else:                                          # geometry sums
                     np.testing.assert_allclose(tb.double().cpu().numpy(), ta.double().cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ta.abs().max()))
+
+
+def test_frozen_image_branch_prefetched_on_its_own_stream(dev):
+    """the frozen 2D network of the NEXT batch runs on its own stream beside the current batch's backward pass
+    (mvpnet3d.prefetch_features_2d, called by train_step) -- it depends on nothing of the 3D network once frozen
+    (mvpnet/models/mvpnet_3d.py:99 under the reference's Freezer).  Same logits and loss as with the branch in front of the 3D forward;
+    a branch that trains (unfreeze) or has no parameters is left alone."""
+    import os
+    import yaml
+    from mvpnet_amd import config as C
+    from mvpnet_amd import mvpnet3d as M
+    from mvpnet_amd.synthetic import make_batch
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'configs.json')) as f:
+        cfg = C.load_cfg(text=yaml.safe_dump(json.load(f)['mvpnet_3d_unet_resnet34_pn2ssg']))
+    torch.manual_seed(0)
+    with pytest.warns(UserWarning, match='NOT loaded'):
+        model = C.build_model_mvpnet_3d(cfg, load_2d_ckpt=False).to(dev).train()
+    model.net_3d.mlp_seg.p = 0.0
+    assert M.net_2d_is_frozen(model)
+    B = 2
+    bt = make_batch(5100, B, config=3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam = np.repeat(bt['cam_matrix'][None, None, :3, :3], 3, 1).repeat(B, 0)
+    batch = {'images': torch.randn(B, 3, 3, 120, 160, device=dev), 'points': t(bt['points'].transpose(0, 2, 1)), 'seg_label': t(bt['seg_label']),
+             'depth': t(bt['depth_mm'].astype(np.int16)), 'cam_matrix': t(cam), 'kinv': t(bt['kinv']), 'pose': t(bt['pose']),
+             'pixel_box': t(bt['pixel_box']), 'k': 3}
+    loss_fn = M.SegLoss()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    outs = []
+    for pre in (False, False, True):
+        model.load_state_dict(sd0)
+        b = dict(batch)
+        if pre:
+            side = torch.cuda.Stream()   # some unrelated work on another stream first: the prefetch must order itself behind the images
+            with torch.cuda.stream(side):
+                torch.randn(1 << 20, device=dev).sum()
+            M.prefetch_features_2d(model, b)
+            assert '_feature_2d' in b
+        preds = model(b)
+        loss = loss_fn(preds, b)['seg_loss']
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((preds['seg_logit'].detach().clone(), float(loss)))
+    # MIOpen's convolutions are not bit-reproducible from call to call (the in-line branch run twice differs too): the prefetched run must
+    # be as close to an in-line run as two in-line runs are to each other (+ a margin), and the feature map itself equal to fp32 rounding
+    base = float((outs[0][0] - outs[1][0]).abs().max())
+    diff = float((outs[0][0] - outs[2][0]).abs().max())
+    print('logits: in-line vs in-line {:.2e}, in-line vs prefetched {:.2e}'.format(base, diff))
+    assert diff <= max(4 * base, 2e-3), (diff, base)
+    with torch.no_grad():
+        b = dict(batch)
+        M.prefetch_features_2d(model, b)
+        torch.cuda.current_stream().wait_event(b['_feature_2d'][1])
+        ref = model.net_2d({'image': batch['images'].reshape(B * 3, 3, 120, 160)})['feature']
+        torch.testing.assert_close(b['_feature_2d'][0], ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    # a training image branch is not prefetched
+    model.net_2d.unfreeze()
+    model.train()
+    assert not M.net_2d_is_frozen(model)
+    b = dict(batch)
+    M.prefetch_features_2d(model, b)
+    assert '_feature_2d' not in b
