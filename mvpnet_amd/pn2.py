@@ -27,6 +27,9 @@ TRAIN_FPS_SHAPE = int(os.environ.get('MVP_TRAIN_FPS_SHAPE', '1'))
 FPS_PREFIX = os.environ.get('MVP_FPS_PREFIX', '1') != '0'
 # The whole geometry plan of a network in ONE library call (mvp_pn2_plan_f32) where its shape allows; 0 = level by level from Python (A/B switch)
 NATIVE_PLAN = os.environ.get('MVP_NATIVE_PLAN', '1') != '0'
+# The segmentation head's SharedMLPDO as the last layer of the last feature-propagation level's chain (it is that level's only consumer);
+# 0 = two chains with the level's output activation in between (A/B switch)
+MERGE_HEAD = os.environ.get('MVP_MERGE_HEAD', '1') != '0'
 
 
 def centroid_levels(xyz, index, counts):
@@ -44,6 +47,12 @@ def centroid_levels(xyz, index, counts):
         return outs
     g = torch.gather(xyz, 1, index.unsqueeze(-1).expand(-1, -1, D))
     return [g if c == M else g[:, :c].contiguous() for c in counts]
+
+
+def _has_hooks(module):
+    """forward (pre-)hooks on `module` or any of its children: a caller that observes a module's output must get THAT module's output, so
+    chains are only merged across module boundaries nobody is watching"""
+    return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
 
 
 class QueryGrouper(nn.Module):
@@ -257,8 +266,12 @@ class FeaturePropagation(nn.Module):
         else:
             raise ValueError('Expected value 3, but {} given.'.format(num_neighbors))
 
-    def forward_rows(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=None):
-        """rows in / rows out: (B,N,3), (B,M,3), (B,N,C1) or None, (B,M,C2) -> (B,N,C_out)."""
+    def forward_rows(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=None, tail=None):
+        """rows in / rows out: (B,N,3), (B,M,3), (B,N,C1) or None, (B,M,C2) -> (B,N,C_out).
+        tail = (single-layer SharedMLPDO, training): the module that is this level's ONLY consumer, run as the last layer of the same chain
+        (PN2SSG: mlp_seg behind the last propagation level) -> (B,N,C_tail): the level's output activation is never materialised, its
+        BatchNorm-backward column sums come from the tail layer's input-gradient epilogue instead of a pass of their own.  Returns None when
+        the chain cannot take it (the caller then runs the two modules one after the other)."""
         B, N, _ = dense_xyz.shape
         if self.interpolator is None:  # broadcast a single global feature
             assert sparse_xyz.size(1) == 1 and sparse_feature.size(1) == 1
@@ -290,13 +303,23 @@ class FeaturePropagation(nn.Module):
                 stat1 = None
                 if bn_training:
                     y1, stat1 = y1[0], (y1[1], y1[2])
+                if tail is not None:
+                    chain = list(self.mlp) + list(tail[0])
+                    if len(tail[0]) == 1 and R.mlp_chain_is_fused(chain) and tail[0][0].bn.training == bn_training:
+                        return R.shared_mlp_rows(y1.view(B * N, c1), chain, first_done=True, first_stat=stat1, dropout_p=tail[0].p, training=tail[1],
+                                                 dropout_last_only=True).view(B, N, -1)
+                    return None
                 return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1).view(B, N, -1)
+            if tail is not None:
+                return None
             new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)
+        if tail is not None:
+            return None
         return R.shared_mlp_rows(new_feature.reshape(B * N, -1), self.mlp).view(B, N, -1)
 
-    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, rows=False, geometry=None):
+    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, rows=False, geometry=None, tail=None):
         if rows:
-            return self.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)
+            return self.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry, tail=tail)
         t = lambda x: None if x is None else x.transpose(1, 2).contiguous()
         return self.forward_rows(t(dense_xyz), t(sparse_xyz), t(dense_feature), t(sparse_feature)).transpose(1, 2).contiguous()
 
@@ -578,10 +601,19 @@ class PN2SSG(nn.Module):
             xyzs.append(xyz)
             feats.append(feature)
         up = feats[-1]
+        x = None
         for level, fp in enumerate(self.fp_modules):
-            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True,
-                    geometry=None if plan is None else plan['fp'][level])
-        x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
+            geo = None if plan is None else plan['fp'][level]
+            if MERGE_HEAD and level + 1 == len(self.fp_modules) and up.is_cuda and not _has_hooks(fp) and not _has_hooks(self.mlp_seg):
+                # the segmentation head's MLP is the last propagation level's only consumer: one chain (no activation tensor in between, no
+                # column-statistics pass of its own in backward)
+                x = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True, geometry=geo, tail=(self.mlp_seg, self.training))
+                if x is not None:
+                    x = x.reshape(B * N, -1)
+                    break
+            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True, geometry=geo)
+        if x is None:
+            x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
         logit = R.linear_rows(x, self.seg_logit.weight, self.seg_logit.bias)  # (B*N, classes)
         # (B,classes,N) as the reference returns it -- as a transposed VIEW of the rows: the loss and the vote kernels take strided logits,
         # the gradient comes back in the same layout (mvpnet3d._SegLossFn), so neither direction pays a transposing copy

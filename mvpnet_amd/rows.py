@@ -1316,7 +1316,7 @@ def relation4_rows(src_xyz, tgt_xyz):
     return out
 
 
-def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max', rel=None):
+def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max', rel=None, dropout_last_only=False):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
     K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108), or their sum with reduce='sum'
@@ -1326,8 +1326,11 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
     rel (R,4): the first layer's input is [x | rel] -- its weight has x.size(1) + 4 columns -- without the concatenated tensor (fused
     chains only: FeatureAggregation)."""
     n = len(mlp)
-    # dropout follows EVERY layer of a SharedMLPDO (mlp.py:86-92): a single-layer chain can still be fused, dropout on its output
-    fused = mlp_chain_is_fused(mlp, dropout_p) and K <= 255
+    # dropout follows EVERY layer of a SharedMLPDO (mlp.py:86-92): a single-layer chain can still be fused, dropout on its output.
+    # dropout_last_only: `mlp` is a SharedMLP followed by a single-layer SharedMLPDO run as ONE chain (PN2SSG: the last feature-propagation
+    # MLP + the segmentation head, whose only consumer it is) -- the dropout belongs to the last layer alone
+    fused = mlp_chain_is_fused(mlp, 0.0 if dropout_last_only else dropout_p) and K <= 255
+    assert fused or not dropout_last_only, 'dropout_last_only needs the fused chain'
     if fused:
         bn_training = mlp[0].bn.training
         params, buffers, eps_mom = [], [], []

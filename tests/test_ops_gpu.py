@@ -1962,3 +1962,47 @@ def test_training_level_without_activation_tensors(dev, cin, widths, N, M, B, bw
         assert rel(gp1[k], gp0[k]) <= tol, (k, rel(gp1[k], gp0[k]))
     for k in b0:
         np.testing.assert_allclose(b1[k].float().cpu().numpy(), b0[k].float().cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_training_level_with_empty_ball_slots_and_a_missing_transposed_index(dev):
+    """The fused training-mode level (csrc/sa_train.hip) on inputs the four-level network never produces but the entry points accept:
+    ball indices with EMPTY slots (-1: an all-zero row that still counts in the batch statistics, as in group_lin_rows_kernel; no
+    contribution to the gradient of zf or of the coordinate columns) and no transposed index / geometry sums handed in (built on the
+    fly).  Against the per-layer path on the same index."""
+    import copy
+    from mvpnet_amd.pn2 import SetAbstraction
+    from mvpnet_amd import rows as R
+    torch.manual_seed(77)
+    B, N, M, cin = 3, 1500, 400, 32
+    base = SetAbstraction(cin, (32, 64, 64), M, 0.2, 32, use_xyz=True).to(dev).train()
+    xyz = torch.rand(B, N, 3, device=dev)
+    feat0 = torch.randn(B, N, cin, device=dev)
+    new_xyz, ball = base.geometry(xyz)[:2]
+    ball = ball.clone()
+    hole = torch.rand(ball.shape, device=dev) < 0.15
+    hole[..., 0] = False
+    ball[hole] = -1                      # empty slots anywhere but the first
+    ball[0, 5] = -1                      # ... and one ball without any neighbour
+    gout = torch.randn(B, M, 64, device=dev)
+    res = []
+    old = R.SA_TRAIN_FUSED
+    try:
+        for flag in (False, True):
+            R.SA_TRAIN_FUSED = flag
+            sa = copy.deepcopy(base)
+            feat = feat0.clone().requires_grad_(True)
+            with R.L.mlp_precision('bf16x6', backward='bf16x6'):
+                _, out = sa(xyz, feat, rows=True, geometry=(new_xyz, ball))   # no transposed index, no geometry sums
+            out.backward(gout)
+            torch.cuda.synchronize()
+            res.append((out.detach(), feat.grad, {k: p.grad.clone() for k, p in sa.named_parameters()}, {k: b.clone() for k, b in sa.named_buffers()}))
+    finally:
+        R.SA_TRAIN_FUSED = old
+    (o0, gx0, gp0, b0), (o1, gx1, gp1, b1) = res
+    np.testing.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=2e-5, atol=2e-5 * float(o0.abs().max()))
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    assert rel(gx1, gx0) <= 2e-5, rel(gx1, gx0)
+    for k in gp0:
+        assert rel(gp1[k], gp0[k]) <= 2e-5, (k, rel(gp1[k], gp0[k]))
+    for k in b0:
+        np.testing.assert_allclose(b1[k].float().cpu().numpy(), b0[k].float().cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
