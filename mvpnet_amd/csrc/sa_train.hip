@@ -1031,8 +1031,10 @@ bool level_supported(int64_t K, int64_t C1, int64_t C2, int64_t C3) {
   return K == 32 && C1 >= 4 && C1 <= 64 && C2 <= 64 && C3 <= 128 && C1 % 4 == 0 && C2 % 4 == 0 && C3 % 4 == 0;
 }
 
-int64_t grid_for(int64_t G, int64_t lds_bytes, int64_t* tiles_per_wg) {
-  const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(4, (150 * 1024) / lds_bytes));
+// persistent workgroups: as many per CU as LDS -- and `max_per_cu`, what the kernel's registers allow -- let be resident AT ONCE (a launch of
+// 768 workgroups on 512 slots runs two rounds for the work of one and a half)
+int64_t grid_for(int64_t G, int64_t lds_bytes, int64_t* tiles_per_wg, int64_t max_per_cu = 4) {
+  const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(max_per_cu, (150 * 1024) / lds_bytes));
   const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(1024, 256 * per_cu), cdiv(G, 16)));
   *tiles_per_wg = cdiv(cdiv(G, wgs), 4) * 4;
   return cdiv(G, *tiles_per_wg);
@@ -1199,7 +1201,9 @@ MVP_API int mvp_sa_train_backward_f32(int layer, const float* zf, const float* x
   // y_2 is re-computed with the forward's pieces when those are 3 (the default: forward bf16x6, backward bf16x3), else with the backward's
   const int nsf = (mlp_fwd_pieces() == 3) ? 3 : ns;
   const int64_t lds = (int64_t)2048 * (nsf * c1b * c2b + ns * ((layer == 3 ? c2b * c3b : 0) + cb * cpb)) + 32 * 1024;
-  const unsigned grid = (unsigned)grid_for(a.s.G, lds, &a.tiles_per_wg);
+  // (registers: two workgroups per CU for the narrow variants -- the kernel's launch bounds --, one for the others)
+  const bool narrow = layer == 3 ? c1b * c2b * c3b <= 2 : c1b * c2b == 1;
+  const unsigned grid = (unsigned)grid_for(a.s.G, lds, &a.tiles_per_wg, narrow ? 2 : 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define MVP_SAB(A_, B_, C_, L_)                                                                                          \
   do {                                                                                                                   \
