@@ -106,12 +106,15 @@ class TimedLifting:
         return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else float('nan')
 
 
+TRAFFIC_FILES = ('r04_step_traffic.json', 'r03_step_traffic.json')  # the newest committed PMC table of the step
+
+
 def lift_traffic(batch):
     """HBM bytes per mvp_lift_f32 launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE of the two lifting
     kernels INSIDE the train step at B = 32, tools/step_counters.sh; FETCH_SIZE doubled per the gfx950 calibration note).  A committed
     measurement, not a live counter read: None for any other batch size."""
-    path = os.path.join(ROOT, 'profiles', 'r03_step_traffic.json')
-    if batch != 32 or not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, 'profiles', n) for n in TRAFFIC_FILES) if os.path.exists(q)), None)
+    if batch != 32 or path is None:
         return None
     with open(path) as f:
         rows = json.load(f)['kernels']
@@ -262,7 +265,7 @@ def parity_info():
            'train_mode_logit_bar': '3e-4 vs the reference fp32 fixture AND max |gpu - f64| <= 1.5 x max |reference fp32 - f64| (25 batch-statistics BatchNorms: the '
                                    'reference fp32 path itself is ~2.7e-4 from the float64 value of its graph, so 1e-4 against it is not attainable by any fp32 implementation)',
            'index_ops': 'bit-exact (FPS, ball query, 3-NN, pixel k-NN)'}
-    for name in ('r03_operating_point_B32.json', 'r02_operating_point_B8_bf16x6_bwd_bf16x3.json'):
+    for name in ('r04_operating_point_B32.json', 'r03_operating_point_B32.json', 'r02_operating_point_B8_bf16x6_bwd_bf16x3.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             with open(path) as f:
@@ -715,7 +718,7 @@ def main():
                                  'latency_ms_B1 = one chunk alone, synchronised per chunk (bounded by the serial FPS chain); _graph = the same forward replayed from one HIP graph (GraphedForward)'},
             'roofline': {'bound': 'hbm', 'kernel': 'mvp_lift_f32 = lift_prepare_kernel + lift_knn_gather_kernel',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': lift_traffic(args.batch), 'traffic_source': 'profiles/r03_step_traffic.json (committed rocprofv3 PMC passes of this step at B=32, not read live)', 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
+                         'traffic': lift_traffic(args.batch), 'traffic_source': 'profiles/{} (committed rocprofv3 PMC passes of this step at B=32, not read live)'.format(next((n for n in TRAFFIC_FILES if os.path.exists(os.path.join(ROOT, 'profiles', n))), 'none')), 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(bt)

@@ -159,9 +159,19 @@ def main():
                 if n_pk:
                     rows.append({'kernel': name[:240], 'packed_fp32': n_pk, 'op_sel_forms_of_4.10': n_bad, 'forms': dict(forms)})
         rows.sort(key=lambda r: (-r['op_sel_forms_of_4.10'], -r['packed_fp32']))
+        # the kernel FAMILIES (name up to the first template bracket) that carry the form at all, whether or not they run in the step
+        fam = collections.Counter()
+        fam_k = collections.Counter()
+        for sym, forms in per_kernel.items():
+            n_bad = sum(c for f, c in forms.items() if is_bad(f))
+            if n_bad:
+                base = re.sub(r'^void ', '', dm.get(sym, sym)).split('<')[0].split('(')[0]
+                fam[base] += n_bad
+                fam_k[base] += 1
         report['libraries'][os.path.basename(lib)] = {
             'bundles': n_b, 'gfx950_code_objects': n_co, 'kernels': tot_kernels, 'packed_fp32_instructions': tot_pk,
             'op_sel_forms_of_4.10_all_kernels': tot_bad, 'kernels_matching_filters': matched,
+            'families_with_the_form': [{'family': f, 'kernels': fam_k[f], 'instructions': c} for f, c in fam.most_common(40)],
             'matching_kernels_with_packed_fp32': rows[:60]}
         print('{}: {} bundles, {} gfx950 code objects, {} kernels, {} packed fp32 instructions, {} with the op_sel form; {} kernels match the filters, {} of them use '
               'packed fp32, {} carry the form'.format(os.path.basename(lib), n_b, n_co, tot_kernels, tot_pk, tot_bad, matched, len(rows),
