@@ -39,3 +39,20 @@ def test_bench_under_an_external_launcher():
     line = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                  '--master-port', '29713', 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--dry'])
     assert line['n_gpus'] == 2
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_host_only_peer_ranks(graph):
+    """MVP_REAL_RANKS = r: the ranks >= r of a bench job are host-only peers (bench.peer_run: the model on the CPU, the parameter broadcast,
+    one dist.GradSync all-reduce per step, the real rank's barriers and closing MAX all-reduce) -- how a one-GPU box runs `--gpus 8` as one
+    real rank + seven peers (tools/multi_rank_host.sh).  With r = 0 EVERY rank is a peer: the collective sequence must be consistent with
+    itself (no deadlock, clean exit), eager and --graph (whose real rank adds five eager steps behind the timed region)."""
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e['MVP_REAL_RANKS'] = '0'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+           '29731' if graph else '29729', 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--train-only', '--extras', 'none'] + (['--graph'] if graph else [])
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]  # peers print no result line
