@@ -525,6 +525,17 @@ def main():
         torch.cuda.synchronize()
     timer.enabled = False
     assert torch.isfinite(loss).item()
+    # spread: the same K steps twice more, untimed for `value` (the contract times exactly K steps above); reported beside it so a reader
+    # sees what one 0.15 s measurement is worth on this box (box-to-box differences are larger: DESIGN.md section 5)
+    repeats = [round(elapsed / args.steps * 1e3, 3)]
+    if world == 1 and not args.graph and not args.host_profile:
+        for _ in range(2):
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            repeats.append(round((time.perf_counter() - tr) / args.steps * 1e3, 3))
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -710,6 +721,7 @@ def main():
             'bf16_contraction': bf16_contraction,
             'dense': dense,
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
+            'ms_per_step_repeats': repeats,
             'with_2d_network': e2e,
             'scene_inference': scene,
             'fwd_only': {'chunks_per_s_per_gpu': round(args.batch / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3),
