@@ -114,6 +114,12 @@ __global__ __launch_bounds__(kPrepThreads) void lift_prepare_kernel(const DepthT
 typedef unsigned int u32x4a __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned int u32x3a __attribute__((ext_vector_type(3), aligned(4)));  // a 5-pixel window row: 6 halfwords from a 4-byte aligned start
 constexpr int kSurvCap = 32;
+#ifdef MVP_LIFT_EXP
+__device__ unsigned long long g_lift_cnt[16];  // task census of the whole-wave path (tools/exp): see mvp_lift_exp_counts
+#define MVP_LIFT_COUNT(i, n) atomicAdd(&g_lift_cnt[i], (unsigned long long)(n))
+#else
+#define MVP_LIFT_COUNT(i, n)
+#endif
 
 template <int K>
 __device__ __forceinline__ void up_insert(float (&ub)[K], float v) {  // ub ascending; keeps the K smallest
@@ -360,6 +366,15 @@ __device__ __forceinline__ void filtered_search(const float4* __restrict__ crec,
     const unsigned long long tasks = __ballot(has);
     if (tasks == 0) break;
     const int owner = __ffsll((long long)tasks) - 1;
+#ifdef MVP_LIFT_EXP
+    if (lane == 0) MVP_LIFT_COUNT(0, 1);                                       // rounds of the loop
+    if (has && t_pend) MVP_LIFT_COUNT(1, 1);                                   // lanes presenting: a pending window,
+    if (has && !t_pend && t_wr < 0) MVP_LIFT_COUNT(2, 1);                      // a whole image,
+    if (has && !t_pend && t_wr >= 0 && t_wr <= 4) MVP_LIFT_COUNT(3, 1);        // a ring up to half-width 4,
+    if (has && !t_pend && t_wr > 4 && t_wr <= 7) MVP_LIFT_COUNT(4, 1);         // 5 .. 7,
+    if (has && !t_pend && t_wr > 7 && t_wr <= 16) MVP_LIFT_COUNT(5, 1);        // 8 .. 16,
+    if (has && !t_pend && t_wr > 16) MVP_LIFT_COUNT(6, 1);                     // wider
+#endif
     // ---- several owners per round trip.  A task whose rectangle is at most 16 x 16 pixels (a 5x5 window, rings up to half-width 7)
     // is ONE step of the tiling below: 16 columns x 4 rows of lanes x 4 loads.  Tasks of different owners are independent, so up to
     // kOwners of them put their loads in flight together and are resolved one after the other -- the wave then pays one memory round
@@ -659,6 +674,14 @@ int launch_lift(const float4* rec, const uint16_t* plane, int pitch, const float
 }  // namespace
 
 #ifdef MVP_LIFT_EXP
+MVP_API int mvp_lift_exp_counts(unsigned long long* host_out, int reset) {
+  const hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lift_cnt), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lift_cnt), z, sizeof(z));
+  }
+  return (int)e;
+}
 MVP_API int mvp_lift_exp_timestamps(unsigned long long* host_out, int n) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lift_ts), sizeof(unsigned long long) * 4 * (size_t)n);
 }

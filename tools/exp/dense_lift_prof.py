@@ -27,3 +27,14 @@ for _ in range(20):
     L.call('mvp_lift_f32', depth, L.ptr(depth), 1, L.ptr(kinv), L.ptr(cam), L.ptr(pose), L.ptr(box), L.ptr(pts), L.ptr(feat), B, nv, h, w, N, C, k,
            L.ptr(ws), L.ptr(knn), None, L.ptr(gxyz), None, None)
 torch.cuda.synchronize()
+# task census of the whole-wave path (an -DMVP_LIFT_EXP build loaded through MVP_LIBRARY)
+import ctypes
+if hasattr(L.lib(), 'mvp_lift_exp_counts'):
+    buf = (ctypes.c_uint64 * 16)()
+    L.lib().mvp_lift_exp_counts(buf, 1)
+    ops.lift(feat, depth, kinv, cam, pose, pts, k=5, box=box)
+    torch.cuda.synchronize()
+    L.lib().mvp_lift_exp_counts(buf, 0)
+    names = ['loop rounds', 'lane-presentations: pending window', 'whole image', 'ring <= 4', 'ring 5..7', 'ring 8..16', 'ring > 16', 'phase-1b rings scanned', 'phase-1b given up']
+    waves = pts.size(0) * pts.size(1) / 64
+    print('per wave of 64 points:', {n: round(buf[i] / waves, 2) for i, n in enumerate(names)})
