@@ -552,13 +552,17 @@ int layer_backward_impl(const float* G, const float* Yi, const float* mean_i, co
   a.R = R; a.C = (int)C; a.Cp = (int)Cp;
   a.pool_dout = pool_dout; a.pool_out = pool_out; a.pool_arg = pool_arg;
   const int64_t ntiles = cdiv(R, 32);
-  const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(ntiles, 8)));
-  a.tiles_per_wg = cdiv(cdiv(ntiles, wgs), 4) * 4;
-  const int64_t grid = cdiv(ntiles, a.tiles_per_wg);
   // c_in slices of at most 64 (96 for one odd-width slice: the 68-column input of the aggregation MLP) per workgroup row
   const int cb = C <= 32 ? 1 : C <= 64 ? 2 : 4;
   const int cpb = Cp <= 32 ? 1 : (Cp <= 64 || Cp > 96 || cb == 4) ? 2 : 3;
   const unsigned gy = (unsigned)cdiv(Cp, 32 * cpb);
+  int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(ntiles, 8)));
+  // The 128-wide variants keep 128 + accumulator registers per lane: ONE workgroup per CU.  More workgroups than are resident at once only
+  // re-stage (and re-split) the 64 KB weight slice per few tiles: as many as fit (MVP_BWD_WIDE_WGS, default 256 over all c_in slices).
+  static const int wide_wgs = []() { const char* e = getenv("MVP_BWD_WIDE_WGS"); return e ? atoi(e) : 256; }();
+  if (cb == 4 && wide_wgs > 0) wgs = std::max<int64_t>(1, std::min<int64_t>(wide_wgs / (pool_dout ? 1 : gy), cdiv(ntiles, 4)));
+  a.tiles_per_wg = cdiv(cdiv(ntiles, wgs), 4) * 4;
+  const int64_t grid = cdiv(ntiles, a.tiles_per_wg);
   const unsigned gyl = pool_dout ? 1u : gy;  // workgroup rows actually launched (the pooled variant covers Cp <= 32 cpb with one)
   // dW through the caller's workspace + an ordered reduction (no atomics, reproducible) when it is large enough
   a.ws = (ws && grid > 1 && grid * (int64_t)gyl * cb * cpb * 1024 <= ws_floats) ? ws : nullptr;
