@@ -96,6 +96,17 @@ int mvp_ball_query_distance_f32(const float* query, const float* key, int64_t B,
                                 int64_t K, int64_t* index, float* distance, mvp_stream_t stream);
 int mvp_ball_query_distance_f64(const double* query, const double* key, int64_t B, int64_t N1, int64_t N2,
                                 float radius, int64_t K, int64_t* index, double* distance, mvp_stream_t stream);
+/* The same two operations for LARGE float32 clouds through a cell grid (csrc/ball_grid.hip): one build launch (bounding box, <= 16^3 cells
+ * of edge >= 1.001 radius, counting sort) + one query launch that tests only the keys of the 27 cells around each query with the identical
+ * float expression and reads the row off a per-query bitmap in key order -- bit-identical index / distance rows for every input (no cap on
+ * the hits, non-finite coordinates included), ~20x fewer pair tests at the reference network's level 1 (8192 keys, radius 0.1).
+ * mvp_ball_query_grid_workspace: bytes of device scratch the call needs, 0 = shape not taken (N2 < 2048, N2 > 32768 or fewer than 2^24 (query, key) pairs: use mvp_ball_query_f32).
+ * The call itself takes any N2 <= 32768 with B * (16 N2 + 16512) bytes of scratch (the same figure).
+ * distance == NULL: ball_query_cuda.ball_query; else ball_query_distance_cuda.ball_query_distance.  workspace: 16-byte aligned, reusable
+ * once the launches have run (stream order). */
+int64_t mvp_ball_query_grid_workspace(int64_t B, int64_t N1, int64_t N2);
+int mvp_ball_query_grid_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float radius, int64_t K,
+                            int64_t* index, float* distance, void* workspace, int64_t workspace_bytes, mvp_stream_t stream);
 
 /* ---- group_points -------------------------------------------------------------------
  * replaces group_points_cuda.group_points_forward / _backward
@@ -646,7 +657,8 @@ int mvp_sa_train_backward_p_f32(int layer, const float* zf, const float* xyz, co
  * replaces the geometry half of SetAbstraction / FeatureInterpolator called level after level from Python (mvpnet/models/pn2/modules.py:
  * 74-87,122-140, pn2ssg.py:92-115): one sampling launch + the centroid prefixes of all levels (mvp_fps_centroid_levels_f32), a ball query per
  * level, 3-NN + interpolation weights per propagation level, optionally (flags bit 0) the transposed index of every ball / 3-NN index
- * (bit 2: the sorted build) and (bit 1) mvp_sa_geom_sums_f32 for the levels with geom[l] != 0 -- the same launches in the same order on
+ * (bit 2: the sorted build) and (bit 1) mvp_sa_geom_sums_f32 for the levels with geom[l] != 0; bit 3: the table ends with one more entry,
+ * scratch of max_l mvp_ball_query_grid_workspace(B, M_l, N_l) bytes, and the levels that function accepts use mvp_ball_query_grid_f32 -- the same launches in the same order on
  * `stream`, from one table of caller-allocated buffers instead of ~25 calls (0.65 ms of host time per plan from Python).
  * xyz (B,N,3); centroids / radius / neighbours: host arrays of `levels` <= 8 entries, centroids non-increasing and <= N.
  * buffers (host array of n_buffers device pointers, all non-NULL, in this order; N_l = N for l = 0, else centroids[l-1]):

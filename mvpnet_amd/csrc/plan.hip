@@ -22,7 +22,9 @@ struct Cursor {
 // level above, so ONE sampling launch + the prefixes give all centroids -- mvp_fps_centroid_levels_f32), radius[l], neighbours[l].
 // Feature propagation level l interpolates level l+1's points onto level l's (level 0 = xyz): 3-NN + weights, for l = levels-1 .. 0.
 // flags: bit 0 = also the transposed indices (mvp_csr_build_i64; bit 2: the sorted build) of every ball / 3-NN index;
-//        bit 1 = also mvp_sa_geom_sums_f32 for the levels whose entry in `geom` is non-zero (needs bit 0).
+//        bit 1 = also mvp_sa_geom_sums_f32 for the levels whose entry in `geom` is non-zero (needs bit 0);
+//        bit 3 = the table ends with one more entry: scratch of max over levels of mvp_ball_query_grid_workspace(B, M_l, N_l) bytes -- the levels
+//                that function accepts then run mvp_ball_query_grid_f32 instead of mvp_ball_query_f32 (same results).
 // buffers: host array of DEVICE pointers, consumed in this order (n_buffers must match exactly, else MVP_EINVAL):
 //   fps_index (B, centroids[0]) int64
 //   per level l:            new_xyz (B,M_l,3) f32, ball (B,M_l,K_l) i64 [, offsets (B,N_l+1) i32, slots (B,M_l*K_l) i32, cursor (B,N_l) i32
@@ -40,9 +42,9 @@ MVP_API int mvp_pn2_plan_f32(const float* xyz, int64_t B, int64_t N, int64_t lev
   MVP_NONNULL(neighbours);
   MVP_NONNULL(buffers);
   MVP_REQUIRE(B >= 0 && N > 0 && levels >= 1 && levels <= 8);
-  const bool csr = flags & 1, geo = (flags & 2) != 0, sorted = (flags & 4) != 0;
+  const bool csr = flags & 1, geo = (flags & 2) != 0, sorted = (flags & 4) != 0, grid = (flags & 8) != 0;
   MVP_REQUIRE(!geo || csr);
-  int64_t expect = 1;
+  int64_t expect = grid ? 2 : 1;
   for (int64_t l = 0; l < levels; ++l) {
     MVP_REQUIRE(centroids[l] > 0 && centroids[l] <= (l == 0 ? N : centroids[l - 1]) && neighbours[l] > 0);
     expect += 2 + (csr ? 3 : 0) + ((geo && geom && geom[l]) ? 2 : 0) + 2 + (csr ? 3 : 0);
@@ -52,6 +54,7 @@ MVP_API int mvp_pn2_plan_f32(const float* xyz, int64_t B, int64_t N, int64_t lev
   if (B == 0) return MVP_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   Cursor c{buffers, n_buffers, 0};
+  void* grid_ws = grid ? buffers[n_buffers - 1] : nullptr;
   int rc;
   int64_t* fps_index = static_cast<int64_t*>(c.next());
   rc = mvp_fps_checked_f32(xyz, B, N, 3, centroids[0], fps_index, fps_shape, fps_status, stream);
@@ -83,7 +86,9 @@ MVP_API int mvp_pn2_plan_f32(const float* xyz, int64_t B, int64_t N, int64_t lev
   for (int64_t l = 0; l < levels; ++l) {
     const float* key = l == 0 ? xyz : new_xyz[l - 1];
     const int64_t Nl = l == 0 ? N : centroids[l - 1], Ml = centroids[l], Kl = neighbours[l];
-    rc = mvp_ball_query_f32(new_xyz[l], key, B, Ml, Nl, radius[l], Kl, ball[l], stream);
+    const int64_t ws_bytes = grid ? mvp_ball_query_grid_workspace(B, Ml, Nl) : 0;
+    rc = ws_bytes > 0 ? mvp_ball_query_grid_f32(new_xyz[l], key, B, Ml, Nl, radius[l], Kl, ball[l], nullptr, grid_ws, ws_bytes, stream)
+                      : mvp_ball_query_f32(new_xyz[l], key, B, Ml, Nl, radius[l], Kl, ball[l], stream);
     if (rc != MVP_OK) return rc;
     if (csr) {
       rc = sorted ? mvp_csr_build_sorted_i64(ball[l], B, Ml * Kl, Nl, off[l], slo[l], cur[l], stream)

@@ -532,6 +532,11 @@ class PN2SSG(nn.Module):
                     level_events.append((ev, None))
                 ev_arr = (ctypes.c_void_p * nl)(*[ev.cuda_event for ev, _ in level_events])
             flags = (1 if with_csr else 0) | (2 if (with_csr and any(geom)) else 0) | (4 if (with_csr and L.DW_WORKSPACE) else 0)
+            from .ext.ball_query_cuda import BALL_GRID
+            ws_bytes = max(int(L.lib().mvp_ball_query_grid_workspace(B, ms[l], N if l == 0 else ms[l - 1])) for l in range(nl)) if BALL_GRID else 0
+            if ws_bytes > 0:  # large levels: ball query through the cell grid (csrc/ball_grid.hip), scratch at the end of the table
+                table.append(e((ws_bytes,), torch.uint8))
+                flags |= 8
             radius = (ctypes.c_float * nl)(*[float(m.radius) for m in mods])
             L.call('mvp_pn2_plan_f32', xyz, L.ptr(xyz), B, N, nl, (ctypes.c_int64 * nl)(*ms), radius, (ctypes.c_int64 * nl)(*ks),
                    (ctypes.c_int32 * nl)(*geom), int(fps_shape), flags, float(self.fp_modules[0].interpolator._eps),

@@ -197,6 +197,87 @@ def test_ball_query_radius_on_a_distance(dev):
     assert idx.tolist() == [[[0, 2, 0, 0]]]
 
 
+def _grid_clouds():
+    rs = np.random.RandomState(4242)
+    inf, nan = np.inf, np.nan
+    def uniform(B, N2, N1, scale=1.0, off=0.0):
+        key = (rs.rand(B, N2, 3) * scale + off).astype(np.float32)
+        q = np.stack([key[b, rs.choice(N2, N1, replace=N1 > N2)] for b in range(B)])
+        return q, key
+    out = []
+    q, key = uniform(3, 8192, 2048)
+    q[:, 0] = 50.0
+    out.append(('uniform', q, key, 0.1, 32))
+    q, key = uniform(2, 5000, 1000, scale=np.array([3.0, 2.0, 1.0]))
+    out.append(('odd sizes', q, key, 0.1, 7))
+    q, key = uniform(2, 4096, 17, scale=0.04)                      # one cell, every key a hit: rows of the first K indices
+    out.append(('one clump', q, key, 0.1, 32))
+    out.append(('one clump, long rows', q, key, 0.1, 200))
+    q, key = uniform(2, 8192, 512)
+    key[:, 4096:] = key[:, :4096]                                    # every point twice
+    key[:, :, 2] = 0.25                                             # ... on a plane
+    q[:, :, 2] = 0.25 + 0.05 * rs.rand(2, 512).astype(np.float32)
+    out.append(('plane with duplicates', q, key, 0.1, 32))
+    q, key = uniform(2, 8192, 600)
+    key[0, ::97] = nan; key[0, 5::101, 1] = inf; key[1, 7::89, 0] = -inf; key[1, 3] = [inf, -inf, nan]
+    q[0, 1] = nan; q[0, 2, 0] = inf; q[1, 4] = -inf
+    out.append(('non-finite coordinates', q, key, 0.1, 32))
+    q, key = uniform(2, 8192, 256)
+    q[:, :64] += np.float32(0.09) * np.sign(q[:, :64] - 0.5)      # around and beyond the faces of the bounding box
+    q[:, 64:96] = q[:, 64:96] * 3 - 1
+    out.append(('queries outside the box', q, key, 0.1, 32))
+    q, key = uniform(2, 8192, 512, scale=3.0, off=1.0e4)
+    out.append(('far from the origin', q, key, 0.2, 32))
+    q, key = uniform(2, 8192, 512, scale=np.array([100.0, 0.5, 0.5]))
+    out.append(('one long axis', q, key, 0.1, 32))
+    q, key = uniform(1, 32768, 4099)
+    out.append(('largest cloud', q, key, 0.05, 32))
+    q, key = uniform(2, 8192, 300)
+    for r in (0.0, -0.1, 1e-30, 1e20, 0.5, float('nan')):
+        out.append(('radius {}'.format(r), q, key, r, 16))
+    lattice = (np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing='ij'), -1).reshape(1, 4096, 3) * np.float32(0.1)).astype(np.float32)
+    out.append(('lattice with the radius on the spacing', lattice[:, ::5].copy(), lattice, 0.1, 8))
+    out.append(('lattice, radius a hair above', lattice[:, ::5].copy(), lattice, float(np.nextafter(np.float32(0.1), np.float32(1))) * 1.0001, 8))
+    return out
+
+
+def test_ball_query_cell_grid_equals_the_sweep(dev):
+    """csrc/ball_grid.hip (what ball_query / ball_query_distance run for float32 clouds of 2048..32768 keys and >= 2^24 pairs) against the sweep kernel of
+    csrc/ball_query.hip on the same inputs: index AND distance rows bit-identical -- clumps (every key a hit), duplicates, planes, NaN / inf
+    coordinates, queries outside the keys' bounding box, offsets of 1e4, anisotropic clouds, degenerate radii, a lattice whose spacing IS
+    the radius (strict <).  A few of them also against the CPU oracle."""
+    from mvpnet_amd.ops import ball_query, ball_query_distance
+    from mvpnet_amd import _lib as L
+    import warnings
+    for name, q, key, r, K in _grid_clouds():
+        tq, tk = g(q, dev), g(key, dev)
+        B, N1, N2 = q.shape[0], q.shape[1], key.shape[1]
+        ws = torch.empty(B * (16 * N2 + 16512), dtype=torch.uint8, device=dev)
+        idx = torch.empty(B, N1, K, dtype=torch.int64, device=dev)
+        idx2, dist = torch.empty_like(idx), torch.empty(B, N1, K, device=dev)
+        L.call('mvp_ball_query_grid_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, float(r), K, L.ptr(idx), L.ptr(dist), L.ptr(ws), ws.numel())
+        L.call('mvp_ball_query_grid_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, float(r), K, L.ptr(idx2), None, L.ptr(ws), ws.numel())
+        eidx = torch.empty_like(idx)
+        edist = torch.empty_like(dist)
+        L.call('mvp_ball_query_distance_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, float(r), K, L.ptr(eidx), L.ptr(edist))
+        assert torch.equal(idx, eidx), name
+        assert torch.equal(idx2, eidx), name
+        assert torch.equal(dist.view(torch.int32), edist.view(torch.int32)), name
+        oidx, odist = ball_query_distance(tq, tk, r, K, transpose=False)   # whichever of the two the shape rule picks
+        assert torch.equal(oidx, eidx) and torch.equal(ball_query(tq, tk, r, K, transpose=False), eidx), name
+        assert torch.equal(odist.view(torch.int32), edist.view(torch.int32)), name
+        if name in ('uniform', 'plane with duplicates', 'non-finite coordinates', 'queries outside the box'):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                oidx, odist = O().ball_query(q, key, r, K, with_distance=True)
+            np.testing.assert_array_equal(idx.cpu().numpy(), oidx, err_msg=name)
+            np.testing.assert_array_equal(dist.cpu().numpy(), odist, err_msg=name)
+    # and the shapes the grid does not take stay with the sweep kernel
+    assert L.lib().mvp_ball_query_grid_workspace(32, 2048, 8192) == 32 * (16 * 8192 + 16512)
+    assert L.lib().mvp_ball_query_grid_workspace(4, 4096, 2047) == 0 and L.lib().mvp_ball_query_grid_workspace(1, 4096, 65536) == 0
+    assert L.lib().mvp_ball_query_grid_workspace(1, 512, 2048) == 0
+
+
 # ------------------------------------------------------------------ 3-NN
 @pytest.mark.parametrize('ci', range(4))
 def test_knn_reference_grid(dev, ci):
