@@ -107,6 +107,16 @@ int mvp_ball_query_distance_f64(const double* query, const double* key, int64_t 
 int64_t mvp_ball_query_grid_workspace(int64_t B, int64_t N1, int64_t N2);
 int mvp_ball_query_grid_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float radius, int64_t K,
                             int64_t* index, float* distance, void* workspace, int64_t workspace_bytes, mvp_stream_t stream);
+/* 3-NN through the same grid (replaces knn_distance_cuda.knn_distance, knn_distance_kernel.cu:35-124,150-190, + the weights of
+ * FeatureInterpolator.forward, modules.py:135-140, as mvp_knn3_weights_f32 does): cells of extent / g per axis, g ~ cbrt(N2) / 1.3; 16 lanes
+ * per query keep the three smallest (distance, key index) pairs of the 27 cells around the query -- strict < on the distance, the lower
+ * index among equals, as the sweep -- and the triple stands when its third distance is below 0.999 x the distance to the nearest face
+ * of the 27-cell block with keys beyond it; otherwise the lanes sweep all keys for that query.  Identical index / distance / weight on
+ * every input.  weight and / or distance may be NULL.  mvp_knn3_grid_workspace: scratch bytes, 0 = stay with the sweep (fewer than 2^24
+ * pairs, N2 < 256 or N2 > 65536); the call takes any 3 <= N2 <= 65536 with B * (16 N2 + 16512) bytes. */
+int64_t mvp_knn3_grid_workspace(int64_t B, int64_t N1, int64_t N2);
+int mvp_knn3_grid_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float eps, int64_t* index, float* weight,
+                      float* distance, void* workspace, int64_t workspace_bytes, mvp_stream_t stream);
 
 /* ---- group_points -------------------------------------------------------------------
  * replaces group_points_cuda.group_points_forward / _backward
@@ -658,7 +668,7 @@ int mvp_sa_train_backward_p_f32(int layer, const float* zf, const float* xyz, co
  * 74-87,122-140, pn2ssg.py:92-115): one sampling launch + the centroid prefixes of all levels (mvp_fps_centroid_levels_f32), a ball query per
  * level, 3-NN + interpolation weights per propagation level, optionally (flags bit 0) the transposed index of every ball / 3-NN index
  * (bit 2: the sorted build) and (bit 1) mvp_sa_geom_sums_f32 for the levels with geom[l] != 0; bit 3: the table ends with one more entry,
- * scratch of max_l mvp_ball_query_grid_workspace(B, M_l, N_l) bytes, and the levels that function accepts use mvp_ball_query_grid_f32 -- the same launches in the same order on
+ * scratch of max_l of mvp_ball_query_grid_workspace(B, M_l, N_l) and mvp_knn3_grid_workspace(B, N_l, M_l) bytes, and the levels those functions accept use mvp_ball_query_grid_f32 / mvp_knn3_grid_f32 -- the same launches in the same order on
  * `stream`, from one table of caller-allocated buffers instead of ~25 calls (0.65 ms of host time per plan from Python).
  * xyz (B,N,3); centroids / radius / neighbours: host arrays of `levels` <= 8 entries, centroids non-increasing and <= N.
  * buffers (host array of n_buffers device pointers, all non-NULL, in this order; N_l = N for l = 0, else centroids[l-1]):

@@ -30,6 +30,7 @@ _SIGNATURES = {
     'mvp_ball_query_distance_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],
     'mvp_ball_query_distance_f64': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr],
     'mvp_ball_query_grid_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _i64, _ptr, _ptr, _ptr, _i64, _ptr],
+    'mvp_knn3_grid_f32': [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
     'mvp_group_points_forward_strided_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_group_points_backward_strided_f32': [_ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interpolate_forward_strided_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr],
@@ -134,7 +135,7 @@ for _n in ['mvp_mlp_forward_f32', 'mvp_mlp_forward_bn_f32', 'mvp_mlp_forward_rel
            'mvp_mlp_weight_grad_f32', 'mvp_mlp_weight_grad_ws_f32', 'mvp_mlp_layer_backward_f32', 'mvp_mlp_layer_backward_ws_f32',
            'mvp_sa_fused_forward_f32', 'mvp_sa_train_forward_f32', 'mvp_sa_train_backward_f32']:
     _SIGNATURES[_n[:-4] + '_p_f32'] = _SIGNATURES[_n][:-1] + [ctypes.c_int, ctypes.c_int, _ptr]
-EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_ball_query_grid_workspace', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
+EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_ball_query_grid_workspace', 'mvp_knn3_grid_workspace', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
            'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode', 'mvp_fps_debug_spin_limit'] + sorted(_SIGNATURES)
 
 
@@ -153,6 +154,8 @@ def lib():
         handle.mvp_lift_workspace_bytes.argtypes = [_i64, _i64, _i64, _i64, _i64]
         handle.mvp_ball_query_grid_workspace.restype = ctypes.c_int64
         handle.mvp_ball_query_grid_workspace.argtypes = [_i64, _i64, _i64]
+        handle.mvp_knn3_grid_workspace.restype = ctypes.c_int64
+        handle.mvp_knn3_grid_workspace.argtypes = [_i64, _i64, _i64]
         handle.mvp_group_lin_partial_count.restype = ctypes.c_int64
         handle.mvp_group_lin_partial_count.argtypes = [_i64, _i64, _i64, _i64]
         handle.mvp_mlp_weight_grad_workspace_floats.restype = ctypes.c_int64

@@ -17,7 +17,15 @@
 // u = (x - min) * inv carries at most 3e-6 of absolute error (u <= 16), so the two cell indices differ by at most 1 per axis -- the
 // clamp to [0, g - 1] is monotone and keeps that -- hence every such pair lies in the 27 cells.  Non-finite coordinates never hit in
 // either kernel (NaN / inf distances fail `d < r2`); they are kept out of the bounding box and land in a clamped cell.
+//
+// The same grid serves the 3-NN search of the feature-propagation levels (KNNDistanceKernel, knn_distance_kernel.cu:35-124; knn.hip sweeps
+// all keys per query): cells of extent / g per axis (g ~ cbrt(N2) / 1.3), 16 lanes per query keep the three smallest (distance, index)
+// pairs of the 27 cells' keys -- the sweep's order: strict < on the distance, the lower key index among equals -- and the result stands
+// when the third distance is below 0.999 x the distance from the query to the nearest face of the 27-cell block that has keys beyond it
+// (every key outside the block is then strictly farther).  Otherwise the 16 lanes sweep all keys for that query: exact on every input,
+// fast where the keys are spread like a sampled surface or volume.
 #include <cfloat>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -31,6 +39,7 @@ constexpr int kBuildThreads = 1024;
 constexpr int kQueryThreads = 256;
 constexpr int kLanesPerQuery = 16;
 constexpr int kQueriesPerWg = kQueryThreads / kLanesPerQuery;
+constexpr int kInFlight = 4;
 constexpr int64_t kGridMinKeys = 2048, kGridMaxKeys = 32768;   // bitmap: N2 / 8 bytes per query, 16 queries per workgroup <= 64 KB of LDS
 constexpr int64_t kGridMinPairs = 1ll << 24;                   // (query, key) pairs of the sweep below which it is not worth two launches
 
@@ -39,7 +48,7 @@ __device__ __forceinline__ int cell_of(float v, float mn, float inv, int g) {
   return (u >= 0.f) ? (int)fminf(u, (float)(g - 1)) : 0;  // NaN -> 0
 }
 
-__global__ __launch_bounds__(kBuildThreads) void ball_grid_build_kernel(const float* __restrict__ key, int N, float cellmin,
+__global__ __launch_bounds__(kBuildThreads) void ball_grid_build_kernel(const float* __restrict__ key, int N, float cellmin, int gmax,
                                                                         int* __restrict__ heads, int* __restrict__ starts,
                                                                         float4* __restrict__ sorted) {
   __shared__ int hist[kGridCells];
@@ -82,12 +91,12 @@ __global__ __launch_bounds__(kBuildThreads) void ball_grid_build_kernel(const fl
     }
     if (!(l <= h)) l = h = 0.f;  // no finite key
     const float ext = h - l;     // may overflow to inf: then one cell
-    const float cell = fmaxf(cellmin, ext * (1.f / kGridAxis));
+    const float cell = fmaxf(cellmin, ext / (float)gmax);
     float inv = (cell > 0.f && cell <= FLT_MAX) ? 1.f / cell : 0.f;
     if (!(inv <= FLT_MAX)) inv = 0.f;
     const float gf = ext * inv;
-    int g = (inv > 0.f && gf >= 0.f) ? (int)fminf(gf, (float)kGridAxis) + 1 : 1;
-    g = min(g, kGridAxis);
+    int g = (inv > 0.f && gf >= 0.f) ? (int)fminf(gf, (float)gmax) + 1 : 1;
+    g = min(g, gmax);
     s_mn[tid] = l;
     s_inv[tid] = inv;
     s_g[tid] = g;
@@ -195,16 +204,24 @@ __global__ __launch_bounds__(kQueryThreads) void ball_grid_query_kernel(const fl
   __builtin_amdgcn_wave_barrier();
   const int T = cum[9];
   unsigned* words = reinterpret_cast<unsigned*>(my);
-  for (int f = l16; f < T; f += kLanesPerQuery) {
-    int j = lo[0] + f;
+  for (int f0 = l16; f0 < T; f0 += kInFlight * kLanesPerQuery) {  // kInFlight records per lane on their way at once: one round trip, not four
+    float4 p[kInFlight];
 #pragma unroll
-    for (int r = 1; r < 9; ++r)
-      if (f >= cum[r]) j = lo[r] + (f - cum[r]);
-    const float4 p = sp[j];
-    const float d = dist2_3(p.x, p.y, p.z, qx, qy, qz);
-    if (d < r2) {
-      const int id = __float_as_int(p.w);
-      atomicOr(&words[id >> 5], 1u << (id & 31));
+    for (int u = 0; u < kInFlight; ++u) {
+      const int f = f0 + u * kLanesPerQuery;
+      int j = lo[0] + f;
+#pragma unroll
+      for (int r = 1; r < 9; ++r)
+        if (f >= cum[r]) j = lo[r] + (f - cum[r]);
+      p[u] = f < T ? sp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kInFlight; ++u) {
+      const float d = dist2_3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+      if (f0 + u * kLanesPerQuery < T && d < r2) {
+        const int id = __float_as_int(p[u].w);
+        atomicOr(&words[id >> 5], 1u << (id & 31));
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -265,6 +282,174 @@ __global__ __launch_bounds__(kQueryThreads) void ball_grid_query_kernel(const fl
   }
 }
 
+
+// ---- 3-NN ------------------------------------------------------------------------------------------------------------------------
+constexpr unsigned long long kKnnEmpty = 0x7f800000ffffffffull;  // (+inf, -1): the sweep kernel's initial slot
+
+__device__ __forceinline__ void top3_insert(unsigned long long (&b)[3], float d, int id) {
+  if (d < INFINITY) {  // the sweep inserts on d < slot (strict): NaN and +inf never enter
+    const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;  // d >= +0: the bits order like the value
+    if (k < b[2]) {
+      if (k < b[1]) {
+        b[2] = b[1];
+        if (k < b[0]) {
+          b[1] = b[0];
+          b[0] = k;
+        } else {
+          b[1] = k;
+        }
+      } else {
+        b[2] = k;
+      }
+    }
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp64(unsigned long long v) {
+  const int lo = __builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(v >> 32), (int)(v >> 32), CTRL, 0xF, 0xF, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long row_min64(unsigned long long v) {  // minimum over the 16 lanes of a row, in every lane
+  unsigned long long o;
+  o = dpp64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = o < v ? o : v;
+  o = dpp64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = o < v ? o : v;
+  o = dpp64<0x141>(v);  // row_half_mirror
+  v = o < v ? o : v;
+  o = dpp64<0x140>(v);  // row_mirror
+  v = o < v ? o : v;
+  return v;
+}
+// the three smallest keys over the 16 lanes' sorted triples, in every lane (keys are distinct except the empty slot)
+__device__ __forceinline__ void row_merge3(unsigned long long (&b)[3]) {
+  unsigned long long r[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const unsigned long long m = row_min64(b[0]);
+    r[s] = m;
+    if (b[0] == m) {
+      b[0] = b[1];
+      b[1] = b[2];
+      b[2] = kKnnEmpty;
+    }
+  }
+  b[0] = r[0];
+  b[1] = r[1];
+  b[2] = r[2];
+}
+
+__global__ __launch_bounds__(kQueryThreads) void knn3_grid_kernel(const float* __restrict__ query, const float* __restrict__ key, int N1, int N2,
+                                                                  const int* __restrict__ heads, const int* __restrict__ starts,
+                                                                  const float4* __restrict__ sorted, int64_t* __restrict__ index,
+                                                                  float* __restrict__ dist, float* __restrict__ weight, float eps) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int grp = tid / kLanesPerQuery, l16 = tid & (kLanesPerQuery - 1);
+  const int qi = blockIdx.x * kQueriesPerWg + grp;
+  if (qi >= N1) return;  // whole 16-lane rows leave together
+  const int* hd = heads + (size_t)b * kGridHead;
+  const float mn[3] = {__int_as_float(hd[0]), __int_as_float(hd[1]), __int_as_float(hd[2])};
+  const float inv[3] = {__int_as_float(hd[3]), __int_as_float(hd[4]), __int_as_float(hd[5])};
+  const int g[3] = {hd[6], hd[7], hd[8]};
+  const int* st = starts + (size_t)b * kGridStarts;
+  const float4* sp = sorted + (size_t)b * N2;
+  const float* kp = key + (size_t)b * N2 * 3;
+  const float* qp = query + ((size_t)b * N1 + qi) * 3;
+  const float q[3] = {qp[0], qp[1], qp[2]};
+  int c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) c[a] = cell_of(q[a], mn[a], inv[a], g[a]);
+  int lo[9], cum[10];
+  cum[0] = 0;
+  {
+    const int xlo = max(c[0] - 1, 0), xhi = min(c[0] + 1, g[0] - 1);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int zz = c[2] + r / 3 - 1, yy = c[1] + r % 3 - 1;
+      const bool in = zz >= 0 && zz < g[2] && yy >= 0 && yy < g[1];
+      const int base = (zz * g[1] + yy) * g[0];
+      const int a0 = in ? st[base + xlo] : 0, e0 = in ? st[base + xhi + 1] : 0;
+      lo[r] = a0;
+      cum[r + 1] = cum[r] + (e0 - a0);
+    }
+  }
+  unsigned long long best[3] = {kKnnEmpty, kKnnEmpty, kKnnEmpty};
+  const int T = cum[9];
+  for (int f0 = l16; f0 < T; f0 += kInFlight * kLanesPerQuery) {
+    float4 p[kInFlight];
+#pragma unroll
+    for (int u = 0; u < kInFlight; ++u) {
+      const int f = f0 + u * kLanesPerQuery;
+      int j = lo[0] + f;
+#pragma unroll
+      for (int r = 1; r < 9; ++r)
+        if (f >= cum[r]) j = lo[r] + (f - cum[r]);
+      p[u] = f < T ? sp[j] : make_float4(NAN, NAN, NAN, 0.f);  // a NaN distance never enters
+    }
+#pragma unroll
+    for (int u = 0; u < kInFlight; ++u) top3_insert(best, dist2_3(p[u].x, p[u].y, p[u].z, q[0], q[1], q[2]), __float_as_int(p[u].w));
+  }
+  row_merge3(best);
+  // does anything outside the 27 cells come closer than the third?  Faces of the block with cells beyond them, 0.1 % inside.
+  float margin = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (inv[a] > 0.f) {
+      const float cell = 1.f / inv[a];
+      if (c[a] >= 2) margin = fminf(margin, q[a] - (mn[a] + (float)(c[a] - 1) * cell));
+      if (c[a] + 2 < g[a]) margin = fminf(margin, (mn[a] + (float)(c[a] + 2) * cell) - q[a]);
+    }
+  }
+  const float m = margin * 0.999f;
+  const float d3 = __uint_as_float((unsigned)(best[2] >> 32));
+  if (!(margin == INFINITY || (m > 0.f && d3 < m * m))) {  // (a NaN margin -- a non-finite query -- lands here too: its distances are NaN either way)
+    best[0] = best[1] = best[2] = kKnnEmpty;
+    for (int j0 = l16; j0 < N2; j0 += kInFlight * kLanesPerQuery) {
+      float x[kInFlight], y[kInFlight], z[kInFlight];
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int j = j0 + u * kLanesPerQuery;
+        const bool in = j < N2;
+        x[u] = in ? kp[(size_t)j * 3] : NAN;
+        y[u] = in ? kp[(size_t)j * 3 + 1] : NAN;
+        z[u] = in ? kp[(size_t)j * 3 + 2] : NAN;
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) top3_insert(best, dist2_3(x[u], y[u], z[u], q[0], q[1], q[2]), j0 + u * kLanesPerQuery);
+    }
+    row_merge3(best);
+  }
+  if (l16 == 0) {
+    float bd[3];
+    const size_t o = ((size_t)b * N1 + qi) * 3;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      bd[s] = __uint_as_float((unsigned)(best[s] >> 32));
+      index[o + s] = (int64_t)(int)(unsigned)best[s];
+      if (dist) dist[o + s] = bd[s];
+    }
+    if (weight) {  // FeatureInterpolator's weights exactly as knn_kernel forms them (modules.py:135-140)
+      float iv[3], sum = 0.f;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        iv[s] = 1.f / (bd[s] < eps ? eps : bd[s]);
+        sum = s == 0 ? iv[0] : sum + iv[s];
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) weight[o + s] = iv[s] / sum;
+    }
+  }
+}
+
+inline int knn_grid_axis(int64_t N2) {
+  static const char* env = getenv("MVP_KNN_GRID_DIV");
+  const double div = env ? atof(env) : 1.3;  // ablation knob; 1.3: 10 cells per axis for 2048 keys, 16 for 8192
+  int g = (int)(cbrt((double)N2) / div + 0.5);
+  return g < 2 ? 2 : (g > kGridAxis ? kGridAxis : g);
+}
+
 inline int64_t grid_rows(int64_t N2) { return cdiv(N2, 128 * kLanesPerQuery); }
 inline int64_t grid_bytes(int64_t B, int64_t N2) { return B * ((int64_t)sizeof(int) * (kGridHead + kGridStarts) + (int64_t)sizeof(float4) * N2); }
 
@@ -299,8 +484,8 @@ MVP_API int mvp_ball_query_grid_f32(const float* query, const float* key, int64_
   float4* sorted = static_cast<float4*>(workspace);
   int* starts = reinterpret_cast<int*>(sorted + (size_t)B * N2);
   int* heads = starts + (size_t)B * kGridStarts;
-  hipLaunchKernelGGL(ball_grid_build_kernel, dim3((unsigned)B), dim3(kBuildThreads), 0, s, key, (int)N2, fabsf(r) * 1.001f, heads, starts,
-                     sorted);
+  hipLaunchKernelGGL(ball_grid_build_kernel, dim3((unsigned)B), dim3(kBuildThreads), 0, s, key, (int)N2, fabsf(r) * 1.001f, kGridAxis, heads,
+                     starts, sorted);
   const int rows = (int)grid_rows(N2);
   const size_t lds = (size_t)kQueriesPerWg * rows * kLanesPerQuery * sizeof(uint4);
   dim3 grid((unsigned)cdiv(N1, kQueriesPerWg), (unsigned)B);
@@ -310,5 +495,35 @@ MVP_API int mvp_ball_query_grid_f32(const float* query, const float* key, int64_
   else
     hipLaunchKernelGGL(ball_grid_query_kernel<false>, grid, dim3(kQueryThreads), lds, s, query, key, (int)N1, (int)N2, r2, (int)K, heads,
                        starts, sorted, rows, index, distance);
+  return mvp_launch_status();
+}
+
+// 3-NN (+ interpolation weights) through the same grid: results identical to mvp_knn_distance_f32 / mvp_knn3_weights_f32 (index; distance
+// and / or weight when non-NULL).  mvp_knn3_grid_workspace: scratch bytes, 0 = shape stays with the sweep kernel (few pairs, or clouds
+// beyond 65536 keys); the call itself takes any 3 <= N2 <= 65536 with B * (16 N2 + 16512) bytes.
+MVP_API int64_t mvp_knn3_grid_workspace(int64_t B, int64_t N1, int64_t N2) {
+  if (B <= 0 || N1 <= 0 || N2 < 256 || N2 > 65536 || B * N1 * N2 < kGridMinPairs) return 0;
+  return grid_bytes(B, N2);
+}
+
+MVP_API int mvp_knn3_grid_f32(const float* query, const float* key, int64_t B, int64_t N1, int64_t N2, float eps, int64_t* index, float* weight,
+                              float* distance, void* workspace, int64_t workspace_bytes, mvp_stream_t stream) {
+  MVP_NONNULL(query);
+  MVP_NONNULL(key);
+  MVP_NONNULL(index);
+  MVP_REQUIRE(B >= 0 && N1 >= 0 && N2 >= 3 && N2 <= 65536 && (weight == nullptr || eps > 0.f));
+  MVP_REQUIRE(N1 < (1ll << 31) && B < 65536);
+  if (B == 0 || N1 == 0) return MVP_OK;
+  MVP_NONNULL(workspace);
+  MVP_REQUIRE(workspace_bytes >= grid_bytes(B, N2) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float4* sorted = static_cast<float4*>(workspace);
+  int* starts = reinterpret_cast<int*>(sorted + (size_t)B * N2);
+  int* heads = starts + (size_t)B * kGridStarts;
+  hipLaunchKernelGGL(ball_grid_build_kernel, dim3((unsigned)B), dim3(kBuildThreads), 0, s, key, (int)N2, 0.f, knn_grid_axis(N2), heads, starts,
+                     sorted);
+  dim3 grid((unsigned)cdiv(N1, kQueriesPerWg), (unsigned)B);
+  hipLaunchKernelGGL(knn3_grid_kernel, grid, dim3(kQueryThreads), 0, s, query, key, (int)N1, (int)N2, heads, starts, sorted, index, distance,
+                     weight, eps);
   return mvp_launch_status();
 }

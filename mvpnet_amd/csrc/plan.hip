@@ -23,8 +23,9 @@ struct Cursor {
 // Feature propagation level l interpolates level l+1's points onto level l's (level 0 = xyz): 3-NN + weights, for l = levels-1 .. 0.
 // flags: bit 0 = also the transposed indices (mvp_csr_build_i64; bit 2: the sorted build) of every ball / 3-NN index;
 //        bit 1 = also mvp_sa_geom_sums_f32 for the levels whose entry in `geom` is non-zero (needs bit 0);
-//        bit 3 = the table ends with one more entry: scratch of max over levels of mvp_ball_query_grid_workspace(B, M_l, N_l) bytes -- the levels
-//                that function accepts then run mvp_ball_query_grid_f32 instead of mvp_ball_query_f32 (same results).
+//        bit 3 = the table ends with one more entry: scratch of max over levels of mvp_ball_query_grid_workspace(B, M_l, N_l) and
+//                mvp_knn3_grid_workspace(B, N_l, M_l) bytes -- the levels those functions accept then run mvp_ball_query_grid_f32 /
+//                mvp_knn3_grid_f32 instead of the sweep kernels (same results).
 // buffers: host array of DEVICE pointers, consumed in this order (n_buffers must match exactly, else MVP_EINVAL):
 //   fps_index (B, centroids[0]) int64
 //   per level l:            new_xyz (B,M_l,3) f32, ball (B,M_l,K_l) i64 [, offsets (B,N_l+1) i32, slots (B,M_l*K_l) i32, cursor (B,N_l) i32
@@ -109,7 +110,9 @@ MVP_API int mvp_pn2_plan_f32(const float* xyz, int64_t B, int64_t N, int64_t lev
     const int64_t Nq = l == 0 ? N : centroids[l - 1], Nk = centroids[l];
     int64_t* index = static_cast<int64_t*>(c.next());
     float* weight = static_cast<float*>(c.next());
-    rc = mvp_knn3_weights_f32(query, new_xyz[l], B, Nq, Nk, knn_eps, index, weight, nullptr, stream);
+    const int64_t ws_bytes = grid ? mvp_knn3_grid_workspace(B, Nq, Nk) : 0;
+    rc = ws_bytes > 0 ? mvp_knn3_grid_f32(query, new_xyz[l], B, Nq, Nk, knn_eps, index, weight, nullptr, grid_ws, ws_bytes, stream)
+                      : mvp_knn3_weights_f32(query, new_xyz[l], B, Nq, Nk, knn_eps, index, weight, nullptr, stream);
     if (rc != MVP_OK) return rc;
     if (csr) {
       int32_t* o = static_cast<int32_t*>(c.next());

@@ -533,7 +533,8 @@ class PN2SSG(nn.Module):
                 ev_arr = (ctypes.c_void_p * nl)(*[ev.cuda_event for ev, _ in level_events])
             flags = (1 if with_csr else 0) | (2 if (with_csr and any(geom)) else 0) | (4 if (with_csr and L.DW_WORKSPACE) else 0)
             from .ext.ball_query_cuda import BALL_GRID
-            ws_bytes = max(int(L.lib().mvp_ball_query_grid_workspace(B, ms[l], N if l == 0 else ms[l - 1])) for l in range(nl)) if BALL_GRID else 0
+            ws_bytes = max(max(int(L.lib().mvp_ball_query_grid_workspace(B, ms[l], N if l == 0 else ms[l - 1])),
+                               int(L.lib().mvp_knn3_grid_workspace(B, N if l == 0 else ms[l - 1], ms[l]))) for l in range(nl)) if BALL_GRID else 0
             if ws_bytes > 0:  # large levels: ball query through the cell grid (csrc/ball_grid.hip), scratch at the end of the table
                 table.append(e((ws_bytes,), torch.uint8))
                 flags |= 8

@@ -422,7 +422,13 @@ def knn3_weights(query, key, eps=1e-10):
         raise RuntimeError('knn3_weights: at least 3 keys expected')
     index = torch.empty((B, N1, 3), dtype=torch.int64, device=q.device)
     weight = torch.empty((B, N1, 3), dtype=torch.float32, device=q.device)
-    L.call('mvp_knn3_weights_f32', q, L.ptr(q), L.ptr(k), B, N1, k.size(1), float(eps), L.ptr(index), L.ptr(weight), None)
+    from .ext.ball_query_cuda import BALL_GRID
+    nbytes = int(L.lib().mvp_knn3_grid_workspace(B, N1, k.size(1))) if BALL_GRID else 0
+    if nbytes > 0:  # many pairs: through the cell grid (csrc/ball_grid.hip), same triples and weights
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        L.call('mvp_knn3_grid_f32', q, L.ptr(q), L.ptr(k), B, N1, k.size(1), float(eps), L.ptr(index), L.ptr(weight), None, L.ptr(ws), nbytes)
+    else:
+        L.call('mvp_knn3_weights_f32', q, L.ptr(q), L.ptr(k), B, N1, k.size(1), float(eps), L.ptr(index), L.ptr(weight), None)
     return index, weight
 
 

@@ -290,6 +290,49 @@ def test_knn_reference_grid(dev, ci):
     np.testing.assert_allclose(dist.cpu().numpy(), gd['c{}_dist'.format(ci)], atol=1e-6)
 
 
+def test_knn3_cell_grid_equals_the_sweep(dev):
+    """mvp_knn3_grid_f32 (csrc/ball_grid.hip: what knn_distance / knn3_weights / the plan run for >= 2^24 pairs) against the sweep kernel
+    mvp_knn3_weights_f32 on the same inputs: index, distance AND weight bit-identical -- sampled volumes and planes, exact duplicates and
+    lattices (ties broken by the lower key index), clumps + far outliers (queries whose 27 cells hold fewer than three keys: the per-query
+    sweep), non-finite coordinates, three keys only, queries outside the keys' box."""
+    from mvpnet_amd import _lib as L
+    rs = np.random.RandomState(99)
+    inf, nan = np.inf, np.nan
+    cases = []
+    key = rs.rand(3, 2048, 3).astype(np.float32); q = rs.rand(3, 8192, 3).astype(np.float32)
+    cases.append(('volume', q, key))
+    k2 = key.copy(); k2[:, :, 2] = 0.5; q2 = q.copy(); q2[:, :, 2] = 0.5 + 0.01 * rs.randn(3, 8192).astype(np.float32)
+    cases.append(('plane', q2, k2))
+    k3 = key.copy(); k3[:, 1024:] = k3[:, :1024]
+    cases.append(('every key twice', q, k3))
+    lat = (np.stack(np.meshgrid(*[np.arange(8)] * 3, indexing='ij'), -1).reshape(1, 512, 3) * np.float32(0.25)).astype(np.float32)
+    qlat = np.concatenate([lat + np.float32(0.125), lat, lat[:, ::-1] + np.float32([0.125, 0, 0])], 1)   # cell centres, lattice points, edge midpoints: ties everywhere
+    cases.append(('lattice', qlat, lat))
+    k4 = (rs.rand(2, 1000, 3) * 0.01).astype(np.float32); k4[:, ::100] += 50.0; q4 = (rs.rand(2, 3000, 3) * 60).astype(np.float32)
+    cases.append(('clump and outliers', q4, k4))
+    k5 = key.copy(); k5[0, ::7] = nan; k5[1, ::5, 0] = inf; k5[2, 3] = [-inf, 0, 0]; q5 = q.copy(); q5[0, 0] = nan; q5[1, 1, 1] = inf; q5[2, 2] = -inf
+    cases.append(('non-finite', q5, k5))
+    cases.append(('three keys', q[:, :500], key[:, :3].copy()))
+    cases.append(('queries outside', q * 3 - 1, key))
+    cases.append(('far from the origin', q * 3 + 1e4, key * 3 + 1e4))
+    cases.append(('odd sizes', q[:, :1001], key[:, :777].copy()))
+    k6 = key.copy(); k6[:, :, 0] *= 200
+    q6 = q.copy(); q6[:, :, 0] *= 200
+    cases.append(('one long axis', q6, k6))
+    for name, qq, kk in cases:
+        tq, tk = g(np.ascontiguousarray(qq), dev), g(np.ascontiguousarray(kk), dev)
+        B, N1, N2 = tq.shape[0], tq.shape[1], tk.shape[1]
+        ws = torch.empty(B * (16 * N2 + 16512), dtype=torch.uint8, device=dev)
+        idx, w, d = torch.empty(B, N1, 3, dtype=torch.int64, device=dev), torch.empty(B, N1, 3, device=dev), torch.empty(B, N1, 3, device=dev)
+        eidx, ew, ed = torch.empty_like(idx), torch.empty_like(w), torch.empty_like(d)
+        L.call('mvp_knn3_grid_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, 1e-10, L.ptr(idx), L.ptr(w), L.ptr(d), L.ptr(ws), ws.numel())
+        L.call('mvp_knn3_weights_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, 1e-10, L.ptr(eidx), L.ptr(ew), L.ptr(ed))
+        assert torch.equal(idx, eidx), name
+        assert torch.equal(d.view(torch.int32), ed.view(torch.int32)), name
+        assert torch.equal(w.view(torch.int32), ew.view(torch.int32)), name
+    assert L.lib().mvp_knn3_grid_workspace(32, 8192, 2048) == 32 * (16 * 2048 + 16512) and L.lib().mvp_knn3_grid_workspace(1, 2048, 512) == 0
+
+
 @pytest.mark.parametrize('B,N1,N2', [(2, 8192, 2048), (3, 2048, 512), (4, 512, 128), (5, 128, 32), (2, 1000, 3),
                                       (1, 77, 1500)])
 @pytest.mark.parametrize('dt', [np.float32, np.float64])

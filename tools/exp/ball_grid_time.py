@@ -43,4 +43,11 @@ for name, kw, B, ms, rs in (('configs[2] B = 32', dict(config=3), 32, (2048, 512
         full = (res[True][1][..., 1:] != res[True][1][..., :1]).sum(-1).add(1).float()
         print('{:22s} {:6d} keys {:5d} queries r {:.1f}: sweep {:7.1f} us   grid (build + query) {:7.1f} us   distinct hits per row {:.1f}'.format(
             name, key.shape[1], m, r, res[False][0], res[True][0], float(full.mean())))
+        from mvpnet_amd import rows as R
+        kn = {}
+        for grid in (False, True):
+            bq.BALL_GRID = grid
+            kn[grid] = (timed(lambda: R.knn3_weights(key, q)), R.knn3_weights(key, q))
+        assert torch.equal(kn[False][1][0], kn[True][1][0]) and torch.equal(kn[False][1][1], kn[True][1][1])
+        print('{:22s} 3-NN of {:5d} points among {:5d}: sweep {:7.1f} us   grid {:7.1f} us'.format('', key.shape[1], m, kn[False][0], kn[True][0]))
         key = q
