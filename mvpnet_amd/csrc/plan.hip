@@ -110,7 +110,7 @@ MVP_API int mvp_pn2_plan_f32(const float* xyz, int64_t B, int64_t N, int64_t lev
     const int64_t Nq = l == 0 ? N : centroids[l - 1], Nk = centroids[l];
     int64_t* index = static_cast<int64_t*>(c.next());
     float* weight = static_cast<float*>(c.next());
-    const int64_t ws_bytes = grid ? mvp_knn3_grid_workspace(B, Nq, Nk) : 0;
+    const int64_t ws_bytes = (grid && !(flags & 16)) ? mvp_knn3_grid_workspace(B, Nq, Nk) : 0;  // (bit 4: ablation, 3-NN stays with the sweep)
     rc = ws_bytes > 0 ? mvp_knn3_grid_f32(query, new_xyz[l], B, Nq, Nk, knn_eps, index, weight, nullptr, grid_ws, ws_bytes, stream)
                       : mvp_knn3_weights_f32(query, new_xyz[l], B, Nq, Nk, knn_eps, index, weight, nullptr, stream);
     if (rc != MVP_OK) return rc;

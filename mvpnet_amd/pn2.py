@@ -537,7 +537,7 @@ class PN2SSG(nn.Module):
                                int(L.lib().mvp_knn3_grid_workspace(B, N if l == 0 else ms[l - 1], ms[l]))) for l in range(nl)) if BALL_GRID else 0
             if ws_bytes > 0:  # large levels: ball query through the cell grid (csrc/ball_grid.hip), scratch at the end of the table
                 table.append(e((ws_bytes,), torch.uint8))
-                flags |= 8
+                flags |= 8 | (16 if os.environ.get('MVP_KNN_GRID', '1') == '0' else 0)
             radius = (ctypes.c_float * nl)(*[float(m.radius) for m in mods])
             L.call('mvp_pn2_plan_f32', xyz, L.ptr(xyz), B, N, nl, (ctypes.c_int64 * nl)(*ms), radius, (ctypes.c_int64 * nl)(*ks),
                    (ctypes.c_int32 * nl)(*geom), int(fps_shape), flags, float(self.fp_modules[0].interpolator._eps),
