@@ -290,6 +290,46 @@ def test_knn_reference_grid(dev, ci):
     np.testing.assert_allclose(dist.cpu().numpy(), gd['c{}_dist'.format(ci)], atol=1e-6)
 
 
+def test_grid_searches_on_random_shapes(dev):
+    """mvp_ball_query_grid_f32 / mvp_knn3_grid_f32 against the sweep entry points on 60 random problems: cloud sizes 3 .. 9000 (ragged, not
+    multiples of anything), 1 .. 3000 queries, radii from 'no hit at all' to 'everything', K 1 .. 70, uniform / clumped / planar /
+    integer-lattice clouds with and without a far outlier.  Bit-identical index, distance and weight rows."""
+    from mvpnet_amd import _lib as L
+    rs = np.random.RandomState(2026)
+    for it in range(60):
+        B = int(rs.randint(1, 4)); N2 = int(rs.choice([3, 5, 17, 64, 200, 777, 2048, 3001, 4096, 9000])); N1 = int(rs.choice([1, 2, 15, 16, 17, 333, 1024, 3000]))
+        kind = it % 4
+        if kind == 0:
+            key = rs.rand(B, N2, 3)
+        elif kind == 1:
+            key = rs.randn(B, N2, 3) * 0.05 + rs.rand(B, 1, 3) + (rs.rand(B, N2, 1) < 0.3) * rs.rand(B, 1, 3)
+        elif kind == 2:
+            key = rs.rand(B, N2, 3); key[:, :, rs.randint(3)] = 0.3
+        else:
+            key = rs.randint(0, 6, size=(B, N2, 3)) * 0.125   # many exact ties and duplicates
+        key = key.astype(np.float32)
+        if it % 5 == 0:
+            key[:, 0] = 1000.0
+        if rs.rand() < 0.5:
+            q = np.stack([key[b, rs.randint(0, N2, N1)] for b in range(B)])
+        else:
+            q = (rs.rand(B, N1, 3) * 1.4 - 0.2).astype(np.float32)
+        r = float(rs.choice([0.01, 0.05, 0.1, 0.125, 0.2, 0.5, 3.0, 2000.0])); K = int(rs.choice([1, 3, 16, 32, 33, 70]))
+        tq, tk = g(np.ascontiguousarray(q), dev), g(key, dev)
+        ws = torch.empty(B * (16 * N2 + 16512), dtype=torch.uint8, device=dev)
+        idx, dist = torch.empty(B, N1, K, dtype=torch.int64, device=dev), torch.empty(B, N1, K, device=dev)
+        eidx, edist = torch.empty_like(idx), torch.empty_like(dist)
+        L.call('mvp_ball_query_grid_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, r, K, L.ptr(idx), L.ptr(dist), L.ptr(ws), ws.numel())
+        L.call('mvp_ball_query_distance_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, r, K, L.ptr(eidx), L.ptr(edist))
+        tag = 'case {}: B {} N1 {} N2 {} r {} K {} kind {}'.format(it, B, N1, N2, r, K, kind)
+        assert torch.equal(idx, eidx) and torch.equal(dist.view(torch.int32), edist.view(torch.int32)), 'ball query, ' + tag
+        i3, w3, d3 = torch.empty(B, N1, 3, dtype=torch.int64, device=dev), torch.empty(B, N1, 3, device=dev), torch.empty(B, N1, 3, device=dev)
+        e3, ew3, ed3 = torch.empty_like(i3), torch.empty_like(w3), torch.empty_like(d3)
+        L.call('mvp_knn3_grid_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, 1e-10, L.ptr(i3), L.ptr(w3), L.ptr(d3), L.ptr(ws), ws.numel())
+        L.call('mvp_knn3_weights_f32', tq, L.ptr(tq), L.ptr(tk), B, N1, N2, 1e-10, L.ptr(e3), L.ptr(ew3), L.ptr(ed3))
+        assert torch.equal(i3, e3) and torch.equal(d3.view(torch.int32), ed3.view(torch.int32)) and torch.equal(w3.view(torch.int32), ew3.view(torch.int32)), '3-NN, ' + tag
+
+
 def test_knn3_cell_grid_equals_the_sweep(dev):
     """mvp_knn3_grid_f32 (csrc/ball_grid.hip: what knn_distance / knn3_weights / the plan run for >= 2^24 pairs) against the sweep kernel
     mvp_knn3_weights_f32 on the same inputs: index, distance AND weight bit-identical -- sampled volumes and planes, exact duplicates and
