@@ -390,9 +390,14 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __re
   int* sl = slots + (size_t)b * E;
   for (int i = tid; i < N; i += 1024) cnt[i] = 0;
   __syncthreads();
-  for (int64_t e = tid; e < E; e += 1024) {
-    const int64_t j = ix[e];
-    if (j >= 0 && j < N) atomicAdd(&cnt[j], 1);
+  // (four index loads in flight per lane: a pass is a chain of load -> LDS atomic per entry, 64 entries per lane at the 8192-point level)
+  for (int64_t e0 = tid; e0 < E; e0 += 4 * 1024) {
+    int64_t j[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) j[u] = e0 + u * 1024 < E ? ix[e0 + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j[u] >= 0 && j[u] < N) atomicAdd(&cnt[j[u]], 1);
   }
   __syncthreads();
   // exclusive scan of cnt over contiguous runs of `per` points per thread
@@ -419,9 +424,13 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __re
       o[j0 + i + 1] = run;
     }
   __syncthreads();
-  for (int64_t e = tid; e < E; e += 1024) {
-    const int64_t j = ix[e];
-    if (j >= 0 && j < N) sl[atomicAdd(&cnt[j], 1)] = (int)e;
+  for (int64_t e0 = tid; e0 < E; e0 += 4 * 1024) {
+    int64_t j[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) j[u] = e0 + u * 1024 < E ? ix[e0 + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j[u] >= 0 && j[u] < N) sl[atomicAdd(&cnt[j[u]], 1)] = (int)(e0 + u * 1024);
   }
   if (!sorted) return;
   __syncthreads();  // (workgroup-scope: the slots written above are read back below by other lanes of THIS workgroup)
