@@ -294,6 +294,14 @@ def relaunch_under_torchrun(gpus, argv):
     return subprocess.call(cmd, env=env)
 
 
+AUTO_GRAPH_RATIO = float(os.environ.get('MVP_AUTO_GRAPH_RATIO', '0.95'))  # --launch auto: host enqueue / wall time above which the replay is chosen
+AUTO_PROBE_WARM, AUTO_PROBE_STEPS = 3, 8
+
+
+def resolve_launch(args, world):
+    return args.launch or ('graph' if args.graph else ('auto' if world > 1 else 'eager'))
+
+
 def dry_run(args):
     """The multi-rank skeleton of the bench with the device work replaced by a host stand-in: rank / world from the environment, gloo,
     parameter broadcast, `steps` iterations of (stand-in step -> dist.GradSync all-reduce), barrier + MAX-over-ranks timing, the
@@ -368,14 +376,26 @@ def peer_run(args):
     D.broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
     sync = D.GradSync(model.parameters())
-    n = args.warmup + args.steps + (5 if args.graph else 0)
-    for it in range(n):
-        if it == args.warmup or it == args.warmup + args.steps:  # before the timed steps; (--graph: + behind them, before the 5 eager steps)
-            torch.distributed.barrier()
+
+    def one():
         for p in params:
             p.grad = torch.zeros_like(p)
         sync(weight_sum=torch.tensor(1.0))
-    if not args.graph:
+
+    launch = resolve_launch(args, world)
+    use_graph = launch == 'graph'
+    if launch == 'auto':  # the real ranks' probe: its eager steps and the MAX all-reduce of their verdicts (a peer has none of its own)
+        for _ in range(AUTO_PROBE_WARM + AUTO_PROBE_STEPS):
+            one()
+        flag = torch.zeros(1, dtype=torch.float64)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        use_graph = flag.item() > 0
+    n = args.warmup + args.steps + (5 if use_graph else 0)
+    for it in range(n):
+        if it == args.warmup or it == args.warmup + args.steps:  # before the timed steps; (graph: + behind them, before the 5 eager steps)
+            torch.distributed.barrier()
+        one()
+    if not use_graph:
         torch.distributed.barrier()
     tmax = torch.zeros(1, dtype=torch.float64)
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -392,6 +412,9 @@ def main():
     ap.add_argument('--train-only', action='store_true', help='skip the extra forward-only (configs[1]) measurement (profiling runs)')
     ap.add_argument('--graph', action='store_true', help='replay forward + backward from ONE captured HIP graph (mvpnet3d.GraphedTrainStep) instead '
                                                          'of ~400 eager launches; same GPU time on an idle host, immune to a busy one')
+    ap.add_argument('--launch', default='', choices=['', 'eager', 'graph', 'auto'], help='eager | graph (= --graph) | auto: a short eager probe decides -- the graph replay when '
+                    'the host cannot keep up with the GPU (enqueue time > {} of the wall time on any rank), eager otherwise.  Default: auto for N > 1 (eight ranks '
+                    'share one host), eager for N = 1'.format(AUTO_GRAPH_RATIO))
     ap.add_argument('--graph-geometry', default='captured', choices=['eager', 'captured'], help='with --graph: next batch geometry issued eagerly on the side '
                     'stream next to the replay (default) or forked inside the captured graph')
     ap.add_argument('--host-profile', action='store_true', help='cProfile the timed loop (host/launch cost), top entries to stderr')
@@ -472,12 +495,47 @@ def main():
 
     state = {'cur': prefetch_geometry(model, fresh(batch))}
 
-    def eager_step():
+    sync_host = [0.0]  # host time inside the gradient all-reduce (a blocking collective -- gloo -- is not launch cost)
+
+    def timed_sync(**kw):
+        ts = time.perf_counter()
+        grad_sync(**kw)
+        sync_host[0] += time.perf_counter() - ts
+
+    def eager_step(sync=None):
         cur, nxt = state['cur'], fresh(batch)
-        out = train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=grad_sync, next_batch=nxt)
+        out = train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=sync if sync is not None else grad_sync, next_batch=nxt)
         state['cur'] = nxt
         return out
 
+    launch = resolve_launch(args, world)
+    auto_probe = None
+    if launch == 'auto':
+        # Eight ranks share one host: where its cores cannot feed the GPU (enqueue time ~ wall time) the replay -- 8 % slower on an idle
+        # host (its nodes dispatch 20 us apart instead of 7) but immune to a busy one -- is the better mode.  A short eager
+        # probe decides, the same way on every rank (MAX over ranks of the verdicts).
+        for _ in range(AUTO_PROBE_WARM):
+            eager_step()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(AUTO_PROBE_STEPS):
+            eager_step(timed_sync if grad_sync is not None else None)
+        t_host = time.perf_counter() - tp - sync_host[0]
+        torch.cuda.synchronize()
+        t_wall = time.perf_counter() - tp - sync_host[0]
+        # (over gloo -- test set-ups only -- the all-reduce blocks the host until the backward pass has run: host and device alternate whatever
+        # the launch mode, no backlog ever builds up and the ratio says nothing; the verdict is then "eager" unless the threshold is 0)
+        blocking = world > 1 and torch.distributed.get_backend() == 'gloo'
+        verdict = AUTO_GRAPH_RATIO <= 0 or (not blocking and t_host > AUTO_GRAPH_RATIO * t_wall)
+        flag = torch.tensor([1.0 if verdict else 0.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        args.graph = flag.item() > 0
+        auto_probe = {'host_enqueue_ms_per_step': round(t_host / AUTO_PROBE_STEPS * 1e3, 3), 'ms_per_step': round(t_wall / AUTO_PROBE_STEPS * 1e3, 3),
+                      'threshold': AUTO_GRAPH_RATIO, 'chosen': 'graph' if args.graph else 'eager',
+                      'note': 'host time inside the gradient all-reduce left out of both (a blocking collective is not launch cost)'}
+    elif launch == 'graph':
+        args.graph = True
     if not args.graph:
 
         def step():
@@ -715,6 +773,7 @@ def main():
                        'cfg': cfg_name, 'chunks_per_gpu': args.batch, 'points': 8192, 'views': '3x160x120', 'feature_channels': 64, 'k': 3,
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world),
                        'launch': 'hip graph (forward + backward; next-batch geometry {}), optimizer eager'.format(args.graph_geometry) if args.graph else 'eager',
+                       'launch_probe': auto_probe,
                        'contraction': contraction_info()},
             'parity': parity_info(),
             'fp32_mfma': fp32_mfma,

@@ -56,3 +56,18 @@ def test_host_only_peer_ranks(graph):
     out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert not [l for l in out.stdout.splitlines() if l.startswith('{')]  # peers print no result line
+
+
+def test_launch_mode_defaults():
+    """--launch: eager for one rank, the probing mode for N > 1 (eight ranks share a host), --graph / --launch graph the replay; the peer ranks
+    of tools/multi_rank_host.sh resolve it the same way (they mirror the probe's collectives)."""
+    import argparse
+    import bench
+    ns = lambda **kw: argparse.Namespace(**dict(dict(launch='', graph=False), **kw))
+    assert bench.resolve_launch(ns(), 1) == 'eager'
+    assert bench.resolve_launch(ns(), 8) == 'auto'
+    assert bench.resolve_launch(ns(graph=True), 8) == 'graph'
+    assert bench.resolve_launch(ns(launch='eager'), 8) == 'eager'
+    assert bench.resolve_launch(ns(launch='auto'), 1) == 'auto'
+    assert 0.0 <= bench.AUTO_GRAPH_RATIO <= 1.0 and bench.AUTO_PROBE_STEPS > 0
+

@@ -12,15 +12,17 @@ line() { python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('$1', 'ms_per_step', d['ms_per_step'], 'chunks/s(all ranks nominal)', d['value'], 'host_enqueue_ms', d.get('host_enqueue_ms_per_step'))" >> $out; }
+        d = json.loads(l); print('$1', 'ms_per_step', d['ms_per_step'], 'chunks/s(all ranks nominal)', d['value'], 'host_enqueue_ms', d.get('host_enqueue_ms_per_step'), 'launch', d['config'].get('launch', '')[:9], (d['config'].get('launch_probe') or {}).get('chosen', ''))" >> $out; }
 echo "host cores: $(nproc)" >> $out
 one() { python $root/bench.py --steps $steps --warmup 6 --no-cpu-baseline --train-only $2 2>/dev/null | line "$1"; }
 eight() { MVP_REAL_RANKS=1 MVP_DIST_BACKEND=gloo MVP_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 \
             $root/bench.py --gpus 8 --steps $steps --warmup 6 --no-cpu-baseline --train-only --extras none $2 2>$root/gpurun_out/multi_rank_host.err | line "$1"; }
 one "1 rank alone, eager" ""
 one "1 rank alone, graph" "--graph"
-eight "1 real + 7 host peers (gloo), eager" ""
+eight "1 real + 7 host peers (gloo), eager" "--launch eager"
 eight "1 real + 7 host peers (gloo), graph" "--graph"
+eight "1 real + 7 host peers (gloo), auto (the default for N > 1)" ""
+MVP_AUTO_GRAPH_RATIO=0 eight "1 real + 7 host peers (gloo), auto forced to the replay" ""
 # two REAL ranks sharing GPU 0 over gloo: the non-dry N > 1 path end to end (each rank gets half the device: not a throughput number)
-MVP_DIST_BACKEND=gloo MVP_DEVICE=0 python $root/bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --train-only 2>>$root/gpurun_out/multi_rank_host.err | line "2 real ranks on one GPU (gloo), eager"
+MVP_DIST_BACKEND=gloo MVP_DEVICE=0 python $root/bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --train-only 2>>$root/gpurun_out/multi_rank_host.err | line "2 real ranks on one GPU (gloo), auto"
 cat $out
