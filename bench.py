@@ -199,6 +199,21 @@ def dense_extra(dev, chunks=2):
     torch.cuda.synchronize()
     lift_ms = float(np.mean([s.elapsed_time(e) for s, e in pairs]))
     achieved = DENSE_LIFT_BYTES_PER_CHUNK * chunks / (lift_ms * 1e-3) / 1e9
+    # the same launch over 16 chunks (the configuration's whole batch on ONE GPU, the two chunks tiled): what the kernel does at this shape
+    # once a launch holds more than one wave per SIMD -- two chunks are 1024 waves on 1024 SIMDs
+    rep = 8
+    big = [x.repeat(rep, *([1] * (x.dim() - 1))) for x in (feat, depth, kinv, cam, pose, pts, box)]
+    for _ in range(2):
+        ops.lift(big[0], big[1], big[2], big[3], big[4], big[5], k=5, box=big[6])
+    s16, e16 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s16.record()
+    for _ in range(5):
+        ops.lift(big[0], big[1], big[2], big[3], big[4], big[5], k=5, box=big[6])
+    e16.record()
+    torch.cuda.synchronize()
+    lift16_ms = s16.elapsed_time(e16) / 5
+    achieved16 = DENSE_LIFT_BYTES_PER_CHUNK * chunks * rep / (lift16_ms * 1e-3) / 1e9
+    del big
     torch.manual_seed(0)
     net2d = SuppliedFeature2D()
     net2d.feature = feat.view(chunks * dense['nv'], dense['h'], dense['w'], 64).permute(0, 3, 1, 2)
@@ -239,6 +254,8 @@ def dense_extra(dev, chunks=2):
     return {'workload': 'configs[4]: 5 views of 320x240, 32768 points per chunk, k = 5, centroids (8192, 2048, 512, 128); {} chunks on this GPU'.format(chunks),
             'lift': {'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': DENSE_LIFT_BYTES_PER_CHUNK * chunks,
                      'achieved_GBps': round(achieved, 1), 'frac_of_hbm_peak': round(achieved / HBM_PEAK_GBS, 4)},
+            'lift_16_chunks': {'ms_per_launch': round(lift16_ms, 4), 'achieved_GBps': round(achieved16, 1), 'frac_of_hbm_peak': round(achieved16 / HBM_PEAK_GBS, 4),
+                               'note': 'the same launch over the configuration\'s whole batch of 16 chunks (the two chunks tiled) on one GPU: 8 waves per SIMD instead of 1'},
             'fwd_only': {'chunks_per_s_per_gpu': round(chunks / (fwd_ms * 1e-3), 1), 'ms_per_batch': round(fwd_ms, 3)},
             'train_step': {'chunks_per_s_per_gpu': round(chunks / (train_ms * 1e-3), 1), 'ms_per_step': round(train_ms, 3),
                            'note': 'fwd + loss + bwd + Adam, eager; parity: tests/test_dense_gpu.py::test_dense_train_step'},
