@@ -1070,6 +1070,9 @@ class LinearRows(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.slice = (c0, cin, tuple(w_full.shape))
+        # a layer that uses the WHOLE weight once (the segmentation head's last layer: 262 144 x 128 -> 20) may put its weight gradient
+        # beside the chain like the shared-MLP layers do (34 us of the training stream)
+        ctx.dw_use = WeightUse([w_full]) if (DW_SIDE_STREAM and sink is None and c0 == 0 and c1 == w2.size(1) and ctx.needs_input_grad[1]) else None
         return y
 
     @staticmethod
@@ -1094,8 +1097,16 @@ class LinearRows(torch.autograd.Function):
             else:
                 # (on the calling stream: without a sink, autograd adds the gradients of a weight's several slices straight away)
                 gw = zero_pool.zeros(shape, torch.float32, w.device)  # accumulated into; columns outside the slice stay zero
-                L.call('mvp_mlp_weight_grad_f32', gy, L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None, L.ptr_at(gw, c0),
-                       gw.numel() // cout, prec=ctx.prec)
+                wg_args = (L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None, L.ptr_at(gw, c0), gw.numel() // cout)
+                use = ctx.dw_use
+                if use is not None and DW_SIDE_STREAM and use.aside_ok():
+                    # (gw itself must not be kept: AccumulateGrad takes a gradient over as it is only while nobody else holds the tensor --
+                    # otherwise it CLONES it on the calling stream, before the side stream has written it; the parameter's .grad keeps the memory)
+                    side_stream.run(gy.device, 'mvp_mlp_weight_grad_f32', wg_args, (gy, x), prec=ctx.prec)
+                else:
+                    L.call('mvp_mlp_weight_grad_f32', gy, *wg_args, prec=ctx.prec)
+                if use is not None:
+                    use.done = True
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         return gx, gw, gb, None, None, None
