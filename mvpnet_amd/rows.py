@@ -223,6 +223,7 @@ weight_slices = WeightSlices()
 # engine, so .grad is complete on the caller's stream when backward() returns.  Fork and join are plain stream waits: they are captured
 # with the step under a hipGraph.  Measured: DESIGN.md section 5.
 DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
+LINEAR_ASIDE = os.environ.get('MVP_LINEAR_ASIDE', '1') != '0'  # (A/B switch: whole-weight linear layers' weight / bias gradients beside the chain)
 _EXP_SKIP_DW = os.environ.get('MVP_EXP_SKIP_DW', '0') == '1'
 
 
@@ -1072,7 +1073,8 @@ class LinearRows(torch.autograd.Function):
         ctx.slice = (c0, cin, tuple(w_full.shape))
         # a layer that uses the WHOLE weight once (the segmentation head's last layer: 262 144 x 128 -> 20) may put its weight gradient
         # beside the chain like the shared-MLP layers do (34 us of the training stream)
-        ctx.dw_use = WeightUse([w_full]) if (DW_SIDE_STREAM and sink is None and c0 == 0 and c1 == w2.size(1) and ctx.needs_input_grad[1]) else None
+        ctx.bias_param = bias if (bias is not None and bias.is_leaf) else None
+        ctx.dw_use = WeightUse([w_full]) if (DW_SIDE_STREAM and LINEAR_ASIDE and sink is None and c0 == 0 and c1 == w2.size(1) and ctx.needs_input_grad[1]) else None
         return y
 
     @staticmethod
@@ -1083,6 +1085,7 @@ class LinearRows(torch.autograd.Function):
         cout = w.size(0)
         gy = gy.contiguous()
         gx = gw = gb = None
+        aside = False
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None, prec=ctx.prec)
@@ -1099,7 +1102,8 @@ class LinearRows(torch.autograd.Function):
                 gw = zero_pool.zeros(shape, torch.float32, w.device)  # accumulated into; columns outside the slice stay zero
                 wg_args = (L.ptr(gy), L.ptr(x), R, cout, ncol, cin, None, None, None, None, L.ptr_at(gw, c0), gw.numel() // cout)
                 use = ctx.dw_use
-                if use is not None and DW_SIDE_STREAM and use.aside_ok():
+                aside = use is not None and DW_SIDE_STREAM and use.aside_ok()
+                if aside:
                     # (gw itself must not be kept: AccumulateGrad takes a gradient over as it is only while nobody else holds the tensor --
                     # otherwise it CLONES it on the calling stream, before the side stream has written it; the parameter's .grad keeps the memory)
                     side_stream.run(gy.device, 'mvp_mlp_weight_grad_f32', wg_args, (gy, x), prec=ctx.prec)
@@ -1108,7 +1112,17 @@ class LinearRows(torch.autograd.Function):
                 if use is not None:
                     use.done = True
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(0)
+            st = side_stream.streams.get(gy.device)
+            bp = ctx.bias_param
+            if (aside and st is not None and gy.device in side_stream.open and bp is not None and bp.grad is None and not bp._backward_hooks
+                    and not bp._post_accumulate_grad_hooks):
+                # the bias gradient (a column sum of the logits' gradient: 20 us + two dispatch gaps) behind the weight gradient on the side
+                # stream: output allocated here, on the calling stream, which is also where it is read after the join
+                gb = torch.empty(cout, dtype=gy.dtype, device=gy.device)
+                with torch.cuda.stream(st[0]):
+                    torch.sum(gy, 0, out=gb)
+            else:
+                gb = gy.sum(0)
         return gx, gw, gb, None, None, None
 
 
