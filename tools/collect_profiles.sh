@@ -8,6 +8,7 @@ cp $g/end_$run/bench_graph.json profiles/${r}_bench_graph.json
 cp $g/end_$run/bench_prof/*/p_kernel_stats.csv profiles/${r}_bench_kernel_stats.csv 2>/dev/null || cp $(find $g/end_$run/bench_prof -name "*kernel_stats.csv" | head -1) profiles/${r}_bench_kernel_stats.csv
 cp $(find $g/ctr_$run/trace -name "*kernel_stats.csv" | head -1) profiles/${r}_step_kernel_stats.csv
 cp $g/${run}_step_traffic.json profiles/${r}_step_traffic.json
+python tools/traffic_table.py profiles/${r}_step_traffic.json > profiles/${r}_step_rooflines.md
 cp $g/end_$run/step_timeline.txt profiles/${r}_step_timeline.txt
 cp $g/end_$run/step_timeline_graph.txt profiles/${r}_step_timeline_graph.txt
 cp $g/end_$run/multi_rank_host.txt profiles/${r}_multi_rank_host.txt
