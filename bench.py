@@ -296,6 +296,59 @@ def parity_info():
     return out
 
 
+def collective_info(dev=None):
+    """What the collective layer of THIS job actually is, from the job itself: backend, the world size the process
+    group reports, every rank's device as gathered with one all_gather_object, and an all-reduce of ones whose sum must be the world
+    size.  With the `nccl` backend (RCCL on ROCm) the checksum tensor lives on the rank's GPU, so a line that carries
+    {'backend': 'nccl', 'allreduce_of_ones': N, N distinct devices} shows that RCCL moved data between N devices."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    backend = dist.get_backend()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = backend == 'nccl' and dev is not None
+    mine = {'rank': rank, 'pid': os.getpid(), 'host': os.uname().nodename,
+            'device': (torch.cuda.get_device_name(dev) + ' #{}'.format(dev.index)) if (dev is not None and dev.type == 'cuda') else 'cpu',
+            'pci_bus_id': getattr(torch.cuda.get_device_properties(dev), 'pci_bus_id', None) if (dev is not None and dev.type == 'cuda') else None}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    ones = torch.ones(4, dtype=torch.float32, device=dev if on_gpu else 'cpu')
+    dist.all_reduce(ones)
+    info = {'backend': backend, 'world_size': world, 'allreduce_of_ones': float(ones[0].item()), 'allreduce_ok': bool((ones == world).all().item()),
+            'allreduce_tensor_device': str(ones.device), 'ranks': everyone}
+    if backend == 'nccl':
+        try:
+            info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            info['rccl_version'] = None
+    return info
+
+
+SETTLE_BLOCK, SETTLE_MAX_BLOCKS, SETTLE_TOL = 10, 12, 0.01
+
+
+SETTLE_BLOCKS_MULTI = 4   # N > 1: a FIXED number of blocks (every step holds a gradient all-reduce: all ranks must run the same count)
+
+
+def settle(step, fixed_blocks=0):
+    """Part of the set-up, before the contract's warm-up steps: run the step in blocks of 10 until a block is within 1 % of the one before
+    it (at most 120 steps, ~1 s).  On a fresh box the first few dozen steps after the model is built are 2-3 % slower than the steady
+    state -- clocks ramping up from idle, the caching allocator's pools of the three streams reaching their final shape, first use of
+    every kernel's code object (BENCH_r04: 7.448 / 7.299 / 7.252 ms for three identical 20-step regions) -- and the contract's 5 warm-up
+    steps (37 ms) end before that does.  The W warm-up and K timed steps behind this are untouched.  -> (blocks run, ms per step of each)."""
+    hist = []
+    for _ in range(fixed_blocks or SETTLE_MAX_BLOCKS):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(SETTLE_BLOCK):
+            step()
+        torch.cuda.synchronize()
+        hist.append((time.perf_counter() - t) / SETTLE_BLOCK * 1e3)
+        if not fixed_blocks and len(hist) >= 3 and abs(hist[-1] - hist[-2]) <= SETTLE_TOL * hist[-2] and abs(hist[-2] - hist[-3]) <= SETTLE_TOL * hist[-3]:
+            break
+    return [round(h, 3) for h in hist]
+
+
 def relaunch_under_torchrun(gpus, argv):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one process per GPU, rendezvous on
     127.0.0.1 (the container hostname may not resolve) at a free port.  Rank 0 of the child job prints the JSON line."""
@@ -364,13 +417,32 @@ def dry_run(args):
     allc = D.all_gather_logits(local, n_chunks)
     assert [int(allc[c, 0, 0]) for c in range(n_chunks)] == list(range(n_chunks))
     same = all(torch.equal(a, b) for a, b in zip(ref0, [p.detach() for p in params]))
+    coll = collective_info()
+    # the strong-scaling leg (the reference's partition: TRAIN.BATCH_SIZE split over the ranks, train_mvpnet_3d.py:68-70) with the stand-in
+    strong_b = max(1, 32 // world)
+    if world > 1:
+        torch.distributed.barrier()
+    ts = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    s_elapsed = time.perf_counter() - ts
+    if world > 1:
+        tmax = torch.tensor([s_elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        s_elapsed = tmax.item()
     if rank == 0:
         print(json.dumps({'metric': 'chunks/sec (8192 pts, 3x160x120 views) fwd+bwd', 'value': round(batch * world * args.steps / max(elapsed, 1e-9), 3),
                           'unit': 'chunks/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': round(elapsed / max(args.steps, 1) * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                           'vs_baseline': None, 'dtype': 'none', 'data': 'none (dry run: host stand-in, NOT a measurement)',
                           'config': {'workload': 'dry run of the launcher / collectives', 'chunks_per_gpu': batch,
-                                     'parallelism': 'dp{} (gloo)'.format(world)}, 'dry': True, 'params_untouched': same}))
+                                     'parallelism': 'dp{} (gloo)'.format(world)}, 'dry': True, 'params_untouched': same,
+                          'collective': coll,
+                          'strong': {'scaling': 'strong', 'global_batch': strong_b * world, 'chunks_per_gpu': strong_b,
+                                     'value': round(strong_b * world * args.steps / max(s_elapsed, 1e-9), 3),
+                                     'ms_per_step': round(s_elapsed / max(args.steps, 1) * 1e3, 3)}}))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -399,6 +471,9 @@ def peer_run(args):
             p.grad = torch.zeros_like(p)
         sync(weight_sum=torch.tensor(1.0))
 
+    for _ in range(SETTLE_BLOCKS_MULTI * SETTLE_BLOCK):  # the real ranks' set-up steps (bench.settle) and their collective census
+        one()
+    collective_info()
     launch = resolve_launch(args, world)
     use_graph = launch == 'graph'
     if launch == 'auto':  # the real ranks' probe: its eager steps and the MAX all-reduce of their verdicts (a peer has none of its own)
@@ -440,6 +515,9 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='chunks per GPU per step (default: TRAIN.BATCH_SIZE of the config = 32)')
     ap.add_argument('--extras', default='auto', choices=['auto', 'all', 'none'], help='side measurements next to the headline: auto = all of them on '
                     'one GPU, only forward-only + sharded scene inference for N > 1 (the scaling runs stay short)')
+    ap.add_argument('--launch-only-peer', type=float, default=0.0, metavar='SECONDS', help='run the real Python training step in a loop for SECONDS and exit '
+                    'without a result line: with MVP_LIBRARY=mvpnet_amd/libmvp_noop.so (make -C mvpnet_amd/csrc noop) the process issues every '
+                    'library call of the step but no kernel of ours runs -- a launch-only peer that loads the host beside ONE timed rank (tools/multi_rank_host.sh)')
     ap.add_argument('--dry', action='store_true', help='launcher / collective plumbing only: gloo on the host, no kernels (CPU test of the N > 1 path)')
     args = ap.parse_args()
 
@@ -525,6 +603,21 @@ def main():
         state['cur'] = nxt
         return out
 
+    if args.launch_only_peer > 0:
+        # (no collectives, no timing contract: the host side of the step as fast as this process gets to run it)
+        t_end, n, tp = time.perf_counter() + args.launch_only_peer, 0, time.perf_counter()
+        while time.perf_counter() < t_end:
+            eager_step()
+            n += 1
+            if n % 64 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        sys.stderr.write('launch-only peer (library {}): {} steps, {:.3f} ms of host time per step\n'.format(
+            os.path.basename(_lib.LIB_PATH), n, (time.perf_counter() - tp) / max(n, 1) * 1e3))
+        return
+
+    settled = settle(eager_step, SETTLE_BLOCKS_MULTI if world > 1 else 0)   # set-up: the box and the allocator pools reach their steady state BEFORE the contract's warm-up
+    coll = collective_info(dev) if world > 1 else None
     launch = resolve_launch(args, world)
     auto_probe = None
     if launch == 'auto':
@@ -598,7 +691,6 @@ def main():
         for _ in range(5):
             eager_step()
         torch.cuda.synchronize()
-    timer.enabled = False
     assert torch.isfinite(loss).item()
     # spread: the same K steps twice more, untimed for `value` (the contract times exactly K steps above); reported beside it so a reader
     # sees what one 0.15 s measurement is worth on this box (box-to-box differences are larger: DESIGN.md section 5)
@@ -611,10 +703,76 @@ def main():
                 step()
             torch.cuda.synchronize()
             repeats.append(round((time.perf_counter() - tr) / args.steps * 1e3, 3))
+    timer.enabled = False   # (the repeats run exactly what the timed region ran, event pairs around the lifting call included)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = tmax.item()
+
+    # The partition the reference actually trains with (mvpnet/train_mvpnet_3d.py:68-70: DataParallel splits the YAML's
+    # TRAIN.BATCH_SIZE = 32 over the GPUs -> 32 / N chunks per GPU) next to the weak-scaling headline: what ONE step costs at 4 / 8 / 16
+    # chunks on this GPU (N = 1: `per_gpu_batch`), and for N > 1 the same job with a global batch of 32 (`strong`).
+    nv_views = batch['depth'].size(1)
+
+    def measure_batch(B, modes, steps=20, warm=6, sync=None):
+        sub = {k: (v[:B] if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == args.batch else v) for k, v in batch.items()}
+        net2d.feature = feature[:B * nv_views]
+        res = {}
+        try:
+            for mode in modes:
+                if mode == 'eager':
+                    st = {'cur': prefetch_geometry(model, fresh(sub))}
+
+                    def one():
+                        cur, nxt = st['cur'], fresh(sub)
+                        train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=sync, next_batch=nxt)
+                        st['cur'] = nxt
+                else:
+                    from mvpnet_amd.mvpnet3d import GraphedTrainStep
+                    gts = GraphedTrainStep(model, loss_fn, optimizer, fresh(sub), fresh(sub), scheduler=scheduler, grad_sync=sync, geometry=args.graph_geometry)
+
+                    def one():
+                        gts.step(sub, sub)
+                for _ in range(warm):
+                    one()
+                torch.cuda.synchronize()
+                if world > 1:
+                    torch.distributed.barrier()
+                tb = time.perf_counter()
+                for _ in range(steps):
+                    one()
+                th = time.perf_counter() - tb
+                torch.cuda.synchronize()
+                if world > 1:
+                    torch.distributed.barrier()
+                tw = time.perf_counter() - tb
+                if world > 1:
+                    tm = torch.tensor([tw], dtype=torch.float64, device=dev)
+                    torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+                    tw = tm.item()
+                res[mode] = {'ms_per_step': round(tw / steps * 1e3, 3), 'chunks_per_s': round(B * world * steps / tw, 1),
+                             'host_enqueue_ms_per_step': round(th / steps * 1e3, 3)}
+        finally:
+            net2d.feature = feature
+        return res
+
+    per_gpu_batch = None
+    if side and not args.graph:
+        per_gpu_batch = {}
+        for B in (4, 8, 16):
+            if B < args.batch:
+                per_gpu_batch[str(B)] = measure_batch(B, ('eager', 'graph'))
+        per_gpu_batch['note'] = ('one train step (fwd + loss + bwd + Adam, next batch geometry prefetched) at B chunks on ONE GPU = what a rank of an N-GPU job runs when the '
+                                 "reference's global batch of 32 is split over N = 32 / B GPUs; eager and replayed from one HIP graph; chunks_per_s is per GPU")
+    strong = None
+    if world > 1 and args.batch // world >= 1 and not args.train_only:
+        sb = args.batch // world
+        r = measure_batch(sb, ('graph' if args.graph else 'eager',), steps=args.steps, warm=max(args.warmup, 3), sync=grad_sync)
+        r = r['graph' if args.graph else 'eager']
+        strong = {'scaling': 'strong', 'global_batch': sb * world, 'chunks_per_gpu': sb, 'value': r['chunks_per_s'], 'ms_per_step': r['ms_per_step'],
+                  'host_enqueue_ms_per_step': r['host_enqueue_ms_per_step'],
+                  'note': "the reference's partition: TRAIN.BATCH_SIZE = {} chunks split over the {} ranks (train_mvpnet_3d.py:68-70), one gradient all-reduce per "
+                          'step; the top-level value is the weak-scaling mode ({} chunks per GPU)'.format(sb * world, world, args.batch)}
 
     # configs[1] (forward only, eval mode) on the same resident batch: reported as an extra field.  Like the training loop, a real
     # inference loop over a scene's chunk batches starts the coordinate-only work of batch i+1 while batch i runs.
@@ -791,7 +949,11 @@ def main():
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world),
                        'launch': 'hip graph (forward + backward; next-batch geometry {}), optimizer eager'.format(args.graph_geometry) if args.graph else 'eager',
                        'launch_probe': auto_probe,
+                       'settle_ms_per_step': settled,   # set-up blocks of 10 steps run BEFORE the warm-up (bench.settle): not part of W or K
                        'contraction': contraction_info()},
+            'collective': coll,
+            'strong': strong,
+            'per_gpu_batch': per_gpu_batch,
             'parity': parity_info(),
             'fp32_mfma': fp32_mfma,
             'bf16_contraction': bf16_contraction,

@@ -489,6 +489,11 @@ MVP_API int mvp_ball_query_grid_f32(const float* query, const float* key, int64_
   const int rows = (int)grid_rows(N2);
   const size_t lds = (size_t)kQueriesPerWg * rows * kLanesPerQuery * sizeof(uint4);
   dim3 grid((unsigned)cdiv(N1, kQueriesPerWg), (unsigned)B);
+  if (lds > 48 * 1024) {  // N2 beyond 24576 keys: above the default dynamic-LDS limit, raised explicitly as fps.hip does
+    const void* k = distance ? reinterpret_cast<const void*>(ball_grid_query_kernel<true>) : reinterpret_cast<const void*>(ball_grid_query_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   if (distance)
     hipLaunchKernelGGL(ball_grid_query_kernel<true>, grid, dim3(kQueryThreads), lds, s, query, key, (int)N1, (int)N2, r2, (int)K, heads, starts,
                        sorted, rows, index, distance);

@@ -607,7 +607,7 @@ __device__ __forceinline__ fps_u64 load_device(const fps_u64* p) {
 template <int D, int PPT, int NT, int W>
 __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out,
                                                               fps_u64* __restrict__ xch /* [B][2][W][64][8] zero on entry */, int* __restrict__ err,
-                                                              int spin_limit) {
+                                                              int* __restrict__ report, int spin_limit) {
   static_assert(PPT % 2 == 0 && NT == 1024, "16 waves, points in pairs");
   constexpr int NR = NT / 16;  // 64 rows per workgroup = one resolver lane per super row
   constexpr int NP = PPT / 2;
@@ -762,7 +762,8 @@ __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __res
       if (__ballot(dead)) {
         if (lane == 0) {
           npick[2] = 1;
-          if (err) *err = 1;
+          if (err) *err = 1;  // this call's own word: the guard of the repair launch queued behind
+          if (report) atomicOr(report, 1);  // the caller's sticky status word: reporting only
         }
       }
       const float v = __uint_as_float(hi);
@@ -846,9 +847,11 @@ int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, h
 
 // The W workgroups of a cloud wait for each other, and an ordinary launch does not promise that they are resident together (the launch is
 // capped at 64 workgroups, but other streams may hold the CUs).  A workgroup that polls `g_fps_spin_limit` times in vain sets the flag
-// (`status` when the caller gave one -- sticky, never cleared here -- else a word of the call's scratch) and leaves -1 in its rows; the
-// ONE-workgroup kernel is queued right behind with the flag as its guard: it returns at once when the flag is 0 and re-samples every cloud
-// of the call when it is not.  The indices a caller reads are therefore the exact chain in either case, and the flag tells that it happened.
+// (a word of THIS call's scratch, zeroed by the call) and leaves -1 in its rows; the ONE-workgroup kernel is queued right behind with that
+// word as its guard: it returns at once when the word is 0 and re-samples every cloud of the call when it is not.  The caller's `status`
+// word is reporting only (sticky, OR-ed into, never read here): a time-out of an earlier call does not make later calls run the repair
+// kernel, and a caller clearing it on another stream cannot switch a pending repair off.  The indices a caller reads are the
+// exact chain in either case, and the status word tells that it happened.
 template <int D, int PPT, int W>
 int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int* status, hipStream_t s) {
   const size_t lds = 32 * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
@@ -864,7 +867,7 @@ int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64
     (void)hipGetLastError();
     rc = MVP_EINVAL;
   }
-  int* err = status ? status : reinterpret_cast<int*>(scratch + xbytes - 16);
+  int* err = reinterpret_cast<int*>(scratch + xbytes - 16);
   if (rc == MVP_OK) {
     auto k = fps_rounds_multi_kernel<D, PPT, 1024, W>;
     if (lds > 48 * 1024) {
@@ -873,7 +876,7 @@ int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64
     }
     if (rc == MVP_OK) {
       hipLaunchKernelGGL(k, dim3((unsigned)(B * W)), dim3(1024), lds, s, pts, (int)N, (int)M, out, reinterpret_cast<fps_u64*>(scratch), err,
-                         g_fps_spin_limit);
+                         status, g_fps_spin_limit);
       rc = mvp_launch_status();
     }
     if (rc == MVP_OK)  // the repair launch (a no-op unless the flag is set)

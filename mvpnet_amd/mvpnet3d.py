@@ -154,9 +154,11 @@ class MVPNet3D(nn.Module):
             plan = self.net_3d.plan_geometry(pts_rows, stream=self._side_stream(pts_rows.device))
         images = data_batch['images']  # (B,nv,3,h,w)
         b, nv, _, h, w = images.shape
-        pre = data_batch.get('_feature_2d')
-        if pre is not None:  # the frozen 2D network already ran for this batch on its own stream (prefetch_features_2d)
-            feature_2d, ev = pre
+        # consumed exactly once (a batch dict that is reused must not feed a stale map to a later step, nor keep the tensor pinned), and only
+        # while the branch is still what it was when the map was made: frozen (an unfrozen branch must run in-line to get its gradient)
+        pre = data_batch.pop('_feature_2d', None) if isinstance(data_batch, dict) else None
+        if pre is not None and net_2d_is_frozen(self) and pre[0].size(0) == b * nv:
+            feature_2d, ev = pre  # the frozen 2D network already ran for this batch on its own stream (prefetch_features_2d)
             torch.cuda.current_stream(feature_2d.device).wait_event(ev)
         else:
             feature_2d = self.net_2d({'image': images.reshape(b * nv, *images.shape[2:])})['feature']  # (B*nv,C,h,w)

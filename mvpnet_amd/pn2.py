@@ -280,8 +280,14 @@ class FeaturePropagation(nn.Module):
             l0 = self.mlp[0]
             c1 = l0.conv.weight.size(0)
             c2 = sparse_feature.size(2)
+            if tail is not None:
+                # can the chain take the tail?  Decided BEFORE any work: the first layer below updates its BatchNorm's running statistics,
+                # so a refusal after it would make the caller's second call update them twice
+                chain = list(self.mlp) + list(tail[0])
+                if not (len(tail[0]) == 1 and R.mlp_chain_is_fused(chain) and tail[0][0].bn.training == l0.bn.training):
+                    return None
             if l0.bn is not None and l0.relu is not None and l0.conv.bias is None and l0.bn.running_mean is not None and \
-                    c1 % 4 == 0 and 256 % (c1 // 4) == 0 and c2 % 4 == 0:
+                    l0.bn.momentum is not None and c1 % 4 == 0 and 256 % (c1 // 4) == 0 and c2 % 4 == 0:
                 # The first shared-MLP layer is linear and so is the interpolation:
                 #   W1.[interp(f_sparse) | f_dense] = interp(W1a.f_sparse) + W1b.f_dense
                 # -> the wide GEMM runs on the M = N/4 sparse points; the interpolation kernel adds the skip part and emits
@@ -304,11 +310,8 @@ class FeaturePropagation(nn.Module):
                 if bn_training:
                     y1, stat1 = y1[0], (y1[1], y1[2])
                 if tail is not None:
-                    chain = list(self.mlp) + list(tail[0])
-                    if len(tail[0]) == 1 and R.mlp_chain_is_fused(chain) and tail[0][0].bn.training == bn_training:
-                        return R.shared_mlp_rows(y1.view(B * N, c1), chain, first_done=True, first_stat=stat1, dropout_p=tail[0].p, training=tail[1],
-                                                 dropout_last_only=True).view(B, N, -1)
-                    return None
+                    return R.shared_mlp_rows(y1.view(B * N, c1), chain, first_done=True, first_stat=stat1, dropout_p=tail[0].p, training=tail[1],
+                                             dropout_last_only=True).view(B, N, -1)
                 return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1).view(B, N, -1)
             if tail is not None:
                 return None

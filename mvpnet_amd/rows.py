@@ -693,7 +693,12 @@ def bn_act_rows(y, bn, relu=True, K=1):
     training = bn.training or bn.running_mean is None
     if bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if bn.momentum is not None:
+        momentum = bn.momentum
+    elif bn.training and bn.num_batches_tracked is not None:
+        momentum = 1.0 / float(bn.num_batches_tracked)  # momentum None = cumulative moving average (nn.BatchNorm); one host read on this rare path
+    else:
+        momentum = 0.0
     return BNActRows.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                            relu, K)
 
@@ -1330,8 +1335,11 @@ def sa_fused_eval(zf, xyz, centre, index, mlp):
 def mlp_chain_is_fused(mlp, dropout_p=0.0):
     """True when `mlp` (a SharedMLP) runs as ONE MLPChainRows node: conv without bias + BatchNorm with running statistics + ReLU
     in every layer, widths the rows kernels tile (C % 4 == 0 and C / 4 divides 256), dropout only behind a single layer."""
+    # (bn.momentum None = PyTorch's cumulative moving average, factor 1 / num_batches_tracked: the kernels take one fixed factor, so such
+    # layers keep the per-layer torch path -- ADVICE r4)
     return (dropout_p == 0 or len(mlp) == 1) and \
-        all(l.bn is not None and l.relu is not None and l.conv.bias is None and l.bn.running_mean is not None for l in mlp) and \
+        all(l.bn is not None and l.relu is not None and l.conv.bias is None and l.bn.running_mean is not None and l.bn.momentum is not None
+            for l in mlp) and \
         all(l.conv.weight.size(0) % 4 == 0 and 256 % (l.conv.weight.size(0) // 4) == 0 for l in mlp)
 
 

@@ -35,29 +35,41 @@ def _adam_reference(params, grads, lr=2e-3, betas=(0.9, 0.999), eps=1e-8):
     return out
 
 
-def oracle_step(sdn, bt, B, class_weight, dtype=torch.float32):
-    """forward + loss + backward of the oracle graph on the host.  dtype float64: the same graph in double with the index sets
-    (FPS, ball query, 3-NN, pixel k-NN) decided in fp32 exactly as in the fp32 run."""
-    from oracle import torch_model as OM
-    from oracle import c_oracle as O
-    sub = {k: bt[k][:B] for k in ('depth_mm', 'kinv', 'pose', 'pixel_box', 'points', 'seg_label', 'feature_2d')}
-    xyz, mask, knn = OM.lifting(sub, 3)
-    points = torch.from_numpy(np.ascontiguousarray(sub['points'].transpose(0, 2, 1)))
-    nv, h, w, c = sub['feature_2d'].shape[1:]
-    feat = torch.from_numpy(np.ascontiguousarray(np.moveaxis(sub['feature_2d'], -1, 2))).reshape(-1, c, h, w)
-    real = dict(fps=O.fps, ball=O.ball_query, knn3=O.knn3)
-    if dtype == torch.float64:
+class fp32_decided_geometry:
+    """While active, the C oracle's index-producing ops (FPS, ball query, 3-NN) decide in float32 whatever precision the graph around them
+    runs in -- the float64 evaluation of a graph then uses exactly the neighbourhoods of the fp32 run (3-NN distances re-evaluated in
+    double from the fp32-chosen neighbours): the "truth" both fp32 implementations approximate."""
+
+    def __enter__(self):
+        from oracle import c_oracle as O
+        self.O = O
+        real = self.real = dict(fps=O.fps, ball=O.ball_query, knn3=O.knn3)
         O.fps = lambda p, m: real['fps'](p.astype(np.float32), m)
         O.ball_query = lambda q, k, r, K, with_distance=False: real['ball'](q.astype(np.float32), k.astype(np.float32), r, K, with_distance)
 
         def knn3_64(q, k):
             i, d = real['knn3'](q.astype(np.float32), k.astype(np.float32))
-            # squared distances in double from the fp32-chosen neighbours
             qq, kk = q.astype(np.float64), k.astype(np.float64)
             d64 = np.stack([((qq - np.take_along_axis(kk, i[:, :, j:j + 1].repeat(3, 2), 1)) ** 2).sum(-1) for j in range(3)], -1)
             return i, d64
         O.knn3 = knn3_64
-    try:
+        return self
+
+    def __exit__(self, *exc):
+        self.O.fps, self.O.ball_query, self.O.knn3 = self.real['fps'], self.real['ball'], self.real['knn3']
+
+
+def oracle_step(sdn, bt, B, class_weight, dtype=torch.float32):
+    """forward + loss + backward of the oracle graph on the host.  dtype float64: the same graph in double with the index sets
+    (FPS, ball query, 3-NN, pixel k-NN) decided in fp32 exactly as in the fp32 run."""
+    from oracle import torch_model as OM
+    sub = {k: bt[k][:B] for k in ('depth_mm', 'kinv', 'pose', 'pixel_box', 'points', 'seg_label', 'feature_2d')}
+    xyz, mask, knn = OM.lifting(sub, 3)
+    points = torch.from_numpy(np.ascontiguousarray(sub['points'].transpose(0, 2, 1)))
+    nv, h, w, c = sub['feature_2d'].shape[1:]
+    feat = torch.from_numpy(np.ascontiguousarray(np.moveaxis(sub['feature_2d'], -1, 2))).reshape(-1, c, h, w)
+    import contextlib
+    with (fp32_decided_geometry() if dtype == torch.float64 else contextlib.nullcontext()):
         sd = {}
         for k, v in sdn.items():
             t = torch.from_numpy(v.copy())
@@ -70,8 +82,6 @@ def oracle_step(sdn, bt, B, class_weight, dtype=torch.float32):
                                             training=True, return_stages=True, update_running=True)
         loss = OM.seg_loss(logit, torch.from_numpy(sub['seg_label']), weight=torch.from_numpy(class_weight).to(dtype))
         loss.backward()
-    finally:
-        O.fps, O.ball_query, O.knn3 = real['fps'], real['ball'], real['knn3']
     grads = collections.OrderedDict((k, v.grad.detach()) for k, v in sd.items() if v.requires_grad and v.grad is not None)
     running = collections.OrderedDict((k, v.detach()) for k, v in sd.items() if 'running' in k)
     return {'logit': logit.detach(), 'loss': loss.detach(), 'grads': grads, 'running': running, 'knn': knn,

@@ -32,6 +32,15 @@ def test_bench_launches_itself(n):
         assert k in line, k
     assert line['n_gpus'] == n and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak' and line['dry'] is True
     assert line['params_untouched'] is True  # broadcast made the ranks equal to rank 0, nothing else wrote the parameters
+    # both scaling modes and the evidence of the collective layer in the line itself
+    st = line['strong']
+    assert st['scaling'] == 'strong' and st['chunks_per_gpu'] == max(1, 32 // n) and st['global_batch'] == st['chunks_per_gpu'] * n and st['value'] > 0
+    co = line['collective']
+    if n == 1:
+        assert co is None
+    else:
+        assert co['backend'] == 'gloo' and co['world_size'] == n and co['allreduce_of_ones'] == n and co['allreduce_ok'] is True
+        assert sorted(r['rank'] for r in co['ranks']) == list(range(n)) and len({r['pid'] for r in co['ranks']}) == n
 
 
 def test_bench_under_an_external_launcher():

@@ -183,29 +183,47 @@ def test_dense_train_step(dev):
         _, _, knn, _, _ = lift(g(bt['feature_2d'], dev), batch['depth'], batch['kinv'], batch['cam_matrix'], batch['pose'],
                                g(bt['points'], dev), k=k, box=batch['pixel_box'], return_image_xyz=True)
     exyz, _ = c_oracle.unproject(bt['depth_mm'].astype(np.float32) / np.float32(1000.), bt['kinv'], bt['pose'], bt['pixel_box'])
-    sd = {}
-    for kk, v in sdn.items():
-        t = torch.from_numpy(v.copy())
-        if t.is_floating_point() and 'running' not in kk:
-            t.requires_grad_(True)
-        sd[kk] = t
+    from tests.operating_point import fp32_decided_geometry
     points = torch.from_numpy(np.ascontiguousarray(bt['points'].transpose(0, 2, 1)))
     feat = torch.from_numpy(np.ascontiguousarray(np.moveaxis(bt['feature_2d'], -1, 2))).reshape(-1, c, h, w)
-    elogit = OM.mvpnet3d_forward(sd, points, feat, torch.from_numpy(exyz), knn.cpu(), training=True, num_centroids=CENTROIDS)
-    eloss = OM.seg_loss(elogit, torch.from_numpy(bt['seg_label']), weight=torch.from_numpy(class_weight))
-    eloss.backward()
+
+    def host_graph(dtype):
+        """the oracle graph on the host in `dtype`; float64 = the same graph in double on the fp32-decided neighbourhoods (the arbiter)"""
+        sd = {}
+        for kk, v in sdn.items():
+            t = torch.from_numpy(v.copy())
+            if t.is_floating_point():
+                t = t.to(dtype)
+                if 'running' not in kk:
+                    t.requires_grad_(True)
+            sd[kk] = t
+        elogit = OM.mvpnet3d_forward(sd, points.to(dtype), feat.to(dtype), torch.from_numpy(exyz).to(dtype), knn.cpu(), training=True,
+                                     num_centroids=CENTROIDS)
+        eloss = OM.seg_loss(elogit, torch.from_numpy(bt['seg_label']), weight=torch.from_numpy(class_weight).to(dtype))
+        eloss.backward()
+        return elogit.detach(), eloss.detach(), sd
+
+    elogit, eloss, sd = host_graph(torch.float32)
+    with fp32_decided_geometry():
+        tlogit, tloss, sd64 = host_graph(torch.float64)
     logit = preds['seg_logit'].detach().cpu()
-    err = float((logit - elogit.detach()).abs().max())
-    print('dense train step: logits max err {:.2e} (mean |logit| {:.2f}), loss {:.6f} vs {:.6f}'.format(err, float(elogit.abs().mean()), float(loss), float(eloss)))
-    assert err <= 1e-3                                     # train-mode BatchNorm at B = 2 (see test_config0_pn2ssg_chunk_yaml)
-    np.testing.assert_allclose(float(loss), float(eloss), rtol=1e-4)
+    gap = lambda a, b: float((a.double() - b.double()).abs().max())
+    mgap = lambda a, b: float((a.double() - b.double()).abs().mean())
+    err, mine, host = gap(logit, elogit), gap(logit, tlogit), gap(elogit, tlogit)
+    print('dense train step: logits GPU vs host fp32 {:.2e}, GPU vs float64 {:.2e} (mean {:.2e}), host fp32 vs float64 {:.2e} (mean {:.2e}); mean |logit| {:.2f}, '
+          'loss {:.6f} vs {:.6f} (float64 {:.6f})'.format(err, mine, mgap(logit, tlogit), host, mgap(elogit, tlogit), float(tlogit.abs().mean()), float(loss),
+                                                         float(eloss), float(tloss)))
+    # VERDICT r4 next #6c: the float64 value of the graph arbitrates (tests/operating_point.py), as at the B = 32 operating point -- within
+    # 1e-4 of the reference arithmetic, or as close to the exact value as the host fp32 path is (max <= 1.5x, mean <= 2x)
+    assert err <= 1e-4 or mine <= 1.5 * host, (err, mine, host)
+    assert mgap(logit, tlogit) <= 2.0 * mgap(elogit, tlogit) + 1e-7
+    assert abs(float(loss) - float(tloss)) <= 2.0 * abs(float(eloss) - float(tloss)) + 2e-5 * abs(float(tloss))
     named = dict(model.named_parameters())
     rel = lambda a, e: float((a.double().reshape(e.shape) - e.double()).norm() / e.double().norm().clamp_min(1e-30))
-    worst = 0.0
-    for name in ('feat_aggreg.mlp.0.conv.weight', 'net_3d.sa_modules.0.mlp.0.conv.weight', 'net_3d.sa_modules.0.mlp.2.conv.weight',
-                 'net_3d.sa_modules.1.mlp.1.conv.weight', 'net_3d.sa_modules.3.mlp.2.conv.weight', 'net_3d.fp_modules.3.mlp.0.conv.weight',
-                 'net_3d.mlp_seg.0.conv.weight', 'net_3d.seg_logit.weight', 'net_3d.sa_modules.0.mlp.1.bn.weight'):
-        r = rel(named[name].grad.cpu(), sd[name].grad)
-        worst = max(worst, r)
-        assert r <= 4e-2, (name, r)   # (the host fp32 path itself is ~1-2 % from float64 on these gradients: tests/operating_point.py)
-    print('dense train step: worst weight-gradient relative L2 vs the host fp32 graph {:.2e}'.format(worst))
+    worst = (0.0, 0.0)
+    for name, p in named.items():                          # EVERY parameter gradient, the R = 524 288 / M = 8192 code paths included
+        ref = sd64[name].grad
+        r, r_host = rel(p.grad.cpu(), ref), rel(sd[name].grad, ref)
+        worst = max(worst, (r, r_host))
+        assert r <= max(2.0 * r_host, 1e-4), (name, r, r_host)   # no worse than 2x the host fp32 path's own error against float64
+    print('dense train step: worst weight-gradient relative L2 vs float64 {:.2e} (the host fp32 graph on that tensor: {:.2e})'.format(*worst))

@@ -105,6 +105,60 @@ def test_pn2ssg_small(dev, mode):
         np.testing.assert_allclose(net.sa_modules[0].mlp[0].bn.running_mean.cpu().numpy(), g['train_running_mean_sa0_0'], rtol=1e-4, atol=1e-6)
 
 
+def test_refused_head_merge_runs_the_last_level_once(dev):
+    """PN2SSG hands the segmentation head to the last propagation level as the tail of its chain; a head the chain
+    cannot take (two layers here) used to be refused only AFTER the level's first layer had run -- the caller's second call then updated
+    that layer's BatchNorm running statistics twice per step.  The refusal is decided before any work now: every BatchNorm of the level
+    advances exactly once, and the logits equal the same network with the merge switched off."""
+    from mvpnet_amd import pn2
+    from mvpnet_amd.pn2 import PN2SSG
+    torch.manual_seed(3)
+    net = PN2SSG(0, 20, dropout_prob=0.0, seg_channels=(64, 32), **CFG).to(dev).train()
+    chunks = [make_chunk(30 + b, nb_pts=1024, nv=2, h=30, w=40, channels=8, with_feature=False) for b in range(2)]
+    points = torch.from_numpy(np.stack([c['points'].T for c in chunks])).to(dev)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    out = net({'points': points})['seg_logit'].detach().clone()
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    assert bns and all(int(m.num_batches_tracked) == 1 for m in bns), [int(m.num_batches_tracked) for m in bns]
+    rm = net.fp_modules[-1].mlp[0].bn.running_mean.clone()
+    net.load_state_dict(sd0)
+    old, pn2.MERGE_HEAD = pn2.MERGE_HEAD, False
+    try:
+        ref = net({'points': points})['seg_logit'].detach()
+    finally:
+        pn2.MERGE_HEAD = old
+    torch.testing.assert_close(out, ref, rtol=0, atol=0)
+    torch.testing.assert_close(rm, net.fp_modules[-1].mlp[0].bn.running_mean, rtol=0, atol=0)
+
+
+def test_cumulative_average_batchnorm_keeps_the_torch_path(dev):
+    """bn.momentum None means a cumulative moving average (factor 1 / num_batches_tracked) in PyTorch; the fused kernels
+    take one fixed factor, so such layers must not take them.  Two training steps of a SetAbstraction level on two feature tensors: the
+    first layer's running mean is the plain average of the two batch means of its pre-BN output (float64 restatement of the layer)."""
+    from mvpnet_amd.pn2 import SetAbstraction
+    from mvpnet_amd import rows as R
+    torch.manual_seed(5)
+    sa = SetAbstraction(8, (16, 16, 32), 64, 0.4, 32, True).to(dev).train()
+    for l in sa.mlp:
+        l.bn.momentum = None
+    assert not R.mlp_chain_is_fused(sa.mlp)
+    xyz = torch.rand(2, 512, 3, device=dev)
+    geo = sa.geometry(xyz)
+    new_xyz, ball = geo[0], geo[1]
+    w1 = sa.mlp[0].conv.weight.detach().double().reshape(16, -1)
+    means = []
+    for _ in range(2):
+        feat = torch.rand(2, 512, 8, device=dev)
+        sa(xyz, feat, rows=True, geometry=geo)
+        idx = ball.reshape(2, -1)
+        gx = torch.gather(xyz.double(), 1, idx.unsqueeze(-1).expand(-1, -1, 3)).view(2, 64, 32, 3) - new_xyz.double().unsqueeze(2)
+        gf = torch.gather(feat.double(), 1, idx.unsqueeze(-1).expand(-1, -1, 8)).view(2, 64, 32, 8)
+        means.append((torch.cat([gf, gx], 3).reshape(-1, 11) @ w1.t()).mean(0))
+    bn = sa.mlp[0].bn
+    assert int(bn.num_batches_tracked) == 2
+    torch.testing.assert_close(bn.running_mean.double(), (means[0] + means[1]) / 2, rtol=1e-5, atol=1e-6)
+
+
 def geometry_chain(points, num_centroids, radius, max_neighbors):
     from mvpnet_amd import ops
     from mvpnet_amd.nn import batch_index_select
@@ -625,6 +679,7 @@ def test_frozen_image_branch_prefetched_on_its_own_stream(dev):
             M.prefetch_features_2d(model, b)
             assert '_feature_2d' in b
         preds = model(b)
+        assert '_feature_2d' not in b   # consumed by the forward (a reused batch dict must not carry a stale map)
         loss = loss_fn(preds, b)['seg_loss']
         loss.backward()
         torch.cuda.synchronize()
@@ -641,10 +696,18 @@ def test_frozen_image_branch_prefetched_on_its_own_stream(dev):
         torch.cuda.current_stream().wait_event(b['_feature_2d'][1])
         ref = model.net_2d({'image': batch['images'].reshape(B * 3, 3, 120, 160)})['feature']
         torch.testing.assert_close(b['_feature_2d'][0], ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
-    # a training image branch is not prefetched
+    # a training image branch is not prefetched, and a map prefetched while the branch was still frozen is dropped once it trains
+    # (the in-line branch must run to take its gradient)
+    stale = dict(batch)
+    M.prefetch_features_2d(model, stale)
+    assert '_feature_2d' in stale
     model.net_2d.unfreeze()
     model.train()
     assert not M.net_2d_is_frozen(model)
     b = dict(batch)
     M.prefetch_features_2d(model, b)
     assert '_feature_2d' not in b
+    model.zero_grad(set_to_none=True)
+    loss_fn(model(stale), stale)['seg_loss'].backward()
+    assert '_feature_2d' not in stale
+    assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in model.net_2d.parameters())

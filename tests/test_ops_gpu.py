@@ -25,6 +25,35 @@ def O():
     return c_oracle
 
 
+class entry_points:
+    """Records which libmvp_hip.so entry points run inside the block (the names as `_lib.call` / `_lib.call_on` resolve them): the tests that
+    are the INDEPENDENT coverage of a routed kernel (float64 torch / CPU oracle) assert that the shape really took it, so a changed routing
+    threshold cannot silently un-test a kernel (VERDICT r4 next #6a)."""
+
+    def __enter__(self):
+        from mvpnet_amd import _lib as L
+        self.L, self.names = L, []
+        self.orig = (L.call, L.call_on)
+        orig_call, orig_on, names = L.call, L.call_on, self.names
+
+        def call(name, *a, **k):
+            names.append(name)
+            return orig_call(name, *a, **k)
+
+        def call_on(stream, name, *a, **k):
+            names.append(name)
+            return orig_on(stream, name, *a, **k)
+
+        L.call, L.call_on = call, call_on
+        return self
+
+    def __exit__(self, *exc):
+        self.L.call, self.L.call_on = self.orig
+
+    def ran(self, prefix):
+        return any(n.startswith(prefix) for n in self.names)
+
+
 def g(a, dev, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dtype is not None:
@@ -181,7 +210,13 @@ def test_ball_query_vs_oracle(dev, B, N1, N2, r, K):
     key = rs.rand(B, N2, 3).astype(np.float32)
     q = np.stack([key[b, rs.choice(N2, N1, replace=False)] for b in range(B)])
     q[:, 0] = 50.0  # a query with no neighbour at all: row must be -1
-    idx, dist = ball_query_distance(g(q, dev), g(key, dev), r, K, transpose=False)
+    with entry_points() as ep:
+        idx, dist = ball_query_distance(g(q, dev), g(key, dev), r, K, transpose=False)
+    # the level-1 shape of the reference network is this test's oracle case of the cell-grid kernel, the others of the sweep kernel
+    from mvpnet_amd import _lib as L
+    assert ep.ran('mvp_ball_query_grid_f32') == (L.lib().mvp_ball_query_grid_workspace(B, N1, N2) > 0), ep.names
+    assert ep.ran('mvp_ball_query_grid_f32') or (N1, N2) != (2048, 8192), ep.names
+    assert ep.ran('mvp_ball_query_distance_f32') or (N1, N2) != (512, 2048), ep.names
     eidx, edist = O().ball_query(q, key, r, K, with_distance=True)
     np.testing.assert_array_equal(idx.cpu().numpy(), eidx)
     np.testing.assert_array_equal(dist.cpu().numpy(), edist)
@@ -231,7 +266,11 @@ def _grid_clouds():
     q, key = uniform(2, 8192, 512, scale=np.array([100.0, 0.5, 0.5]))
     out.append(('one long axis', q, key, 0.1, 32))
     q, key = uniform(1, 32768, 4099)
-    out.append(('largest cloud', q, key, 0.05, 32))
+    out.append(('largest cloud', q, key, 0.05, 32))      # 64 KB of dynamic LDS per workgroup (the explicit attribute)
+    q, key = uniform(2, 2048, 700)
+    out.append(('smallest cloud', q, key, 0.2, 32))      # N2 = 2048: the lower end of the shape rule
+    q, key = uniform(1, 24577, 333)
+    out.append(('just above 48 KB of bitmap', q, key, 0.05, 16))
     q, key = uniform(2, 8192, 300)
     for r in (0.0, -0.1, 1e-30, 1e20, 0.5, float('nan')):
         out.append(('radius {}'.format(r), q, key, r, 16))
@@ -370,6 +409,14 @@ def test_knn3_cell_grid_equals_the_sweep(dev):
         assert torch.equal(idx, eidx), name
         assert torch.equal(d.view(torch.int32), ed.view(torch.int32)), name
         assert torch.equal(w.view(torch.int32), ew.view(torch.int32)), name
+        if name in ('lattice', 'every key twice', 'non-finite', 'queries outside'):
+            # ... and directly against the CPU oracle (VERDICT r4 next #6b: the grid kernel's own oracle cases -- ties on a lattice and on
+            # duplicated keys go to the lower key index, test_knn_distance.py:7-23 / knn_distance_kernel.cu:94-107).  Rows of a query with a
+            # non-finite coordinate are left out: every distance is NaN / inf there and the reference's result is its initial value.
+            oidx, odist = O().knn3(np.ascontiguousarray(qq), np.ascontiguousarray(kk))
+            ok = np.isfinite(qq).all(-1)
+            np.testing.assert_array_equal(idx.cpu().numpy()[ok], oidx[ok], err_msg=name)
+            np.testing.assert_array_equal(d.cpu().numpy()[ok], odist[ok], err_msg=name)
     assert L.lib().mvp_knn3_grid_workspace(32, 8192, 2048) == 32 * (16 * 2048 + 16512) and L.lib().mvp_knn3_grid_workspace(1, 2048, 512) == 0
 
 
@@ -380,7 +427,10 @@ def test_knn_vs_oracle(dev, B, N1, N2, dt):
     from mvpnet_amd.ops import knn_distance
     rs = np.random.RandomState(N1 * 7 + N2)
     q, key = rs.rand(B, N1, 3).astype(dt), rs.rand(B, N2, 3).astype(dt)
-    idx, dist = knn_distance(g(q, dev), g(key, dev), 3, transpose=False)
+    with entry_points() as ep:
+        idx, dist = knn_distance(g(q, dev), g(key, dev), 3, transpose=False)
+    # (8192 queries among 2048 keys in float32 = the finest propagation level: this test's oracle case of the grid 3-NN kernel)
+    assert ep.ran('mvp_knn3_grid_f32') == ((N1, N2) == (8192, 2048) and dt == np.float32), ep.names
     eidx, edist = O().knn3(q, key)
     np.testing.assert_array_equal(idx.cpu().numpy(), eidx)
     np.testing.assert_array_equal(dist.cpu().numpy(), edist)
@@ -1649,13 +1699,20 @@ def test_set_abstraction_against_float64_reference(dev, cin, widths, N, M, train
     new_xyz, ball = geo[0], geo[1]
     assert int(ball.min()) >= 0
     gout = torch.randn(B, M, widths[-1], device=dev)
-    if training:
-        _, out = sa(xyz, feat, rows=True, geometry=geo)
-        out.backward(gout)
-        torch.cuda.synchronize()
-    else:
-        with torch.no_grad():
+    with entry_points() as ep:
+        if training:
             _, out = sa(xyz, feat, rows=True, geometry=geo)
+            out.backward(gout)
+            torch.cuda.synchronize()
+        else:
+            with torch.no_grad():
+                _, out = sa(xyz, feat, rows=True, geometry=geo)
+    # which kernels this case is the independent coverage OF: levels 1 / 2 of the reference network take the fused training passes
+    # (csrc/sa_train.hip) resp. the fused inference level (csrc/sa_fused.hip); the featureless and the 128-wide level the per-layer kernels
+    fusable = cin == 64
+    assert ep.ran('mvp_sa_train_forward_f32') == (training and fusable) and ep.ran('mvp_sa_train_backward_f32') == (training and fusable), ep.names
+    assert ep.ran('mvp_sa_train_backward1_f32') == (training and fusable) and ep.ran('mvp_sa_train_stats1_f32') == (training and fusable), ep.names
+    assert ep.ran('mvp_sa_fused_forward_f32') == ((not training) and widths[2] <= 128), ep.names
     ref, f64, ws = _sa_reference_f64(sa, xyz, feat, new_xyz, ball, training)
     scale = float(ref.abs().max())
     err = float((out.double() - ref).abs().max())
@@ -2014,7 +2071,35 @@ def test_multi_workgroup_sampler_times_out_loudly_and_is_repaired(dev):
     finally:
         L.lib().mvp_fps_debug_spin_limit(old)
     np.testing.assert_array_equal(idx.cpu().numpy(), exp)       # repaired by the one-workgroup kernel
-    assert L.fps_timed_out(dev, reset=True)                      # ... and reported
+    assert L.fps_timed_out(dev)                                  # ... and reported (sticky: not reset here)
+    # the caller's word is REPORTING only -- the repair launch is guarded by the call's own scratch word.  With the sticky
+    # word still 1 a healthy call must not run the one-workgroup repair (5x the time), and a caller that clears the word on another
+    # stream while a timed-out call is in flight cannot switch that call's repair off.
+    def timed():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.farthest_point_sample(pts, 700, transpose=False)
+        a.record()
+        out = ops.farthest_point_sample(pts, 700, transpose=False)
+        b.record()
+        torch.cuda.synchronize()
+        return out, a.elapsed_time(b)
+    idx, t_sticky = timed()                                      # status word is 1, no time-out
+    np.testing.assert_array_equal(idx.cpu().numpy(), exp)
+    old = L.lib().mvp_fps_debug_spin_limit(1)
+    try:
+        side = torch.cuda.Stream()
+        idx2 = ops.farthest_point_sample(pts, 700, transpose=False)   # times out, repaired ...
+        with torch.cuda.stream(side):
+            L.fps_status(dev).zero_()                                 # ... whatever happens to the caller's word meanwhile
+        torch.cuda.synchronize()
+    finally:
+        L.lib().mvp_fps_debug_spin_limit(old)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), exp)
+    L.fps_timed_out(dev, reset=True)
+    idx, t_clear = timed()
+    np.testing.assert_array_equal(idx.cpu().numpy(), exp)
+    assert t_sticky < 1.6 * t_clear, 'a healthy call behind a sticky status word ran the repair kernel ({:.3f} vs {:.3f} ms)'.format(t_sticky, t_clear)
+    L.fps_timed_out(dev, reset=True)
     # the raw entry point without the repair's guard set: status stays 0, nothing is re-sampled
     idx = ops.farthest_point_sample(pts, 700, transpose=False)
     np.testing.assert_array_equal(idx.cpu().numpy(), exp)
