@@ -378,7 +378,9 @@ int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t*
 /* The K = 1 forms with DROPOUT behind the activation (SharedMLPDO: Conv + BN + ReLU + Dropout, common/nn/modules/mlp.py:86-92; the
  * reference runs nn.Dropout as its own pass and keeps the mask): out = act(bn(y)) * keep / (1 - drop_p) with keep a counter-based hash of
  * (seed, row * C + column) that forward and backward regenerate -- no mask tensor.  0 <= drop_p < 1, R * C < 2^32.  Independent
- * Bernoulli(1 - drop_p) per element like torch's, not the same random stream. */
+ * Bernoulli(1 - drop_p) per element like torch's, not the same random stream.
+ * mvp_bn_rows_backward[_dropout]_f32 with K = 1 and dy == NULL: only `stat` (the two BatchNorm-backward column sums) is produced -- the
+ * caller forms dy itself (mvp_mlp_layer_backward_wide_p_f32, mode 2). */
 int mvp_bn_rows_forward_dropout_f32(const float* y, const float* gamma, const float* beta, int64_t R, int64_t C, int training, float eps,
                                     float momentum, int relu, float* running_mean, float* running_var, double* stat, float* mean,
                                     float* invstd, float* out, double* partial, float drop_p, uint64_t seed, mvp_stream_t stream);
@@ -541,6 +543,34 @@ int mvp_mlp_layer_backward_ws_f32(const float* G, const float* Yi, const float* 
                                const float* W, int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ,
                                double* stat_prev, double* partial, const float* pool_dout, const float* pool_out,
                                const uint8_t* pool_arg, float* workspace, int64_t workspace_floats, mvp_stream_t stream);
+/* One-pass backward of a shared-MLP layer with up to 128 channels on either side (csrc/mlp_bwd_wide.hip, round 5): what
+ * mvp_mlp_layer_backward_f32 computes -- BatchNorm-backward finish of layer i, dW_i, dz_{i-1} with the ReLU mask and the two
+ * BatchNorm-backward column sums of layer i-1 -- with the row tile staged in LDS (64 rows per persistent workgroup, transpose reads feed
+ * the dW contraction): 2 C + 2 Cp floats of HBM traffic per row at 128 channels, where the register-resident kernel has to slice c_in.
+ * Replaces autograd through common/nn/modules/conv.py:41-51 for the 128-wide layers of mvpnet/models/pn2/pn2ssg.py:69-82,101-118.
+ *   mode 0: G (R,C) is dy_i itself (Yi, mean_i .. stat_i unused);
+ *   mode 1: G is dz_i = the gradient w.r.t. layer i's activation, ReLU mask applied: dy_i = gamma_i*invstd_i * (dz_i - stat_i[c]/R -
+ *           xhat_i * stat_i[C+c]/R), xhat_i from Yi (training = 0 drops the batch terms);
+ *   mode 2: G is da_i = the gradient w.r.t. the layer's OUTPUT -- after its ReLU and, with drop_p > 0, after the dropout of
+ *           mvp_bn_rows_forward_dropout_f32(drop_p, drop_seed) -- dz_i is formed while the rows are loaded (keep mask regenerated, ReLU mask
+ *           from Yi, beta_i needed), then as mode 1; stat_i = the sums mvp_bn_rows_backward[_dropout]_f32 leaves with dy == NULL.
+ *   dgamma_i / dbeta_i (C, may be NULL; modes 1, 2) <- stat_i[C + c] / stat_i[c].
+ *   X (R,ldx) = y_{i-1} with act_* (all four) = BatchNorm + ReLU of layer i-1, or the plain layer input with act_* NULL;
+ *   dW (C,lddw) += dy_i^T . input;  dZ (R,Cp) = (dy_i . W) [* relu'(bn_{i-1}(y_{i-1}))];  stat_prev (2 Cp, with act_*) += the column
+ *   sums of dZ and dZ * xhat_{i-1} (fp64 atomics, one per column and workgroup: no reduction launch).
+ *   ticket: one zeroed int32 of caller memory, or NULL.  With it the workgroups take their tiles in ticket order, so a CU that another
+ *           stream keeps busy costs its share of the tiles instead of a second round; NULL = static round-robin.
+ *   workspace / workspace_floats: as mvp_mlp_layer_backward_ws_f32 (reproducible weight gradient: ordered reduction, static tile order);
+ *           NULL / 0 = fp32 atomics.
+ *   precision / precision_backward: as every `_p_f32` entry point (-1 = the process defaults).  Needs a 1- or 2-piece backward split
+ *   (bf16 / bf16x3), C, Cp <= 128, C % 4 == Cp % 4 == ldx % 4 == 0, 16-byte aligned G / Yi / X / dZ: MVP_EUNSUPPORTED otherwise (callers
+ *   then take mvp_mlp_layer_backward_f32 or the three separate entry points). */
+int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                      const float* beta_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, int mode,
+                                      float drop_p, uint64_t drop_seed, const float* X, int64_t ldx, const float* act_mean,
+                                      const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
+                                      int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
+                                      float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
 /* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
  * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,

@@ -135,6 +135,9 @@ for _n in ['mvp_mlp_forward_f32', 'mvp_mlp_forward_bn_f32', 'mvp_mlp_forward_rel
            'mvp_mlp_weight_grad_f32', 'mvp_mlp_weight_grad_ws_f32', 'mvp_mlp_layer_backward_f32', 'mvp_mlp_layer_backward_ws_f32',
            'mvp_sa_fused_forward_f32', 'mvp_sa_train_forward_f32', 'mvp_sa_train_backward_f32']:
     _SIGNATURES[_n[:-4] + '_p_f32'] = _SIGNATURES[_n][:-1] + [ctypes.c_int, ctypes.c_int, _ptr]
+# (precision as arguments from the start: there is no process-default twin of this one)
+_SIGNATURES['mvp_mlp_layer_backward_wide_p_f32'] = [_ptr] * 9 + [ctypes.c_int, ctypes.c_int, _f32, ctypes.c_uint64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
+                                                    _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_ball_query_grid_workspace', 'mvp_knn3_grid_workspace', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
            'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode', 'mvp_fps_debug_spin_limit'] + sorted(_SIGNATURES)
 
@@ -353,11 +356,28 @@ _DW_WS = {}
 _DW_WS_NAMES = {'mvp_mlp_weight_grad_f32': 'mvp_mlp_weight_grad_ws_f32', 'mvp_mlp_layer_backward_f32': 'mvp_mlp_layer_backward_ws_f32'}
 
 
-def _with_dw_workspace(index, stream_handle, args):
+def dw_workspace(index, stream_handle):
+    """The weight-gradient workspace of (device, stream) in the reproducible mode (a kernel and its reduction run in order on that stream)."""
     ws = _DW_WS.get((index, stream_handle))
     if ws is None:
         ws = _DW_WS[(index, stream_handle)] = torch.empty(lib().mvp_mlp_weight_grad_workspace_floats(), dtype=torch.float32,
                                                           device=torch.device('cuda', index))
+    return ws
+
+
+def current_dw_workspace(device):
+    """(pointer, floats) of the calling stream's weight-gradient workspace in the reproducible mode, (None, 0) otherwise: for entry points
+    that take the workspace as plain arguments (mvp_mlp_layer_backward_wide_p_f32)."""
+    if not DW_WORKSPACE:
+        return None, 0
+    index = device.index
+    handle = _raw_stream(index) if (_raw_stream is not None and index == _raw_device()) else torch.cuda.current_stream(device).cuda_stream
+    ws = dw_workspace(index, handle)
+    return ws.data_ptr(), ws.numel()
+
+
+def _with_dw_workspace(index, stream_handle, args):
+    ws = dw_workspace(index, stream_handle)
     return args + (ws.data_ptr(), ws.numel())
 
 

@@ -1,0 +1,430 @@
+// mlp_bwd_wide.hip -- the whole backward of ONE 128-wide shared-MLP layer (pointwise conv + BatchNorm + ReLU on rows, C_out, C_in <= 128)
+// in one pass over its tensors, for gfx950.  Reference: autograd through common/nn/modules/conv.py:41-51 for the layers of
+// mvpnet/models/pn2/pn2ssg.py:69-82,101-118 with 128 channels (the last propagation level, the segmentation head, level 3's middle layer).
+//
+// What it replaces.  The per-layer path makes three passes and a reduction launch per layer,
+//     dy_i     = gamma*invstd * (dz_i - dbeta/R - xhat_i * dgamma/R)       bn_rows_bwd_kernel      reads dz_i, y_i        writes dy_i
+//     dz_{i-1} = (dy_i . W_i) * relu'(bn(y_{i-1})) (+ two column sums)      mlp_fwd_kernel<WT>      reads dy_i, y_{i-1}    writes dz_{i-1}
+//     dW_i    += dy_i^T . a_{i-1}                                           mlp_dw_bf_kernel        reads dy_i, y_{i-1}    (side stream)
+// = 5 C_i + 3 C_{i-1} floats per row, the last two sharing the chip and the HBM (each takes ~1.7x its time alone).  The register-resident
+// one-kernel backward of mlp_bwd.hip reads each tensor once but keeps one wave's 32 rows of everything in registers: at 128 channels it
+// needs c_in slicing (dy_i re-read) and runs at one wave per SIMD -- measured slower than the three kernels in rounds 2, 3 and 4.
+//
+// Decomposition here: the TILE lives in LDS, not in registers.  A persistent workgroup of 8 waves takes 64 rows at a time:
+//   P1  every thread turns its 16-byte pieces of dz_i / y_i / y_{i-1} (full 512-byte rows per wave instruction, prefetched one tile ahead)
+//       into dy_i and a_{i-1}, splits them into bf16 pieces and writes them ROW-MAJOR into LDS (8 bytes per piece and lane);
+//   P2  wave w contracts  dX[32 rows, 32 c_in]   = dy . W        over c_out: A = 16-byte row fragments of dy, B = the resident W image,
+//                    and  dW[32 c_out, 64 c_in] += dy^T . a      over the 64 rows: both operands need "8 rows of one channel" per lane --
+//       read from the SAME row-major images with ds_read_b64_tr_b16, the CDNA4 transpose read (4 x 4 bf16 blocks come back transposed):
+//       no second copy of dy in LDS, no register transposes;
+//   P3  the dX tile goes through LDS (it aliases the dy image) to become full rows;
+//   P4  every thread meets ITS y_{i-1} values (still in registers) again: ReLU mask, xhat, the two BatchNorm-backward column sums of layer
+//       i-1, 16-byte streaming stores of dz_{i-1}.
+// dW stays in accumulator registers for the whole kernel (2 tiles of 32 x 32 per wave) and is flushed once per workgroup.
+// Traffic: 2 C_i + 2 C_{i-1} floats per row.  LDS: W image 68 KB + dy 34 KB + a 34 KB (2 pieces) = 136 KB: one workgroup per CU, 2 waves
+// per SIMD; tiles are handed out through a ticket so that a CU that is busy with another stream's workgroup (the sampler holds 16 CUs
+// for a millisecond beside the backward pass) costs its share of the tiles, not a second round.
+#include "mlp_common.h"
+#include "dropout.h"
+#include <algorithm>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kWT = 512;    // threads: 8 waves
+constexpr int kTR = 64;     // rows per tile
+constexpr int kWCh = 128;   // channel capacity on both sides
+constexpr int kRowB = 272;  // bytes per LDS image row: 128 bf16 + 16 bytes of padding (see the bank notes at the W image)
+
+struct WideArgs {
+  const float* G;        // (R, C): dy_i (mode 0), dz_i (mode 1) or da_i = gradient w.r.t. the layer's (dropped-out) activation (mode 2)
+  const float* Yi;       // (R, C) pre-BN output of layer i (modes 1, 2)
+  const float* mean_i;
+  const float* invstd_i;
+  const float* gamma_i;
+  const float* beta_i;   // mode 2 (the ReLU mask is re-created from Yi)
+  const double* stat_i;  // (2 C): column sums of dz_i and dz_i * xhat_i
+  float* dgamma_i;       // (C) <- stat_i[C + c] / (C) <- stat_i[c], may be null
+  float* dbeta_i;
+  float inv_rows;        // 1 / R with batch statistics, 0 with running statistics
+  int mode;
+  Dropout drop;          // mode 2: keep mask of the dropout behind layer i (thresh 0 = none)
+  const float* X;        // (R, ldx): y_{i-1}
+  int ldx;
+  InAct act;             // BatchNorm + ReLU of layer i-1 (mean == nullptr: X is the plain input)
+  const float* W;        // (C, ldw)
+  int ldw;
+  float* dW;             // (C, lddw) accumulated into
+  int lddw;
+  float* ws;             // nullptr: fp32 atomics; else this launch's partial tiles (dw_reduce_kernel<4, 4> adds them in order)
+  float* dZ;             // (R, Cp)
+  double* stat_prev;     // (2 Cp) accumulated into (fp64 atomics, one per column and workgroup); nullptr without act
+  int* ticket;           // zero on entry: tiles beyond the first of each workgroup are taken by ticket; nullptr: static round-robin
+  int64_t R;
+  int C, Cp, ntiles;
+};
+
+__device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {  // ds_read_b64_tr_b16: lane p of a 16-lane group supplies 8 bytes, gets column p of the 4 x 16 block
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <int NS>
+__global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
+  using SP = SplitPairs<NS>;
+  constexpr int kWimg = kWCh * kRowB;   // 32 KB per piece
+  constexpr int kTimg = kTR * kRowB;    // 16 KB per piece
+  constexpr int oW = 0, oDy = NS * kWimg, oA = oDy + NS * kTimg, oMisc = oA + NS * kTimg, oCst = oMisc + 64;  // + 11 x 128 column constants
+  static_assert(2 * NS * kTimg >= kTR * kWCh * 4, "the dX staging tile aliases the dy / a images");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int* misc = reinterpret_cast<int*>(lds + oMisc);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int c4 = tid & 31, cc = 4 * c4, rbase = tid >> 5;  // this thread's 4 columns and its rows rbase + 16 j of every tile
+  const int C = p.C, Cp = p.Cp;
+  const bool has_act = p.act.mean != nullptr;
+  const bool cok = cc < C, xok = cc < Cp;
+
+  // ---- W_i -> LDS once: image[piece][c_in][c_out] (B operand of dX: lane = c_in, 8 consecutive c_out per 16-byte slot).
+  // Banks: every image row is 272 bytes = 17 slots of 16 bytes, so (a) the 16 lanes that a ds_read_b128 serves together -- 16 different rows,
+  // one slot index -- land on 16 different slots of the 256-byte bank row, and (b) rows r, r + 4, r + 8, r + 12 start 64 bytes apart
+  // (mod 256), which is what the transpose reads of P2b use: each of their 32-lane groups takes 64 bytes of four such rows.  Plain padding
+  // instead of an XOR permutation keeps every LDS address of the tile loop "per-lane base + immediate".
+  for (int t = tid; t < kWCh * 32; t += kWT) {
+    const int ci = t & 127, cq = t >> 7, co = 4 * cq;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (co + e < C && ci < Cp) ? p.W[(size_t)(co + e) * p.ldw + ci] : 0.f;
+    unsigned a[NS], b[NS];
+    split_pair<NS>(v[0], v[1], a);
+    split_pair<NS>(v[2], v[3], b);
+#pragma unroll
+    for (int pc = 0; pc < NS; ++pc)
+      *reinterpret_cast<uint2*>(lds + oW + pc * kWimg + ci * kRowB + cq * 8) = make_uint2(a[pc], b[pc]);
+  }
+  if (p.mode != 0 && p.dgamma_i && blockIdx.x == 0)
+    for (int col = tid; col < C; col += kWT) {
+      p.dbeta_i[col] = (float)p.stat_i[col];
+      p.dgamma_i[col] = (float)p.stat_i[C + col];
+    }
+  // ---- column constants -> LDS (11 x 128 floats): kept in registers they are 44 of the 256 a wave has at two waves per SIMD; P1 and P4 read
+  // their 16-byte pieces per tile instead.  [0] mean_i [1] invstd_i [2] gamma_i*invstd_i [3] dbeta/R [4] dgamma/R [5] gamma_i [6] beta_i
+  // [7..10] mean / invstd / gamma / beta of layer i-1
+  {
+    float* cst = reinterpret_cast<float*>(lds + oCst);
+    for (int t = tid; t < 11 * kWCh; t += kWT) {
+      const int k = t >> 7, col = t & 127;
+      float v = 0.f;
+      if (k < 7) {
+        if (p.mode != 0 && col < C) {
+          const float isd = p.invstd_i[col], gam = p.gamma_i[col];
+          v = k == 0 ? p.mean_i[col] : k == 1 ? isd : k == 2 ? gam * isd : k == 3 ? (float)p.stat_i[col] * p.inv_rows
+              : k == 4 ? (float)p.stat_i[C + col] * p.inv_rows : k == 5 ? gam : (p.mode == 2 ? p.beta_i[col] : 0.f);
+        }
+      } else if (has_act && col < Cp) {
+        v = k == 7 ? p.act.mean[col] : k == 8 ? p.act.invstd[col] : k == 9 ? p.act.gamma[col] : p.act.beta[col];
+      }
+      cst[t] = v;
+    }
+  }
+  f32x16 accw[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accw[b][i] = 0.f;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, tsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = p.ntiles, step = (int)gridDim.x;
+  f32x4 gq[4], yq[4], xq[4];
+  auto load_tile = [&](int t) {  // the thread's pieces of tile t (rows past R clamped: their values are masked in P1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = min((int64_t)t * kTR + rbase + 16 * j, p.R - 1);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      gq[j] = cok ? *reinterpret_cast<const f32x4*>(p.G + (size_t)r * C + cc) : z;
+      yq[j] = (cok && p.mode != 0) ? *reinterpret_cast<const f32x4*>(p.Yi + (size_t)r * C + cc) : z;
+      xq[j] = xok ? *reinterpret_cast<const f32x4*>(p.X + (size_t)r * p.ldx + cc) : z;
+    }
+  };
+  int cur = (int)blockIdx.x;
+  if (tid == 0) misc[0] = p.ticket ? step + atomicAdd(p.ticket, 1) : cur + step;
+  if (cur < ntiles) load_tile(cur);
+  __syncthreads();  // W image complete, first ticket visible
+  int nxt = misc[0];
+  for (int it = 0; cur < ntiles; ++it) {
+    unsigned char* const L = lds;
+    float* const stage = reinterpret_cast<float*>(L + oDy);
+    // ---- P1: dy_i and a_{i-1} of this thread's 16 elements -> bf16 pieces -> the row-major LDS images
+    f32x4 xk[4];
+    const f32x4* cst = reinterpret_cast<const f32x4*>(L + oCst) + c4;
+    const f32x4 mu = cst[0 * 32], is = cst[1 * 32], sc = cst[2 * 32], db = cst[3 * 32], dg = cst[4 * 32], ga = cst[5 * 32], be = cst[6 * 32];
+    f32x4 pm = cst[7 * 32], pi = cst[8 * 32], pg = cst[9 * 32], pb = cst[10 * 32];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rbase + 16 * j;
+      const int64_t grow = (int64_t)cur * kTR + r;
+      const bool rok = grow < p.R;
+      float d[4], a[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = gq[j][e];
+        if (p.mode != 0) {
+          const float xh = (yq[j][e] - mu[e]) * is[e];
+          if (p.mode == 2) {
+            if (p.drop.thresh) v *= p.drop.factor((unsigned)(grow * C + cc + e));
+            v = (xh * ga[e] + be[e] > 0.f) ? v : 0.f;
+          }
+          v = sc[e] * ((v - db[e]) - xh * dg[e]);
+        }
+        d[e] = (rok && cok) ? v : 0.f;
+        float x = xq[j][e];
+        if (has_act) {
+          const float z = ((x - pm[e]) * pi[e]) * pg[e] + pb[e];
+          x = z > 0.f ? z : 0.f;
+        }
+        a[e] = (rok && xok) ? x : 0.f;
+      }
+      xk[j] = xq[j];
+      unsigned d0[NS], d1[NS], a0[NS], a1[NS];
+      split_pair<NS>(d[0], d[1], d0);
+      split_pair<NS>(d[2], d[3], d1);
+      split_pair<NS>(a[0], a[1], a0);
+      split_pair<NS>(a[2], a[3], a1);
+      const int off = r * kRowB + c4 * 8;
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) {
+        *reinterpret_cast<uint2*>(L + oDy + pc * kTimg + off) = make_uint2(d0[pc], d1[pc]);
+        *reinterpret_cast<uint2*>(L + oA + pc * kTimg + off) = make_uint2(a0[pc], a1[pc]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the prefetch must not be hoisted above the consumption of the current tile's registers: twice the registers)
+    if (nxt < ntiles) load_tile(nxt);  // in flight under P2 .. P4
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid == 0) misc[(it + 1) & 1] = p.ticket ? step + atomicAdd(p.ticket, 1) : nxt + step;
+    __syncthreads();
+    const int after = misc[(it + 1) & 1];
+
+    // ---- P2a: dX[32 rb .. +31][32 cb .. +31] = sum over c_out of dy . W   (8 steps of 16 c_out)
+    f32x16 accz;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accz[i] = 0.f;
+    {
+      const int rb = wave >> 2, cb = wave & 3;
+      const int ar = 32 * rb + n, br = 32 * cb + n;
+      const unsigned char* pa = L + oDy + ar * kRowB + h * 16;
+      const unsigned char* pbw = L + oW + br * kRowB + h * 16;
+      // one step's fragments are requested while the step before is in the matrix pipe (two sets of 4 x 16 bytes)
+      u32x4 fa[2][NS], fb[2][NS];
+      auto frag = [&](int ks, int buf) {
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) {
+          fa[buf][pc] = *reinterpret_cast<const u32x4*>(pa + pc * kTimg + ks * 32);
+          fb[buf][pc] = *reinterpret_cast<const u32x4*>(pbw + pc * kWimg + ks * 32);
+        }
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) frag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int qd = 0; qd < SP::N; ++qd)
+          accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][SP::A[qd]]), __builtin_bit_cast(bf16x8, fb[ks & 1][SP::B[qd]]),
+                                                         accz, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- P2b: dW[32 a .. +31][32 b .. +31] += sum over the tile's rows of dy^T . a   (4 steps of 16 rows; both operands by transpose read)
+    {
+      const int a = wave >> 1, b0 = 2 * (wave & 1);
+      const int grp = lane >> 4, q = lane & 15, hh = grp >> 1, cg = grp & 1;
+      // step ks, lane half hh, read j2 take rows 16 ks + 2 hh + j2 + {0, 4, 8, 12} (any 16 distinct rows per step do, as long as both operands
+      // agree: k is a summation index) -- four rows whose 64-byte pieces tile the 64 banks; this lane SUPPLIES the 8 bytes of row
+      // .. + 4 (q >> 2), columns 32 block + 16 cg + 4 (q & 3) .. + 3, and receives column 16 cg + q of the four rows
+      const int lrow = (2 * hh + 4 * (q >> 2)) * kRowB + (16 * cg + 4 * (q & 3)) * 2;
+      const unsigned char* pA = L + oDy + lrow + 32 * a * 2;
+      const unsigned char* pB = L + oA + lrow + 32 * b0 * 2;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 fa[NS], fb[2][NS];
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) {
+          uint2 lo[3], hi[3];
+#pragma unroll
+          for (int j2 = 0; j2 < 2; ++j2) {
+            const int o = pc * kTimg + (16 * ks + j2) * kRowB;
+            const uint2 va = lds_tr16(pA + o), vb0 = lds_tr16(pB + o), vb1 = lds_tr16(pB + o + 64);
+            if (j2 == 0) { lo[0] = va; lo[1] = vb0; lo[2] = vb1; } else { hi[0] = va; hi[1] = vb0; hi[2] = vb1; }
+          }
+          fa[pc] = u32x4{lo[0].x, lo[0].y, hi[0].x, hi[0].y};
+          fb[0][pc] = u32x4{lo[1].x, lo[1].y, hi[1].x, hi[1].y};
+          fb[1][pc] = u32x4{lo[2].x, lo[2].y, hi[2].x, hi[2].y};
+        }
+#pragma unroll
+        for (int qd = 0; qd < SP::N; ++qd)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+            accw[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[SP::A[qd]]), __builtin_bit_cast(bf16x8, fb[bb][SP::B[qd]]),
+                                                               accw[bb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();  // every wave is done reading the dy / a images
+    // ---- P3: the dX tile (lane = column, registers = rows) -> full rows in LDS (aliases the images)
+    {
+      const int rb = wave >> 2, cb = wave & 3;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) stage[(32 * rb + 8 * (i >> 2) + 4 * h + (i & 3)) * kWCh + 32 * cb + n] = accz[i];
+    }
+    __syncthreads();
+    // ---- P4: ReLU mask of layer i-1, its two BatchNorm-backward column sums, streaming stores
+    pm = cst[7 * 32]; pi = cst[8 * 32]; pg = cst[9 * 32]; pb = cst[10 * 32];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rbase + 16 * j;
+      const int64_t grow = (int64_t)cur * kTR + r;
+      f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * kWCh + cc);
+      if (has_act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xk[j][e] - pm[e]) * pi[e];
+          float d = (xh * pg[e] + pb[e] > 0.f) ? v[e] : 0.f;
+          d = (grow < p.R && xok) ? d : 0.f;
+          v[e] = d;
+          ssum[e] += d;
+          tsum[e] += d * xh;
+        }
+      }
+      if (grow < p.R && xok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.dZ + (size_t)grow * Cp + cc));
+    }
+    __syncthreads();  // the staging tile is the next tile's dy image
+    cur = nxt;
+    nxt = after;
+  }
+
+  // ---- column sums of dz_{i-1}: 16 threads per column quadruple -> LDS -> one fp64 atomic per column and workgroup
+  if (p.stat_prev) {
+    double* sred = reinterpret_cast<double*>(lds + oDy);  // [2][16][128]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sred[(0 * 16 + rbase) * kWCh + cc + e] = (double)ssum[e];
+      sred[(1 * 16 + rbase) * kWCh + cc + e] = (double)tsum[e];
+    }
+    __syncthreads();
+    if (tid < 2 * kWCh) {
+      const int which = tid >> 7, col = tid & 127;
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += sred[(which * 16 + k) * kWCh + col];
+      if (col < Cp) atomicAdd(p.stat_prev + which * Cp + col, s);
+    }
+  }
+  // ---- dW: one flush per workgroup
+  {
+    const int a = wave >> 1, b0 = 2 * (wave & 1);
+    if (p.ws) {  // layout of dw_reduce_kernel<4, 4>: (split = workgroup, blocks in (a, b) order, register, lane)
+      float* t = p.ws + (size_t)blockIdx.x * (16 * 1024);
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(accw[bb][i], t + ((a * 4 + b0 + bb) * 16 + i) * 64 + lane);
+    } else {
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int ci = 32 * (b0 + bb) + n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = 32 * a + 8 * (i >> 2) + 4 * h + (i & 3);
+          if (co < C && ci < Cp) atomicAdd(p.dW + (size_t)co * p.lddw + ci, accw[bb][i]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// One-pass backward of shared-MLP layer i with up to 128 channels on either side (see the top of the file and include/mvp_hip.h).
+MVP_API int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                              const float* beta_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, int mode,
+                                              float drop_p, uint64_t drop_seed, const float* X, int64_t ldx, const float* act_mean,
+                                              const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
+                                              int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
+                                              float* workspace, int64_t workspace_floats, int precision, int precision_backward,
+                                              mvp_stream_t stream) {
+  MVP_NONNULL(G);
+  MVP_NONNULL(X);
+  MVP_NONNULL(W);
+  MVP_NONNULL(dW);
+  MVP_NONNULL(dZ);
+  MVP_REQUIRE(mode >= 0 && mode <= 2);
+  if (mode != 0) {
+    MVP_NONNULL(Yi);
+    MVP_NONNULL(mean_i);
+    MVP_NONNULL(invstd_i);
+    MVP_NONNULL(gamma_i);
+    MVP_NONNULL(stat_i);
+    if (mode == 2) MVP_NONNULL(beta_i);
+    if (dgamma_i) MVP_NONNULL(dbeta_i);
+  }
+  if (act_mean) {
+    MVP_NONNULL(act_invstd);
+    MVP_NONNULL(act_gamma);
+    MVP_NONNULL(act_beta);
+    MVP_NONNULL(stat_prev);
+  }
+  MVP_REQUIRE(R >= 0 && C > 0 && Cp > 0 && ldx >= Cp && ldw >= Cp && lddw >= Cp && R < (1ll << 31) * kTR);
+  MVP_REQUIRE((precision == -1 || precision == 0 || precision == 1 || precision == 3 || precision == 6) &&
+              (precision_backward == -1 || precision_backward == 1 || precision_backward == 3 || precision_backward == 6));
+  const int terms = precision >= 0 ? precision : mlp_terms();
+  const int bwd = precision_backward >= 0 ? precision_backward : mlp_terms_bwd();
+  const int ns = terms == 0 ? 0 : (bwd == 6 ? 3 : bwd == 1 ? 1 : 2);
+  // 16-byte row pieces: every row of G / Yi / X / dZ must start on a 16-byte boundary and hold whole quadruples
+  if (ns == 0 || ns == 3 || C > kWCh || Cp > kWCh || C % 4 || Cp % 4 || ldx % 4 || ((uintptr_t)G | (uintptr_t)X | (uintptr_t)dZ | (uintptr_t)Yi) % 16)
+    return MVP_EUNSUPPORTED;
+  Dropout drop;
+  if (make_dropout(mode == 2 ? drop_p : 0.f, drop_seed, R, C, 1, &drop) != MVP_OK) return MVP_EINVAL;
+  if (R == 0) return MVP_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WideArgs a;
+  a.G = G; a.Yi = Yi; a.mean_i = mean_i; a.invstd_i = invstd_i; a.gamma_i = gamma_i; a.beta_i = beta_i; a.stat_i = stat_i;
+  a.dgamma_i = dgamma_i; a.dbeta_i = dbeta_i;
+  a.inv_rows = training ? 1.0f / (float)R : 0.f;
+  a.mode = mode; a.drop = drop;
+  a.X = X; a.ldx = (int)ldx;
+  a.act = InAct{act_mean, act_invstd, act_gamma, act_beta};
+  a.W = W; a.ldw = (int)ldw; a.dW = dW; a.lddw = (int)lddw; a.dZ = dZ;
+  a.stat_prev = act_mean ? stat_prev : nullptr;
+  a.R = R; a.C = (int)C; a.Cp = (int)Cp;
+  a.ntiles = (int)cdiv(R, kTR);
+  static const int cus = []() {
+    const char* e = getenv("MVP_BWD_WIDE_WGS");
+    int n = e ? atoi(e) : 0, dev = 0;
+    if (n <= 0 && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n > 0 ? n : 256;
+  }();
+  const int grid = std::min(a.ntiles, cus);
+  // reproducible mode: partial tiles through the workspace + ordered reduction, and a STATIC tile order (the ticket would make a
+  // workgroup's share, hence the order of its fp32 additions, differ from run to run)
+  a.ws = (workspace && grid > 1 && (int64_t)grid * 16 * 1024 <= workspace_floats) ? workspace : nullptr;
+  a.ticket = a.ws ? nullptr : ticket;
+  const size_t lds1 = 1 * (kWCh * kRowB + 2 * kTR * kRowB) + 64 + 11 * kWCh * 4, lds2 = 2 * (kWCh * kRowB + 2 * kTR * kRowB) + 64 + 11 * kWCh * 4;  // 75 / 142 KB
+  if (ns == 1) {
+    auto k = mlp_bwd_wide_kernel<1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWT), lds1, s, a);
+  } else {
+    auto k = mlp_bwd_wide_kernel<2>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWT), lds2, s, a);
+  }
+  int rc = mvp_launch_status();
+  if (rc != MVP_OK) return rc;
+  if (a.ws) {
+    hipLaunchKernelGGL((dw_reduce_kernel<4, 4>), dim3(16 * 16), dim3(256), 0, s, a.ws, grid, 1, 1, (int)C, (int)Cp, dW, (int)lddw);
+    rc = mvp_launch_status();
+  }
+  return rc;
+}

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include "common.h"
 #include "stats_reduce.h"
+#include "dropout.h"
 
 namespace {
 
@@ -545,21 +546,6 @@ __device__ __forceinline__ ColParams load_col_params(const float* mean, const fl
   p.bb[0] = be.x; p.bb[1] = be.y; p.bb[2] = be.z; p.bb[3] = be.w;
   return p;
 }
-// Dropout folded into the BatchNorm + ReLU passes of a layer (SharedMLPDO, mlp.py:86-92: dropout behind the layer): the keep mask is a
-// counter-based hash of (seed, element index), so forward and backward regenerate it instead of storing it -- no mask tensor, no
-// fused_dropout / masked_scale launches.  (The reference draws its mask from torch's Philox stream: the masks differ, the
-// distribution -- independent Bernoulli(1 - p) per element, kept values scaled by 1 / (1 - p) -- is the same.)
-struct Dropout {
-  unsigned thresh;  // keep when hash >= thresh; 0 = no dropout
-  unsigned seed;
-  float scale;      // 1 / (1 - p)
-  __device__ __forceinline__ float factor(unsigned e) const {  // e = r * C + c
-    unsigned x = e + seed * 0x9E3779B9u;
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;  // lowbias32
-    return x >= thresh ? scale : 0.f;
-  }
-};
-
 struct BwdAct {  // f = dz, g = dz * xhat with dz = da * [bn(y) > 0] (relu) : BatchNorm backward sums
   const float *da, *y, *mean, *invstd, *gamma, *beta;
   int relu;
@@ -1209,18 +1195,6 @@ MVP_API int mvp_interp_rows_backward_f32(const float* grad_out, const int64_t* i
 }
 
 namespace {
-// p in [0, 1): keep threshold on a 32-bit hash; R * C must fit the 32-bit element counter
-inline int make_dropout(float p, uint64_t seed, int64_t R, int64_t C, int64_t K, Dropout* d) {
-  *d = Dropout{0u, 0u, 1.0f};
-  if (p == 0.f) return MVP_OK;
-  if (!(p > 0.f && p < 1.f) || K != 1 || R * C >= (1ll << 32)) return MVP_EINVAL;
-  double t = (double)p * 4294967296.0;
-  if (t < 1.0) t = 1.0;
-  if (t > 4294967295.0) t = 4294967295.0;
-  *d = Dropout{(unsigned)t, (unsigned)(seed ^ (seed >> 32)), 1.0f / (1.0f - p)};
-  return MVP_OK;
-}
-
 int bn_rows_forward_impl(const float* y, const float* gamma, const float* beta, int64_t G, int64_t K,
                                     int64_t C, int training, float eps, float momentum, int relu, float* running_mean,
                                     float* running_var, double* stat, float* mean, float* invstd, float* out,
@@ -1293,7 +1267,7 @@ int bn_rows_backward_impl(const float* dsrc, const float* out, const uint8_t* ar
   MVP_NONNULL(gamma);
   MVP_NONNULL(beta);
   MVP_NONNULL(stat);
-  MVP_NONNULL(dy);
+  if (K != 1) MVP_NONNULL(dy);  // K == 1, dy == NULL: the two column sums only (the one-pass layer backward forms dy itself: mlp_bwd_wide.hip)
   if (dgamma) MVP_NONNULL(dbeta);
   MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);
   if (K > 1 && arg) MVP_NONNULL(out);  // K > 1 with arg == NULL: backward of the SUM over K
@@ -1307,7 +1281,7 @@ int bn_rows_backward_impl(const float* dsrc, const float* out, const uint8_t* ar
     rc = launch_colstats(BwdSum{dsrc, y, mean, invstd, gamma, beta, (int)K, relu}, R, C, stat, partial, true, s);
   else
     rc = launch_colstats(BwdMax{dsrc, out, y, mean, invstd, gamma, beta, arg, (int)K, relu}, G, C, stat, partial, true, s);
-  if (rc || R == 0) return rc;
+  if (rc || R == 0 || dy == nullptr) return rc;
   if (K > 1) {  // through the max over K: one lane per group streams its K rows
     dim3 pgrid((unsigned)cdiv(G * (C / 4), kRT));
     if (relu)

@@ -24,6 +24,21 @@ FUSE_BWD_MAX_CIN = int(os.environ.get('MVP_BWD_FUSE_MAXCIN', '96'))
 # Column statistics of the tile kernels: below this many rows (R / 128 workgroups) the workgroups add into `stat` with fp64 atomics, from it on
 # through per-tile slots + a reduction launch (atomics queue per address: ~10 ns each)
 PARTIAL_MIN_ROWS = int(os.environ.get('MVP_PARTIAL_MIN_ROWS', '65536'))
+# Layers with 65 .. 128 channels on either side (the last propagation level, the segmentation head, level 3's middle layer): the whole
+# backward of a layer -- BatchNorm finish, weight gradient, input gradient + the previous layer's ReLU mask and column sums -- in ONE pass
+# with the row tile staged in LDS (mvp_mlp_layer_backward_wide_p_f32, csrc/mlp_bwd_wide.hip) instead of finish pass + input-gradient GEMM +
+# reduction launch on the training stream and the weight-gradient GEMM beside them.  MVP_BWD_WIDE=0: the per-layer kernels (A/B switch).
+WIDE_BWD = os.environ.get('MVP_BWD_WIDE', '1') != '0'
+WIDE_BWD_MIN_ROWS = int(os.environ.get('MVP_BWD_WIDE_MIN_ROWS', '16384'))  # (fewer rows than ~one tile per CU: the tile kernels' narrow variants)
+
+
+def wide_backward_ok(prec, R, cout, cin, ldx):
+    """True when a layer (R rows, cin -> cout, input row stride ldx) takes the one-pass wide backward: a one- or two-piece backward split,
+    more than 64 and at most 128 channels, whole 16-byte quadruples per row."""
+    return (WIDE_BWD and prec[0] != 0 and prec[1] in (1, 3) and R >= WIDE_BWD_MIN_ROWS and 64 < max(cout, cin) <= 128 and
+            cout % 4 == 0 and cin % 4 == 0 and ldx % 4 == 0)
+
+
 # Set-abstraction levels (K = 32 neighbours, max pooling): run the LAST shared-MLP layer without ever storing its (B*M*32, C) output --
 # forward leaves per-ball max / min of the pre-BN values (mvp_mlp_forward_pool_f32), backward re-computes the layer from its input inside
 # the one-kernel layer backward (POOL front end).  Needs C_out, C_in <= 64 and >= 32768 rows (levels 1 and, with 64-wide MLPs, 2).
@@ -907,6 +922,9 @@ class MLPChainRows(torch.autograd.Function):
         # last layer: through max-over-K + ReLU + BN
         cl = ys[-1].size(1)
         pool = None
+        wl = params[3 * (nl - 1)]
+        last_wide = bool(not ctx.pooled and K == 1 and nl >= 2 and wl is not None and g.is_cuda and
+                         wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32)
         if ctx.pooled:
             # the last layer's (R, cl) output does not exist: its BatchNorm-backward column sums come from the (G, cl) tensors, dy_L is
             # formed inside the one-kernel layer backward from the re-computed y_L
@@ -915,6 +933,14 @@ class MLPChainRows(torch.autograd.Function):
             L.call('mvp_pool_backward_stats_f32', g, L.ptr(g), L.ptr(out), L.ptr(ysel), L.ptr(means[-1]), L.ptr(invstds[-1]), G, cl, 1,
                    L.ptr(stat_l), L.ptr(_cs_partial(G, cl, g.device)))
             pool = (g, out, arg)
+            dy, dgam, dbet = None, None, None
+        elif last_wide:
+            # the last layer goes through the one-pass wide backward (mode 2): only the two column sums of dz_L = g * keep * relu'(bn(y_L)) are
+            # computed here; the finish, the masks and dy_L happen while that kernel loads its rows (no dy_L tensor, no finish pass)
+            stat_d = torch.empty(2 * cl, dtype=torch.float64, device=g.device)
+            L.call('mvp_bn_rows_backward_dropout_f32', g, L.ptr(g), L.ptr(ys[-1]), L.ptr(means[-1]), L.ptr(invstds[-1]), L.ptr(params[-2]),
+                   L.ptr(params[-1]), R, cl, 1, int(training), L.ptr(stat_d), None, None, None, L.ptr(_cs_partial(R, cl, g.device)),
+                   ctx.dropout[0], ctx.dropout[1])
             dy, dgam, dbet = None, None, None
         elif ctx.dropout[0] > 0:  # the keep mask is regenerated from (p, seed) inside the BatchNorm-backward passes
             stat_d = torch.empty(2 * cl, dtype=torch.float64, device=g.device)
@@ -941,6 +967,8 @@ class MLPChainRows(torch.autograd.Function):
         gcur, pending = dy, None
         if pool is not None:
             gcur, pending = None, stat_l
+        elif last_wide:
+            gcur, pending = g, stat_d
         dw_aside = bool(DW_SIDE_STREAM and ctx.dw_use is not None and ctx.dw_use.aside_ok())
         for i in range(nl - 1, -1, -1):
             w = params[3 * i]
@@ -950,8 +978,10 @@ class MLPChainRows(torch.autograd.Function):
             src = None if w is None else (x0 if i == 0 else ys[i - 1])
             pool_here = pool is not None and i == nl - 1
             rel, w0_param = ctx.rel if i == 0 else (None, None)
-            fuse = pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and rel is None and
-                                 (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
+            wide = bool(i > 0 and w is not None and not pool_here and rel is None and need_dz and wide_backward_ok(ctx.prec, R, cout, cin, src.size(1)))
+            fuse = wide or pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and rel is None and
+                                         (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
+            assert wide or not (last_wide and i == nl - 1)
             if pending is not None and not fuse:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)
                 dyi = torch.empty((R, cout), dtype=torch.float32, device=dev)
@@ -989,7 +1019,22 @@ class MLPChainRows(torch.autograd.Function):
                     L.call('mvp_mlp_input_grad_f32', gcur, L.ptr(gcur), R, cout, L.ptr(wf), cin_f, None, None, None, None, None, L.ptr(dz), None, None, prec=ctx.prec)
                     dx0 = dz
                 break
-            if fuse:
+            if wide:
+                # mode 0: gcur is dy_i; 1: dz_i (finish inside); 2: the gradient of the layer's (dropped-out) activation (last layer)
+                mode = 0 if pending is None else (2 if (last_wide and i == nl - 1) else 1)
+                dgb = torch.empty((2, cout), dtype=torch.float32, device=dev) if pending is not None else None
+                ticket = zero_pool.zeros(2, torch.int32, dev)
+                ws_ptr, ws_floats = L.current_dw_workspace(dev)
+                fin = pending is not None
+                L.call('mvp_mlp_layer_backward_wide_f32', src, L.ptr(gcur), L.ptr(ys[i]) if fin else None, L.ptr(means[i]) if fin else None,
+                       L.ptr(invstds[i]) if fin else None, L.ptr(params[3 * i + 1]) if fin else None, L.ptr(params[3 * i + 2]) if mode == 2 else None,
+                       L.ptr(pending), L.ptr(None if dgb is None else dgb[0]), L.ptr(None if dgb is None else dgb[1]), int(training), mode,
+                       float(ctx.dropout[0]) if mode == 2 else 0.0, int(ctx.dropout[1]) if mode == 2 else 0, L.ptr(src), src.size(1), L.ptr(act[0]),
+                       L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]), L.ptr(w), cin, R, cout, cin, L.ptr(dw), cin, L.ptr(dz), L.ptr(stat), L.ptr(ticket),
+                       ws_ptr, ws_floats, prec=ctx.prec)
+                if pending is not None:
+                    grads[3 * i + 1], grads[3 * i + 2] = dgb[0], dgb[1]
+            elif fuse:
                 dgb = torch.empty((2, cout), dtype=torch.float32, device=dev) if pending is not None else None
                 part = torch.empty(L.lib().mvp_mlp_layer_backward_partial_count(R, cin), dtype=torch.float64, device=dev) if (i > 0 and need_dz) else None
                 L.call('mvp_mlp_layer_backward_f32', src, L.ptr(gcur), L.ptr(ys[i]) if (pending is not None and not pool_here) else None,

@@ -1197,6 +1197,99 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
         L.set_mlp_precision_backward('bf16x3')
 
 
+@pytest.mark.parametrize('R,C,Cp,ldx', [(262144, 128, 128, 128), (64, 128, 128, 128), (6001, 128, 128, 128), (40000, 96, 128, 132), (9999, 128, 72, 72),
+                                        (1, 68, 100, 100), (20000, 64, 128, 128)])
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16x3-ws', 'bf16'])
+def test_mlp_layer_backward_wide(dev, R, C, Cp, ldx, precision):
+    """mvp_mlp_layer_backward_wide_p_f32 (csrc/mlp_bwd_wide.hip: the one-pass backward of a 128-wide layer with the row tile staged in LDS
+    and transpose reads feeding the weight-gradient contraction) against a float64 evaluation of the steps it fuses (autograd through
+    common/nn/modules/conv.py:41-51): BatchNorm-backward finish of layer i, dW_i, dz_{i-1} with the ReLU mask of layer i-1 and its two
+    column sums.  All three sources of dy_i -- given (mode 0), from dz_i (mode 1), from the gradient of the layer's activation with the ReLU
+    mask re-created from y_i (mode 2) and the dropout keep mask regenerated (mode 2 + drop_p: against mvp_bn_rows_backward_dropout_f32's
+    own dy) --, with and without the previous layer's activation, row counts that are not multiples of the 64-row tile, channel counts
+    below 128, a row stride wider than the layer, the ticket and the static tile order, and the reproducible mode's workspace path."""
+    from mvpnet_amd import _lib as L
+    ws_mode = precision.endswith('-ws')
+    precision = precision.replace('-ws', '')
+    prec = (L.MLP_PRECISIONS['bf16x6' if precision == 'bf16x3' else 'bf16'], L.MLP_PRECISIONS[precision])
+    loose = {'bf16x3': 16.0, 'bf16': 4096.0}[precision]
+    hi = torch.float64
+    torch.manual_seed(R + C + Cp)
+    w = torch.randn(C, Cp, device=dev) * 0.2
+    x = torch.randn(R, ldx, device=dev)
+    gsrc = torch.randn(R, C, device=dev)
+    yi = torch.randn(R, C, device=dev) * 1.5 + 0.2
+    mean_i, invstd_i, gamma_i = torch.randn(C, device=dev) * 0.3, torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5
+    beta_i = torch.randn(C, device=dev) * 0.2
+    stat_i = torch.randn(2 * C, device=dev, dtype=hi) * R * 0.01
+    pm, pi = torch.randn(Cp, device=dev) * 0.3, torch.rand(Cp, device=dev) + 0.5
+    pg, pb = torch.rand(Cp, device=dev) + 0.5, torch.randn(Cp, device=dev) * 0.2
+    wsbuf = torch.empty(L.lib().mvp_mlp_weight_grad_workspace_floats(), device=dev) if ws_mode else None
+    xh_i = (yi.to(hi) - mean_i.to(hi)) * invstd_i.to(hi)
+    for mode, drop_p in ((0, 0.0), (1, 0.0), (2, 0.0), (2, 0.4)):
+        if drop_p > 0 and 256 % (C // 4):   # (the rows kernels that supply this case's reference tile C / 4 | 256 only)
+            continue
+        for use_act in (False, True):
+            for ticket in ((True, False) if (mode == 1 and not ws_mode) else (True,)):
+                seed = 123456789012345
+                if mode == 0:
+                    dy = gsrc.to(hi)
+                else:
+                    dzi = gsrc.to(hi)
+                    if mode == 2:
+                        if drop_p > 0:   # the library's own dz of the dropped-out layer (same keep mask): its finish pass with zero batch terms and unit scale
+                            one, zero = torch.ones(C, device=dev), torch.zeros(2 * C, dtype=hi, device=dev)
+                            dzf = torch.empty(R, C, device=dev)
+                            sd = torch.zeros(2 * C, dtype=hi, device=dev)
+                            L.call('mvp_bn_rows_backward_dropout_f32', gsrc, L.ptr(gsrc), L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(beta_i),
+                                   R, C, 1, 0, L.ptr(sd), L.ptr(dzf), None, None, None, drop_p, seed)
+                            # eval-mode finish: dy = gamma * invstd * dz  ->  dz = dy / (gamma * invstd)
+                            dzi = dzf.to(hi) / (gamma_i.to(hi) * invstd_i.to(hi))
+                        else:
+                            dzi = torch.where(xh_i * gamma_i.to(hi) + beta_i.to(hi) > 0, dzi, torch.zeros_like(dzi))
+                    dy = (gamma_i.to(hi) * invstd_i.to(hi)) * ((dzi - stat_i[:C] / R) - xh_i * (stat_i[C:] / R))
+                a = x[:, :Cp].to(hi)
+                xh = (a - pm.to(hi)) * pi.to(hi)
+                if use_act:
+                    a = torch.relu(xh * pg.to(hi) + pb.to(hi))
+                ref_dw = dy.t() @ a
+                ref_dz = dy @ w.to(hi)
+                if use_act:
+                    ref_dz = torch.where(xh * pg.to(hi) + pb.to(hi) > 0, ref_dz, torch.zeros_like(ref_dz))
+                dw = torch.zeros(C, Cp + 4, device=dev)   # a column slice of a wider gradient (lddw > Cp)
+                dz = torch.full((R, Cp), float('nan'), device=dev)
+                stat = torch.zeros(2 * Cp, dtype=hi, device=dev)
+                tk = torch.zeros(1, dtype=torch.int32, device=dev)
+                dgb = torch.full((2, C), float('nan'), device=dev)
+                act = (pm, pi, pg, pb) if use_act else (None,) * 4
+                L.call('mvp_mlp_layer_backward_wide_f32', gsrc, L.ptr(gsrc), L.ptr(yi) if mode else None, L.ptr(mean_i) if mode else None,
+                       L.ptr(invstd_i) if mode else None, L.ptr(gamma_i) if mode else None, L.ptr(beta_i) if mode == 2 else None,
+                       L.ptr(stat_i) if mode else None, L.ptr(dgb[0]) if mode else None, L.ptr(dgb[1]) if mode else None, 1, mode, drop_p, seed,
+                       L.ptr(x), ldx, *[L.ptr(t) for t in act], L.ptr(w), Cp, R, C, Cp, L.ptr(dw), Cp + 4, L.ptr(dz), L.ptr(stat) if use_act else None,
+                       L.ptr(tk) if ticket else None, L.ptr(wsbuf), 0 if wsbuf is None else wsbuf.numel(), prec=prec)
+                tag = 'mode={} drop={} act={} ticket={}'.format(mode, drop_p, use_act, ticket)
+                sw = max(1.0, float(ref_dw.abs().max()))
+                np.testing.assert_allclose(dw[:, :Cp].cpu().numpy(), ref_dw.cpu().numpy(), rtol=1e-4 * loose, atol=3e-5 * sw * loose, err_msg=tag)
+                assert float(dw[:, Cp:].abs().max()) == 0.0, tag
+                if mode:
+                    np.testing.assert_array_equal(dgb[0].cpu().numpy(), stat_i[C:].float().cpu().numpy())
+                    np.testing.assert_array_equal(dgb[1].cpu().numpy(), stat_i[:C].float().cpu().numpy())
+                sz = max(1.0, float(ref_dz.abs().max()))
+                np.testing.assert_allclose(dz.cpu().numpy(), ref_dz.cpu().numpy(), rtol=1e-5 * loose, atol=2e-5 * sz * loose, err_msg=tag)
+                if use_act:
+                    big = max(1.0, R / 5000.0)
+                    np.testing.assert_allclose(stat[:Cp].cpu().numpy(), ref_dz.sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
+                    np.testing.assert_allclose(stat[Cp:].cpu().numpy(), (ref_dz * xh).sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
+                if ticket and R > 64 and not ws_mode:   # (the reproducible mode keeps a static tile order)
+                    assert int(tk) > 0, tag   # tiles beyond each workgroup's first were taken by ticket
+    # what the entry point refuses (callers then take mvp_mlp_layer_backward_f32 or the three separate kernels)
+    bad = L.lib().mvp_mlp_layer_backward_wide_p_f32
+    args = lambda Cx, Cpx, p1: (L.ptr(gsrc), None, None, None, None, None, None, None, None, 1, 0, 0.0, 0, L.ptr(x), ldx, None, None, None, None, L.ptr(w), Cpx,
+                                 R, Cx, Cpx, L.ptr(dw), Cp + 4, L.ptr(dz), None, None, None, 0, 6, p1, None)
+    assert bad(*args(C, Cp, 6)) != 0   # three-piece backward split
+    assert bad(*args(132, Cp, 3)) != 0 and bad(*args(C, 130, 3)) != 0
+
+
 @pytest.mark.parametrize('R,Cin,Cout', [(3000, 64, 64), (70000, 32, 64), (140000, 64, 128), (40000, 320, 256)])
 @pytest.mark.parametrize('stream', [0, 1])
 def test_mlp_forward_with_bn_finalize(dev, R, Cin, Cout, stream):
