@@ -28,6 +28,7 @@
 #include "dropout.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -70,40 +71,116 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {  // ds_read_
   return __builtin_bit_cast(uint2, v);
 }
 
-template <int NS>
+#ifdef MVP_WIDE_PROF  /* experiment build (tools/exp/wide_prof.sh): per-workgroup wall-clock ticks (100 MHz) spent in each phase of the tile loop */
+__device__ unsigned long long g_wide_prof[1024][8];
+#define WIDE_T(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); g_wide_prof[blockIdx.x][k] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define WIDE_T(k) do { } while (0)
+#endif
+
+struct TileRegs {  // one thread's 16-byte pieces of a tile: rows rbase + 16 j of dz_i / y_i / y_{i-1}
+  f32x4 g[4], y[4], x[4];
+};
+
+// MODE >= 0: the FAST variants -- C == Cp == 128, layer i-1 has an activation, the source of dy_i known at compile time: no column masks
+// and no per-element branches in P1 / P4 (as run-time tests they were 2/3 of P1's ~700 instructions per thread, and P1 was half the
+// kernel).  MODE == -1: everything decided at run time (narrower layers, plain inputs: tests and odd networks).
+template <int NS, int MODE>
 __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
+  constexpr bool FULL = MODE >= 0;
   using SP = SplitPairs<NS>;
-  constexpr int kWimg = kWCh * kRowB;   // 32 KB per piece
-  constexpr int kTimg = kTR * kRowB;    // 16 KB per piece
+  constexpr int kWimg = kWCh * kRowB;   // 34 KB per piece
+  constexpr int kTimg = kTR * kRowB;    // 17 KB per piece
   constexpr int oW = 0, oDy = NS * kWimg, oA = oDy + NS * kTimg, oMisc = oA + NS * kTimg, oCst = oMisc + 64;  // + 11 x 128 column constants
   static_assert(2 * NS * kTimg >= kTR * kWCh * 4, "the dX staging tile aliases the dy / a images");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int* misc = reinterpret_cast<int*>(lds + oMisc);
+  unsigned char* const L = lds;
+  float* const stage = reinterpret_cast<float*>(L + oDy);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MVP_WIDE_PROF
+  unsigned long long tprev_ = wall_clock64();
+#endif
   const int n = lane & 31, h = lane >> 5;
   const int c4 = tid & 31, cc = 4 * c4, rbase = tid >> 5;  // this thread's 4 columns and its rows rbase + 16 j of every tile
-  const int C = p.C, Cp = p.Cp;
-  const bool has_act = p.act.mean != nullptr;
-  const bool cok = cc < C, xok = cc < Cp;
+  const int C = FULL ? kWCh : p.C, Cp = FULL ? kWCh : p.Cp;
+  const bool has_act = FULL || p.act.mean != nullptr;
+  const bool cok = FULL || cc < C, xok = FULL || cc < Cp;
+  const int ntiles = p.ntiles, step = (int)gridDim.x;
+  const int mode = MODE >= 0 ? MODE : p.mode;
+
+  // ---- global addressing: a scalar tile base + per-thread element offsets that do not depend on the tile (4 per tensor); only the LAST
+  // tile of a row count that is not a multiple of 64 clamps its rows (its values are masked in P1 / P4)
+  int offg[4], offx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    offg[j] = (rbase + 16 * j) * C + (cok ? cc : 0);
+    offx[j] = (rbase + 16 * j) * p.ldx + (xok ? cc : 0);
+  }
+  const int tail_rows = (int)(p.R - (int64_t)(ntiles - 1) * kTR);  // rows of the last tile: 1 .. 64
+  auto load_gy_row = [&](TileRegs& t, int tile, int j) {
+    const float* Gt = p.G + (size_t)tile * kTR * C;
+    const float* Yt = (mode != 0 ? p.Yi : p.G) + (size_t)tile * kTR * C;
+    const bool clamp = tile == ntiles - 1 && tail_rows < kTR;
+    const int o = clamp ? min(rbase + 16 * j, tail_rows - 1) * C + (cok ? cc : 0) : offg[j];
+    t.g[j] = *reinterpret_cast<const f32x4*>(Gt + o);
+    if (mode != 0) t.y[j] = *reinterpret_cast<const f32x4*>(Yt + o);
+  };
+  auto load_gy = [&](TileRegs& t, int tile) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_gy_row(t, tile, j);
+  };
+  auto load_x = [&](TileRegs& t, int tile) {
+    const float* Xt = p.X + (size_t)tile * kTR * p.ldx;
+    const bool clamp = tile == ntiles - 1 && tail_rows < kTR;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.x[j] = *reinterpret_cast<const f32x4*>(Xt + (clamp ? min(rbase + 16 * j, tail_rows - 1) * p.ldx + (xok ? cc : 0) : offx[j]));
+  };
+  TileRegs ta;
+  int cur = (int)blockIdx.x;
+  if (tid == 0) misc[0] = p.ticket ? step + atomicAdd(p.ticket, 1) : cur + step;
+  if (cur < ntiles) {  // in flight under the staging of the W image
+    load_gy(ta, cur);
+    load_x(ta, cur);
+  }
 
   // ---- W_i -> LDS once: image[piece][c_in][c_out] (B operand of dX: lane = c_in, 8 consecutive c_out per 16-byte slot).
   // Banks: every image row is 272 bytes = 17 slots of 16 bytes, so (a) the 16 lanes that a ds_read_b128 serves together -- 16 different rows,
   // one slot index -- land on 16 different slots of the 256-byte bank row, and (b) rows r, r + 4, r + 8, r + 12 start 64 bytes apart
   // (mod 256), which is what the transpose reads of P2b use: each of their 32-lane groups takes 64 bytes of four such rows.  Plain padding
   // instead of an XOR permutation keeps every LDS address of the tile loop "per-lane base + immediate".
-  for (int t = tid; t < kWCh * 32; t += kWT) {
-    const int ci = t & 127, cq = t >> 7, co = 4 * cq;
-    float v[4];
+  // A thread takes a 4 (c_out) x 4 (c_in) block: four 16-byte loads along c_in (coalesced), transposed in registers into 8-byte pieces
+  // along c_out; all loads of both rounds are requested before the first is used.
+  {
+    f32x4 wv[2][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (co + e < C && ci < Cp) ? p.W[(size_t)(co + e) * p.ldw + ci] : 0.f;
-    unsigned a[NS], b[NS];
-    split_pair<NS>(v[0], v[1], a);
-    split_pair<NS>(v[2], v[3], b);
+    for (int rd = 0; rd < 2; ++rd) {
+      const int t = tid + rd * kWT, ci4 = t & 31, co4 = t >> 5;  // c_in 4 ci4 .. + 3, c_out 4 co4 .. + 3
 #pragma unroll
-    for (int pc = 0; pc < NS; ++pc)
-      *reinterpret_cast<uint2*>(lds + oW + pc * kWimg + ci * kRowB + cq * 8) = make_uint2(a[pc], b[pc]);
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        wv[rd][e] = z;
+        if (FULL) wv[rd][e] = *reinterpret_cast<const f32x4*>(p.W + (size_t)(4 * co4 + e) * p.ldw + 4 * ci4);  // (ldw % 4 == 0, checked by the host)
+        else
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (4 * co4 + e < C && 4 * ci4 + k < Cp) wv[rd][e][k] = p.W[(size_t)(4 * co4 + e) * p.ldw + 4 * ci4 + k];
+      }
+    }
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int t = tid + rd * kWT, ci4 = t & 31, co4 = t >> 5;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // c_in 4 ci4 + k: the four c_out values wv[rd][0..3][k]
+        unsigned a[NS], b[NS];
+        split_pair<NS>(wv[rd][0][k], wv[rd][1][k], a);
+        split_pair<NS>(wv[rd][2][k], wv[rd][3][k], b);
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) *reinterpret_cast<uint2*>(lds + oW + pc * kWimg + (4 * ci4 + k) * kRowB + co4 * 8) = make_uint2(a[pc], b[pc]);
+      }
+    }
   }
-  if (p.mode != 0 && p.dgamma_i && blockIdx.x == 0)
+  if (mode != 0 && p.dgamma_i && blockIdx.x == 0)
     for (int col = tid; col < C; col += kWT) {
       p.dbeta_i[col] = (float)p.stat_i[col];
       p.dgamma_i[col] = (float)p.stat_i[C + col];
@@ -117,10 +194,10 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       const int k = t >> 7, col = t & 127;
       float v = 0.f;
       if (k < 7) {
-        if (p.mode != 0 && col < C) {
+        if (mode != 0 && col < C) {
           const float isd = p.invstd_i[col], gam = p.gamma_i[col];
           v = k == 0 ? p.mean_i[col] : k == 1 ? isd : k == 2 ? gam * isd : k == 3 ? (float)p.stat_i[col] * p.inv_rows
-              : k == 4 ? (float)p.stat_i[C + col] * p.inv_rows : k == 5 ? gam : (p.mode == 2 ? p.beta_i[col] : 0.f);
+              : k == 4 ? (float)p.stat_i[C + col] * p.inv_rows : k == 5 ? gam : (mode == 2 ? p.beta_i[col] : 0.f);
         }
       } else if (has_act && col < Cp) {
         v = k == 7 ? p.act.mean[col] : k == 8 ? p.act.invstd[col] : k == 9 ? p.act.gamma[col] : p.act.beta[col];
@@ -134,107 +211,79 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) accw[b][i] = 0.f;
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, tsum[4] = {0.f, 0.f, 0.f, 0.f};
-
-  const int ntiles = p.ntiles, step = (int)gridDim.x;
-  f32x4 gq[4], yq[4], xq[4];
-  auto load_tile = [&](int t) {  // the thread's pieces of tile t (rows past R clamped: their values are masked in P1)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t r = min((int64_t)t * kTR + rbase + 16 * j, p.R - 1);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      gq[j] = cok ? *reinterpret_cast<const f32x4*>(p.G + (size_t)r * C + cc) : z;
-      yq[j] = (cok && p.mode != 0) ? *reinterpret_cast<const f32x4*>(p.Yi + (size_t)r * C + cc) : z;
-      xq[j] = xok ? *reinterpret_cast<const f32x4*>(p.X + (size_t)r * p.ldx + cc) : z;
-    }
-  };
-  int cur = (int)blockIdx.x;
-  if (tid == 0) misc[0] = p.ticket ? step + atomicAdd(p.ticket, 1) : cur + step;
-  if (cur < ntiles) load_tile(cur);
-  __syncthreads();  // W image complete, first ticket visible
+  __syncthreads();  // W image and constants complete, first ticket visible
+  WIDE_T(0);
   int nxt = misc[0];
-  for (int it = 0; cur < ntiles; ++it) {
-    unsigned char* const L = lds;
-    float* const stage = reinterpret_cast<float*>(L + oDy);
-    // ---- P1: dy_i and a_{i-1} of this thread's 16 elements -> bf16 pieces -> the row-major LDS images
-    f32x4 xk[4];
-    const f32x4* cst = reinterpret_cast<const f32x4*>(L + oCst) + c4;
-    const f32x4 mu = cst[0 * 32], is = cst[1 * 32], sc = cst[2 * 32], db = cst[3 * 32], dg = cst[4 * 32], ga = cst[5 * 32], be = cst[6 * 32];
-    f32x4 pm = cst[7 * 32], pi = cst[8 * 32], pg = cst[9 * 32], pb = cst[10 * 32];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rbase + 16 * j;
-      const int64_t grow = (int64_t)cur * kTR + r;
-      const bool rok = grow < p.R;
-      float d[4], a[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = gq[j][e];
-        if (p.mode != 0) {
-          const float xh = (yq[j][e] - mu[e]) * is[e];
-          if (p.mode == 2) {
-            if (p.drop.thresh) v *= p.drop.factor((unsigned)(grow * C + cc + e));
-            v = (xh * ga[e] + be[e] > 0.f) ? v : 0.f;
-          }
-          v = sc[e] * ((v - db[e]) - xh * dg[e]);
-        }
-        d[e] = (rok && cok) ? v : 0.f;
-        float x = xq[j][e];
-        if (has_act) {
-          const float z = ((x - pm[e]) * pi[e]) * pg[e] + pb[e];
-          x = z > 0.f ? z : 0.f;
-        }
-        a[e] = (rok && xok) ? x : 0.f;
-      }
-      xk[j] = xq[j];
-      unsigned d0[NS], d1[NS], a0[NS], a1[NS];
-      split_pair<NS>(d[0], d[1], d0);
-      split_pair<NS>(d[2], d[3], d1);
-      split_pair<NS>(a[0], a[1], a0);
-      split_pair<NS>(a[2], a[3], a1);
-      const int off = r * kRowB + c4 * 8;
-#pragma unroll
-      for (int pc = 0; pc < NS; ++pc) {
-        *reinterpret_cast<uint2*>(L + oDy + pc * kTimg + off) = make_uint2(d0[pc], d1[pc]);
-        *reinterpret_cast<uint2*>(L + oA + pc * kTimg + off) = make_uint2(a0[pc], a1[pc]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // (the prefetch must not be hoisted above the consumption of the current tile's registers: twice the registers)
-    if (nxt < ntiles) load_tile(nxt);  // in flight under P2 .. P4
-    __builtin_amdgcn_sched_barrier(0);
-    if (tid == 0) misc[(it + 1) & 1] = p.ticket ? step + atomicAdd(p.ticket, 1) : nxt + step;
-    __syncthreads();
-    const int after = misc[(it + 1) & 1];
+  int it = 0;
+  const f32x4* cst = reinterpret_cast<const f32x4*>(L + oCst) + c4;
 
-    // ---- P2a: dX[32 rb .. +31][32 cb .. +31] = sum over c_out of dy . W   (8 steps of 16 c_out)
-    f32x16 accz;
+  // One tile.  `tc` holds its rows, requested while the tile before was in P2 .. P4; they are consumed by P1 (y_{i-1} moves to `xk` for P4) and
+  // the next tile's are requested into the same registers right behind it.  (A second register set, requested a whole tile ahead, was
+  // measured: P1 is bound by its arithmetic, not by the loads, and the 32 extra registers spill.)
+  TileRegs& tc = ta;
+  f32x4 xk[4];
+  while (cur < ntiles) {
+    if (tid == 0) misc[(it + 1) & 1] = p.ticket ? step + atomicAdd(p.ticket, 1) : nxt + step;
+    const bool tail = cur == ntiles - 1 && tail_rows < kTR;
+    const int rows_here = tail ? tail_rows : kTR;
+    // y_{i-1} of this tile moves to `xk` (P1 and P4 read it there) and the NEXT tile's is requested at once: a third of the tile's bytes gets
+    // a whole tile of lead instead of P2 .. P4
 #pragma unroll
-    for (int i = 0; i < 16; ++i) accz[i] = 0.f;
-    {
-      const int rb = wave >> 2, cb = wave & 3;
-      const int ar = 32 * rb + n, br = 32 * cb + n;
-      const unsigned char* pa = L + oDy + ar * kRowB + h * 16;
-      const unsigned char* pbw = L + oW + br * kRowB + h * 16;
-      // one step's fragments are requested while the step before is in the matrix pipe (two sets of 4 x 16 bytes)
-      u32x4 fa[2][NS], fb[2][NS];
-      auto frag = [&](int ks, int buf) {
+    for (int j = 0; j < 4; ++j) xk[j] = tc.x[j];
+    if (nxt < ntiles) load_x(tc, nxt);
+    // ---- P1: dy_i and a_{i-1} of this thread's 16 elements -> bf16 pieces -> the row-major LDS images (the row masks only in the last,
+    // partial tile: `tailc`)
+    auto p1 = [&](auto tailc) {
+      constexpr bool TAIL = decltype(tailc)::value;
+      const f32x4 mu = cst[0 * 32], is = cst[1 * 32], sc = cst[2 * 32], db = cst[3 * 32], dg = cst[4 * 32], ga = cst[5 * 32], be = cst[6 * 32];
+      const f32x4 pm = cst[7 * 32], pi = cst[8 * 32], pg = cst[9 * 32], pb = cst[10 * 32];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rbase + 16 * j;
+        const bool rok = !TAIL || r < rows_here;
+        float d[4], a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = tc.g[j][e];
+          if (mode != 0) {
+            const float xh = (tc.y[j][e] - mu[e]) * is[e];
+            if (mode == 2) {
+              if (p.drop.thresh) v *= p.drop.factor((unsigned)(((int64_t)cur * kTR + r) * C + cc + e));
+              v = (xh * ga[e] + be[e] > 0.f) ? v : 0.f;
+            }
+            v = sc[e] * ((v - db[e]) - xh * dg[e]);
+          }
+          d[e] = (rok && cok) ? v : 0.f;
+          float x = xk[j][e];
+          if (has_act) {
+            const float z = ((x - pm[e]) * pi[e]) * pg[e] + pb[e];
+            x = z > 0.f ? z : 0.f;
+          }
+          a[e] = (rok && xok) ? x : 0.f;
+        }
+        if (nxt < ntiles) load_gy_row(tc, nxt, j);  // this row's registers are free: the next tile's row is requested at once
+        unsigned d0[NS], d1[NS], a0[NS], a1[NS];
+        split_pair<NS>(d[0], d[1], d0);
+        split_pair<NS>(d[2], d[3], d1);
+        split_pair<NS>(a[0], a[1], a0);
+        split_pair<NS>(a[2], a[3], a1);
+        const int off = r * kRowB + c4 * 8;
 #pragma unroll
         for (int pc = 0; pc < NS; ++pc) {
-          fa[buf][pc] = *reinterpret_cast<const u32x4*>(pa + pc * kTimg + ks * 32);
-          fb[buf][pc] = *reinterpret_cast<const u32x4*>(pbw + pc * kWimg + ks * 32);
+          *reinterpret_cast<uint2*>(L + oDy + pc * kTimg + off) = make_uint2(d0[pc], d1[pc]);
+          *reinterpret_cast<uint2*>(L + oA + pc * kTimg + off) = make_uint2(a0[pc], a1[pc]);
         }
-      };
-      frag(0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) frag(ks + 1, (ks + 1) & 1);
-#pragma unroll
-        for (int qd = 0; qd < SP::N; ++qd)
-          accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][SP::A[qd]]), __builtin_bit_cast(bf16x8, fb[ks & 1][SP::B[qd]]),
-                                                         accz, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);  // one row at a time: interleaved, the four rows' arithmetic costs ~40 registers
       }
-    }
-    // ---- P2b: dW[32 a .. +31][32 b .. +31] += sum over the tile's rows of dy^T . a   (4 steps of 16 rows; both operands by transpose read)
+    };
+    if (tail) p1(std::true_type{}); else p1(std::false_type{});
+    WIDE_T(1);
+    __syncthreads();
+    WIDE_T(2);
+    const int after = misc[(it + 1) & 1];
+
+    // ---- P2b (first: the dX accumulator of P2a is then not alive beside this block's 24 fragment registers):
+    // dW[32 a .. +31][32 b .. +31] += sum over the tile's rows of dy^T . a   (4 steps of 16 rows; both operands by transpose read)
     {
       const int a = wave >> 1, b0 = 2 * (wave & 1);
       const int grp = lane >> 4, q = lane & 15, hh = grp >> 1, cg = grp & 1;
@@ -269,7 +318,38 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // ---- P2a: dX[32 rb .. +31][32 cb .. +31] = sum over c_out of dy . W   (8 steps of 16 c_out)
+    f32x16 accz;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accz[i] = 0.f;
+    {
+      const int rb = wave >> 2, cb = wave & 3;
+      const int ar = 32 * rb + n, br = 32 * cb + n;
+      const unsigned char* pa = L + oDy + ar * kRowB + h * 16;
+      const unsigned char* pbw = L + oW + br * kRowB + h * 16;
+      // one step's fragments are requested while the step before is in the matrix pipe (two sets of 4 x 16 bytes)
+      u32x4 fa[2][NS], fb[2][NS];
+      auto frag = [&](int ks, int buf) {
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) {
+          fa[buf][pc] = *reinterpret_cast<const u32x4*>(pa + pc * kTimg + ks * 32);
+          fb[buf][pc] = *reinterpret_cast<const u32x4*>(pbw + pc * kWimg + ks * 32);
+        }
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) frag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int qd = 0; qd < SP::N; ++qd)
+          accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][SP::A[qd]]), __builtin_bit_cast(bf16x8, fb[ks & 1][SP::B[qd]]),
+                                                         accz, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    WIDE_T(3);
     __syncthreads();  // every wave is done reading the dy / a images
+    WIDE_T(4);
     // ---- P3: the dX tile (lane = column, registers = rows) -> full rows in LDS (aliases the images)
     {
       const int rb = wave >> 2, cb = wave & 3;
@@ -277,29 +357,39 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       for (int i = 0; i < 16; ++i) stage[(32 * rb + 8 * (i >> 2) + 4 * h + (i & 3)) * kWCh + 32 * cb + n] = accz[i];
     }
     __syncthreads();
+    WIDE_T(5);
     // ---- P4: ReLU mask of layer i-1, its two BatchNorm-backward column sums, streaming stores
-    pm = cst[7 * 32]; pi = cst[8 * 32]; pg = cst[9 * 32]; pb = cst[10 * 32];
+    auto p4 = [&](auto tailc) {
+      constexpr bool TAIL = decltype(tailc)::value;
+      const f32x4 pm = cst[7 * 32], pi = cst[8 * 32], pg = cst[9 * 32], pb = cst[10 * 32];
+      float* Zt = p.dZ + (size_t)cur * kTR * Cp;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rbase + 16 * j;
-      const int64_t grow = (int64_t)cur * kTR + r;
-      f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * kWCh + cc);
-      if (has_act) {
+      for (int j = 0; j < 4; ++j) {
+        const int r = rbase + 16 * j;
+        const bool rok = !TAIL || r < rows_here;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * kWCh + cc);
+        if (has_act) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xh = (xk[j][e] - pm[e]) * pi[e];
-          float d = (xh * pg[e] + pb[e] > 0.f) ? v[e] : 0.f;
-          d = (grow < p.R && xok) ? d : 0.f;
-          v[e] = d;
-          ssum[e] += d;
-          tsum[e] += d * xh;
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (xk[j][e] - pm[e]) * pi[e];
+            float d = (xh * pg[e] + pb[e] > 0.f) ? v[e] : 0.f;
+            if (TAIL || !FULL) d = (rok && xok) ? d : 0.f;
+            v[e] = d;
+            ssum[e] += d;
+            tsum[e] += d * xh;
+          }
         }
+        if (rok && xok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Zt + r * Cp + cc));
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (grow < p.R && xok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.dZ + (size_t)grow * Cp + cc));
-    }
+    };
+    if (tail) p4(std::true_type{}); else p4(std::false_type{});
+    WIDE_T(6);
     __syncthreads();  // the staging tile is the next tile's dy image
+    WIDE_T(7);
     cur = nxt;
     nxt = after;
+    ++it;
   }
 
   // ---- column sums of dz_{i-1}: 16 threads per column quadruple -> LDS -> one fp64 atomic per column and workgroup
@@ -409,17 +499,27 @@ MVP_API int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, c
   a.ws = (workspace && grid > 1 && (int64_t)grid * 16 * 1024 <= workspace_floats) ? workspace : nullptr;
   a.ticket = a.ws ? nullptr : ticket;
   const size_t lds1 = 1 * (kWCh * kRowB + 2 * kTR * kRowB) + 64 + 11 * kWCh * 4, lds2 = 2 * (kWCh * kRowB + 2 * kTR * kRowB) + 64 + 11 * kWCh * 4;  // 75 / 142 KB
+  const bool fast = C == kWCh && Cp == kWCh && act_mean != nullptr && (ldw & 3) == 0 && ((uintptr_t)W & 15) == 0;
+  const size_t ldsz = ns == 1 ? lds1 : lds2;
+#define MVP_WIDE_LAUNCH(NS_, MODE_)                                                                                            \
+  do {                                                                                                                         \
+    auto k = mlp_bwd_wide_kernel<NS_, MODE_>;                                                                                  \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz); \
+    if (e != hipSuccess) return (int)e;                                                                                        \
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWT), ldsz, s, a);                                                        \
+  } while (0)
   if (ns == 1) {
-    auto k = mlp_bwd_wide_kernel<1>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWT), lds1, s, a);
+    if (!fast) MVP_WIDE_LAUNCH(1, -1);
+    else if (mode == 0) MVP_WIDE_LAUNCH(1, 0);
+    else if (mode == 1) MVP_WIDE_LAUNCH(1, 1);
+    else MVP_WIDE_LAUNCH(1, 2);
   } else {
-    auto k = mlp_bwd_wide_kernel<2>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWT), lds2, s, a);
+    if (!fast) MVP_WIDE_LAUNCH(2, -1);
+    else if (mode == 0) MVP_WIDE_LAUNCH(2, 0);
+    else if (mode == 1) MVP_WIDE_LAUNCH(2, 1);
+    else MVP_WIDE_LAUNCH(2, 2);
   }
+#undef MVP_WIDE_LAUNCH
   int rc = mvp_launch_status();
   if (rc != MVP_OK) return rc;
   if (a.ws) {
@@ -428,3 +528,14 @@ MVP_API int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, c
   }
   return rc;
 }
+
+#ifdef MVP_WIDE_PROF
+MVP_API int mvp_wide_prof_read(unsigned long long* out, int reset) {  // out[1024][8]
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_prof), sizeof(unsigned long long) * 1024 * 8);
+  if (e == hipSuccess && reset) {
+    static unsigned long long zeros[1024 * 8];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_wide_prof), zeros, sizeof(zeros));
+  }
+  return (int)e;
+}
+#endif

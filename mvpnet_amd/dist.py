@@ -27,6 +27,10 @@ def init_from_env(backend=None):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:  # MVP_DIST_BACKEND: debugging aid (e.g. two ranks on ONE GPU over gloo; RCCL refuses duplicate devices)
             backend = os.environ.get('MVP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if backend == 'gloo' and os.environ.get('MASTER_ADDR') in ('127.0.0.1', 'localhost') and os.path.isdir('/sys/class/net/lo'):
+            # single-node gloo (tests, --dry, the one-GPU debugging set-ups): pin the transport to the loopback interface.  Left alone gloo
+            # looks its interface up through the HOSTNAME, which on a container whose name does not resolve can stall every rank for minutes
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -17,6 +17,20 @@ KW = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
 CFG = dict(num_centroids=(256, 64, 16, 4), radius=(0.1, 0.2, 0.4, 0.8), max_neighbors=(32, 32, 32, 32))
 
 
+def _spawn(fn, args, nprocs, limit=300.0):
+    """mp.spawn with a bounded join: ranks that never come back (a rendezvous that does not complete, a device that two processes fight
+    over) fail THIS test after `limit` seconds -- with the children killed -- instead of holding the whole GPU test run."""
+    import time
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=5.0):
+        if time.time() - t0 > limit:
+            for pr in ctx.processes:
+                if pr.is_alive():
+                    pr.kill()
+            pytest.fail('spawned ranks did not finish within {:.0f} s'.format(limit))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -100,7 +114,7 @@ def _worker(rank, world, port, tmp):
 
 def test_two_ranks_one_gpu(tmp_path):
     assert torch.cuda.is_available()
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _spawn(_worker, (2, _free_port(), str(tmp_path)), 2)
     r0, r1 = [torch.load(os.path.join(str(tmp_path), 'r{}.pt'.format(r))) for r in range(2)]
     for a, b in zip(r0['params'], r1['params']):
         assert torch.equal(a, b)
@@ -174,7 +188,7 @@ def test_ragged_chunks_and_empty_rank(tmp_path):
     fewer chunks than ranks: every rank's vote equals the reference's sequential loop (one chunk at a time, logits cut to the chunk's
     true length, test_mvpnet_3d.py:142-174)."""
     assert torch.cuda.is_available()
-    mp.spawn(_worker_ragged, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _spawn(_worker_ragged, (2, _free_port(), str(tmp_path)), 2)
     r0, r1 = [torch.load(os.path.join(str(tmp_path), 'g{}.pt'.format(r))) for r in range(2)]
     for k in ('mean', 'label', 'cnt', 'm1', 'c1'):
         assert torch.equal(r0[k], r1[k]), k
