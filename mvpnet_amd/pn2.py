@@ -145,26 +145,27 @@ class SetAbstraction(nn.Module):
         csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
         csr_geo = tuple(geometry[2:6]) if len(geometry) >= 6 else csr   # (+ the geometry sums of the fused training path)
         M, K = new_xyz.size(1), self.max_neighbors
-        l0 = self.mlp[0]
-        c1 = l0.conv.weight.size(0)
+        ps = R.parts(self.mlp)
+        q0 = ps[0]
+        w0 = q0.w
+        c1 = w0.size(0)
         # the linear-first factorisation hands shared_mlp_rows a chain whose first layer is already applied: only its fused
         # path (R.mlp_chain_is_fused) can take that
-        if (self.use_xyz or not use_feature) and R.mlp_chain_is_fused(self.mlp) and K <= 255:
+        if (self.use_xyz or not use_feature) and R.mlp_chain_is_fused(self.mlp, ps=ps) and K <= 255:
             # The first shared-MLP layer is linear, so its feature columns commute with the grouping:
             #   W1.[f(idx) | xyz(idx) - c] = (W1f.f)(idx) + W1xyz.(xyz(idx) - c)
             # -> the 1x1 conv over the feature runs on the N points instead of the M*K = 8N grouped rows, and the
             #    grouped tensor has C_1 instead of C+3 columns.  The 3 coordinate columns are applied to the difference
             #    inside the grouping kernel (same operation order as modules.py:27 + conv; no cancellation).
-            w1 = l0.conv.weight.reshape(c1, -1)                       # columns [feature (C) | xyz (3)]
             zf = None
             # one gradient buffer for the weight's two column groups (feature columns here, coordinate columns in the grouping kernel)
-            sink = R.WeightGradSink(l0.conv.weight, 2) if (use_feature and torch.is_grad_enabled() and l0.conv.weight.requires_grad) else None
+            sink = R.WeightGradSink(w0, 2) if (use_feature and torch.is_grad_enabled() and w0.requires_grad) else None
             if use_feature:
                 cf = feature.size(2)
                 pad = (-cf) % 4
                 f = torch.nn.functional.pad(feature, (0, pad)) if pad else feature
-                zf = R.linear_rows(f.reshape(B * N, -1), l0.conv.weight, cols=(0, cf), sink=sink).view(B, N, c1)
-            bn_training = l0.bn.training
+                zf = R.linear_rows(f.reshape(B * N, -1), w0, cols=(0, cf), sink=sink).view(B, N, c1)
+            bn_training = q0.bn.training
             if not bn_training and not torch.is_grad_enabled():
                 # inference: gather -> 3 layers -> max in ONE kernel, nothing between the gathered rows and (B,M,C_3) touches HBM
                 fused = R.sa_fused_eval(zf, xyz, new_xyz, ball, self.mlp)
@@ -174,7 +175,7 @@ class SetAbstraction(nn.Module):
                 # training: the whole level without any (B,M,K,C) tensor -- every pass re-creates the ball's rows from zf (csrc/sa_train.hip)
                 return new_xyz, R.sa_level_train(zf, xyz, new_xyz, ball, self.mlp, csr=csr_geo, sink=sink)
             # (B,M,K,C_1): conv output of layer 1; in training also its batch statistics AND the BatchNorm finalize, from the same call
-            y1 = R.group_lin_rows(zf, xyz, new_xyz, l0.conv.weight, ball, want_stat=l0.bn if bn_training else False, csr=csr, sink=sink)
+            y1 = R.group_lin_rows(zf, xyz, new_xyz, w0, ball, want_stat=q0.bn if bn_training else False, csr=csr, sink=sink)
             stat1 = None
             if bn_training:
                 y1, stat1 = y1[0], (y1[1], y1[2])
@@ -277,17 +278,18 @@ class FeaturePropagation(nn.Module):
             assert sparse_xyz.size(1) == 1 and sparse_feature.size(1) == 1
             new_feature = torch.cat([sparse_feature.expand(-1, N, -1), dense_feature], dim=2)
         else:
-            l0 = self.mlp[0]
-            c1 = l0.conv.weight.size(0)
+            q0 = R.Parts(self.mlp._modules['0'])
+            w0 = q0.w
+            c1 = w0.size(0)
             c2 = sparse_feature.size(2)
             if tail is not None:
                 # can the chain take the tail?  Decided BEFORE any work: the first layer below updates its BatchNorm's running statistics,
                 # so a refusal after it would make the caller's second call update them twice
                 chain = list(self.mlp) + list(tail[0])
-                if not (len(tail[0]) == 1 and R.mlp_chain_is_fused(chain) and tail[0][0].bn.training == l0.bn.training):
+                if not (len(tail[0]) == 1 and R.mlp_chain_is_fused(chain) and q0.bn is not None and tail[0][0].bn.training == q0.bn.training):
                     return None
-            if l0.bn is not None and l0.relu is not None and l0.conv.bias is None and l0.bn.running_mean is not None and \
-                    l0.bn.momentum is not None and c1 % 4 == 0 and 256 % (c1 // 4) == 0 and c2 % 4 == 0:
+            if q0.bn is not None and q0.relu is not None and q0.bias is None and q0.rm is not None and \
+                    q0.bn.momentum is not None and c1 % 4 == 0 and 256 % (c1 // 4) == 0 and c2 % 4 == 0:
                 # The first shared-MLP layer is linear and so is the interpolation:
                 #   W1.[interp(f_sparse) | f_dense] = interp(W1a.f_sparse) + W1b.f_dense
                 # -> the wide GEMM runs on the M = N/4 sparse points; the interpolation kernel adds the skip part and emits
@@ -296,16 +298,16 @@ class FeaturePropagation(nn.Module):
                 geometry = self.interpolator.geometry(dense_xyz, sparse_xyz) if geometry is None else geometry
                 index, weight = geometry[0], geometry[1]
                 csr = tuple(geometry[2:4]) if len(geometry) >= 4 else None
-                w1 = l0.conv.weight.reshape(c1, -1)                    # columns [interpolated (C2) | skip (C1)]
+                ctot = w0.numel() // c1                               # columns [interpolated (C2) | skip (C1)]
                 sink = None
-                if dense_feature is not None and torch.is_grad_enabled() and l0.conv.weight.requires_grad:
-                    sink = R.WeightGradSink(l0.conv.weight, 2)  # one gradient buffer for the weight's two column groups
-                z = R.linear_rows(sparse_feature.reshape(B * M, c2), l0.conv.weight, cols=(0, c2), sink=sink).view(B, M, c1)
+                if dense_feature is not None and torch.is_grad_enabled() and w0.requires_grad:
+                    sink = R.WeightGradSink(w0, 2)  # one gradient buffer for the weight's two column groups
+                z = R.linear_rows(sparse_feature.reshape(B * M, c2), w0, cols=(0, c2), sink=sink).view(B, M, c1)
                 zs = None
                 if dense_feature is not None:
-                    zs = R.linear_rows(dense_feature.reshape(B * N, -1), l0.conv.weight, cols=(c2, w1.size(1)), sink=sink).view(B, N, c1)
-                bn_training = l0.bn.training
-                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=l0.bn if bn_training else False, csr=csr)
+                    zs = R.linear_rows(dense_feature.reshape(B * N, -1), w0, cols=(c2, ctot), sink=sink).view(B, N, c1)
+                bn_training = q0.bn.training
+                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=q0.bn if bn_training else False, csr=csr)
                 stat1 = None
                 if bn_training:
                     y1, stat1 = y1[0], (y1[1], y1[2])

@@ -47,6 +47,33 @@ POOL_WITHOUT_Y = os.environ.get('MVP_POOL_NO_Y', '1') != '0'
 FUSE_DROPOUT = os.environ.get('MVP_FUSE_DROPOUT', '1') != '0'
 
 
+class Parts:
+    """What the hot paths read of one Conv + BN + ReLU layer (common/nn/modules/conv.py:4-51), fetched straight from the module's
+    parameter / buffer / sub-module dictionaries: `layer.conv.weight` goes through nn.Module.__getattr__ (a Python function with three
+    dictionary probes) per dot -- ~1300 such calls per training step were 0.5 ms of its host time.  Nothing is cached: the dictionaries are
+    read on every call, so replaced parameters / modules are seen."""
+    __slots__ = ('conv', 'w', 'bias', 'bn', 'relu', 'gamma', 'beta', 'rm', 'rv', 'nbt')
+
+    def __init__(self, layer):
+        mods = layer._modules
+        conv = self.conv = mods['conv']
+        cp = conv._parameters
+        self.w, self.bias = cp['weight'], cp.get('bias')
+        bn = self.bn = mods.get('bn')
+        self.relu = mods.get('relu')
+        if bn is None:
+            self.gamma = self.beta = self.rm = self.rv = self.nbt = None
+        else:
+            bp, bb = bn._parameters, bn._buffers
+            self.gamma, self.beta = bp.get('weight'), bp.get('bias')
+            self.rm, self.rv, self.nbt = bb.get('running_mean'), bb.get('running_var'), bb.get('num_batches_tracked')
+
+
+def parts(mlp):
+    """[Parts(layer) for layer in mlp] for a SharedMLP / list of Conv*BNReLU layers."""
+    return [Parts(l) for l in (mlp._modules.values() if isinstance(mlp, torch.nn.ModuleList) else mlp)]
+
+
 def _round4(c):
     return (c + 3) // 4 * 4
 
@@ -1222,9 +1249,10 @@ def sa_level_train_ok(zf, mlp, K):
         return False
     if L.DW_WORKSPACE:  # the reproducible mode keeps the per-layer path: its weight gradients go through a workspace + ordered reduction,
         return False    # the fused passes flush theirs (and the coordinate-column sums) with fp32 atomics
-    c1, c2, c3 = (l.conv.weight.size(0) for l in mlp)
-    return sa_level_train_widths_ok(c1, c2, c3) and all(l.bn.training for l in mlp) and L.current_precision()[0] != 0 and \
-        all(l.conv.weight.is_contiguous() for l in mlp)
+    ps = parts(mlp)
+    c1, c2, c3 = (q.w.size(0) for q in ps)
+    return sa_level_train_widths_ok(c1, c2, c3) and all(q.bn.training for q in ps) and L.current_precision()[0] != 0 and \
+        all(q.w.is_contiguous() for q in ps)
 
 
 class SALevelTrain(torch.autograd.Function):
@@ -1334,12 +1362,12 @@ def sa_level_train(zf, xyz, centre, index, mlp, csr=None, sink=None):
     of build_csr(index, N) [and geom_sums] when the geometry plan holds them; sink = the WeightGradSink of the first layer's weight."""
     offsets, slots = (csr[0], csr[1]) if csr is not None else (None, None)
     dsum, gsum = (csr[2], csr[3]) if csr is not None and len(csr) >= 4 else (None, None)
-    l1, l2, l3 = mlp
-    bns = [(l.bn.running_mean, l.bn.running_var, l.bn.num_batches_tracked, l.bn.eps, 0.1 if l.bn.momentum is None else l.bn.momentum) for l in mlp]
-    W2 = l2.conv.weight.reshape(l2.conv.weight.size(0), -1)
-    W3 = l3.conv.weight.reshape(l3.conv.weight.size(0), -1)
-    return SALevelTrain.apply(zf.contiguous(), xyz.contiguous(), centre.contiguous(), index.contiguous(), offsets, slots, dsum, gsum, l1.conv.weight, sink, bns,
-                              W2, W3, l1.bn.weight, l1.bn.bias, l2.bn.weight, l2.bn.bias, l3.bn.weight, l3.bn.bias)
+    q1, q2, q3 = parts(mlp)
+    bns = [(q.rm, q.rv, q.nbt, q.bn.eps, 0.1 if q.bn.momentum is None else q.bn.momentum) for q in (q1, q2, q3)]
+    W2 = q2.w.reshape(q2.w.size(0), -1)
+    W3 = q3.w.reshape(q3.w.size(0), -1)
+    return SALevelTrain.apply(zf.contiguous(), xyz.contiguous(), centre.contiguous(), index.contiguous(), offsets, slots, dsum, gsum, q1.w, sink, bns,
+                              W2, W3, q1.gamma, q1.beta, q2.gamma, q2.beta, q3.gamma, q3.beta)
 
 
 SA_FUSED_EVAL = os.environ.get('MVP_SA_FUSED', '1') != '0'
@@ -1377,15 +1405,22 @@ def sa_fused_eval(zf, xyz, centre, index, mlp):
     return out
 
 
-def mlp_chain_is_fused(mlp, dropout_p=0.0):
+def mlp_chain_is_fused(mlp, dropout_p=0.0, ps=None):
     """True when `mlp` (a SharedMLP) runs as ONE MLPChainRows node: conv without bias + BatchNorm with running statistics + ReLU
-    in every layer, widths the rows kernels tile (C % 4 == 0 and C / 4 divides 256), dropout only behind a single layer."""
-    # (bn.momentum None = PyTorch's cumulative moving average, factor 1 / num_batches_tracked: the kernels take one fixed factor, so such
-    # layers keep the per-layer torch path -- ADVICE r4)
-    return (dropout_p == 0 or len(mlp) == 1) and \
-        all(l.bn is not None and l.relu is not None and l.conv.bias is None and l.bn.running_mean is not None and l.bn.momentum is not None
-            for l in mlp) and \
-        all(l.conv.weight.size(0) % 4 == 0 and 256 % (l.conv.weight.size(0) // 4) == 0 for l in mlp)
+    in every layer, widths the rows kernels tile (C % 4 == 0 and C / 4 divides 256), dropout only behind a single layer.
+    ps: parts(mlp) when the caller already has them."""
+    ps = parts(mlp) if ps is None else ps
+    if not (dropout_p == 0 or len(ps) == 1):
+        return False
+    for q in ps:
+        # (bn.momentum None = PyTorch's cumulative moving average, factor 1 / num_batches_tracked: the kernels take one fixed factor, so such
+        # layers keep the per-layer torch path -- ADVICE r4)
+        if q.bn is None or q.relu is None or q.bias is not None or q.rm is None or q.bn.momentum is None:
+            return False
+        c = q.w.size(0)
+        if c % 4 or 256 % (c // 4):
+            return False
+    return True
 
 
 def relation4_rows(src_xyz, tgt_xyz):
@@ -1413,25 +1448,26 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
     # dropout follows EVERY layer of a SharedMLPDO (mlp.py:86-92): a single-layer chain can still be fused, dropout on its output.
     # dropout_last_only: `mlp` is a SharedMLP followed by a single-layer SharedMLPDO run as ONE chain (PN2SSG: the last feature-propagation
     # MLP + the segmentation head, whose only consumer it is) -- the dropout belongs to the last layer alone
-    fused = mlp_chain_is_fused(mlp, 0.0 if dropout_last_only else dropout_p) and K <= 255
+    ps = parts(mlp)
+    fused = mlp_chain_is_fused(mlp, 0.0 if dropout_last_only else dropout_p, ps) and K <= 255
     assert fused or not dropout_last_only, 'dropout_last_only needs the fused chain'
     if fused:
-        bn_training = mlp[0].bn.training
+        bn_training = ps[0].bn.training
         params, buffers, eps_mom = [], [], []
-        for li, layer in enumerate(mlp):
-            w = None if (first_done and li == 0) else layer.conv.weight.reshape(layer.conv.weight.size(0), -1)
-            params += [w, layer.bn.weight, layer.bn.bias]
-            buffers.append((layer.bn.running_mean, layer.bn.running_var, layer.bn.num_batches_tracked if bn_training else None))
-            eps_mom.append((layer.bn.eps, 0.1 if layer.bn.momentum is None else layer.bn.momentum))
+        for li, q in enumerate(ps):
+            w = None if (first_done and li == 0) else (q.w if q.w.dim() == 2 else q.w.reshape(q.w.size(0), -1))
+            params += [w, q.gamma, q.beta]
+            buffers.append((q.rm, q.rv, q.nbt if bn_training else None))
+            eps_mom.append((q.bn.eps, q.bn.momentum))
         opts = {'sum': bool(reduce == 'sum' and K > 1)}
         if rel is not None:
             assert not first_done and rel.dim() == 2 and rel.size(1) == 4 and rel.size(0) == x.size(0)
-            opts['rel'] = (rel.contiguous(), mlp[0].conv.weight)
+            opts['rel'] = (rel.contiguous(), ps[0].w)
         if DW_SIDE_STREAM and torch.is_grad_enabled():  # (a first layer that ran before the grouping has its own use: WeightGradSink)
-            opts['use'] = WeightUse([l.conv.weight for li, l in enumerate(mlp) if not (first_done and li == 0)])
+            opts['use'] = WeightUse([q.w for li, q in enumerate(ps) if not (first_done and li == 0)])
         # dropout behind the (single) layer: folded into the BatchNorm + ReLU passes (mvp_bn_rows_forward_dropout_f32) unless a graph is
         # being captured (the seed would be baked into the capture; torch's own dropout advances its Philox offset per replay)
-        fold = dropout_p > 0 and training and K == 1 and 0 < dropout_p < 1 and FUSE_DROPOUT and x.size(0) * mlp[-1].conv.weight.size(0) < 2 ** 32 and \
+        fold = dropout_p > 0 and training and K == 1 and 0 < dropout_p < 1 and FUSE_DROPOUT and x.size(0) * ps[-1].w.size(0) < 2 ** 32 and \
             not torch.cuda.is_current_stream_capturing()
         if fold:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())  # torch's CPU generator: follows torch.manual_seed
