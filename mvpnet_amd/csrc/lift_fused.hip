@@ -380,8 +380,11 @@ __device__ __forceinline__ void filtered_search(const float4* __restrict__ crec,
     // kOwners of them put their loads in flight together and are resolved one after the other -- the wave then pays one memory round
     // trip per kOwners tasks instead of one per task (two dense 5-view chunks: ~130 such tasks per wave with one wave per SIMD,
     // 190 of the kernel's 200 us).  Same candidates, same arithmetic, same (distance, id) order per owner: identical results.
-    constexpr int kOwners = T == 64 ? 8 : 4;  // (one-wave workgroups run at ~1 wave per SIMD: registers are free, round trips are not)
-    {
+#ifndef MVP_LIFT_OWNERS_BIG
+#define MVP_LIFT_OWNERS_BIG 4   /* owners per round trip of the 256-point workgroups (1 = one task per round trip: the round-3 path) */
+#endif
+    constexpr int kOwners = T == 64 ? 8 : MVP_LIFT_OWNERS_BIG;  // (one-wave workgroups run at ~1 wave per SIMD: registers are free, round trips are not)
+    if constexpr (kOwners > 1) {
       const bool small = has && (t_uhi - t_ulo) < 16 && (t_vhi - t_vlo) < 16;
       unsigned long long sm = __ballot(small);
       if (__popcll(sm) >= 2) {

@@ -13,5 +13,9 @@ cp $g/end_$run/step_timeline.txt profiles/${r}_step_timeline.txt
 cp $g/end_$run/step_timeline_graph.txt profiles/${r}_step_timeline_graph.txt
 cp $g/end_$run/multi_rank_host.txt profiles/${r}_multi_rank_host.txt
 cp $(find $g/end_$run/dense_lift -name "*kernel_stats.csv" | head -1) profiles/${r}_dense_lift_kernel_stats.csv
+cp $g/end_$run/step_dump.txt profiles/${r}_step_dump.txt
+cp $g/end_$run/wide_time.txt profiles/${r}_wide_backward_alone.txt
+cp $g/end_$run/graph_node_cost.txt profiles/${r}_graph_node_cost.txt
+cp $g/end_$run/graphgap.txt profiles/${r}_graphgap.txt
 [ -f $g/operating_point_B32.json ] && cp $g/operating_point_B32.json profiles/${r}_operating_point_B32.json
 ls -la profiles | grep ${r}_

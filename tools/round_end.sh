@@ -7,7 +7,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/end_$tag
 mkdir -p $out
 cd $root
-python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q --timeout 400 > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('build+smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
 python bench.py > $out/bench.json 2> $out/bench.err; cut -c1-400 $out/bench.json
 python bench.py --graph --no-cpu-baseline > $out/bench_graph.json 2> $out/bench_graph.err; cut -c1-200 $out/bench_graph.json
@@ -15,12 +15,17 @@ python bench.py --graph --no-cpu-baseline > $out/bench_graph.json 2> $out/bench_
 bash tools/step_counters.sh $tag > $out/counters.log 2>&1
 python tools/step_timeline.py $root/gpurun_out/ctr_$tag/trace/p_kernel_trace.csv > $out/step_timeline.txt 2>&1
 head -12 $out/step_timeline.txt
+python tools/step_dump.py $root/gpurun_out/ctr_$tag/trace/p_kernel_trace.csv > $out/step_dump.txt 2>&1; tail -1 $out/step_dump.txt
 # the SAME step replayed from one HIP graph, traced the same way: where eager and replay differ
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $out/graph_trace -o p -- python $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --train-only --graph > $out/graph_trace.log 2>&1)
 python tools/step_timeline.py $out/graph_trace/p_kernel_trace.csv > $out/step_timeline_graph.txt 2>&1
 head -4 $out/step_timeline_graph.txt
 # eight ranks on one host: one real rank + seven host-only peers over gloo, and two real ranks sharing the GPU (the non-dry N > 1 path)
-bash tools/multi_rank_host.sh 30 > $out/multi_rank_host.log 2>&1; cp $root/gpurun_out/multi_rank_host.txt $out/ 2>/dev/null
+timeout 900 bash tools/multi_rank_host.sh 30 > $out/multi_rank_host.log 2>&1; cp $root/gpurun_out/multi_rank_host.txt $out/ 2>/dev/null
 # the lifting launch at configs[4] by kernel time
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/dense_lift -o p -- python $root/tools/exp/dense_lift_prof.py > $out/dense_lift.log 2>&1)
 grep lift_ $out/dense_lift/p_kernel_stats.csv | cut -c1-200
+# round 5: the one-pass wide layer backward alone (time, fraction of the HBM peak, the three kernels it replaces), what a graph node costs per kernel kind
+python tools/exp/wide_time.py 2>&1 | grep -v amdgpu.ids > $out/wide_time.txt; cat $out/wide_time.txt
+python tools/exp/graphgap/node_cost.py 2>&1 | grep -v amdgpu.ids > $out/graph_node_cost.txt
+(cd tools/exp/graphgap && ./graphgap 150 4000 8 0 && ./graphgap 150 4000 8 64) > $out/graphgap.txt 2>&1
