@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int i = 0; i < 16; ++i) accw[b][i] = 0.f;
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, tsum[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ssum4 = {0.f, 0.f, 0.f, 0.f}, tsum4 = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();  // W image and constants complete, first ticket visible
   WIDE_T(0);
   int nxt = misc[0];
@@ -223,14 +223,21 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   TileRegs& tc = ta;
   f32x4 xk[4];
   while (cur < ntiles) {
-    if (tid == 0) misc[(it + 1) & 1] = p.ticket ? step + atomicAdd(p.ticket, 1) : nxt + step;
+    // The ticket for the tile after next is requested FIRST and consumed last (behind P1): a returning atomic counts in vmcnt like a load and
+    // returns in order, so waiting for one issued BEHIND this tile's prefetches would drain them all (~2 us of exposed latency per tile)
+    int tk = 0;
+    if (tid == 0 && p.ticket) tk = atomicAdd(p.ticket, 1);
+    const int nload = min(nxt, ntiles - 1);  // the prefetches below are UNCONDITIONAL (a load inside a branch makes the compiler wait for everything
+                                             // outstanding at the join); past the last tile they re-read it and nobody uses the values
     const bool tail = cur == ntiles - 1 && tail_rows < kTR;
     const int rows_here = tail ? tail_rows : kTR;
     // y_{i-1} of this tile moves to `xk` (P1 and P4 read it there) and the NEXT tile's is requested at once: a third of the tile's bytes gets
     // a whole tile of lead instead of P2 .. P4
 #pragma unroll
     for (int j = 0; j < 4; ++j) xk[j] = tc.x[j];
-    if (nxt < ntiles) load_x(tc, nxt);
+#if !(defined(MVP_WIDE_EXP) && MVP_WIDE_EXP == 3)
+    load_x(tc, nload);
+#endif
     // ---- P1: dy_i and a_{i-1} of this thread's 16 elements -> bf16 pieces -> the row-major LDS images (the row masks only in the last,
     // partial tile: `tailc`)
     auto p1 = [&](auto tailc) {
@@ -241,33 +248,51 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       for (int j = 0; j < 4; ++j) {
         const int r = rbase + 16 * j;
         const bool rok = !TAIL || r < rows_here;
-        float d[4], a[4];
+        // (vector arithmetic on the 16-byte pieces: the compiler emits packed fp32 operations on aligned register pairs -- plain forms, no
+        // op_sel swizzle, tests/test_isa_cpu.py -- which halves this part of P1; each operation still rounds once, -ffp-contract=off)
+        f32x4 d = tc.g[j];
+        if (mode != 0) {
+          const f32x4 xh = (tc.y[j] - mu) * is;
+          if (mode == 2) {
+            const f32x4 zz = xh * ga + be;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = tc.g[j][e];
-          if (mode != 0) {
-            const float xh = (tc.y[j][e] - mu[e]) * is[e];
-            if (mode == 2) {
+            for (int e = 0; e < 4; ++e) {
+              float v = d[e];
               if (p.drop.thresh) v *= p.drop.factor((unsigned)(((int64_t)cur * kTR + r) * C + cc + e));
-              v = (xh * ga[e] + be[e] > 0.f) ? v : 0.f;
+              d[e] = (zz[e] > 0.f) ? v : 0.f;
             }
-            v = sc[e] * ((v - db[e]) - xh * dg[e]);
           }
-          d[e] = (rok && cok) ? v : 0.f;
-          float x = xk[j][e];
-          if (has_act) {
-            const float z = ((x - pm[e]) * pi[e]) * pg[e] + pb[e];
-            x = z > 0.f ? z : 0.f;
-          }
-          a[e] = (rok && xok) ? x : 0.f;
+          d = sc * ((d - db) - xh * dg);
         }
-        if (nxt < ntiles) load_gy_row(tc, nxt, j);  // this row's registers are free: the next tile's row is requested at once
+        f32x4 a = xk[j];
+        if (has_act) {
+          a = ((a - pm) * pi) * pg + pb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+        }
+        if (TAIL || !FULL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            d[e] = (rok && cok) ? d[e] : 0.f;
+            a[e] = (rok && xok) ? a[e] : 0.f;
+          }
+        }
+#if !(defined(MVP_WIDE_EXP) && MVP_WIDE_EXP == 3)   /* (3: timing experiment, wrong results: no global loads in the loop) */
+        load_gy_row(tc, nload, j);  // this row's registers are free: the next tile's row is requested at once
+#endif
         unsigned d0[NS], d1[NS], a0[NS], a1[NS];
+#if defined(MVP_WIDE_EXP) && MVP_WIDE_EXP == 2   /* (timing experiment: wrong results) P1 without the splits */
+        for (int pc = 0; pc < NS; ++pc) { d0[pc] = __float_as_uint(d[0]); d1[pc] = __float_as_uint(d[2]); a0[pc] = __float_as_uint(a[0]); a1[pc] = __float_as_uint(a[2]); }
+#else
         split_pair<NS>(d[0], d[1], d0);
         split_pair<NS>(d[2], d[3], d1);
         split_pair<NS>(a[0], a[1], a0);
         split_pair<NS>(a[2], a[3], a1);
+#endif
         const int off = r * kRowB + c4 * 8;
+#if defined(MVP_WIDE_EXP) && MVP_WIDE_EXP == 1   /* (timing experiment: wrong results) P1 without its LDS writes */
+        if (d0[0] == 0x12345678u)
+#endif
 #pragma unroll
         for (int pc = 0; pc < NS; ++pc) {
           *reinterpret_cast<uint2*>(L + oDy + pc * kTimg + off) = make_uint2(d0[pc], d1[pc]);
@@ -277,6 +302,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       }
     };
     if (tail) p1(std::true_type{}); else p1(std::false_type{});
+    if (tid == 0) misc[(it + 1) & 1] = p.ticket ? step + tk : nxt + step;
     WIDE_T(1);
     __syncthreads();
     WIDE_T(2);
@@ -369,15 +395,16 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
         const bool rok = !TAIL || r < rows_here;
         f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * kWCh + cc);
         if (has_act) {
+          const f32x4 xh = (xk[j] - pm) * pi;
+          const f32x4 zz = xh * pg + pb;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float xh = (xk[j][e] - pm[e]) * pi[e];
-            float d = (xh * pg[e] + pb[e] > 0.f) ? v[e] : 0.f;
+            float d = (zz[e] > 0.f) ? v[e] : 0.f;
             if (TAIL || !FULL) d = (rok && xok) ? d : 0.f;
             v[e] = d;
-            ssum[e] += d;
-            tsum[e] += d * xh;
           }
+          ssum4 += v;
+          tsum4 += v * xh;
         }
         if (rok && xok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Zt + r * Cp + cc));
         __builtin_amdgcn_sched_barrier(0);
@@ -397,8 +424,8 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     double* sred = reinterpret_cast<double*>(lds + oDy);  // [2][16][128]
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      sred[(0 * 16 + rbase) * kWCh + cc + e] = (double)ssum[e];
-      sred[(1 * 16 + rbase) * kWCh + cc + e] = (double)tsum[e];
+      sred[(0 * 16 + rbase) * kWCh + cc + e] = (double)ssum4[e];
+      sred[(1 * 16 + rbase) * kWCh + cc + e] = (double)tsum4[e];
     }
     __syncthreads();
     if (tid < 2 * kWCh) {

@@ -9,7 +9,7 @@ for f in *.hip; do
   o=build/${f%.hip}.o
   if [ "$f" = "mlp_bwd_wide.hip" ]; then
     o=/tmp/mlp_bwd_wide_prof.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden -fno-slp-vectorize -DMVP_WIDE_PROF -c $f -o $o || exit 1
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden -fno-slp-vectorize -DMVP_WIDE_PROF ${MVP_WIDE_EXP:+-DMVP_WIDE_EXP=$MVP_WIDE_EXP} -c $f -o $o || exit 1
   fi
   objs="$objs $o"
 done

@@ -29,3 +29,9 @@ grep lift_ $out/dense_lift/p_kernel_stats.csv | cut -c1-200
 python tools/exp/wide_time.py 2>&1 | grep -v amdgpu.ids > $out/wide_time.txt; cat $out/wide_time.txt
 python tools/exp/graphgap/node_cost.py 2>&1 | grep -v amdgpu.ids > $out/graph_node_cost.txt
 (cd tools/exp/graphgap && ./graphgap 150 4000 8 0 && ./graphgap 150 4000 8 64) > $out/graphgap.txt 2>&1
+# gpurun merges at most 64 MiB back: drop what nothing reads (the full bench's kernel trace, per-dispatch counter dumps beyond the merged table)
+find $root/gpurun_out -name "*_kernel_trace.csv" -size +12M -delete
+find $root/gpurun_out -type f -size +16M -delete
+rm -rf $out/bench_prof/*/*_agent_info.csv 2>/dev/null
+du -sh $root/gpurun_out | tail -1
+du -s $root/gpurun_out/* | sort -n | tail -5
