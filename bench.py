@@ -106,7 +106,7 @@ class TimedLifting:
         return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else float('nan')
 
 
-TRAFFIC_FILES = ('r04_step_traffic.json', 'r03_step_traffic.json')  # the newest committed PMC table of the step
+TRAFFIC_FILES = ('r05_step_traffic.json', 'r04_step_traffic.json', 'r03_step_traffic.json')  # the newest committed PMC table of the step
 
 
 def lift_traffic(batch):
@@ -282,7 +282,7 @@ def parity_info():
            'train_mode_logit_bar': '3e-4 vs the reference fp32 fixture AND max |gpu - f64| <= 1.5 x max |reference fp32 - f64| (25 batch-statistics BatchNorms: the '
                                    'reference fp32 path itself is ~2.7e-4 from the float64 value of its graph, so 1e-4 against it is not attainable by any fp32 implementation)',
            'index_ops': 'bit-exact (FPS, ball query, 3-NN, pixel k-NN)'}
-    for name in ('r04_operating_point_B32.json', 'r03_operating_point_B32.json', 'r02_operating_point_B8_bf16x6_bwd_bf16x3.json'):
+    for name in ('r05_operating_point_B32.json', 'r04_operating_point_B32.json', 'r03_operating_point_B32.json', 'r02_operating_point_B8_bf16x6_bwd_bf16x3.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             with open(path) as f:
@@ -294,6 +294,32 @@ def parity_info():
                                       'worst_grad_relL2_cpu32_vs_f64': rep['grads_worst']['cpu32_vs_f64_relL2']}
             break
     return out
+
+
+def pin_to_core_block(local_rank, env=os.environ):
+    """One rank = one contiguous block of an eighth of the host's cores (at least 8): `taskset` from inside.  On the 256-core hosts of this pool a
+    rank whose threads (Python, the autograd engine's, the HIP runtime's) are free to roam both sockets pays 6.0 ms of enqueue time per step, pinned to 32
+    neighbouring cores 4.5 ms (tools/multi_rank_host.sh, profiles/r05_multi_rank_host.txt) -- and eight ranks of a node must not share cores anyway.
+    MVP_CPU_AFFINITY=0 leaves the mask alone, MVP_CPU_AFFINITY=a-b sets an explicit range.  -> (original mask, description)."""
+    if not hasattr(os, 'sched_getaffinity'):
+        return None, 'unsupported'
+    orig = os.sched_getaffinity(0)
+    want = env.get('MVP_CPU_AFFINITY', 'auto')
+    if want == '0':
+        return orig, 'unchanged ({} cores)'.format(len(orig))
+    cores = sorted(orig)
+    if want != 'auto':
+        a, b = (int(x) for x in want.split('-'))
+        pick = [c for c in cores if a <= c <= b]
+    else:
+        per = max(8, len(cores) // 8)
+        blocks = max(1, len(cores) // per)
+        start = (local_rank % blocks) * per
+        pick = cores[start:start + per]
+    if not pick:
+        return orig, 'unchanged ({} cores)'.format(len(orig))
+    os.sched_setaffinity(0, pick)
+    return orig, 'cores {}-{} ({} of {})'.format(pick[0], pick[-1], len(pick), len(cores))
 
 
 def collective_info(dev=None):
@@ -536,6 +562,7 @@ def main():
 
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (there is no CPU fallback of the product path)'
     _lib.lib()
+    orig_affinity, affinity = pin_to_core_block(int(os.environ.get('LOCAL_RANK', '0')))
     rank, world, local = D.init_from_env()
     side = (args.extras == 'all' or (args.extras == 'auto' and world == 1)) and not args.train_only  # B = 1 latency, fp32-MFMA step, 2D network, dense config
     assert world == args.gpus, 'WORLD_SIZE ({}) != --gpus ({})'.format(world, args.gpus)
@@ -949,6 +976,7 @@ def main():
                        'parallelism': 'dp{} (one process per GPU, 1 grad all-reduce/step)'.format(world),
                        'launch': 'hip graph (forward + backward; next-batch geometry {}), optimizer eager'.format(args.graph_geometry) if args.graph else 'eager',
                        'launch_probe': auto_probe,
+                       'cpu_affinity': affinity,   # bench.pin_to_core_block: one block of an eighth of the host's cores per rank
                        'settle_ms_per_step': settled,   # set-up blocks of 10 steps run BEFORE the warm-up (bench.settle): not part of W or K
                        'contraction': contraction_info()},
             'collective': coll,
@@ -971,6 +999,8 @@ def main():
                          'traffic': lift_traffic(args.batch), 'traffic_source': 'profiles/{} (committed rocprofv3 PMC passes of this step at B=32, not read live)'.format(next((n for n in TRAFFIC_FILES if os.path.exists(os.path.join(ROOT, 'profiles', n))), 'none')), 'ms_per_launch': round(lift_ms, 4), 'algorithmic_bytes_per_launch': LIFT_BYTES_PER_CHUNK * args.batch},
         }
         if world == 1 and not args.no_cpu_baseline:
+            if orig_affinity is not None:
+                os.sched_setaffinity(0, orig_affinity)  # the host baseline gets every core it had
             out['cpu_baseline'] = cpu_baseline(bt)
         print(json.dumps(out))
     if world > 1:

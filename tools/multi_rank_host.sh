@@ -23,15 +23,15 @@ for l in sys.stdin:
 ncores=$(nproc)
 echo "host cores: $ncores" >> $out
 make -C $root/mvpnet_amd/csrc noop > $root/gpurun_out/noop_build.log 2>&1 || echo "noop build FAILED" >> $out
-one() { $3 python $root/bench.py --steps $steps --warmup 6 --no-cpu-baseline --train-only $2 2>/dev/null | line "$1"; }
+one() { MVP_CPU_AFFINITY=0 $3 python $root/bench.py --steps $steps --warmup 6 --no-cpu-baseline --train-only $2 2>/dev/null | line "$1"; }
 
 # ---- part 1: launch-only peers
 per=$((ncores / 8))
 peers() {  # $1 = pin (0/1), $2 = seconds
   pids=""
   for r in 1 2 3 4 5 6 7; do
-    pin=""; [ "$1" = "1" ] && pin="taskset -c $((r * per))-$((r * per + per - 1))"
-    MVP_LIBRARY=$root/mvpnet_amd/libmvp_noop.so $pin python $root/bench.py --launch-only-peer $2 --no-cpu-baseline --train-only > /dev/null 2>> $root/gpurun_out/multi_rank_peers.err &
+    ppin=""; [ "$1" = "1" ] && ppin="taskset -c $((r * per))-$((r * per + per - 1))"
+    MVP_CPU_AFFINITY=0 MVP_LIBRARY=$root/mvpnet_amd/libmvp_noop.so $ppin python $root/bench.py --launch-only-peer $2 --no-cpu-baseline --train-only > /dev/null 2>> $root/gpurun_out/multi_rank_peers.err &
     pids="$pids $!"
   done
 }
@@ -39,7 +39,7 @@ peers() {  # $1 = pin (0/1), $2 = seconds
 one "1 rank alone, eager" ""
 one "1 rank alone, graph" "--graph"
 one "1 rank alone, eager, pinned to $per cores" "" "taskset -c 0-$((per - 1))"
-MVP_LIBRARY=$root/mvpnet_amd/libmvp_noop.so python $root/bench.py --launch-only-peer 5 --no-cpu-baseline --train-only > /dev/null 2>> $root/gpurun_out/multi_rank_peers.err
+MVP_CPU_AFFINITY=0 MVP_LIBRARY=$root/mvpnet_amd/libmvp_noop.so python $root/bench.py --launch-only-peer 5 --no-cpu-baseline --train-only > /dev/null 2>> $root/gpurun_out/multi_rank_peers.err
 echo "a launch-only process alone: $(tail -1 $root/gpurun_out/multi_rank_peers.err)" >> $out
 for pin in 0 1; do
   peers $pin 75
