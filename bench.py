@@ -296,30 +296,46 @@ def parity_info():
     return out
 
 
+def _physical_cores(cpus):
+    """[[logical cpus of one physical core], ...] in (package, core) order, from sysfs; one list per cpu when the topology is not readable."""
+    by = {}
+    for c in cpus:
+        try:
+            base = '/sys/devices/system/cpu/cpu{}/topology/'.format(c)
+            with open(base + 'physical_package_id') as f:
+                pk = int(f.read())
+            with open(base + 'core_id') as f:
+                co = int(f.read())
+        except (OSError, ValueError):
+            pk, co = 0, c
+        by.setdefault((pk, co), []).append(c)
+    return [by[k] for k in sorted(by)]
+
+
 def pin_to_core_block(local_rank, env=os.environ):
-    """One rank = one contiguous block of an eighth of the host's cores (at least 8): `taskset` from inside.  On the 256-core hosts of this pool a
-    rank whose threads (Python, the autograd engine's, the HIP runtime's) are free to roam both sockets pays 6.0 ms of enqueue time per step, pinned to 32
-    neighbouring cores 4.5 ms (tools/multi_rank_host.sh, profiles/r05_multi_rank_host.txt) -- and eight ranks of a node must not share cores anyway.
-    MVP_CPU_AFFINITY=0 leaves the mask alone, MVP_CPU_AFFINITY=a-b sets an explicit range.  -> (original mask, description)."""
+    """One rank = one block of an eighth of the host's PHYSICAL cores (at least 4) with their SMT siblings: `taskset` from inside, so that the
+    eight ranks of a node never share a core (on the pool's 2 x 64-core hosts: 16 cores + 16 siblings per rank, all on one socket).  For ONE rank it
+    changes nothing measurable (4.83 against 4.81 ms of enqueue time per step, same box); it is the deployment shape INTEGRATION.md recommends.
+    MVP_CPU_AFFINITY=0 leaves the mask alone, MVP_CPU_AFFINITY=a-b sets an explicit range of logical cpus.  -> (original mask, description)."""
     if not hasattr(os, 'sched_getaffinity'):
         return None, 'unsupported'
     orig = os.sched_getaffinity(0)
     want = env.get('MVP_CPU_AFFINITY', 'auto')
     if want == '0':
-        return orig, 'unchanged ({} cores)'.format(len(orig))
-    cores = sorted(orig)
+        return orig, 'unchanged ({} cpus)'.format(len(orig))
     if want != 'auto':
         a, b = (int(x) for x in want.split('-'))
-        pick = [c for c in cores if a <= c <= b]
+        pick = [c for c in sorted(orig) if a <= c <= b]
     else:
-        per = max(8, len(cores) // 8)
-        blocks = max(1, len(cores) // per)
+        phys = _physical_cores(sorted(orig))
+        per = max(4, len(phys) // 8)
+        blocks = max(1, len(phys) // per)
         start = (local_rank % blocks) * per
-        pick = cores[start:start + per]
+        pick = sorted(c for core in phys[start:start + per] for c in core)
     if not pick:
-        return orig, 'unchanged ({} cores)'.format(len(orig))
+        return orig, 'unchanged ({} cpus)'.format(len(orig))
     os.sched_setaffinity(0, pick)
-    return orig, 'cores {}-{} ({} of {})'.format(pick[0], pick[-1], len(pick), len(cores))
+    return orig, '{} logical cpus of {} ({} .. {})'.format(len(pick), len(orig), pick[0], pick[-1])
 
 
 def collective_info(dev=None):
