@@ -34,8 +34,7 @@ namespace {
 
 constexpr int kWT = 512;    // threads: 8 waves
 constexpr int kTR = 64;     // rows per tile
-constexpr int kWCh = 128;   // channel capacity on both sides
-constexpr int kRowB = 272;  // bytes per LDS image row: 128 bf16 + 16 bytes of padding (see the bank notes at the W image)
+constexpr int kWCh = 128;   // channel capacity on both sides (the CH = 64 instances: layers with at most 64)
 
 struct WideArgs {
   const float* G;        // (R, C): dy_i (mode 0), dz_i (mode 1) or da_i = gradient w.r.t. the layer's (dropped-out) activation (mode 2)
@@ -78,21 +77,32 @@ __device__ unsigned long long g_wide_prof[1024][8];
 #define WIDE_T(k) do { } while (0)
 #endif
 
-struct TileRegs {  // one thread's 16-byte pieces of a tile: rows rbase + 16 j of dz_i / y_i / y_{i-1}
-  f32x4 g[4], y[4], x[4];
+template <int NJ>
+struct TileRegs {  // one thread's 16-byte pieces of a tile: rows rbase + RPP j of dz_i / y_i / y_{i-1}
+  f32x4 g[NJ], y[NJ], x[NJ];
 };
 
 // MODE >= 0: the FAST variants -- C == Cp == 128, layer i-1 has an activation, the source of dy_i known at compile time: no column masks
 // and no per-element branches in P1 / P4 (as run-time tests they were 2/3 of P1's ~700 instructions per thread, and P1 was half the
 // kernel).  MODE == -1: everything decided at run time (narrower layers, plain inputs: tests and odd networks).
-template <int NS, int MODE>
+// CH = 128 or 64: the channel capacity of the instance (row pieces, images and the MFMA tiling follow it).  CH = 64 is the shape of the
+// aggregation MLP's inner layers (786 432 rows x 64 -> 64): 16 pieces per row, 32 rows per pass of the 512 threads, waves 0 - 3 take the four
+// dX tiles and waves 4 - 7 the four dW tiles; 58 KB of LDS.
+template <int NS, int MODE, int CH>
 __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   constexpr bool FULL = MODE >= 0;
   using SP = SplitPairs<NS>;
-  constexpr int kWimg = kWCh * kRowB;   // 34 KB per piece
+  constexpr int Q = CH / 4;          // 16-byte pieces per row
+  constexpr int RPP = kWT / Q;       // rows per pass of the workgroup's threads: 16 (CH 128) / 32 (CH 64)
+  constexpr int NJ = kTR / RPP;      // passes per tile: 4 / 2
+  constexpr int CB = CH / 32;        // 32-column blocks
+  constexpr bool SPLIT = CH == 64;   // dX and dW tiles on different waves (4 + 4) instead of 1 + 2 per wave
+  constexpr int NB = SPLIT ? 1 : 2;  // dW tiles per wave
+  constexpr int kRowB = CH * 2 + 16; // bytes per LDS image row: CH bf16 + 16 bytes of padding (see the bank notes at the W image)
+  constexpr int kWimg = CH * kRowB;     // 34 KB per piece (CH 128)
   constexpr int kTimg = kTR * kRowB;    // 17 KB per piece
-  constexpr int oW = 0, oDy = NS * kWimg, oA = oDy + NS * kTimg, oMisc = oA + NS * kTimg, oCst = oMisc + 64;  // + 11 x 128 column constants
-  static_assert(2 * NS * kTimg >= kTR * kWCh * 4, "the dX staging tile aliases the dy / a images");
+  constexpr int oW = 0, oDy = NS * kWimg, oA = oDy + NS * kTimg, oMisc = oA + NS * kTimg, oCst = oMisc + 64;  // + 11 x CH column constants
+  static_assert(2 * NS * kTimg >= kTR * CH * 4, "the dX staging tile aliases the dy / a images");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int* misc = reinterpret_cast<int*>(lds + oMisc);
   unsigned char* const L = lds;
@@ -102,8 +112,8 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   unsigned long long tprev_ = wall_clock64();
 #endif
   const int n = lane & 31, h = lane >> 5;
-  const int c4 = tid & 31, cc = 4 * c4, rbase = tid >> 5;  // this thread's 4 columns and its rows rbase + 16 j of every tile
-  const int C = FULL ? kWCh : p.C, Cp = FULL ? kWCh : p.Cp;
+  const int c4 = tid % Q, cc = 4 * c4, rbase = tid / Q;  // this thread's 4 columns and its rows rbase + RPP j of every tile
+  const int C = FULL ? CH : p.C, Cp = FULL ? CH : p.Cp;
   const bool has_act = FULL || p.act.mean != nullptr;
   const bool cok = FULL || cc < C, xok = FULL || cc < Cp;
   const int ntiles = p.ntiles, step = (int)gridDim.x;
@@ -111,32 +121,32 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
 
   // ---- global addressing: a scalar tile base + per-thread element offsets that do not depend on the tile (4 per tensor); only the LAST
   // tile of a row count that is not a multiple of 64 clamps its rows (its values are masked in P1 / P4)
-  int offg[4], offx[4];
+  int offg[NJ], offx[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    offg[j] = (rbase + 16 * j) * C + (cok ? cc : 0);
-    offx[j] = (rbase + 16 * j) * p.ldx + (xok ? cc : 0);
+  for (int j = 0; j < NJ; ++j) {
+    offg[j] = (rbase + RPP * j) * C + (cok ? cc : 0);
+    offx[j] = (rbase + RPP * j) * p.ldx + (xok ? cc : 0);
   }
   const int tail_rows = (int)(p.R - (int64_t)(ntiles - 1) * kTR);  // rows of the last tile: 1 .. 64
-  auto load_gy_row = [&](TileRegs& t, int tile, int j) {
+  auto load_gy_row = [&](TileRegs<NJ>& t, int tile, int j) {
     const float* Gt = p.G + (size_t)tile * kTR * C;
     const float* Yt = (mode != 0 ? p.Yi : p.G) + (size_t)tile * kTR * C;
     const bool clamp = tile == ntiles - 1 && tail_rows < kTR;
-    const int o = clamp ? min(rbase + 16 * j, tail_rows - 1) * C + (cok ? cc : 0) : offg[j];
+    const int o = clamp ? min(rbase + RPP * j, tail_rows - 1) * C + (cok ? cc : 0) : offg[j];
     t.g[j] = *reinterpret_cast<const f32x4*>(Gt + o);
     if (mode != 0) t.y[j] = *reinterpret_cast<const f32x4*>(Yt + o);
   };
-  auto load_gy = [&](TileRegs& t, int tile) {
+  auto load_gy = [&](TileRegs<NJ>& t, int tile) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) load_gy_row(t, tile, j);
+    for (int j = 0; j < NJ; ++j) load_gy_row(t, tile, j);
   };
-  auto load_x = [&](TileRegs& t, int tile) {
+  auto load_x = [&](TileRegs<NJ>& t, int tile) {
     const float* Xt = p.X + (size_t)tile * kTR * p.ldx;
     const bool clamp = tile == ntiles - 1 && tail_rows < kTR;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t.x[j] = *reinterpret_cast<const f32x4*>(Xt + (clamp ? min(rbase + 16 * j, tail_rows - 1) * p.ldx + (xok ? cc : 0) : offx[j]));
+    for (int j = 0; j < NJ; ++j) t.x[j] = *reinterpret_cast<const f32x4*>(Xt + (clamp ? min(rbase + RPP * j, tail_rows - 1) * p.ldx + (xok ? cc : 0) : offx[j]));
   };
-  TileRegs ta;
+  TileRegs<NJ> ta;
   int cur = (int)blockIdx.x;
   if (tid == 0) misc[0] = p.ticket ? step + atomicAdd(p.ticket, 1) : cur + step;
   if (cur < ntiles) {  // in flight under the staging of the W image
@@ -152,10 +162,11 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   // A thread takes a 4 (c_out) x 4 (c_in) block: four 16-byte loads along c_in (coalesced), transposed in registers into 8-byte pieces
   // along c_out; all loads of both rounds are requested before the first is used.
   {
-    f32x4 wv[2][4];
+    constexpr int NRD = (Q * Q + kWT - 1) / kWT;  // rounds over the Q x Q blocks: 2 (CH 128) / 1 (CH 64: half of the threads)
+    f32x4 wv[NRD][4];
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const int t = tid + rd * kWT, ci4 = t & 31, co4 = t >> 5;  // c_in 4 ci4 .. + 3, c_out 4 co4 .. + 3
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int t = min(tid + rd * kWT, Q * Q - 1), ci4 = t % Q, co4 = t / Q;  // c_in 4 ci4 .. + 3, c_out 4 co4 .. + 3
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -168,8 +179,9 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       }
     }
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const int t = tid + rd * kWT, ci4 = t & 31, co4 = t >> 5;
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int t = tid + rd * kWT, ci4 = t % Q, co4 = t / Q;
+      if (t >= Q * Q) break;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {  // c_in 4 ci4 + k: the four c_out values wv[rd][0..3][k]
         unsigned a[NS], b[NS];
@@ -190,8 +202,8 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   // [7..10] mean / invstd / gamma / beta of layer i-1
   {
     float* cst = reinterpret_cast<float*>(lds + oCst);
-    for (int t = tid; t < 11 * kWCh; t += kWT) {
-      const int k = t >> 7, col = t & 127;
+    for (int t = tid; t < 11 * CH; t += kWT) {
+      const int k = t / CH, col = t % CH;
       float v = 0.f;
       if (k < 7) {
         if (mode != 0 && col < C) {
@@ -205,9 +217,9 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       cst[t] = v;
     }
   }
-  f32x16 accw[2];
+  f32x16 accw[NB];
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int i = 0; i < 16; ++i) accw[b][i] = 0.f;
   f32x4 ssum4 = {0.f, 0.f, 0.f, 0.f}, tsum4 = {0.f, 0.f, 0.f, 0.f};
@@ -220,8 +232,8 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   // One tile.  `tc` holds its rows, requested while the tile before was in P2 .. P4; they are consumed by P1 (y_{i-1} moves to `xk` for P4) and
   // the next tile's are requested into the same registers right behind it.  (A second register set, requested a whole tile ahead, was
   // measured: P1 is bound by its arithmetic, not by the loads, and the 32 extra registers spill.)
-  TileRegs& tc = ta;
-  f32x4 xk[4];
+  TileRegs<NJ>& tc = ta;
+  f32x4 xk[NJ];
   while (cur < ntiles) {
     // The ticket for the tile after next is requested FIRST and consumed last (behind P1): a returning atomic counts in vmcnt like a load and
     // returns in order, so waiting for one issued BEHIND this tile's prefetches would drain them all (~2 us of exposed latency per tile)
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     // y_{i-1} of this tile moves to `xk` (P1 and P4 read it there) and the NEXT tile's is requested at once: a third of the tile's bytes gets
     // a whole tile of lead instead of P2 .. P4
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xk[j] = tc.x[j];
+    for (int j = 0; j < NJ; ++j) xk[j] = tc.x[j];
 #if !(defined(MVP_WIDE_EXP) && MVP_WIDE_EXP == 3)
     load_x(tc, nload);
 #endif
@@ -242,11 +254,11 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     // partial tile: `tailc`)
     auto p1 = [&](auto tailc) {
       constexpr bool TAIL = decltype(tailc)::value;
-      const f32x4 mu = cst[0 * 32], is = cst[1 * 32], sc = cst[2 * 32], db = cst[3 * 32], dg = cst[4 * 32], ga = cst[5 * 32], be = cst[6 * 32];
-      const f32x4 pm = cst[7 * 32], pi = cst[8 * 32], pg = cst[9 * 32], pb = cst[10 * 32];
+      const f32x4 mu = cst[0 * Q], is = cst[1 * Q], sc = cst[2 * Q], db = cst[3 * Q], dg = cst[4 * Q], ga = cst[5 * Q], be = cst[6 * Q];
+      const f32x4 pm = cst[7 * Q], pi = cst[8 * Q], pg = cst[9 * Q], pb = cst[10 * Q];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = rbase + 16 * j;
+      for (int j = 0; j < NJ; ++j) {
+        const int r = rbase + RPP * j;
         const bool rok = !TAIL || r < rows_here;
         // (vector arithmetic on the 16-byte pieces: the compiler emits packed fp32 operations on aligned register pairs -- plain forms, no
         // op_sel swizzle, tests/test_isa_cpu.py -- which halves this part of P1; each operation still rounds once, -ffp-contract=off)
@@ -310,8 +322,8 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
 
     // ---- P2b (first: the dX accumulator of P2a is then not alive beside this block's 24 fragment registers):
     // dW[32 a .. +31][32 b .. +31] += sum over the tile's rows of dy^T . a   (4 steps of 16 rows; both operands by transpose read)
-    {
-      const int a = wave >> 1, b0 = 2 * (wave & 1);
+    if (!SPLIT || wave >= 4) {  // (wave-uniform; CH 64: waves 4 - 7 take one dW tile each, waves 0 - 3 the dX tiles below)
+      const int a = SPLIT ? (wave - 4) >> 1 : wave >> 1, b0 = SPLIT ? (wave - 4) & 1 : 2 * (wave & 1);
       const int grp = lane >> 4, q = lane & 15, hh = grp >> 1, cg = grp & 1;
       // step ks, lane half hh, read j2 take rows 16 ks + 2 hh + j2 + {0, 4, 8, 12} (any 16 distinct rows per step do, as long as both operands
       // agree: k is a summation index) -- four rows whose 64-byte pieces tile the 64 banks; this lane SUPPLIES the 8 bytes of row
@@ -321,35 +333,37 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       const unsigned char* pB = L + oA + lrow + 32 * b0 * 2;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        u32x4 fa[NS], fb[2][NS];
+        u32x4 fa[NS], fb[NB][NS];
 #pragma unroll
         for (int pc = 0; pc < NS; ++pc) {
-          uint2 lo[3], hi[3];
+          uint2 lo[1 + NB], hi[1 + NB];
 #pragma unroll
           for (int j2 = 0; j2 < 2; ++j2) {
             const int o = pc * kTimg + (16 * ks + j2) * kRowB;
-            const uint2 va = lds_tr16(pA + o), vb0 = lds_tr16(pB + o), vb1 = lds_tr16(pB + o + 64);
-            if (j2 == 0) { lo[0] = va; lo[1] = vb0; lo[2] = vb1; } else { hi[0] = va; hi[1] = vb0; hi[2] = vb1; }
+            uint2* dst = j2 == 0 ? lo : hi;
+            dst[0] = lds_tr16(pA + o);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) dst[1 + bb] = lds_tr16(pB + o + 64 * bb);
           }
           fa[pc] = u32x4{lo[0].x, lo[0].y, hi[0].x, hi[0].y};
-          fb[0][pc] = u32x4{lo[1].x, lo[1].y, hi[1].x, hi[1].y};
-          fb[1][pc] = u32x4{lo[2].x, lo[2].y, hi[2].x, hi[2].y};
+#pragma unroll
+          for (int bb = 0; bb < NB; ++bb) fb[bb][pc] = u32x4{lo[1 + bb].x, lo[1 + bb].y, hi[1 + bb].x, hi[1 + bb].y};
         }
 #pragma unroll
         for (int qd = 0; qd < SP::N; ++qd)
 #pragma unroll
-          for (int bb = 0; bb < 2; ++bb)
+          for (int bb = 0; bb < NB; ++bb)
             accw[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[SP::A[qd]]), __builtin_bit_cast(bf16x8, fb[bb][SP::B[qd]]),
                                                                accw[bb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // ---- P2a: dX[32 rb .. +31][32 cb .. +31] = sum over c_out of dy . W   (8 steps of 16 c_out)
+    // ---- P2a: dX[32 rb .. +31][32 cb .. +31] = sum over c_out of dy . W   (CH / 16 steps of 16 c_out)
     f32x16 accz;
 #pragma unroll
     for (int i = 0; i < 16; ++i) accz[i] = 0.f;
-    {
-      const int rb = wave >> 2, cb = wave & 3;
+    if (!SPLIT || wave < 4) {
+      const int rb = wave / CB, cb = wave % CB;
       const int ar = 32 * rb + n, br = 32 * cb + n;
       const unsigned char* pa = L + oDy + ar * kRowB + h * 16;
       const unsigned char* pbw = L + oW + br * kRowB + h * 16;
@@ -364,8 +378,8 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       };
       frag(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) frag(ks + 1, (ks + 1) & 1);
+      for (int ks = 0; ks < CH / 16; ++ks) {
+        if (ks + 1 < CH / 16) frag(ks + 1, (ks + 1) & 1);
 #pragma unroll
         for (int qd = 0; qd < SP::N; ++qd)
           accz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][SP::A[qd]]), __builtin_bit_cast(bf16x8, fb[ks & 1][SP::B[qd]]),
@@ -377,23 +391,23 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     __syncthreads();  // every wave is done reading the dy / a images
     WIDE_T(4);
     // ---- P3: the dX tile (lane = column, registers = rows) -> full rows in LDS (aliases the images)
-    {
-      const int rb = wave >> 2, cb = wave & 3;
+    if (!SPLIT || wave < 4) {
+      const int rb = wave / CB, cb = wave % CB;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) stage[(32 * rb + 8 * (i >> 2) + 4 * h + (i & 3)) * kWCh + 32 * cb + n] = accz[i];
+      for (int i = 0; i < 16; ++i) stage[(32 * rb + 8 * (i >> 2) + 4 * h + (i & 3)) * CH + 32 * cb + n] = accz[i];
     }
     __syncthreads();
     WIDE_T(5);
     // ---- P4: ReLU mask of layer i-1, its two BatchNorm-backward column sums, streaming stores
     auto p4 = [&](auto tailc) {
       constexpr bool TAIL = decltype(tailc)::value;
-      const f32x4 pm = cst[7 * 32], pi = cst[8 * 32], pg = cst[9 * 32], pb = cst[10 * 32];
+      const f32x4 pm = cst[7 * Q], pi = cst[8 * Q], pg = cst[9 * Q], pb = cst[10 * Q];
       float* Zt = p.dZ + (size_t)cur * kTR * Cp;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = rbase + 16 * j;
+      for (int j = 0; j < NJ; ++j) {
+        const int r = rbase + RPP * j;
         const bool rok = !TAIL || r < rows_here;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * kWCh + cc);
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * CH + cc);
         if (has_act) {
           const f32x4 xh = (xk[j] - pm) * pi;
           const f32x4 zz = xh * pg + pb;
@@ -419,35 +433,35 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     ++it;
   }
 
-  // ---- column sums of dz_{i-1}: 16 threads per column quadruple -> LDS -> one fp64 atomic per column and workgroup
+  // ---- column sums of dz_{i-1}: RPP threads per column quadruple -> LDS -> one fp64 atomic per column and workgroup
   if (p.stat_prev) {
-    double* sred = reinterpret_cast<double*>(lds + oDy);  // [2][16][128]
+    double* sred = reinterpret_cast<double*>(lds);  // [2][RPP][CH] = 32 KB from the start of the allocation (every image is dead: the loop ended on a barrier)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      sred[(0 * 16 + rbase) * kWCh + cc + e] = (double)ssum4[e];
-      sred[(1 * 16 + rbase) * kWCh + cc + e] = (double)tsum4[e];
+      sred[(0 * RPP + rbase) * CH + cc + e] = (double)ssum4[e];
+      sred[(1 * RPP + rbase) * CH + cc + e] = (double)tsum4[e];
     }
     __syncthreads();
-    if (tid < 2 * kWCh) {
-      const int which = tid >> 7, col = tid & 127;
+    if (tid < 2 * CH) {
+      const int which = tid / CH, col = tid % CH;
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += sred[(which * 16 + k) * kWCh + col];
+      for (int k = 0; k < RPP; ++k) s += sred[(which * RPP + k) * CH + col];
       if (col < Cp) atomicAdd(p.stat_prev + which * Cp + col, s);
     }
   }
   // ---- dW: one flush per workgroup
-  {
-    const int a = wave >> 1, b0 = 2 * (wave & 1);
-    if (p.ws) {  // layout of dw_reduce_kernel<4, 4>: (split = workgroup, blocks in (a, b) order, register, lane)
-      float* t = p.ws + (size_t)blockIdx.x * (16 * 1024);
+  if (!SPLIT || wave >= 4) {
+    const int a = SPLIT ? (wave - 4) >> 1 : wave >> 1, b0 = SPLIT ? (wave - 4) & 1 : 2 * (wave & 1);
+    if (p.ws) {  // layout of dw_reduce_kernel<CB, CB>: (split = workgroup, blocks in (a, b) order, register, lane)
+      float* t = p.ws + (size_t)blockIdx.x * (CB * CB * 1024);
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
+      for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(accw[bb][i], t + ((a * 4 + b0 + bb) * 16 + i) * 64 + lane);
+        for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(accw[bb][i], t + ((a * CB + b0 + bb) * 16 + i) * 64 + lane);
     } else {
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
+      for (int bb = 0; bb < NB; ++bb) {
         const int ci = 32 * (b0 + bb) + n;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -520,37 +534,43 @@ MVP_API int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, c
     if (n <= 0 && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
     return n > 0 ? n : 256;
   }();
-  const int grid = std::min(a.ntiles, cus);
+  const int cb_host = (C <= 64 && Cp <= 64) ? 2 : 4;  // 32-column blocks of the instance that runs (CH = 64 / 128)
+  // (CH = 64: 58 KB of LDS per workgroup -- two fit a CU when their registers do; the ticket makes a surplus workgroup harmless)
+  const int grid = std::min(a.ntiles, cb_host == 2 ? 2 * cus : cus);
   // reproducible mode: partial tiles through the workspace + ordered reduction, and a STATIC tile order (the ticket would make a
   // workgroup's share, hence the order of its fp32 additions, differ from run to run)
-  a.ws = (workspace && grid > 1 && (int64_t)grid * 16 * 1024 <= workspace_floats) ? workspace : nullptr;
+  a.ws = (workspace && grid > 1 && (int64_t)grid * cb_host * cb_host * 1024 <= workspace_floats) ? workspace : nullptr;
   a.ticket = a.ws ? nullptr : ticket;
-  const size_t lds1 = 1 * (kWCh * kRowB + 2 * kTR * kRowB) + 64 + 11 * kWCh * 4, lds2 = 2 * (kWCh * kRowB + 2 * kTR * kRowB) + 64 + 11 * kWCh * 4;  // 75 / 142 KB
-  const bool fast = C == kWCh && Cp == kWCh && act_mean != nullptr && (ldw & 3) == 0 && ((uintptr_t)W & 15) == 0;
-  const size_t ldsz = ns == 1 ? lds1 : lds2;
-#define MVP_WIDE_LAUNCH(NS_, MODE_)                                                                                            \
+  // CH = 64 instances for layers with at most 64 channels on both sides (the aggregation MLP's inner layers), CH = 128 otherwise
+  const int ch = (C <= 64 && Cp <= 64) ? 64 : kWCh;
+  const bool fast = C == ch && Cp == ch && act_mean != nullptr && (ldw & 3) == 0 && ((uintptr_t)W & 15) == 0;
+  const size_t row_b = (size_t)ch * 2 + 16;
+  const size_t ldsz = std::max<size_t>((size_t)ns * (ch * row_b + 2 * kTR * row_b) + 64 + 11 * (size_t)ch * 4, (size_t)2 * (kWT / (ch / 4)) * ch * 8);
+#define MVP_WIDE_LAUNCH(NS_, MODE_, CH_)                                                                                       \
   do {                                                                                                                         \
-    auto k = mlp_bwd_wide_kernel<NS_, MODE_>;                                                                                  \
+    auto k = mlp_bwd_wide_kernel<NS_, MODE_, CH_>;                                                                             \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz); \
     if (e != hipSuccess) return (int)e;                                                                                        \
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWT), ldsz, s, a);                                                        \
   } while (0)
-  if (ns == 1) {
-    if (!fast) MVP_WIDE_LAUNCH(1, -1);
-    else if (mode == 0) MVP_WIDE_LAUNCH(1, 0);
-    else if (mode == 1) MVP_WIDE_LAUNCH(1, 1);
-    else MVP_WIDE_LAUNCH(1, 2);
-  } else {
-    if (!fast) MVP_WIDE_LAUNCH(2, -1);
-    else if (mode == 0) MVP_WIDE_LAUNCH(2, 0);
-    else if (mode == 1) MVP_WIDE_LAUNCH(2, 1);
-    else MVP_WIDE_LAUNCH(2, 2);
-  }
+#define MVP_WIDE_MODES(NS_, CH_)                          \
+  do {                                                    \
+    if (!fast) MVP_WIDE_LAUNCH(NS_, -1, CH_);             \
+    else if (mode == 0) MVP_WIDE_LAUNCH(NS_, 0, CH_);     \
+    else if (mode == 1) MVP_WIDE_LAUNCH(NS_, 1, CH_);     \
+    else MVP_WIDE_LAUNCH(NS_, 2, CH_);                    \
+  } while (0)
+  if (ns == 1 && ch == 64) MVP_WIDE_MODES(1, 64);
+  else if (ns == 1) MVP_WIDE_MODES(1, 128);
+  else if (ch == 64) MVP_WIDE_MODES(2, 64);
+  else MVP_WIDE_MODES(2, 128);
+#undef MVP_WIDE_MODES
 #undef MVP_WIDE_LAUNCH
   int rc = mvp_launch_status();
   if (rc != MVP_OK) return rc;
   if (a.ws) {
-    hipLaunchKernelGGL((dw_reduce_kernel<4, 4>), dim3(16 * 16), dim3(256), 0, s, a.ws, grid, 1, 1, (int)C, (int)Cp, dW, (int)lddw);
+    if (cb_host == 2) hipLaunchKernelGGL((dw_reduce_kernel<2, 2>), dim3(4 * 16), dim3(256), 0, s, a.ws, grid, 1, 1, (int)C, (int)Cp, dW, (int)lddw);
+    else hipLaunchKernelGGL((dw_reduce_kernel<4, 4>), dim3(16 * 16), dim3(256), 0, s, a.ws, grid, 1, 1, (int)C, (int)Cp, dW, (int)lddw);
     rc = mvp_launch_status();
   }
   return rc;

@@ -20,6 +20,7 @@ class FusedAdam(torch.optim.Adam):
         kwargs.pop('foreach', None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False, fused=False, **kwargs)
         self._plans = {}  # group index -> cached pointer arrays (parameters and moments do not move; gradients are re-read every step)
+        self._step_bufs = {}  # group index -> (host buffer of the group's step counts, its 0-dim views = the states' 'step' tensors)
 
     def _plan(self, gi, plist):
         key = tuple(id(p) for p in plist)
@@ -36,6 +37,22 @@ class FusedAdam(torch.optim.Adam):
                 'numel': (ctypes.c_int64 * n)(*[p.numel() for p in plist]), 'keep': (moments1, moments2)}
         self._plans[gi] = plan
         return plan
+
+    def _advance_steps(self, gi, plist):
+        """+1 on every parameter's step count -> the counts as floats.  Every parameter keeps its OWN host-side float32 step tensor, as
+        torch.optim.Adam does (state_dict / checkpoints interchange), but the tensors of a group are 0-dim VIEWS of one host buffer: one
+        in-place add and one tolist() per step instead of a 77-tensor foreach add and 77 float() calls (0.3 ms of the step's host time).
+        load_state_dict / anybody replacing a state's 'step' is noticed by identity and the buffer rebuilt from the values found."""
+        cache = self._step_bufs.get(gi)
+        state = self.state
+        if cache is None or len(cache[1]) != len(plist) or any(state[p]['step'] is not v for p, v in zip(plist, cache[1])):
+            base = torch.tensor([float(state[p]['step']) for p in plist], dtype=torch.float32)
+            views = [base[i] for i in range(len(plist))]
+            for p, v in zip(plist, views):
+                state[p]['step'] = v
+            cache = self._step_bufs[gi] = (base, views)
+        cache[0].add_(1.0)
+        return cache[0].tolist()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -55,17 +72,7 @@ class FusedAdam(torch.optim.Adam):
                     st['step'] = torch.tensor(0.0, dtype=torch.float32)
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            # every parameter keeps its OWN host-side step tensor, as torch.optim.Adam does (a tensor shared between the states would be
-            # incremented once per parameter by torch's Adam after a checkpoint round trip); one foreach call advances them all
-            steps = []
-            for p in plist:
-                st = self.state[p]
-                t = st['step']
-                if not torch.is_tensor(t) or t.is_cuda or t.dtype != torch.float32:
-                    t = st['step'] = torch.tensor(float(t), dtype=torch.float32)
-                steps.append(t)
-            torch._foreach_add_(steps, 1)
-            counts = [float(t) for t in steps]
+            counts = self._advance_steps(gi, plist)
             plan = self._plan(gi, plist)
             grads = []
             g_arr = plan['g']

@@ -32,11 +32,20 @@ WIDE_BWD = os.environ.get('MVP_BWD_WIDE', '1') != '0'
 WIDE_BWD_MIN_ROWS = int(os.environ.get('MVP_BWD_WIDE_MIN_ROWS', '16384'))  # (fewer rows than ~one tile per CU: the tile kernels' narrow variants)
 
 
+# ... and, in its 64-channel instance, the 64 -> 64 layers over very many rows (the aggregation MLP's inner layers: 786 432 rows), where the
+# register-resident one-kernel backward runs at one wave per SIMD.  MVP_BWD_WIDE64=0: those layers stay on mvp_mlp_layer_backward_f32.
+WIDE_BWD_64 = os.environ.get('MVP_BWD_WIDE64', '1') != '0'
+WIDE_BWD_64_MIN_ROWS = int(os.environ.get('MVP_BWD_WIDE64_MIN_ROWS', '262144'))
+
+
 def wide_backward_ok(prec, R, cout, cin, ldx):
     """True when a layer (R rows, cin -> cout, input row stride ldx) takes the one-pass wide backward: a one- or two-piece backward split,
-    more than 64 and at most 128 channels, whole 16-byte quadruples per row."""
-    return (WIDE_BWD and prec[0] != 0 and prec[1] in (1, 3) and R >= WIDE_BWD_MIN_ROWS and 64 < max(cout, cin) <= 128 and
-            cout % 4 == 0 and cin % 4 == 0 and ldx % 4 == 0)
+    whole 16-byte quadruples per row, and either more than 64 and at most 128 channels or the 64 -> 64 shape over very many rows."""
+    if not (WIDE_BWD and prec[0] != 0 and prec[1] in (1, 3) and cout % 4 == 0 and cin % 4 == 0 and ldx % 4 == 0):
+        return False
+    if 64 < max(cout, cin) <= 128:
+        return R >= WIDE_BWD_MIN_ROWS
+    return WIDE_BWD_64 and cout == 64 and cin == 64 and R >= WIDE_BWD_64_MIN_ROWS
 
 
 # Set-abstraction levels (K = 32 neighbours, max pooling): run the LAST shared-MLP layer without ever storing its (B*M*32, C) output --

@@ -1198,7 +1198,9 @@ def test_mlp_layer_backward_fused(dev, R, C, Cp, ldx, precision):
 
 
 @pytest.mark.parametrize('R,C,Cp,ldx', [(262144, 128, 128, 128), (64, 128, 128, 128), (6001, 128, 128, 128), (40000, 96, 128, 132), (9999, 128, 72, 72),
-                                        (1, 68, 100, 100), (20000, 64, 128, 128)])
+                                        (1, 68, 100, 100), (20000, 64, 128, 128),
+                                        # the 64-channel instance (C, Cp <= 64): the aggregation MLP's shape, partial tiles, narrower layers, a wider row stride
+                                        (393216, 64, 64, 64), (6001, 64, 64, 64), (64, 64, 64, 64), (9999, 48, 64, 68), (20000, 64, 32, 32), (3, 16, 16, 16)])
 @pytest.mark.parametrize('precision', ['bf16x3', 'bf16x3-ws', 'bf16'])
 def test_mlp_layer_backward_wide(dev, R, C, Cp, ldx, precision):
     """mvp_mlp_layer_backward_wide_p_f32 (csrc/mlp_bwd_wide.hip: the one-pass backward of a 128-wide layer with the row tile staged in LDS
@@ -1226,6 +1228,11 @@ def test_mlp_layer_backward_wide(dev, R, C, Cp, ldx, precision):
     pg, pb = torch.rand(Cp, device=dev) + 0.5, torch.randn(Cp, device=dev) * 0.2
     wsbuf = torch.empty(L.lib().mvp_mlp_weight_grad_workspace_floats(), device=dev) if ws_mode else None
     xh_i = (yi.to(hi) - mean_i.to(hi)) * invstd_i.to(hi)
+    # The two ReLU masks are DECISIONS: they are taken as the kernel takes them, in float32 with its operation order (numpy: one rounding per
+    # operation, no fused multiply-add) -- a float64 mask flips one borderline element in ~10^7, and a flipped element is off by its whole value
+    f32 = lambda t: t.detach().cpu().numpy().astype(np.float32)
+    mask_i = torch.from_numpy((((f32(yi) - f32(mean_i)) * f32(invstd_i)) * f32(gamma_i) + f32(beta_i)) > 0).to(dev)
+    mask_prev = torch.from_numpy((((f32(x[:, :Cp]) - f32(pm)) * f32(pi)) * f32(pg) + f32(pb)) > 0).to(dev)
     for mode, drop_p in ((0, 0.0), (1, 0.0), (2, 0.0), (2, 0.4)):
         if drop_p > 0 and 256 % (C // 4):   # (the rows kernels that supply this case's reference tile C / 4 | 256 only)
             continue
@@ -1246,7 +1253,7 @@ def test_mlp_layer_backward_wide(dev, R, C, Cp, ldx, precision):
                             # eval-mode finish: dy = gamma * invstd * dz  ->  dz = dy / (gamma * invstd)
                             dzi = dzf.to(hi) / (gamma_i.to(hi) * invstd_i.to(hi))
                         else:
-                            dzi = torch.where(xh_i * gamma_i.to(hi) + beta_i.to(hi) > 0, dzi, torch.zeros_like(dzi))
+                            dzi = torch.where(mask_i, dzi, torch.zeros_like(dzi))
                     dy = (gamma_i.to(hi) * invstd_i.to(hi)) * ((dzi - stat_i[:C] / R) - xh_i * (stat_i[C:] / R))
                 a = x[:, :Cp].to(hi)
                 xh = (a - pm.to(hi)) * pi.to(hi)
@@ -1255,7 +1262,7 @@ def test_mlp_layer_backward_wide(dev, R, C, Cp, ldx, precision):
                 ref_dw = dy.t() @ a
                 ref_dz = dy @ w.to(hi)
                 if use_act:
-                    ref_dz = torch.where(xh * pg.to(hi) + pb.to(hi) > 0, ref_dz, torch.zeros_like(ref_dz))
+                    ref_dz = torch.where(mask_prev, ref_dz, torch.zeros_like(ref_dz))
                 dw = torch.zeros(C, Cp + 4, device=dev)   # a column slice of a wider gradient (lddw > Cp)
                 dz = torch.full((R, Cp), float('nan'), device=dev)
                 stat = torch.zeros(2 * Cp, dtype=hi, device=dev)
