@@ -344,6 +344,14 @@ int mvp_csr_build_sorted_i64(const int64_t* index, int64_t B, int64_t E, int64_t
 int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_t* offsets, const int32_t* slots, const float* weight,
                                      int64_t B, int64_t N, int64_t C, int64_t E, int64_t S, int64_t ld, float* grad_feature,
                                      mvp_stream_t stream);
+/* The same gather with the BatchNorm-backward finish of the gathered tensor's layer applied on load (round 5): dz / y (B * E / S, ld), stat (2 C)
+ * = column sums of dz and dz * xhat over all rows; gathered rows = gamma*invstd * (dz - stat[c]/R - xhat * stat[C+c]/R).  Replaces
+ * mvp_bn_rows_backward_finish_f32 + mvp_gather_rows_backward_csr_f32 where the finished gradient has no other consumer (FeaturePropagation
+ * without a skip feature, mvpnet/models/pn2/modules.py:178-186, pn2ssg.py:101-112: the last propagation level). */
+int mvp_gather_rows_backward_csr_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd, const float* gamma,
+                                            const double* stat, int training, const int32_t* offsets, const int32_t* slots, const float* weight,
+                                            int64_t B, int64_t N, int64_t C, int64_t E, int64_t S, int64_t ld, float* grad_feature,
+                                            mvp_stream_t stream);
 /* out (B,N2,C) = 3-point interpolation of feature (B,N1,C) (+ add (B,N2,C) if not NULL): feature propagation with the (linear)
  * first shared-MLP layer applied before the interpolation (pn2/modules.py:135-145,178-186):
  *   W.[interp(f_sparse) | skip] = interp(Wa.f_sparse) + Wb.skip.

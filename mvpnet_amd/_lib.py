@@ -82,6 +82,7 @@ _SIGNATURES = {
     'mvp_csr_build_i64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_csr_build_sorted_i64': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_gather_rows_backward_csr_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    'mvp_gather_rows_backward_csr_finish_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     'mvp_interp_add_rows_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
     'mvp_interp_add_rows_bn_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_interp_rows_backward_f32': [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],

@@ -472,19 +472,52 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __re
 
 // grad_feature[b,j,:] = sum over the slots p of point j of  w[p] * grad_out[b, slot / S, :]   (w == nullptr: 1; S = slots per row:
 // 1 for the grouping, 3 for the 3-NN interpolation).  One lane per (point, 4 channels).
+// FINISH: gout holds dz (the gradient w.r.t. a BatchNorm'd layer's activation, ReLU mask applied) and the rows that are gathered are
+// dy = gamma*invstd * (dz - dbeta/R - xhat * dgamma/R), formed while they are loaded (yrows = the layer's pre-BN output, stat = its two
+// column sums): the BatchNorm-backward finish pass in front of an interpolation backward -- read dz, y, write dy, 402 MB for the last
+// propagation level -- and the dy tensor are gone; every gathered row is read three times through L2 instead.
+struct GatherFinish {
+  const float *y, *mean, *invstd, *gamma;
+  const double* stat;
+  float inv_rows;
+};
+template <bool FINISH>
 __global__ __launch_bounds__(kRT) void gather_bwd_csr_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
                                                              const int* __restrict__ slots, const float* __restrict__ w, int N,
-                                                             int C, int64_t E, int S, int ld, float* __restrict__ gfeat) {
+                                                             int C, int64_t E, int S, int ld, float* __restrict__ gfeat, GatherFinish fin) {
   const int b = blockIdx.y;
   const int C4 = C >> 2;
   const int64_t t = (int64_t)blockIdx.x * kRT + threadIdx.x;
   const int64_t j = t / C4;
   const int c = (int)(t - j * C4) * 4;
   if (j >= N) return;
+  float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* yb = nullptr;
+  if constexpr (FINISH) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mu[i] = fin.mean[c + i];
+      is[i] = fin.invstd[c + i];
+      sc[i] = fin.gamma[c + i] * is[i];
+      db[i] = (float)fin.stat[c + i] * fin.inv_rows;
+      dg[i] = (float)fin.stat[C + c + i] * fin.inv_rows;
+    }
+    yb = fin.y + (size_t)b * (E / S) * ld;
+  }
+  auto row = [&](int e) -> float4 {  // the gathered row's four values: dy itself, or dy formed from (dz, y) -- same operation order as bn_rows_bwd_kernel
+    float4 a = ld4(gout + (size_t)b * (E / S) * ld + (size_t)(e / S) * ld + c);
+    if constexpr (FINISH) {
+      const float4 yy = ld4(yb + (size_t)(e / S) * ld + c);
+      a.x = sc[0] * ((a.x - db[0]) - ((yy.x - mu[0]) * is[0]) * dg[0]);
+      a.y = sc[1] * ((a.y - db[1]) - ((yy.y - mu[1]) * is[1]) * dg[1]);
+      a.z = sc[2] * ((a.z - db[2]) - ((yy.z - mu[2]) * is[2]) * dg[2]);
+      a.w = sc[3] * ((a.w - db[3]) - ((yy.w - mu[3]) * is[3]) * dg[3]);
+    }
+    return a;
+  };
   const int* o = offsets + (size_t)b * (N + 1) + j;
   const int p0 = o[0], p1 = o[1];
   const int* sl = slots + (size_t)b * E;
-  const float* g = gout + (size_t)b * (E / S) * ld;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int p = p0;
   for (; p + 3 < p1; p += 4) {  // four independent row loads in flight (8 slots per point on average in the grouping)
@@ -495,7 +528,7 @@ __global__ __launch_bounds__(kRT) void gather_bwd_csr_kernel(const float* __rest
     float ww[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      a[u] = ld4(g + (size_t)(e[u] / S) * ld + c);
+      a[u] = row(e[u]);
       ww[u] = w ? w[(size_t)b * E + e[u]] : 1.f;
     }
 #pragma unroll
@@ -505,14 +538,14 @@ __global__ __launch_bounds__(kRT) void gather_bwd_csr_kernel(const float* __rest
   }
   for (; p + 1 < p1; p += 2) {  // two independent row loads in flight
     const int e0 = sl[p], e1 = sl[p + 1];
-    const float4 a = ld4(g + (size_t)(e0 / S) * ld + c), bb = ld4(g + (size_t)(e1 / S) * ld + c);
+    const float4 a = row(e0), bb = row(e1);
     const float w0 = w ? w[(size_t)b * E + e0] : 1.f, w1 = w ? w[(size_t)b * E + e1] : 1.f;
     acc.x += a.x * w0; acc.y += a.y * w0; acc.z += a.z * w0; acc.w += a.w * w0;
     acc.x += bb.x * w1; acc.y += bb.y * w1; acc.z += bb.z * w1; acc.w += bb.w * w1;
   }
   if (p < p1) {
     const int e0 = sl[p];
-    const float4 a = ld4(g + (size_t)(e0 / S) * ld + c);
+    const float4 a = row(e0);
     const float w0 = w ? w[(size_t)b * E + e0] : 1.f;
     acc.x += a.x * w0; acc.y += a.y * w0; acc.z += a.z * w0; acc.w += a.w * w0;
   }
@@ -1119,8 +1152,36 @@ MVP_API int mvp_gather_rows_backward_csr_f32(const float* grad_out, const int32_
   MVP_NONNULL(grad_feature);
   MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && E >= 0 && S >= 1 && E % S == 0 && ld >= C && ld % 4 == 0 && B < 65536);
   if (B == 0) return MVP_OK;
-  hipLaunchKernelGGL(gather_bwd_csr_kernel, dim3((unsigned)cdiv(N * (C / 4), kRT), (unsigned)B), dim3(kRT), 0,
-                     static_cast<hipStream_t>(stream), grad_out, offsets, slots, weight, (int)N, (int)C, E, (int)S, (int)ld, grad_feature);
+  hipLaunchKernelGGL(gather_bwd_csr_kernel<false>, dim3((unsigned)cdiv(N * (C / 4), kRT), (unsigned)B), dim3(kRT), 0,
+                     static_cast<hipStream_t>(stream), grad_out, offsets, slots, weight, (int)N, (int)C, E, (int)S, (int)ld, grad_feature,
+                     GatherFinish{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f});
+  return mvp_launch_status();
+}
+
+// The same gather with the BatchNorm-backward FINISH of the layer whose pre-BN output the gathered tensor is, applied while the rows are
+// loaded: dz (B * E / S, ld) = the gradient w.r.t. that layer's activation (ReLU mask applied), y = its pre-BN output (same shape), stat
+// (2 C) = the column sums of dz and dz * xhat over all B * E / S rows; the gathered rows are dy = gamma*invstd * (dz - stat[c]/R - xhat *
+// stat[C+c]/R) (training = 0 drops the batch terms).  What mvp_bn_rows_backward_finish_f32 followed by mvp_gather_rows_backward_csr_f32
+// computes, without the dy tensor (the last propagation level of the reference network: 402 MB of traffic and a launch less).
+MVP_API int mvp_gather_rows_backward_csr_finish_f32(const float* dz, const float* y, const float* mean, const float* invstd, const float* gamma,
+                                                    const double* stat, int training, const int32_t* offsets, const int32_t* slots,
+                                                    const float* weight, int64_t B, int64_t N, int64_t C, int64_t E, int64_t S, int64_t ld,
+                                                    float* grad_feature, mvp_stream_t stream) {
+  MVP_NONNULL(dz);
+  MVP_NONNULL(y);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(stat);
+  MVP_NONNULL(offsets);
+  MVP_NONNULL(slots);
+  MVP_NONNULL(grad_feature);
+  MVP_REQUIRE(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && E >= 0 && S >= 1 && E % S == 0 && ld >= C && ld % 4 == 0 && B < 65536);
+  if (B == 0) return MVP_OK;
+  const int64_t rows = B * (E / S);
+  hipLaunchKernelGGL(gather_bwd_csr_kernel<true>, dim3((unsigned)cdiv(N * (C / 4), kRT), (unsigned)B), dim3(kRT), 0,
+                     static_cast<hipStream_t>(stream), dz, offsets, slots, weight, (int)N, (int)C, E, (int)S, (int)ld, grad_feature,
+                     GatherFinish{y, mean, invstd, gamma, stat, (training && rows > 0) ? 1.0f / (float)rows : 0.f});
   return mvp_launch_status();
 }
 

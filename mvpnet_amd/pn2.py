@@ -307,14 +307,17 @@ class FeaturePropagation(nn.Module):
                 if dense_feature is not None:
                     zs = R.linear_rows(dense_feature.reshape(B * N, -1), w0, cols=(c2, ctot), sink=sink).view(B, N, c1)
                 bn_training = q0.bn.training
-                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=q0.bn if bn_training else False, csr=csr)
+                # no skip feature (the level that lands on the input cloud): the first layer's gradient has ONE consumer, the interpolation's gather
+                # backward -- its BatchNorm-backward finish is then applied there, on load (rows.DeferredFinish)
+                defer = R.DeferredFinish() if (zs is None and bn_training and torch.is_grad_enabled()) else None
+                y1 = R.interp_add_rows(z, index, weight, zs, want_stat=q0.bn if bn_training else False, csr=csr, defer=defer)
                 stat1 = None
                 if bn_training:
                     y1, stat1 = y1[0], (y1[1], y1[2])
                 if tail is not None:
                     return R.shared_mlp_rows(y1.view(B * N, c1), chain, first_done=True, first_stat=stat1, dropout_p=tail[0].p, training=tail[1],
-                                             dropout_last_only=True).view(B, N, -1)
-                return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1).view(B, N, -1)
+                                             dropout_last_only=True, defer=defer).view(B, N, -1)
+                return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1, defer=defer).view(B, N, -1)
             if tail is not None:
                 return None
             new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)

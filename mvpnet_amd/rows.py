@@ -617,11 +617,26 @@ def interp_rows(feature, index, weight):
     return InterpRows.apply(feature.contiguous(), index.contiguous(), weight.contiguous())
 
 
+class DeferredFinish:
+    """Hand-over between two autograd nodes: a shared-MLP chain whose first layer ran BEFORE it (the linear-first factorisation) ends its
+    backward with the BatchNorm-backward finish of that layer, dz_0 -> dy_0 -- a pass over the largest tensor of the level whose only
+    consumer, when the level has no skip feature, is the interpolation's gather backward.  With one of these shared by the two nodes the
+    chain returns dz_0 UNFINISHED and leaves (y_0, mean, invstd, gamma, the two column sums) here; the interpolation node's backward then
+    gathers through mvp_gather_rows_backward_csr_finish_f32, which forms dy_0 while it loads the rows (csrc/rows.hip).
+    MVP_DEFER_FINISH=0: the finish pass stays (A/B switch)."""
+    ENABLED = os.environ.get('MVP_DEFER_FINISH', '1') != '0'
+    __slots__ = ('info', 'accepts')
+
+    def __init__(self):
+        self.info = None      # set by the chain's backward: (y0, mean, invstd, gamma, stat, training)
+        self.accepts = False  # set by the interpolation node's forward when its backward can take the hand-over (gather path, no skip term)
+
+
 class InterpAddRows(torch.autograd.Function):
     """out = interp(feature; index, weight) (+ add); want_stat: also the float64 column sums [sum out | sum out^2]."""
 
     @staticmethod
-    def forward(ctx, feature, index, weight, add, want_stat, offsets=None, slots=None):
+    def forward(ctx, feature, index, weight, add, want_stat, offsets=None, slots=None, defer=None):
         L.require_gpu(feature, index, weight, add)
         B, N1, C = feature.shape
         N2 = index.size(1)
@@ -643,6 +658,9 @@ class InterpAddRows(torch.autograd.Function):
         ctx.save_for_backward(index, weight, offsets, slots)
         ctx.dims = (B, N1, C, N2)
         ctx.has_add = add is not None
+        ctx.defer = defer
+        if defer is not None:
+            defer.accepts = bool(DeferredFinish.ENABLED and add is None and offsets is not None and feature.requires_grad)
         if want_stat:
             ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
             if mi is not None:
@@ -661,22 +679,32 @@ class InterpAddRows(torch.autograd.Function):
         grad = None
         if ctx.needs_input_grad[0]:
             grad = torch.empty((B, N1, C), dtype=torch.float32, device=g.device)
-            if offsets is not None:
+            info = None if ctx.defer is None else ctx.defer.info
+            if info is not None:
+                # grad_out is dz_0, handed over unfinished by the chain behind this node: dy_0 is formed while the rows are gathered
+                y0, mean, invstd, gamma, stat, training = info
+                ctx.defer.info = None
+                L.call('mvp_gather_rows_backward_csr_finish_f32', g, L.ptr(g), L.ptr(y0), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat),
+                       int(training), L.ptr(offsets), L.ptr(slots), L.ptr(weight), B, N1, C, 3 * N2, 3, C, L.ptr(grad))
+            elif offsets is not None:
                 L.call('mvp_gather_rows_backward_csr_f32', g, L.ptr(g), L.ptr(offsets), L.ptr(slots), L.ptr(weight), B, N1, C, 3 * N2, 3, C,
                        L.ptr(grad))
             else:
                 L.call('mvp_interp_rows_backward_f32', g, L.ptr(g), L.ptr(index), L.ptr(weight), B, N1, C, N2, C, L.ptr(grad))
-        return grad, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None), None, None, None
+        elif ctx.defer is not None:
+            ctx.defer.info = None
+        return grad, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None), None, None, None, None
 
 
-def interp_add_rows(feature, index, weight, add=None, want_stat=False, csr=None):
+def interp_add_rows(feature, index, weight, add=None, want_stat=False, csr=None, defer=None):
     """feature (B,N1,C), index / weight (B,N2,3), add (B,N2,C) or None -> (B,N2,C) [, stat (2C) float64].
-    csr: (offsets, slots) of build_csr(index, N1) when the geometry plan already holds it."""
+    csr: (offsets, slots) of build_csr(index, N1) when the geometry plan already holds it.
+    defer: a DeferredFinish shared with the shared-MLP chain that consumes the output (shared_mlp_rows(..., defer=))"""
     if feature.dtype != torch.float32 or feature.size(2) % 4:
         raise RuntimeError('interp_add_rows: float32 feature with C % 4 == 0 expected')
     offsets, slots = csr if csr is not None else (None, None)
     return InterpAddRows.apply(feature.contiguous(), index.contiguous(), weight.contiguous(), None if add is None else add.contiguous(),
-                               want_stat if isinstance(want_stat, torch.nn.Module) else bool(want_stat), offsets, slots)
+                               want_stat if isinstance(want_stat, torch.nn.Module) else bool(want_stat), offsets, slots, defer)
 
 
 class BNActRows(torch.autograd.Function):
@@ -808,6 +836,7 @@ class MLPChainRows(torch.autograd.Function):
         opts = pool_sum if isinstance(pool_sum, dict) else {'sum': bool(pool_sum)}
         drop_p, drop_seed = opts.get('drop_p', 0.0), opts.get('drop_seed', 0)
         ctx.dw_use = opts.get('use')
+        ctx.defer = opts.get('defer')
         pool_sum = bool(opts.get('sum', False))
         # 'rel': (rel (R,4), first conv weight): the first layer's input is [x0 | rel] without the concatenated tensor -- its weight has
         # x0.size(1) + 4 columns, the last four meet `rel` in the kernel's epilogue (mvp_mlp_forward_rel_bn_f32)
@@ -1018,6 +1047,14 @@ class MLPChainRows(torch.autograd.Function):
             fuse = wide or pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and rel is None and
                                          (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
             assert wide or not (last_wide and i == nl - 1)
+            if pending is not None and w is None and ctx.defer is not None and ctx.defer.accepts and ctx.defer.info is None:
+                # i == 0, x0 was this layer's pre-BN output and its ONLY consumer gathers it (DeferredFinish): dz_0 goes back unfinished, the
+                # gather forms dy_0 on load.  The BatchNorm parameter gradients are the two column sums themselves.
+                ctx.defer.info = (ys[0], means[0], invstds[0], params[1], pending, training)
+                dgb = pending.view(2, cout).to(torch.float32)
+                grads[1], grads[2] = dgb[1], dgb[0]
+                dx0 = gcur
+                break
             if pending is not None and not fuse:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)
                 dyi = torch.empty((R, cout), dtype=torch.float32, device=dev)
@@ -1444,7 +1481,8 @@ def relation4_rows(src_xyz, tgt_xyz):
     return out
 
 
-def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max', rel=None, dropout_last_only=False):
+def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max', rel=None, dropout_last_only=False,
+                    defer=None):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
     K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108), or their sum with reduce='sum'
@@ -1472,6 +1510,8 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
         if rel is not None:
             assert not first_done and rel.dim() == 2 and rel.size(1) == 4 and rel.size(0) == x.size(0)
             opts['rel'] = (rel.contiguous(), ps[0].w)
+        if defer is not None and first_done and bn_training:
+            opts['defer'] = defer   # (rows.DeferredFinish: the finish of the first layer's gradient may be left to the node in front)
         if DW_SIDE_STREAM and torch.is_grad_enabled():  # (a first layer that ran before the grouping has its own use: WeightGradSink)
             opts['use'] = WeightUse([q.w for li, q in enumerate(ps) if not (first_done and li == 0)])
         # dropout behind the (single) layer: folded into the BatchNorm + ReLU passes (mvp_bn_rows_forward_dropout_f32) unless a graph is

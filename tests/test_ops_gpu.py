@@ -1070,6 +1070,56 @@ def test_interp_add_rows_vs_torch(dev, B, N1, N2, C, with_add):
     assert torch.equal(out2, out.detach())
 
 
+@pytest.mark.parametrize('training', [1, 0])
+@pytest.mark.parametrize('B,N1,N2,C', [(2, 300, 1000, 128), (3, 64, 257, 32), (1, 2048, 8192, 64)])
+def test_gather_backward_with_finish(dev, B, N1, N2, C, training):
+    """mvp_gather_rows_backward_csr_finish_f32 (the BatchNorm-backward finish applied while the gather loads its rows) against the two
+    entry points it replaces, mvp_bn_rows_backward_finish_f32 then mvp_gather_rows_backward_csr_f32, and against a float64 statement of
+    both: the lists are sorted, so the two GPU results add in the same order and differ only by the rounding of dy (which the two-kernel
+    form stores as float32 and the fused form keeps in registers -- the same float32 expression, hence bit-equal)."""
+    from mvpnet_amd import rows as R, _lib as L
+    rs = np.random.RandomState(11)
+    Rr = B * N2
+    dz = rs.randn(Rr, C).astype(np.float32)
+    y = (rs.randn(Rr, C) * 1.5 + 0.3).astype(np.float32)
+    gamma = (rs.rand(C) + 0.5).astype(np.float32)
+    beta = rs.randn(C).astype(np.float32)
+    mean = y.astype(np.float64).mean(0)
+    invstd = 1.0 / np.sqrt(y.astype(np.float64).var(0) + 1e-5)
+    xhat = (y.astype(np.float64) - mean) * invstd
+    stat = np.concatenate([dz.astype(np.float64).sum(0), (dz.astype(np.float64) * xhat).sum(0)])
+    idx = rs.randint(0, N1, (B, N2, 3)).astype(np.int64)
+    wgt = rs.rand(B, N2, 3).astype(np.float32)
+    # float64 statement
+    dy = dz.astype(np.float64)
+    if training:
+        dy = dy - stat[:C] / Rr - xhat * (stat[C:] / Rr)
+    dy = (dy * (gamma * invstd)).reshape(B, N2, C)
+    want = np.zeros((B, N1, C))
+    for b in range(B):
+        for k in range(3):
+            np.add.at(want[b], idx[b, :, k], dy[b] * wgt[b, :, k, None])
+    t = lambda a: g(a, dev)
+    dz_t, y_t, mean_t, invstd_t = t(dz), t(y), t(mean.astype(np.float32)), t(invstd.astype(np.float32))
+    gamma_t, beta_t, stat_t, wgt_t = t(gamma), t(beta), t(stat), t(wgt)
+    offsets, slots = R.build_csr(t(idx).view(B, 3 * N2), N1, sorted=True)
+    dy_t = torch.empty_like(dz_t)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    with entry_points() as seen:
+        L.call('mvp_bn_rows_backward_finish_f32', dz_t, L.ptr(dz_t), L.ptr(y_t), L.ptr(mean_t), L.ptr(invstd_t), L.ptr(gamma_t), L.ptr(beta_t),
+               Rr, C, training, L.ptr(stat_t), L.ptr(dy_t), L.ptr(dgb[0]), L.ptr(dgb[1]))
+        two = torch.empty((B, N1, C), dtype=torch.float32, device=dev)
+        L.call('mvp_gather_rows_backward_csr_f32', dy_t, L.ptr(dy_t), L.ptr(offsets), L.ptr(slots), L.ptr(wgt_t), B, N1, C, 3 * N2, 3, C,
+               L.ptr(two))
+        one = torch.empty((B, N1, C), dtype=torch.float32, device=dev)
+        L.call('mvp_gather_rows_backward_csr_finish_f32', dz_t, L.ptr(dz_t), L.ptr(y_t), L.ptr(mean_t), L.ptr(invstd_t), L.ptr(gamma_t),
+               L.ptr(stat_t), training, L.ptr(offsets), L.ptr(slots), L.ptr(wgt_t), B, N1, C, 3 * N2, 3, C, L.ptr(one))
+    assert 'mvp_gather_rows_backward_csr_finish_f32' in seen.names
+    np.testing.assert_allclose(one.cpu().numpy(), want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+    np.testing.assert_array_equal(one.cpu().numpy(), two.cpu().numpy())
+    np.testing.assert_allclose(dgb.cpu().numpy(), np.stack([stat[C:], stat[:C]]), rtol=1e-6)
+
+
 @pytest.mark.parametrize('want_sorted', [True, False])
 @pytest.mark.parametrize('B,E,N', [(3, 5000, 700), (32, 65536, 8192), (2, 3 * 8192, 2048), (2, 70000, 32768), (1, 50000, 60000), (2, 100, 5)])
 def test_csr_build(dev, B, E, N, want_sorted):
