@@ -770,6 +770,13 @@ def main():
                         cur, nxt = st['cur'], fresh(sub)
                         train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=sync, next_batch=nxt)
                         st['cur'] = nxt
+                elif mode == 'graph_x2':  # two captured copies replayed in turn: the host enqueues step i + 1 while step i runs
+                    from mvpnet_amd.mvpnet3d import PipelinedTrainStep
+                    gts = PipelinedTrainStep(model, loss_fn, optimizer, fresh(sub), fresh(sub), depth=2, scheduler=scheduler, grad_sync=sync,
+                                             geometry=args.graph_geometry)
+
+                    def one():
+                        gts.step(sub, sub)
                 else:
                     from mvpnet_amd.mvpnet3d import GraphedTrainStep
                     gts = GraphedTrainStep(model, loss_fn, optimizer, fresh(sub), fresh(sub), scheduler=scheduler, grad_sync=sync, geometry=args.graph_geometry)
@@ -804,9 +811,9 @@ def main():
         per_gpu_batch = {}
         for B in (4, 8, 16):
             if B < args.batch:
-                per_gpu_batch[str(B)] = measure_batch(B, ('eager', 'graph'))
+                per_gpu_batch[str(B)] = measure_batch(B, ('eager', 'graph', 'graph_x2'))
         per_gpu_batch['note'] = ('one train step (fwd + loss + bwd + Adam, next batch geometry prefetched) at B chunks on ONE GPU = what a rank of an N-GPU job runs when the '
-                                 "reference's global batch of 32 is split over N = 32 / B GPUs; eager and replayed from one HIP graph; chunks_per_s is per GPU")
+                                 "reference's global batch of 32 is split over N = 32 / B GPUs; eager, replayed from one HIP graph, and from two captured copies of the step replayed in turn (graph_x2: the host enqueues step i + 1 while step i runs); chunks_per_s is per GPU")
     strong = None
     if world > 1 and args.batch // world >= 1 and not args.train_only:
         sb = args.batch // world

@@ -211,6 +211,21 @@ __device__ __forceinline__ float fmax_dpp(float v) {
   return fmaxf(v, o);
 }
 
+// wave maximum of a signed integer, uniform.  v_max_i32 with a DPP source operand, in place (the masked row_bcast steps leave the other
+// rows as they are); s_nop 1 = the two wait states a DPP read needs behind the VALU write of its source.
+__device__ __forceinline__ int wave_imax(int v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 template <int D, int PPT, int NT, bool LDS_PTS>
 __global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ pts, int N, int M,
                                                       int64_t* __restrict__ out, const int* __restrict__ guard) {
@@ -339,22 +354,44 @@ __global__ __launch_bounds__(NT) void fps_fast_kernel(const float* __restrict__ 
 #ifdef MVP_FPS_TRACE
 __device__ unsigned* g_fps_trace = nullptr;  // (tools/exp) [cloud][round][8] words written by the resolving wave
 #endif
-template <int D, int PPT, int NT>
+// Rows of RL lanes (RL = 16 in rounds 3-4).  The number of picks a round can accept is bounded by the first two of the cloud's top points
+// that share a row (the second of them is that row's second best and so the bound B): with R rows that is a birthday problem, ~sqrt(pi R / 2)
+// picks -- 6.5 measured with the 32 rows of 512 threads.  Narrower rows give more of them: RL = 1 makes every LANE a row (no cross-lane
+// reduction at all in front of the exchange; 512 - 1024 rows).  The resolving wave then reads E = rows / 64 results per lane, takes B and the
+// arg-max over all of them, and compacts the results above B -- a few dozen at most -- into one per lane through a wave-private LDS list; from
+// there on the walk is the one above.  More than 64 results above B (rare: the top 65 points in 65 different rows): every resolver lane folds
+// its E results into one "super row" (its best is the candidate, its other results join the bound) -- exact for the same reason any partition
+// of the points into rows is.
+template <int NT, int RL>
+struct RoundsCfg {
+  static constexpr int NR = NT / RL;                       // rows
+  static constexpr int E = NR > kWave ? NR / kWave : 1;    // row results per resolver lane
+  static constexpr int kMaxPick = NR > kWave ? 96 : 32;    // [2][kMaxPick / 2] picks of a round
+  static constexpr int kPartBytes = 2 * (NR > kWave ? NR : kWave) * 16;
+  static constexpr int kHeadBytes = kPartBytes + kWave * 8 + kMaxPick * 32 + 16;  // row results, compaction list, picks, counts
+};
+
+template <int D, int PPT, int NT, int RL = 16>
 __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out, int dbg) {
   static_assert(PPT % 2 == 0, "points are processed in pairs");
-  constexpr int NR = NT / 16;  // rows = candidates per round (<= 64: one lane of the resolving wave each)
+  using Cfg = RoundsCfg<NT, RL>;
+  constexpr int NR = Cfg::NR;  // rows = candidates per round
+  constexpr int E = Cfg::E;
   constexpr int NP = PPT / 2;
-  constexpr int kMaxPick = 32;
-  static_assert(NR <= kWave, "one resolver lane per row");
+  constexpr int kMaxPick = Cfg::kMaxPick;
+  static_assert(RL == 1 || RL == 2 || RL == 4 || RL == 8 || RL == 16, "a row is a power-of-two group of lanes inside a DPP row");
+  static_assert(NR <= kWave || NR % kWave == 0, "whole row results per resolver lane");
   using K = Key<float>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [2][NR] row results (key hi, key lo, second-best value, pad), picked coordinates + count, output buffer, SoA copy of the cloud.
+  // [2][NR] row results (key hi, key lo, second-best value, pad), compaction list of the resolver, picked coordinates + count, output
+  // buffer, SoA copy of the cloud.
   // A pick is stored as (x, x, y, y, z, z, -, -): the lanes load ready-made register pairs for the packed update (see splat2).
   uint4* part = reinterpret_cast<uint4*>(smem);
-  float* cen = reinterpret_cast<float*>(smem + 2 * kWave * 16);      // [kMaxPick][8]
-  int* npick = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 32);  // [2]
-  int* sout = reinterpret_cast<int*>(smem + 2 * kWave * 16 + kMaxPick * 32 + 16);
-  float* sx = reinterpret_cast<float*>(smem + 2 * kWave * 16 + kMaxPick * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15));
+  uint2* cand = reinterpret_cast<uint2*>(smem + Cfg::kPartBytes);                  // [kWave]
+  float* cen = reinterpret_cast<float*>(smem + Cfg::kPartBytes + kWave * 8);      // [kMaxPick][8]
+  int* npick = reinterpret_cast<int*>(smem + Cfg::kPartBytes + kWave * 8 + kMaxPick * 32);  // [2]
+  int* sout = reinterpret_cast<int*>(smem + Cfg::kHeadBytes);
+  float* sx = reinterpret_cast<float*>(smem + Cfg::kHeadBytes + (((size_t)M * 4 + 15) & ~(size_t)15));
   float* sy = sx + N;
   float* sz = sy + N;
 
@@ -368,7 +405,7 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
   // Point j lives in slot j / NT of thread (j0 % NR) * 16 + j0 / NR, j0 = j % NT: CONSECUTIVE indices sit in DIFFERENT rows.  The deeper
   // set-abstraction levels sample clouds that are themselves in sampling order (the centroids of the level above), where the next
   // samples are the next indices -- with consecutive indices in one row every round would accept a single pick.
-  const int pj = (tid & 15) * NR + (tid >> 4);  // this thread's point index within a block of NT
+  const int pj = (tid % RL) * NR + tid / RL;  // this thread's point index within a block of NT
   f32x2 px[NP], py[NP], pz[NP], md[NP];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
@@ -408,6 +445,12 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
 #ifdef MVP_FPS_VGPRS
   asm volatile("v_mov_b32 v" MVP_FPS_VGPRS ", 0" ::: "v" MVP_FPS_VGPRS);  // (tools/exp) forces the wave's register allocation up
 #endif
+#ifdef MVP_FPS_PHASES
+  long long ph_t = (long long)__builtin_readcyclecounter(), ph_acc[5] = {0, 0, 0, 0, 0};  // (tools/exp) cycles of wave 0 per phase
+#define MVP_PH(i) { const long long ph_n = (long long)__builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
+#else
+#define MVP_PH(i)
+#endif
   while (it < M) {
     ++rounds_done;
     // ---- A. apply the picks of the last round (sample 0 first) to this lane's points ----
@@ -432,6 +475,7 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
         md[i] = m;
       }
     }
+    MVP_PH(0)
     // ---- B. this lane's best (value, first slot) and second-best value ----
     float m1 = -3.f, m2 = -3.f;
     int bi = 0;
@@ -446,56 +490,135 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
     }
     // ---- C. row (16 lanes) best key and second-best value ----
     K k = m1 >= 0.f ? K::make(m1, pj + bi * NT) : K::none();
-    const K mine = k;
-    key_max_row<K, 16>(k);  // every lane of the row holds the row's best key
-    const bool winner = (mine.hi == k.hi) && (mine.lo == k.lo) && (m1 >= 0.f);
-    float sec = winner ? m2 : m1;  // the winner lane offers its second best, the others their best
-    sec = fmax_dpp<kDppXor1>(sec);
-    sec = fmax_dpp<kDppXor2>(sec);
-    sec = fmax_dpp<kDppHalfMirror>(sec);
-    sec = fmax_dpp<kDppMirror>(sec);
-    uint4* cur = part + (par ^ 1) * kWave;
+    float sec = m2;  // RL == 1: the lane is the row
+    if constexpr (RL > 1) {
+      const K mine = k;
+      key_max_row<K, RL>(k);  // every lane of the row holds the row's best key
+      const bool winner = (mine.hi == k.hi) && (mine.lo == k.lo) && (m1 >= 0.f);
+      sec = winner ? m2 : m1;  // the winner lane offers its second best, the others their best
+      sec = fmax_dpp<kDppXor1>(sec);
+      if (RL > 2) sec = fmax_dpp<kDppXor2>(sec);
+      if (RL > 4) sec = fmax_dpp<kDppHalfMirror>(sec);
+      if (RL > 8) sec = fmax_dpp<kDppMirror>(sec);
+    }
+    uint4* cur = part + (par ^ 1) * (NR > kWave ? NR : kWave);
 #ifdef MVP_FPS_TRACE
-    if ((lane & 15) == 0) cur[tid >> 4] = make_uint4(k.hi, k.lo, __float_as_uint(sec), (unsigned)rounds_done);
+    if ((tid % RL) == 0) cur[tid / RL] = make_uint4(k.hi, k.lo, __float_as_uint(sec), (unsigned)rounds_done);
 #else
-    if ((lane & 15) == 0) cur[tid >> 4] = make_uint4(k.hi, k.lo, __float_as_uint(sec), 0u);
+    if ((tid % RL) == 0) cur[tid / RL] = make_uint4(k.hi, k.lo, __float_as_uint(sec), 0u);
 #endif
     __syncthreads();
+    MVP_PH(1)
     // ---- D. one wave walks the row winners ----
     if (wave == 0) {
-      uint4 e = make_uint4(0u, 0u, __float_as_uint(-3.f), 0u);
-      if (lane < NR) e = cur[lane];
+      unsigned hi = 0u, lo = 0u;  // this lane's candidate (none: 0, 0)
+      float bound;                // B = the largest value of any point that is not a candidate
+      bool is_best;               // the true arg-max (always the first pick): the largest value, lowest index among equals
+      if constexpr (E == 1) {
+        uint4 e = make_uint4(0u, 0u, __float_as_uint(-3.f), 0u);
+        if (lane < NR) e = cur[lane];
 #ifdef MVP_FPS_TRACE
-      if (lane < NR && e.w != (unsigned)rounds_done) atomicAdd(reinterpret_cast<unsigned*>(sz + N) + 4096, 1u);  // a row result of another round
+        if (lane < NR && e.w != (unsigned)rounds_done) atomicAdd(reinterpret_cast<unsigned*>(sz + N) + 4096, 1u);  // a row result of another round
 #endif
-      const unsigned hi = e.x, lo = e.y;
-      const float v = __uint_as_float(hi);
-      const bool valid = (hi | lo) != 0u;
-      float bound = __uint_as_float(e.z);  // B = the largest second-best of any row
-      bound = fmax_dpp<kDppXor1>(bound);
-      bound = fmax_dpp<kDppXor2>(bound);
-      bound = fmax_dpp<kDppHalfMirror>(bound);
-      bound = fmax_dpp<kDppMirror>(bound);
-      bound = fmax_dpp<kDppBcast15, 0xA>(bound);
-      bound = fmax_dpp<kDppBcast31, 0xC>(bound);
-      bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), 63));
-      // the true arg-max (always the first pick): the largest value, lowest index among equals
-      float vm = valid ? v : -3.f;
-      vm = fmax_dpp<kDppXor1>(vm);
-      vm = fmax_dpp<kDppXor2>(vm);
-      vm = fmax_dpp<kDppHalfMirror>(vm);
-      vm = fmax_dpp<kDppMirror>(vm);
-      vm = fmax_dpp<kDppBcast15, 0xA>(vm);
-      vm = fmax_dpp<kDppBcast31, 0xC>(vm);
-      vm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vm), 63));
-      const unsigned long long tops = __ballot(valid && v == vm);
-      bool is_best = valid && v == vm;
-      if (tops & (tops - 1)) {  // several rows hold the maximal value: the full (value, index) key decides
-        K g{hi, lo};
+        hi = e.x;
+        lo = e.y;
+        const float v1 = __uint_as_float(hi);
+        const bool valid1 = (hi | lo) != 0u;
+        bound = __uint_as_float(e.z);
+        bound = fmax_dpp<kDppXor1>(bound);
+        bound = fmax_dpp<kDppXor2>(bound);
+        bound = fmax_dpp<kDppHalfMirror>(bound);
+        bound = fmax_dpp<kDppMirror>(bound);
+        bound = fmax_dpp<kDppBcast15, 0xA>(bound);
+        bound = fmax_dpp<kDppBcast31, 0xC>(bound);
+        bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), 63));
+        float vm = valid1 ? v1 : -3.f;
+        vm = fmax_dpp<kDppXor1>(vm);
+        vm = fmax_dpp<kDppXor2>(vm);
+        vm = fmax_dpp<kDppHalfMirror>(vm);
+        vm = fmax_dpp<kDppMirror>(vm);
+        vm = fmax_dpp<kDppBcast15, 0xA>(vm);
+        vm = fmax_dpp<kDppBcast31, 0xC>(vm);
+        vm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vm), 63));
+        const unsigned long long tops = __ballot(valid1 && v1 == vm);
+        is_best = valid1 && v1 == vm;
+        if (tops & (tops - 1)) {  // several rows hold the maximal value: the full (value, index) key decides
+          K g{hi, lo};
+          key_max_wave_to_lane63(g);
+          const K gbest = g.lane(63);
+          is_best = valid1 && hi == gbest.hi && lo == gbest.lo;
+        }
+      } else {
+        // E row results per lane: B and the arg-max over all of them, then the results above B compacted to one per lane
+        uint4 e[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) e[q] = cur[lane + q * kWave];
+        float bnd = -3.f;
+        K bk = K::none();
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          bnd = fmaxf(bnd, __uint_as_float(e[q].z));
+          const K kq{e[q].x, e[q].y};
+          if (kq.gt(bk)) bk = kq;
+        }
+        bnd = fmax_dpp<kDppXor1>(bnd);
+        bnd = fmax_dpp<kDppXor2>(bnd);
+        bnd = fmax_dpp<kDppHalfMirror>(bnd);
+        bnd = fmax_dpp<kDppMirror>(bnd);
+        bnd = fmax_dpp<kDppBcast15, 0xA>(bnd);
+        bnd = fmax_dpp<kDppBcast31, 0xC>(bnd);
+        bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bnd), 63));
+        K g = bk;
         key_max_wave_to_lane63(g);
         const K gbest = g.lane(63);
-        is_best = valid && hi == gbest.hi && lo == gbest.lo;
+        bool el[E];
+        unsigned long long emq[E];
+        int total = 0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const bool vq = (e[q].x | e[q].y) != 0u;
+          el[q] = vq && (__uint_as_float(e[q].x) > bound || (e[q].x == gbest.hi && e[q].y == gbest.lo));
+          emq[q] = __ballot(el[q]);
+          total += (int)__popcll(emq[q]);
+        }
+        if (total <= kWave) {
+          int base = 0;
+#pragma unroll
+          for (int q = 0; q < E; ++q) {
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(emq[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emq[q], 0u));
+            if (el[q]) cand[base + below] = make_uint2(e[q].x, e[q].y);
+            base += (int)__popcll(emq[q]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (lane < total) {
+            const uint2 c = cand[lane];
+            hi = c.x;
+            lo = c.y;
+          }
+        } else {
+          // more results above B than lanes: each lane's best is its candidate, its other results bound the round
+          hi = bk.hi;
+          lo = bk.lo;
+          float b2 = bound;
+#pragma unroll
+          for (int q = 0; q < E; ++q) {
+            const bool vq = (e[q].x | e[q].y) != 0u;
+            if (vq && !(e[q].x == bk.hi && e[q].y == bk.lo)) b2 = fmaxf(b2, __uint_as_float(e[q].x));
+          }
+          b2 = fmax_dpp<kDppXor1>(b2);
+          b2 = fmax_dpp<kDppXor2>(b2);
+          b2 = fmax_dpp<kDppHalfMirror>(b2);
+          b2 = fmax_dpp<kDppMirror>(b2);
+          b2 = fmax_dpp<kDppBcast15, 0xA>(b2);
+          b2 = fmax_dpp<kDppBcast31, 0xC>(b2);
+          bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2), 63));
+        }
+        is_best = (hi | lo) != 0u && hi == gbest.hi && lo == gbest.lo;
       }
+      const float v = __uint_as_float(hi);
+      const bool valid = (hi | lo) != 0u;
       const bool elig = valid && (v > bound || is_best);
       unsigned long long em = __ballot(elig);
       const int cidx = (int)~lo;
@@ -505,45 +628,104 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
         y = sy[cidx];
         z = D == 3 ? sz[cidx] : 0.f;
       }
-      int rank = 0;
-      bool hit = false;  // an earlier (larger key) eligible candidate lies closer than this one's running distance
-      for (unsigned long long mm = em; mm != 0; mm &= mm - 1) {
-        const int j = __ffsll((long long)mm) - 1;
-        const unsigned jh = (unsigned)__builtin_amdgcn_readlane((int)hi, j), jl = (unsigned)__builtin_amdgcn_readlane((int)lo, j);
-        const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j));
-        const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), j));
-        const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), j));
-        const bool before = jh > hi || (jh == hi && jl > lo);
-        const float d = D == 3 ? dist2_3(x, y, z, jx, jy, jz) : dist2_2(x, y, jx, jy);
-        rank += before ? 1 : 0;
-        hit = hit || (before && d < v);
-      }
-      // accepted = the eligible candidates of rank < L, L = the smallest rank that was hit (or all of them), capped
-      int L = elig && hit ? rank : 0x7fffffff;
-      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor1, 0xF, 0xF, false));
-      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor2, 0xF, 0xF, false));
-      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppHalfMirror, 0xF, 0xF, false));
-      L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppMirror, 0xF, 0xF, false));
-      L = min(min(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 16)), min(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 48)));
-      L = min(min(L, (int)__popcll(em)), min(kMaxPick / 2, M - it));  // (int): min(int, unsigned) would resolve to the double overload
-      if (elig && rank < L) {
-        float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + rank) * 8;
-        *reinterpret_cast<float4*>(cdst) = make_float4(x, x, y, y);
-        *reinterpret_cast<f32x2*>(cdst + 4) = f32x2{z, z};
-#ifdef MVP_FPS_TRACE
-        cdst[6] = __uint_as_float((unsigned)rounds_done);
+      int L;
+#ifdef MVP_FPS_PHASES
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-        sout[it + rank] = cidx;
+      MVP_PH(2)
+      if (!(dbg & 2)) {
+        // ---- greedy: the resolver keeps the candidates' running distances EXACT while it picks (round 5) ----
+        // The walk of rounds 3-4 (below, MVP_FPS_DEBUG=2) stops at the first candidate that an earlier pick of the round lies closer to than
+        // its running distance -- and the candidates are the cloud's largest holes' points, i.e. neighbours of each other: 5 - 9 picks per
+        // round however many rows offer candidates (measured: 32 rows 5.3, 512 rows 9.3).  But the resolver has what it takes to UPDATE
+        // such a candidate instead of giving up: its coordinates and the pick's, and min(v, d) with the pinned-rounding distance is
+        // exactly what the lanes will compute for it in the next round's pass A (min is exact, so the order of the picks does not matter).
+        // So: pick the arg-max of the candidates' CURRENT values while it is above B -- every point that is not a candidate is at most B
+        // and only shrinks, hence that arg-max is the arg-max over the whole cloud: the next sample of the one-at-a-time chain --, apply
+        // it to all candidates, repeat.  A round ends when the candidates are used up (their values fell to B), not at the first conflict.
+        // Values as their bit patterns: running distances are >= +0 and "no candidate" is -3, for which signed integer order IS the float
+        // order -- integer min / max have no canonicalisation and take a DPP operand (wave_imax: 12 issue slots instead of 30).
+        int cvi = elig ? (int)hi : __float_as_int(-3.f);
+        const int boundi = __float_as_int(bound);
+        const int cap = min(kMaxPick / 2, M - it);
+        int w = __ffsll((long long)__ballot(is_best)) - 1;  // the first pick: the true arg-max, unconditionally
+        int myrank = -1;                                    // this lane's candidate is pick number `myrank` of the round
+        L = 0;
+        if (w >= 0) {
+          for (;;) {
+            myrank = lane == w ? L : myrank;
+            ++L;
+            if (L >= cap) break;
+            const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), w));
+            const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), w));
+            const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), w));
+            const float d = D == 3 ? dist2_3(x, y, z, jx, jy, jz) : dist2_2(x, y, jx, jy);
+            cvi = min(cvi, __float_as_int(d));  // (the pick itself: d = 0; lanes without a candidate stay at -3; a NaN distance leaves cv as fminf does)
+            const int vm = wave_imax(cvi);
+            if (!(vm > boundi)) break;
+            const unsigned long long tops = __ballot(cvi == vm);
+            if (tops & (tops - 1)) {  // equal values: the lowest index (largest ~index) is the first maximum
+              K g = cvi == vm ? K{(unsigned)vm, lo} : K::none();
+              key_max_wave_to_lane63(g);
+              const K gb = g.lane(63);
+              w = __ffsll((long long)__ballot(cvi == vm && lo == gb.lo)) - 1;
+            } else {
+              w = __ffsll((long long)tops) - 1;
+            }
+          }
+        }
+        if (myrank >= 0) {
+          float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + myrank) * 8;
+          *reinterpret_cast<float4*>(cdst) = make_float4(x, x, y, y);
+          *reinterpret_cast<f32x2*>(cdst + 4) = f32x2{z, z};
+#ifdef MVP_FPS_TRACE
+          cdst[6] = __uint_as_float((unsigned)rounds_done);
+#endif
+          sout[it + myrank] = cidx;
+        }
+      } else {
+        int rank = 0;
+        bool hit = false;  // an earlier (larger key) eligible candidate lies closer than this one's running distance
+        for (unsigned long long mm = em; mm != 0; mm &= mm - 1) {
+          const int j = __ffsll((long long)mm) - 1;
+          const unsigned jh = (unsigned)__builtin_amdgcn_readlane((int)hi, j), jl = (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+          const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j));
+          const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), j));
+          const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), j));
+          const bool before = jh > hi || (jh == hi && jl > lo);
+          const float d = D == 3 ? dist2_3(x, y, z, jx, jy, jz) : dist2_2(x, y, jx, jy);
+          rank += before ? 1 : 0;
+          hit = hit || (before && d < v);
+        }
+        // accepted = the eligible candidates of rank < L, L = the smallest rank that was hit (or all of them), capped
+        L = elig && hit ? rank : 0x7fffffff;
+        L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor1, 0xF, 0xF, false));
+        L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppXor2, 0xF, 0xF, false));
+        L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppHalfMirror, 0xF, 0xF, false));
+        L = min(L, __builtin_amdgcn_update_dpp(L, L, kDppMirror, 0xF, 0xF, false));
+        L = min(min(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 16)), min(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 48)));
+        L = min(min(L, (int)__popcll(em)), min(kMaxPick / 2, M - it));  // (int): min(int, unsigned) would resolve to the double overload
+        if (elig && rank < L) {
+          float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + rank) * 8;
+          *reinterpret_cast<float4*>(cdst) = make_float4(x, x, y, y);
+          *reinterpret_cast<f32x2*>(cdst + 4) = f32x2{z, z};
+#ifdef MVP_FPS_TRACE
+          cdst[6] = __uint_as_float((unsigned)rounds_done);
+#endif
+          sout[it + rank] = cidx;
+        }
       }
       if (lane == 0) npick[par ^ 1] = L;
 #ifdef MVP_FPS_TRACE
       if (lane == 0 && rounds_done <= 1024)
-        reinterpret_cast<uint4*>(sz + N)[rounds_done - 1] = make_uint4((unsigned)it | ((unsigned)L << 16), (unsigned)em, __float_as_uint(bound), __float_as_uint(vm));
+        reinterpret_cast<uint4*>(sz + N)[rounds_done - 1] = make_uint4((unsigned)it | ((unsigned)L << 16), (unsigned)em, __float_as_uint(bound), (unsigned)__popcll(em));
 #endif
+      MVP_PH(3)
     }
     __syncthreads();
     par ^= 1;
     it += npick[par];
+    MVP_PH(4)
   }
   __syncthreads();
   for (int i = tid; i < M; i += NT) o[i] = sout[i];
@@ -552,7 +734,11 @@ __global__ __launch_bounds__(NT) void fps_rounds_kernel(const float* __restrict_
     for (int i = tid; i < 4096; i += NT)
       g_fps_trace[(size_t)b * 4096 + i] = i >= 4092 ? reinterpret_cast<unsigned*>(sz + N)[4096 + (i & 1)] : i < 4 * min(rounds_done, 1023) ? reinterpret_cast<unsigned*>(sz + N)[i] : 0u;
 #endif
-  if (dbg && tid == 0) o[0] = rounds_done;  // (tools/exp: rounds taken; the first sample is always 0)
+  if ((dbg & 1) && tid == 0) o[0] = rounds_done;  // (tools/exp: rounds taken; the first sample is always 0)
+#ifdef MVP_FPS_PHASES
+  if ((dbg & 1) && tid == 0)
+    for (int i = 0; i < 5; ++i) o[1 + i] = ph_acc[i];
+#endif
 }
 
 #ifdef MVP_FPS_TRACE
@@ -560,9 +746,9 @@ extern "C" __attribute__((visibility("default"))) int mvp_fps_exp_trace(void* bu
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_trace), &buf, sizeof(buf));
 }
 #endif
-template <int D, int PPT, int NT>
+template <int D, int PPT, int NT, int RL = 16>
 int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
-  const size_t head = 2 * kWave * 16 + 32 * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
+  const size_t head = RoundsCfg<NT, RL>::kHeadBytes + (((size_t)M * 4 + 15) & ~(size_t)15);
   size_t bytes = head + (size_t)N * 3 * sizeof(float);
   if (bytes > 150 * 1024) return MVP_EUNSUPPORTED;
   static const int pad = []() { const char* e = getenv("MVP_FPS_LDS_PAD"); return e ? atoi(e) : 0; }();
@@ -570,7 +756,7 @@ int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* ou
   bytes += 16384 + 16;
 #endif
   if (pad) bytes = 160 * 1024;  // (tools/exp) the workgroup takes the whole LDS of its CU: nothing else is co-resident
-  auto k = fps_rounds_kernel<D, PPT, NT>;
+  auto k = fps_rounds_kernel<D, PPT, NT, RL>;
   if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
@@ -1012,7 +1198,19 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int sh
       else if (N > 512 && N <= 1024) rc = launch_rounds<D, 4, 256>(pts, B, N, M, out, s);
       else if (N > 1024 && N <= 2048) rc = launch_rounds<D, 4, 512>(pts, B, N, M, out, s);
       else if (N > 2048 && N <= 4096) rc = launch_rounds<D, 4, 1024>(pts, B, N, M, out, s);
-      else if (N > 4096 && N <= 8192) rc = (shape == 1 && B >= 8) ? launch_rounds<D, 16, 512>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024>(pts, B, N, M, out, s);
+      else if (N > 4096 && N <= 8192) {
+        // lanes per row (MVP_FPS_RL: A/B switch; 16 = the 32 / 64 rows of rounds 3-4).  With the greedy resolver every lane is a row at 512
+        // threads (512 rows: 18.8 picks per round, 1.41 -> 1.28 ms at B = 32) and two lanes at 1024 (512 rows: 19.9 picks, 1.22 -> 1.08 ms at
+        // B = 1; 1024 rows cost the resolver 16 results per lane to scan): tools/exp/README.md, round 5.
+        static const int rl_env = []() { const char* e = getenv("MVP_FPS_RL"); return e ? atoi(e) : 0; }();
+        const bool narrow = shape == 1 && B >= 8;  // 512 threads: the chain hides beside other kernels (training), half the issue slots
+        const int rl = rl_env ? rl_env : (narrow ? 1 : 2);
+        if (rl == 1) rc = narrow ? launch_rounds<D, 16, 512, 1>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024, 1>(pts, B, N, M, out, s);
+        else if (rl == 2) rc = narrow ? launch_rounds<D, 16, 512, 2>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024, 2>(pts, B, N, M, out, s);
+        else if (rl == 4) rc = narrow ? launch_rounds<D, 16, 512, 4>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024, 4>(pts, B, N, M, out, s);
+        else if (rl == 8) rc = narrow ? launch_rounds<D, 16, 512, 8>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024, 8>(pts, B, N, M, out, s);
+        else rc = narrow ? launch_rounds<D, 16, 512>(pts, B, N, M, out, s) : launch_rounds<D, 8, 1024>(pts, B, N, M, out, s);
+      }
       if (rc != MVP_EUNSUPPORTED) return rc;
     }
   }

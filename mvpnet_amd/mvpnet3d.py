@@ -406,8 +406,10 @@ class GraphedTrainStep:
     COPY_KEYS = ('images', 'points', 'seg_label', 'depth', 'cam_matrix', 'kinv', 'pose', 'pixel_box', 'image_xyz', 'knn_indices', 'flip', 'z_rot')
 
     def __init__(self, model, loss_fn, optimizer, batch, next_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, warmup=3,
-                 geometry='captured'):
-        """geometry='captured' (default): the fork / join of the next batch's coordinate-only work lives inside the graph (no per-step
+                 geometry='captured', plan=None):
+        """plan: the static geometry plan of ANOTHER GraphedTrainStep of the same model and shapes (PipelinedTrainStep: several captured copies
+        of the step replayed in turn hand the next batch's geometry to each other through one set of plan tensors).
+        geometry='captured' (default): the fork / join of the next batch's coordinate-only work lives inside the graph (no per-step
         host work besides the replay: 3.8 ms of host time per step).  geometry='eager': only the training stream is captured; the
         FPS chain, ball queries, 3-NN and transposed indices of the NEXT batch (~40 launches) are issued eagerly on the side stream next
         to the replay and copied into the static plan afterwards.  Measured on an idle host (B = 32): 9.82 ms either way against
@@ -428,10 +430,12 @@ class GraphedTrainStep:
                 optimizer.zero_grad(set_to_none=True)
                 loss = loss_fn(model(dict(self.static)), self.static)['seg_loss']
                 loss.backward()
-            plan = net.net_3d.plan_geometry(self.static['points'].transpose(1, 2).contiguous())
+            if plan is None:
+                plan = net.net_3d.plan_geometry(self.static['points'].transpose(1, 2).contiguous())
+                plan = {'sa': plan['sa'], 'fp': plan['fp'], 'event': None, 'stream': None}
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.plan = {'sa': plan['sa'], 'fp': plan['fp'], 'event': None, 'stream': None}  # static geometry of the CURRENT batch
+        self.plan = plan  # static geometry of the CURRENT batch
         optimizer.zero_grad(set_to_none=True)
         R.weight_slices.refresh(dev)  # the slice table exists before the capture: the refresh launch becomes a node of the graph
         self.graph = torch.cuda.CUDAGraph()
@@ -443,6 +447,10 @@ class GraphedTrainStep:
             self._capture(model, loss_fn, dev, geometry)
         finally:
             R.DW_SIDE_STREAM = aside
+        # the gradients the replay writes (tensors of this graph's pool); `rebind`: another captured copy of the step shares the parameters, so
+        # before the eager tail (all-reduce, clipping, optimizer) reads `.grad` it must point at THIS copy's tensors again
+        self.grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
+        self.rebind = False
 
     def _capture(self, model, loss_fn, dev, geometry):
         with torch.cuda.graph(self.graph):
@@ -482,6 +490,9 @@ class GraphedTrainStep:
             del net
         else:
             self.graph.replay()
+        if self.rebind:
+            for p, g in self.grads:
+                p.grad = g
         if self.grad_sync is not None:
             self.grad_sync(weight_sum=getattr(self.loss_fn, 'last_weight_sum', None))
         if self.max_grad_norm > 0:
@@ -490,3 +501,27 @@ class GraphedTrainStep:
         if self.scheduler is not None:
             self.scheduler.step()
         return self.loss.detach(), self.preds
+
+
+class PipelinedTrainStep:
+    """`depth` captured copies of the training step (GraphedTrainStep) replayed in turn.  A second launch of the SAME executable graph does not
+    return to the host before the first one has run (measured, tools/exp/README.md round 5): with one copy the host's share of a step -- input
+    copies, the graph launch of ~190 nodes, the optimizer launch -- and the replay alternate, which at 4 chunks per GPU (the reference's
+    partition of its batch of 32 over 8 GPUs, train_mvpnet_3d.py:68-70) is 1.7 ms of host time in front of every 1.3 ms replay.  With two copies
+    the host enqueues step i + 1 while step i runs; everything stays in order on ONE stream (inputs of copy B are copied behind copy A's
+    replay and optimizer launch), the copies share the parameters, the optimizer state and the static geometry plan (copy A's replay writes the
+    plan of batch i + 1 that copy B's replay reads), each has its own static inputs and gradient tensors (`rebind`).
+    step(batch, next_batch) as GraphedTrainStep.step: batches arrive in sequence."""
+
+    def __init__(self, model, loss_fn, optimizer, batch, next_batch, depth=2, **kw):
+        first = GraphedTrainStep(model, loss_fn, optimizer, batch, next_batch, **kw)
+        kw = dict(kw, warmup=0)
+        self.copies = [first] + [GraphedTrainStep(model, loss_fn, optimizer, batch, next_batch, plan=first.plan, **kw) for _ in range(depth - 1)]
+        for c in self.copies:
+            c.rebind = len(self.copies) > 1
+        self.turn = 0
+
+    def step(self, batch=None, next_batch=None):
+        c = self.copies[self.turn]
+        self.turn = (self.turn + 1) % len(self.copies)
+        return c.step(batch, next_batch)

@@ -257,7 +257,7 @@ def test_mvpnet3d_full_chunk(dev):
         np.testing.assert_allclose(logit.cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])
 
 
-@pytest.mark.parametrize('geometry', ['eager', 'captured'])
+@pytest.mark.parametrize('geometry', ['eager', 'captured', 'pipelined'])
 def test_graphed_train_step_matches_eager(dev, geometry):
     """mvpnet3d.GraphedTrainStep (forward + backward replayed from one HIP graph, geometry of the next batch forked inside it)
     follows the eager train_step: three iterations on two alternating batches (input copies, the geometry hand-over between
@@ -265,7 +265,7 @@ def test_graphed_train_step_matches_eager(dev, geometry):
     the fp32 atomics alone, eager against eager as well)."""
     import copy
     from mvpnet_amd.pn2 import PN2SSG
-    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss, train_step, GraphedTrainStep, prefetch_geometry
+    from mvpnet_amd.mvpnet3d import MVPNet3D, SegLoss, train_step, GraphedTrainStep, PipelinedTrainStep, prefetch_geometry
     kw = dict(nb_pts=1024, nv=2, h=30, w=40, channels=16)
 
     def build():
@@ -300,7 +300,11 @@ def test_graphed_train_step_matches_eager(dev, geometry):
     o2 = torch.optim.SGD(m2.parameters(), lr=0.05)
     static_feat = fa.clone()
     m2.net_2d.feature = static_feat
-    g = GraphedTrainStep(m2, SegLoss(), o2, dict(ba), dict(bb), warmup=1, geometry=geometry)
+    if geometry == 'pipelined':  # two captured copies of the step replayed in turn (shared plan tensors, per-copy inputs and gradients)
+        g = PipelinedTrainStep(m2, SegLoss(), o2, dict(ba), dict(bb), depth=2, warmup=1, geometry='captured')
+        assert len(g.copies) == 2 and g.copies[0].plan is g.copies[1].plan and g.copies[0].graph is not g.copies[1].graph
+    else:
+        g = GraphedTrainStep(m2, SegLoss(), o2, dict(ba), dict(bb), warmup=1, geometry=geometry)
     # the warm-up iterations inside the constructor trained nothing (no optimizer step) but moved BN running statistics
     m2.load_state_dict(copy.deepcopy(build().state_dict()))
     graphed = []
