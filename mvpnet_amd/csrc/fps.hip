@@ -16,6 +16,8 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <float.h>
+#include <string.h>
 
 namespace {
 
@@ -766,6 +768,489 @@ int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* ou
   return mvp_launch_status();
 }
 
+// ---- rounds with a resolver wave of its own: picks stream to the other waves while the round is still being resolved ----------------
+// Where fps_rounds_kernel's time goes once the greedy resolver takes ~19 picks per round (phase cycles of wave 0, tools/exp/fps_phases.sh;
+// 8192 -> 2048, 512 threads): applying the picks to the points 0.39 us per pick (~800 us), resolving them 0.17 us per pick + 1.3 us of
+// scan per round (~470 us) -- one after the other: seven waves wait while wave 0 resolves, then wave 0 updates its own points like
+// everybody else.  Here the resolver is a wave that owns NO points.  It publishes every pick (coordinates, then a stamped count) the moment
+// it is decided; the worker waves poll the count and apply picks while the resolver is already deciding the next ones, so a round costs
+// max(resolve, update) instead of their sum, and ONE barrier (row results complete) instead of two.  Same rows, same candidates, same
+// greedy order as fps_rounds_kernel: the picks are the one-at-a-time chain's, bit for bit.
+//   control word (LDS): round << 8 | done << 7 | picks published so far -- the stamp makes a stale word of the previous round read as
+//   "nothing yet"; cen[] needs no double buffer: the resolver writes round r + 1's picks behind the barrier that every worker passes only
+//   after it has applied all of round r's.
+template <int NTW, int RL>
+struct StreamCfg {
+  static constexpr int NR = NTW / RL;                      // rows
+  static constexpr int E = (NR + kWave - 1) / kWave;       // row results per resolver lane
+  static constexpr int kCap = 48;                          // picks per round
+  static constexpr int kHeadBytes = E * kWave * 16 + kWave * 8 + kCap * 32 + 16;  // row results, compaction list, picks, control word
+};
+
+// SORT: the cloud is put into Morton order first (a counting sort on 12-bit cell codes, in LDS, ~20 us) and worker wave w takes the w-th
+// run of it -- a spatially compact piece whose bounding box it keeps.  A pick farther from the box than the wave's largest running
+// distance cannot change any of its points: the lower bound is formed with the SAME rounded operations as the distances themselves
+// (clamp the pick into the box, dist2 to the clamped point: every |coordinate difference| of a point inside the box is at least the
+// clamped one's, and rounded subtraction, multiplication and addition are monotone), so skipping the pass is exact, not approximate.
+// With ~2000 samples taken most picks touch two or three of the eight pieces.  Which lane holds which point does not matter for the
+// result (any partition into rows gives the exact chain); keys carry the ORIGINAL indices, ties break as in the oracle.
+constexpr int kMortonCells = 4096;
+__device__ __forceinline__ int morton4(int v) {  // 4 bits -> every third bit
+  v = (v | (v << 4)) & 0x0C3;
+  return (v | (v << 2)) & 0x249;
+}
+__device__ __forceinline__ int morton_cell(float x, float y, float z, const float* lo, const float* sc) {
+  const int qx = (int)fminf(fmaxf((x - lo[0]) * sc[0], 0.f), 15.f);
+  const int qy = (int)fminf(fmaxf((y - lo[1]) * sc[1], 0.f), 15.f);
+  const int qz = (int)fminf(fmaxf((z - lo[2]) * sc[2], 0.f), 15.f);
+  return morton4(qx) | (morton4(qy) << 1) | (morton4(qz) << 2);
+}
+
+template <int D, int PPT, int NTW, int RL, bool SORT = false>
+__global__ __launch_bounds__(NTW + kWave) void fps_stream_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out, int dbg,
+                                                                 int head_bytes) {
+  static_assert(PPT % 2 == 0, "points are processed in pairs");
+  using Cfg = StreamCfg<NTW, RL>;
+  constexpr int NR = Cfg::NR, E = Cfg::E, NP = PPT / 2, kCap = Cfg::kCap;
+  static_assert(RL == 1 || RL == 2 || RL == 4 || RL == 8 || RL == 16, "a row is a power-of-two group of lanes inside a DPP row");
+  static_assert(NTW % kWave == 0 && NTW % RL == 0, "whole waves, whole rows");
+  constexpr int kNone = (int)0xC0400000;  // bits of -3.f: "no point" -- below every running distance in signed integer order
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* part = reinterpret_cast<uint4*>(smem);                                         // [E * 64] row results (key hi, key lo, second best, -)
+  uint2* cand = reinterpret_cast<uint2*>(smem + E * kWave * 16);                        // [64] compaction list of the resolver
+  float* cen = reinterpret_cast<float*>(smem + E * kWave * 16 + kWave * 8);             // [kCap][8] picks of the round: x, x, y, y, z, z, -, -
+  int* ctl = reinterpret_cast<int*>(smem + E * kWave * 16 + kWave * 8 + kCap * 32);     // control word
+  int* sout = reinterpret_cast<int*>(smem + Cfg::kHeadBytes);
+  float* sx = reinterpret_cast<float*>(smem + head_bytes);  // head_bytes >= kHeadBytes + 4 M (and, SORT, the histogram that aliases the head)
+  float* sy = sx + N;
+  float* sz = sy + N;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const bool worker = tid < NTW;  // wave-uniform: the last wave resolves
+  const float* p = pts + (size_t)b * N * D;
+  int64_t* o = out + (size_t)b * M;
+
+  const int pj = (tid % RL) * NR + tid / RL;  // consecutive indices sit in different rows (see fps_rounds_kernel)
+  f32x2 px[NP], py[NP], pz[NP], md[NP];
+  int oi[SORT ? PPT : 1];                            // (SORT) original index of every slot
+  float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f};  // (SORT) bounding box of this wave's points
+  if constexpr (SORT) {
+    constexpr int T = NTW + kWave;
+    static_assert(T >= 512, "the scan takes eight cells per thread");
+    int* hist = reinterpret_cast<int*>(smem);                           // [4096], aliases the head region (initialised afterwards)
+    unsigned short* order = reinterpret_cast<unsigned short*>(sz + N);  // 2 x [N] sorted position -> point (ping-pong)
+    float* red = reinterpret_cast<float*>(smem + head_bytes + (size_t)N * 12 + 2 * (((size_t)N * 2 + 15) & ~(size_t)15));  // [16][8]
+    const int wave = tid / kWave;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = tid; j < N; j += T) {
+      const float x = p[(size_t)j * D + 0], y = p[(size_t)j * D + 1], z = D == 3 ? p[(size_t)j * D + 2] : 0.f;
+      sx[j] = x;
+      sy[j] = y;
+      sz[j] = z;
+      mn[0] = fminf(mn[0], x), mn[1] = fminf(mn[1], y), mn[2] = fminf(mn[2], z);
+      mx[0] = fmaxf(mx[0], x), mx[1] = fmaxf(mx[1], y), mx[2] = fmaxf(mx[2], z);
+    }
+    for (int i = tid; i < kMortonCells; i += T) hist[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      for (int m = 1; m < kWave; m <<= 1) {
+        mn[k] = fminf(mn[k], __shfl_xor(mn[k], m, kWave));
+        mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], m, kWave));
+      }
+    if (lane == 0)
+      for (int k = 0; k < 3; ++k) {
+        red[wave * 8 + k] = mn[k];
+        red[wave * 8 + 4 + k] = mx[k];
+      }
+    __syncthreads();
+    float lo[3], sc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float l = INFINITY, h = -INFINITY;
+      for (int w = 0; w < T / kWave; ++w) {
+        l = fminf(l, red[w * 8 + k]);
+        h = fmaxf(h, red[w * 8 + 4 + k]);
+      }
+      float s1 = h > l ? 16.f / (h - l) : 0.f;
+      if (!(s1 <= FLT_MAX)) s1 = 0.f;
+      lo[k] = (l >= -FLT_MAX && l <= FLT_MAX) ? l : 0.f;
+      sc[k] = s1;
+    }
+    // Three counting sorts on quantised coordinates = a balanced k-d partition into eight pieces: by x over the whole cloud, by y inside each
+    // half of that order, by z inside each quarter.  The halves / quarters are the position ranges of four / two worker waves, so every
+    // wave's run of the final order is one k-d cell: compact, and no run straddles a jump of a space-filling curve (a Morton order was
+    // tried first: one of the eight runs then has a box over most of the cloud and applies 98 % of the picks).
+    static_assert(NTW == 8 * kWave, "eight worker waves, one k-d cell each");
+    constexpr int RUN = PPT * kWave;  // positions per worker wave
+    unsigned short* ord_in = order;
+    unsigned short* ord_out = order + ((N + 7) & ~7);
+    int* wsum = reinterpret_cast<int*>(red) + 16 * 8;  // [16]
+#pragma unroll 1
+    for (int level = 0; level < 3; ++level) {
+      const float* coord = level == 0 ? sx : level == 1 ? sy : sz;
+      const int gshift = level == 0 ? 31 : level == 1 ? 2 : 1;    // group = position / (RUN << gshift): whole cloud, halves, quarters
+      const int qbits = 12 - level;                               // 4096 keys: group bits + coordinate bits
+      const float qs = sc[level] * (float)(1 << (qbits - 4)), qmax = (float)((1 << qbits) - 1);
+      auto key_of = [&](int pos, int j) {
+        const int g = level == 0 ? 0 : pos / (RUN << gshift);
+        return (g << qbits) | (int)fminf(fmaxf((coord[j] - lo[level]) * qs, 0.f), qmax);
+      };
+      for (int pos = tid; pos < N; pos += T) atomicAdd(&hist[key_of(pos, level == 0 ? pos : ord_in[pos])], 1);
+      __syncthreads();
+      int c8[8], s8 = 0;
+      if (tid < 512) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c8[k] = hist[tid * 8 + k];
+          s8 += c8[k];
+        }
+      }
+      int inc = s8;
+      for (int m = 1; m < kWave; m <<= 1) {
+        const int o2 = __shfl_up(inc, m, kWave);
+        if (lane >= m) inc += o2;
+      }
+      if (lane == kWave - 1) wsum[wave] = inc;
+      __syncthreads();
+      if (tid < 512) {
+        int run = inc - s8;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          hist[tid * 8 + k] = run;
+          run += c8[k];
+        }
+      }
+      __syncthreads();
+      for (int pos = tid; pos < N; pos += T) {
+        const int j = level == 0 ? pos : ord_in[pos];
+        ord_out[atomicAdd(&hist[key_of(pos, j)], 1)] = (unsigned short)j;
+      }
+      __syncthreads();
+      for (int i = tid; i < kMortonCells; i += T) hist[i] = 0;
+      unsigned short* t2 = ord_in;
+      ord_in = ord_out;
+      ord_out = t2;
+      __syncthreads();
+    }
+    order = ord_in;
+    if (worker) {
+      float wl[3] = {INFINITY, INFINITY, INFINITY}, wh[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int pos = wave * (PPT * kWave) + i * kWave + lane;
+        float x = 0.f, y = 0.f, z = 0.f, m = -2.f;
+        int j = 0;
+        if (pos < N) {
+          j = order[pos];
+          x = sx[j];
+          y = sy[j];
+          z = sz[j];
+          m = INFINITY;
+          wl[0] = fminf(wl[0], x), wl[1] = fminf(wl[1], y), wl[2] = fminf(wl[2], z);
+          wh[0] = fmaxf(wh[0], x), wh[1] = fmaxf(wh[1], y), wh[2] = fmaxf(wh[2], z);
+        }
+        oi[i] = j;
+        px[i >> 1][i & 1] = x;
+        py[i >> 1][i & 1] = y;
+        pz[i >> 1][i & 1] = z;
+        md[i >> 1][i & 1] = m;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        for (int m = 1; m < kWave; m <<= 1) {
+          wl[k] = fminf(wl[k], __shfl_xor(wl[k], m, kWave));
+          wh[k] = fmaxf(wh[k], __shfl_xor(wh[k], m, kWave));
+        }
+        blo[k] = wl[k];
+        bhi[k] = wh[k];
+      }
+    }
+    __syncthreads();  // the histogram is dead: the head region may be initialised
+  } else if (worker) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int j = pj + i * NTW;
+      float x = 0.f, y = 0.f, z = 0.f, m = -2.f;  // padding slot: never a maximum
+      if (j < N) {
+        x = p[(size_t)j * D + 0];
+        y = p[(size_t)j * D + 1];
+        z = D == 3 ? p[(size_t)j * D + 2] : 0.f;
+        m = INFINITY;
+        sx[j] = x;
+        sy[j] = y;
+        if (D == 3) sz[j] = z;
+      }
+      px[i >> 1][i & 1] = x;
+      py[i >> 1][i & 1] = y;
+      pz[i >> 1][i & 1] = z;
+      md[i >> 1][i & 1] = m;
+    }
+  }
+  if (!worker) {
+    // The resolver's chain of dependent instructions is the round's critical path, and it shares its SIMD with worker waves that issue a
+    // dense stream of independent packed arithmetic: at equal priority the arbiter gives it one slot in three (measured: the streamed kernel
+    // no faster than the serial one, slower with more workers).  With the highest wave priority its instructions issue when they are ready
+    // and the workers fill the gaps in between.
+    __builtin_amdgcn_s_setprio(3);
+    for (int i = lane + NR; i < E * kWave; i += kWave) part[i] = make_uint4(0u, 0u, (unsigned)kNone, 0u);  // rows that do not exist
+    if (lane == 0) {
+      sout[0] = 0;
+      cen[0] = cen[1] = p[0];
+      cen[2] = cen[3] = p[1];
+      cen[4] = cen[5] = D == 3 ? p[2] : 0.f;
+      *ctl = 0x80 | 1;  // round 0: the first sample is point 0
+    }
+  }
+  __syncthreads();
+
+  int it = 0;        // samples taken
+  int round = 0;
+  int produced = 1;  // (resolver) picks of the round it resolved last
+  int rounds_done = 0;
+  float wmax = INFINITY;  // (SORT) no point of this wave has a larger running distance (as of the round's start)
+#ifdef MVP_FPS_PHASES
+  int n_updates = 0;  // (tools/exp) picks this wave applied to its points (the others were culled by its box)
+  long long sph_t = (long long)__builtin_readcyclecounter(), sph_acc[3] = {0, 0, 0};  // (tools/exp) the resolver's cycles: scan, picks, waiting
+#define MVP_SPH(i) { const long long sph_n = (long long)__builtin_readcyclecounter(); sph_acc[i] += sph_n - sph_t; sph_t = sph_n; }
+#else
+#define MVP_SPH(i)
+#endif
+  for (;;) {
+    int total;
+    if (worker) {
+      // ---- A. apply the round's picks as they are published ----
+      int applied = 0;
+      for (;;) {
+        const int c = __hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int n = (c >> 8) == round ? (c & 0x7f) : 0;
+        for (; applied < n; ++applied) {
+          const f32x2* cv = reinterpret_cast<const f32x2*>(cen) + applied * 4;
+          const f32x2 c2x = cv[0], c2y = cv[1], c2z = cv[2];
+          if constexpr (SORT) {
+            // the pick against this wave's box (same rounded operations as the distances: see above); uniform across the wave
+            const float qx = __builtin_amdgcn_fmed3f(c2x[0], blo[0], bhi[0]), qy = __builtin_amdgcn_fmed3f(c2y[0], blo[1], bhi[1]);
+            const float qz = __builtin_amdgcn_fmed3f(c2z[0], blo[2], bhi[2]);
+            const float lbd = D == 3 ? dist2_3(qx, qy, qz, c2x[0], c2y[0], c2z[0]) : dist2_2(qx, qy, c2x[0], c2y[0]);
+            if (lbd >= wmax) continue;  // (a NaN bound never skips)
+          }
+#ifdef MVP_FPS_PHASES
+          ++n_updates;
+#endif
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const f32x2 dx = px[i] - c2x, dy = py[i] - c2y;
+            f32x2 d = dx * dx + dy * dy;  // -ffp-contract=off: every packed op rounds once, like the scalar oracle
+            if (D == 3) {
+              const f32x2 dz = pz[i] - c2z;
+              d = d + dz * dz;
+            }
+            f32x2 m = md[i];
+            m[0] = fminf(m[0], d[0]);
+            m[1] = fminf(m[1], d[1]);
+            md[i] = m;
+          }
+        }
+        if ((c >> 8) == round && (c & 0x80)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      total = applied;
+    } else {
+      total = produced;
+    }
+    it += total;
+    if (it >= M) break;
+    ++rounds_done;
+    if (worker) {
+      // ---- B. this lane's best (value, first slot) and second-best value; C. its row's ----
+      float m1 = -3.f, m2 = -3.f;
+      int bi = 0;  // SORT: the best point's original index; else its slot
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float x = md[i >> 1][i & 1];
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, x);
+        if (SORT ? (x > m1 || (x == m1 && x >= 0.f && oi[SORT ? i : 0] < bi)) : x > m1) {  // (sorted slots do not ascend with the index)
+          m1 = x;
+          bi = SORT ? oi[SORT ? i : 0] : i;
+        }
+      }
+      if constexpr (SORT) wmax = __int_as_float(wave_imax(__float_as_int(m1)));
+      using K = Key<float>;
+      K k = m1 >= 0.f ? K::make(m1, SORT ? bi : pj + bi * NTW) : K::none();
+      float sec = m2;
+      if constexpr (RL > 1) {
+        const K mine = k;
+        key_max_row<K, RL>(k);
+        const bool winner = (mine.hi == k.hi) && (mine.lo == k.lo) && (m1 >= 0.f);
+        sec = winner ? m2 : m1;
+        sec = fmax_dpp<kDppXor1>(sec);
+        if (RL > 2) sec = fmax_dpp<kDppXor2>(sec);
+        if (RL > 4) sec = fmax_dpp<kDppHalfMirror>(sec);
+        if (RL > 8) sec = fmax_dpp<kDppMirror>(sec);
+      }
+      if ((tid % RL) == 0) part[tid / RL] = make_uint4(k.hi, k.lo, __float_as_uint(sec), 0u);
+    }
+    __syncthreads();  // the row results are complete; every worker has applied all picks of the round before
+    ++round;
+    if (!worker) {
+      MVP_SPH(2)
+      // ---- D. the resolver: B and the arg-max over all row results, the results above B one per lane, greedy picks ----
+      uint4 e[E];
+#pragma unroll
+      for (int q = 0; q < E; ++q) e[q] = part[lane + q * kWave];
+      int bnd = kNone, vb = kNone;
+#pragma unroll
+      for (int q = 0; q < E; ++q) {
+        bnd = max(bnd, (int)e[q].z);
+        vb = max(vb, (e[q].x | e[q].y) != 0u ? (int)e[q].x : kNone);
+      }
+      int boundi = wave_imax(bnd);   // B = the largest value of any point that is not a row's best
+      const int vmi = wave_imax(vb); // the largest value of all
+      // the true arg-max: the largest value, lowest index (largest ~index; all ~index have the top bit set: signed order = unsigned order)
+      int lb = (int)0x80000000;
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        if ((e[q].x | e[q].y) != 0u && (int)e[q].x == vmi) lb = max(lb, (int)e[q].y);
+      const int lobest = wave_imax(lb);
+      bool el[E];
+      unsigned long long emq[E];
+      int total_el = 0;
+#pragma unroll
+      for (int q = 0; q < E; ++q) {
+        const bool vq = (e[q].x | e[q].y) != 0u;
+        el[q] = vq && ((int)e[q].x > boundi || ((int)e[q].x == vmi && (int)e[q].y == lobest));
+        emq[q] = __ballot(el[q]);
+        total_el += (int)__popcll(emq[q]);
+      }
+      unsigned hi = 0u, lo = 0u;
+      if (total_el <= kWave) {
+        int base = 0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(emq[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emq[q], 0u));
+          if (el[q]) cand[base + below] = make_uint2(e[q].x, e[q].y);
+          base += (int)__popcll(emq[q]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < total_el) {
+          const uint2 c = cand[lane];
+          hi = c.x;
+          lo = c.y;
+        }
+      } else {
+        // more results above B than lanes: each lane's best is its candidate, its other results join the bound
+        int bh = kNone, bl = (int)0x80000000;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const bool vq = (e[q].x | e[q].y) != 0u;
+          if (vq && ((int)e[q].x > bh || ((int)e[q].x == bh && (int)e[q].y > bl))) {
+            bh = (int)e[q].x;
+            bl = (int)e[q].y;
+          }
+        }
+        int b2 = boundi;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const bool vq = (e[q].x | e[q].y) != 0u;
+          if (vq && !((int)e[q].x == bh && (int)e[q].y == bl)) b2 = max(b2, (int)e[q].x);
+        }
+        boundi = wave_imax(b2);
+        if (bh != kNone) {
+          hi = (unsigned)bh;
+          lo = (unsigned)bl;
+        }
+      }
+      const bool valid = (hi | lo) != 0u;
+      const bool is_best = valid && (int)hi == vmi && (int)lo == lobest;
+      const bool elig = valid && ((int)hi > boundi || is_best);
+      const int cidx = (int)~lo;
+      float x = 0.f, y = 0.f, z = 0.f;
+      if (elig) {
+        x = sx[cidx];
+        y = sy[cidx];
+        z = D == 3 ? sz[cidx] : 0.f;
+      }
+      int cvi = elig ? (int)hi : kNone;
+      // (`it` depends on `worker` and so counts as divergent to the compiler: without the readfirstlane the whole loop is built on exec masks)
+      const int it_u = __builtin_amdgcn_readfirstlane(it);
+      const int cap = min(kCap, M - it_u);
+      int w = __ffsll((long long)__ballot(is_best)) - 1;  // the first pick: the true arg-max, unconditionally
+      int myrank = -1;
+      int L = 0;
+      const int stamp = __builtin_amdgcn_readfirstlane(round) << 8;
+      MVP_SPH(0)
+      if (w >= 0) {
+        for (;;) {
+          const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), w));
+          const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), w));
+          const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), w));
+          myrank = lane == w ? L : myrank;
+          if (lane == w) {
+            // coordinates first, then the count that makes them visible to the workers: the LDS performs one wave's instructions in order,
+            // so the count needs no wait for the coordinates in front of it (only the compiler must keep the order).  (Lane 0 publishing the
+            // read-out coordinates instead of lane w its own: 830 against 788 us, same box.)
+            float* cdst = cen + L * 8;
+            *reinterpret_cast<float4*>(cdst) = make_float4(x, x, y, y);
+            *reinterpret_cast<f32x2*>(cdst + 4) = f32x2{z, z};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __hip_atomic_store(ctl, stamp | (L + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          ++L;
+          if (L >= cap) break;
+          const float d = D == 3 ? dist2_3(x, y, z, jx, jy, jz) : dist2_2(x, y, jx, jy);
+          cvi = min(cvi, __float_as_int(d));
+          const int vm = wave_imax(cvi);
+          if (!(vm > boundi)) break;
+          const unsigned long long tops = __ballot(cvi == vm);
+          if (tops & (tops - 1)) {  // equal values: the lowest index is the first maximum
+            const int lm = wave_imax(cvi == vm ? (int)lo : (int)0x80000000);
+            w = __ffsll((long long)__ballot(cvi == vm && (int)lo == lm)) - 1;
+          } else {
+            w = __ffsll((long long)tops) - 1;
+          }
+        }
+      }
+      // (w < 0 cannot happen while it < M: some row holds a real point; the done word keeps the workers from waiting for ever all the same)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (lane == 0) __hip_atomic_store(ctl, stamp | 0x80 | L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (myrank >= 0) sout[it_u + myrank] = cidx;
+      produced = L;
+      MVP_SPH(1)
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < M; i += NTW + kWave) o[i] = sout[i];
+  if ((dbg & 1) && tid == 0) o[0] = rounds_done;
+#ifdef MVP_FPS_PHASES
+  if ((dbg & 1) && tid == NTW)
+    for (int i = 0; i < 3; ++i) o[1 + i] = sph_acc[i];
+  if ((dbg & 1) && worker && lane == 0) o[4 + tid / kWave] = n_updates;
+#endif
+#undef MVP_SPH
+}
+
+template <int D, int PPT, int NTW, int RL, bool SORT = false>
+int launch_stream(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s) {
+  if ((int64_t)PPT * NTW < N || (SORT && N > 65535)) return MVP_EUNSUPPORTED;
+  size_t head = StreamCfg<NTW, RL>::kHeadBytes + (((size_t)M * 4 + 15) & ~(size_t)15);
+  if (SORT && head < (size_t)kMortonCells * 4) head = (size_t)kMortonCells * 4;  // the histogram aliases the head region
+  size_t bytes = head + (size_t)N * 3 * sizeof(float);
+  if (SORT) bytes += 2 * (((size_t)N * 2 + 15) & ~(size_t)15) + 16 * 8 * 4 + 16 * 4;  // order (twice), per-wave boxes, wave sums
+  if (bytes > 156 * 1024) return MVP_EUNSUPPORTED;
+  auto k = fps_stream_kernel<D, PPT, NTW, RL, SORT>;
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  static const int dbg = []() { const char* e = getenv("MVP_FPS_DEBUG"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NTW + kWave), bytes, s, pts, (int)N, (int)M, out, dbg, (int)head);
+  return mvp_launch_status();
+}
+
 // What the workgroups of one cloud exchange through: 64-bit relaxed atomics at device scope (single-copy atomic and coherent across the
 // XCDs by the memory model; 16-byte plain accesses with the sc1 bit turned out to tear: a reader saw the new half of an entry beside
 // the old one).  Every 64-bit unit carries the round stamp, so a reader knows each unit is of THIS round.
@@ -1194,6 +1679,21 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int sh
   if constexpr (std::is_same<T, float>::value) {
     if (rounds && M > 1) {
       int rc = MVP_EUNSUPPORTED;
+      // 4097 .. 8192 points: a resolver wave of its own, picks streamed to eight worker waves that hold one k-d cell of the cloud each
+      // (fps_stream_kernel<.., SORT>).  MVP_FPS_STREAM=0: the kernels below; =<worker threads>[:lanes per row][:s]: experiment shapes.
+      static const char* st = getenv("MVP_FPS_STREAM");
+      static const int st_threads = st ? atoi(st) : 512;
+      static const int st_rl = []() { const char* c = st ? strchr(st, ':') : nullptr; return c ? atoi(c + 1) : 1; }();
+      static const bool st_sort = !st || strstr(st, ":s") != nullptr;
+      if (st_threads > 0 && N > 4096 && N <= 8192) {  // (2048 -> 512 through it: 195 against 178 us -- the three sorts in front do not pay there)
+        int r2 = MVP_EUNSUPPORTED;
+        if (st_sort && st_threads == 512 && st_rl == 1) r2 = launch_stream<D, 16, 512, 1, true>(pts, B, N, M, out, s);
+        else if (st_sort && st_threads == 512 && st_rl == 2 && N > 4096) r2 = launch_stream<D, 16, 512, 2, true>(pts, B, N, M, out, s);
+        else if (!st_sort && st_threads == 512 && st_rl == 1 && N > 4096) r2 = launch_stream<D, 16, 512, 1>(pts, B, N, M, out, s);
+        else if (!st_sort && st_threads == 512 && st_rl == 2 && N > 4096) r2 = launch_stream<D, 16, 512, 2>(pts, B, N, M, out, s);
+        else if (!st_sort && st_threads == 896 && st_rl == 2 && N > 4096) r2 = launch_stream<D, 10, 896, 2>(pts, B, N, M, out, s);
+        if (r2 != MVP_EUNSUPPORTED) return r2;
+      }
       if (N > 256 && N <= 512) rc = launch_rounds<D, 2, 256>(pts, B, N, M, out, s);
       else if (N > 512 && N <= 1024) rc = launch_rounds<D, 4, 256>(pts, B, N, M, out, s);
       else if (N > 1024 && N <= 2048) rc = launch_rounds<D, 4, 512>(pts, B, N, M, out, s);
