@@ -504,14 +504,15 @@ class GraphedTrainStep:
 
 
 class PipelinedTrainStep:
-    """`depth` captured copies of the training step (GraphedTrainStep) replayed in turn.  A second launch of the SAME executable graph does not
-    return to the host before the first one has run (measured, tools/exp/README.md round 5): with one copy the host's share of a step -- input
-    copies, the graph launch of ~190 nodes, the optimizer launch -- and the replay alternate, which at 4 chunks per GPU (the reference's
-    partition of its batch of 32 over 8 GPUs, train_mvpnet_3d.py:68-70) is 1.7 ms of host time in front of every 1.3 ms replay.  With two copies
-    the host enqueues step i + 1 while step i runs; everything stays in order on ONE stream (inputs of copy B are copied behind copy A's
-    replay and optimizer launch), the copies share the parameters, the optimizer state and the static geometry plan (copy A's replay writes the
-    plan of batch i + 1 that copy B's replay reads), each has its own static inputs and gradient tensors (`rebind`).
-    step(batch, next_batch) as GraphedTrainStep.step: batches arrive in sequence."""
+    """`depth` captured copies of the training step (GraphedTrainStep) replayed in turn: the host can enqueue step i + 1 (input copies, the
+    graph launch of ~190 nodes, the optimizer launch) while copy A's replay of step i still runs, whatever the runtime does with a second
+    launch of one executable graph.  Everything stays in order on ONE stream (inputs of copy B are copied behind copy A's replay and optimizer
+    launch); the copies share the parameters, the optimizer state and the static geometry plan (copy A's replay writes the plan of batch
+    i + 1 that copy B's replay reads); each has its own static inputs and gradient tensors (`rebind`).
+    Measured (bench field per_gpu_batch, `graph_x2`): at 4 chunks per GPU -- the reference's partition of its batch of 32
+    over 8 GPUs, train_mvpnet_3d.py:68-70 -- 2.73 ms against 2.71 for one copy: the replay is GPU-bound there (2.09 ms of kernels on the
+    training stream), the host needs 0.7 ms per step and runs ahead either way.  Kept as the measurement it is and for hosts slower than the
+    replay.  step(batch, next_batch) as GraphedTrainStep.step: batches arrive in sequence."""
 
     def __init__(self, model, loss_fn, optimizer, batch, next_batch, depth=2, **kw):
         first = GraphedTrainStep(model, loss_fn, optimizer, batch, next_batch, **kw)

@@ -17,7 +17,7 @@ if [ ! -f $root/tools/exp/libmvp_fpsphase.so ] || [ fps.hip -nt $root/tools/exp/
 fi
 cd $root
 [ "$1" = "build" ] && exit 0
-for rl in ${FPS_RLS:-16 4 2 1}; do
+for rl in ${FPS_RLS:-16 1}; do
   MVP_FPS_RL=$rl MVP_LIBRARY=$root/tools/exp/libmvp_fpsphase.so python tools/exp/fps_phases.py 2>&1 | grep "RL="
   MVP_FPS_DEBUG=2 MVP_FPS_RL=$rl MVP_LIBRARY=$root/tools/exp/libmvp_fpsphase.so python tools/exp/fps_phases.py 2>&1 | grep "RL="
 done

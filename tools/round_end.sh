@@ -29,6 +29,13 @@ grep lift_ $out/dense_lift/p_kernel_stats.csv | cut -c1-200
 python tools/exp/wide_time.py 2>&1 | grep -v amdgpu.ids > $out/wide_time.txt; cat $out/wide_time.txt
 python tools/exp/graphgap/node_cost.py 2>&1 | grep -v amdgpu.ids > $out/graph_node_cost.txt
 (cd tools/exp/graphgap && ./graphgap 150 4000 8 0 && ./graphgap 150 4000 8 64) > $out/graphgap.txt 2>&1
+# round 5 (second half): the sampler alone, level by level, bit-compared with the one-sample kernels -- the kernels of rounds 3-4 (MVP_FPS_STREAM=0)
+# and the resolver-wave kernel; the resolver's phases (a -DMVP_FPS_PHASES build of the library); the B = 4 step kernel by kernel
+(MVP_FPS_ROUNDS=0 python tools/exp/run_fps_rounds.py > /dev/null 2>&1; echo "== MVP_FPS_STREAM=0 (fps_rounds_kernel)"; MVP_FPS_STREAM=0 python tools/exp/run_fps_rounds.py 2>&1 | grep "us$\|equal"; \
+ echo "== default (fps_stream_kernel for 4097 .. 8192 points)"; python tools/exp/run_fps_rounds.py 2>&1 | grep "us$\|equal") > $out/fps_levels.txt 2>&1
+bash tools/exp/fps_phases.sh build > /dev/null 2>&1
+(MVP_LIBRARY=$root/tools/exp/libmvp_fpsphase.so python tools/exp/fps_stream_phases.py 2>&1 | grep "STREAM=\|picks applied"; MVP_FPS_STREAM=0 bash tools/exp/fps_phases.sh 2>&1 | grep "RL=") > $out/fps_phases.txt 2>&1
+bash tools/exp/b4_trace.sh > $out/b4_trace.log 2>&1; cp $root/gpurun_out/b4/timeline_graph.txt $out/b4_timeline_graph.txt; cp $root/gpurun_out/b4/timeline_eager.txt $out/b4_timeline_eager.txt
 # gpurun merges at most 64 MiB back: drop what nothing reads (the full bench's kernel trace, per-dispatch counter dumps beyond the merged table)
 find $root/gpurun_out -name "*_kernel_trace.csv" -size +12M -delete
 find $root/gpurun_out -type f -size +16M -delete
