@@ -1275,19 +1275,23 @@ __device__ __forceinline__ fps_u64 load_device(const fps_u64* p) {
 // round; the readers spin until all units of an entry carry the stamp.  All W workgroups of a cloud must be resident together: the host launches at most 64 workgroups of 1024 threads (a quarter of
 // the CUs), and a reader that spins 2^22 times without seeing its partners sets an error flag and lets the kernel end (wrong samples,
 // no hang).
+constexpr int kMultiMaxPick = 64;                                   // [2][32] picks of a round
+constexpr int kMultiHeadBytes = kMultiMaxPick * 32 + 16 + kWave * 32;  // picks, counts, compaction list
 template <int D, int PPT, int NT, int W>
 __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __restrict__ pts, int N, int M, int64_t* __restrict__ out,
                                                               fps_u64* __restrict__ xch /* [B][2][W][64][8] zero on entry */, int* __restrict__ err,
-                                                              int* __restrict__ report, int spin_limit) {
+                                                              int* __restrict__ report, int spin_limit, int walk) {
   static_assert(PPT % 2 == 0 && NT == 1024, "16 waves, points in pairs");
-  constexpr int NR = NT / 16;  // 64 rows per workgroup = one resolver lane per super row
+  constexpr int NR = NT / 16;  // 64 rows per workgroup
   constexpr int NP = PPT / 2;
-  constexpr int kMaxPick = 32;
+  constexpr int kMaxPick = kMultiMaxPick;
+  constexpr int kNone = (int)0xC0400000;  // bits of -3.f (see fps_stream_kernel)
   using K = Key<float>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* cen = reinterpret_cast<float*>(smem);                      // [kMaxPick][8]: (x,x,y,y,z,z,-,-) per pick, two halves
   int* npick = reinterpret_cast<int*>(smem + kMaxPick * 32);        // [2] + dead flag
-  int* sout = reinterpret_cast<int*>(smem + kMaxPick * 32 + 16);    // [M] (workgroup 0 of the cloud writes it out)
+  uint4* cand = reinterpret_cast<uint4*>(smem + kMaxPick * 32 + 16);            // [64][2] compaction list of the resolver: key, coordinates
+  int* sout = reinterpret_cast<int*>(smem + kMaxPick * 32 + 16 + kWave * 32);   // [M] (workgroup 0 of the cloud writes it out)
   const int b = blockIdx.x / W, w = blockIdx.x % W;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const float* p = pts + (size_t)b * N * D;
@@ -1391,6 +1395,9 @@ __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __res
       unsigned hi = 0u, lo = 0u;
       float second = -3.f, x = 0.f, y = 0.f, z = 0.f;
       bool dead = false;
+      unsigned ehi[W], elo[W];  // the W results of row `lane` kept apart (greedy resolver: 4 x 64 rows instead of 64 super rows)
+      int esec[W];
+      float ecx[W], ecy[W], ecz[W];
 #pragma unroll
       for (int ww = 0; ww < W; ++ww) {
         const fps_u64* src = xb + (((size_t)(rounds_done & 1) * W + ww) * NR + lane) * 8;
@@ -1415,6 +1422,12 @@ __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __res
         e1.x = (unsigned)u2;
         e1.y = (unsigned)u3;
         e1.z = (unsigned)u4;
+        ehi[ww] = none ? 0u : e0.x;
+        elo[ww] = e0.y;
+        esec[ww] = (int)e0.z;
+        ecx[ww] = __uint_as_float(e1.x);
+        ecy[ww] = __uint_as_float(e1.y);
+        ecz[ww] = __uint_as_float(e1.z);
         const float s2 = __uint_as_float(e0.z);
         const bool better = e0.x > hi || (e0.x == hi && e0.y > lo);
         // the loser of the two bests is one more "not a row winner" value
@@ -1437,6 +1450,103 @@ __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __res
           if (report) atomicOr(report, 1);  // the caller's sticky status word: reporting only
         }
       }
+      if (!walk) {
+        // ---- greedy resolver over the W x 64 rows (round 5; see fps_rounds_kernel / fps_stream_kernel): the same entries, the same code
+        // and hence the same picks in every workgroup of the cloud ----
+        int bnd = kNone, vb = kNone;
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) {
+          bnd = max(bnd, esec[ww]);
+          vb = max(vb, (ehi[ww] | elo[ww]) != 0u ? (int)ehi[ww] : kNone);
+        }
+        int boundi = wave_imax(bnd);
+        const int vmi = wave_imax(vb);
+        int lb = (int)0x80000000;
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww)
+          if ((ehi[ww] | elo[ww]) != 0u && (int)ehi[ww] == vmi) lb = max(lb, (int)elo[ww]);
+        const int lobest = wave_imax(lb);
+        bool el[W];
+        unsigned long long emq[W];
+        int total_el = 0;
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) {
+          const bool vq = (ehi[ww] | elo[ww]) != 0u;
+          el[ww] = vq && ((int)ehi[ww] > boundi || ((int)ehi[ww] == vmi && (int)elo[ww] == lobest));
+          emq[ww] = __ballot(el[ww]);
+          total_el += (int)__popcll(emq[ww]);
+        }
+        unsigned ghi = 0u, glo = 0u;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (total_el <= kWave) {
+          int base = 0;
+#pragma unroll
+          for (int ww = 0; ww < W; ++ww) {
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(emq[ww] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emq[ww], 0u));
+            if (el[ww]) {
+              cand[(base + below) * 2] = make_uint4(ehi[ww], elo[ww], 0u, 0u);
+              cand[(base + below) * 2 + 1] = make_uint4(__float_as_uint(ecx[ww]), __float_as_uint(ecy[ww]), __float_as_uint(ecz[ww]), 0u);
+            }
+            base += (int)__popcll(emq[ww]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (lane < total_el) {
+            const uint4 c0 = cand[lane * 2], c1 = cand[lane * 2 + 1];
+            ghi = c0.x;
+            glo = c0.y;
+            gx = __uint_as_float(c1.x);
+            gy = __uint_as_float(c1.y);
+            gz = __uint_as_float(c1.z);
+          }
+        } else {
+          // more results above B than lanes: the super rows of rounds 3-4 (the fold above) with their bound
+          ghi = hi;
+          glo = lo;
+          gx = x;
+          gy = y;
+          gz = z;
+          boundi = wave_imax(__float_as_int(second));
+        }
+        const bool gvalid = (ghi | glo) != 0u;
+        const bool gbest = gvalid && (int)ghi == vmi && (int)glo == lobest;
+        const bool gelig = gvalid && ((int)ghi > boundi || gbest);
+        const int gidx = (int)~glo;
+        int cvi = gelig ? (int)ghi : kNone;
+        const int cap = min(kMaxPick / 2, M - it);
+        int wl = __ffsll((long long)__ballot(gbest)) - 1;
+        int myrank = -1;
+        int L = 0;
+        if (wl >= 0) {
+          for (;;) {
+            myrank = lane == wl ? L : myrank;
+            ++L;
+            if (L >= cap) break;
+            const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gx), wl));
+            const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gy), wl));
+            const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gz), wl));
+            const float d = D == 3 ? dist2_3(gx, gy, gz, jx, jy, jz) : dist2_2(gx, gy, jx, jy);
+            cvi = min(cvi, __float_as_int(d));
+            const int vm2 = wave_imax(cvi);
+            if (!(vm2 > boundi)) break;
+            const unsigned long long tops2 = __ballot(cvi == vm2);
+            if (tops2 & (tops2 - 1)) {
+              const int lm = wave_imax(cvi == vm2 ? (int)glo : (int)0x80000000);
+              wl = __ffsll((long long)__ballot(cvi == vm2 && (int)glo == lm)) - 1;
+            } else {
+              wl = __ffsll((long long)tops2) - 1;
+            }
+          }
+        }
+        if (myrank >= 0) {
+          float* cdst = cen + ((par ^ 1) * kMaxPick / 2 + myrank) * 8;
+          *reinterpret_cast<float4*>(cdst) = make_float4(gx, gx, gy, gy);
+          *reinterpret_cast<f32x2*>(cdst + 4) = f32x2{gz, gz};
+          if (w == 0) sout[it + myrank] = gidx;
+        }
+        if (lane == 0) npick[par ^ 1] = max(L, 1);
+      } else {
       const float v = __uint_as_float(hi);
       const bool valid = (hi | lo) != 0u;
       float bound = second;
@@ -1493,6 +1603,7 @@ __global__ __launch_bounds__(NT) void fps_rounds_multi_kernel(const float* __res
         if (w == 0) sout[it + rank] = cidx;
       }
       if (lane == 0) npick[par ^ 1] = max(L, 1);
+      }
     }
     __syncthreads();
     if (npick[2]) break;  // a partner workgroup never showed up (see above): end instead of hanging
@@ -1525,7 +1636,8 @@ int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, h
 // exact chain in either case, and the status word tells that it happened.
 template <int D, int PPT, int W>
 int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int* status, hipStream_t s) {
-  const size_t lds = 32 * 32 + 16 + (((size_t)M * 4 + 15) & ~(size_t)15);
+  const size_t lds = kMultiHeadBytes + (((size_t)M * 4 + 15) & ~(size_t)15);
+  static const int walk = []() { const char* e = getenv("MVP_FPS_MULTI_WALK"); return e ? atoi(e) : 0; }();  // (A/B: the resolver of rounds 3-4)
   if (lds > 150 * 1024 || B * W > 64) return MVP_EUNSUPPORTED;  // (64: two such launches on two streams still fit the chip together)
   const size_t xbytes = (size_t)B * 2 * W * 64 * 8 * sizeof(fps_u64) + 16;
   char* scratch = nullptr;  // stream-ordered scratch owned by this call (as launch_global): exchange buffer + error flag
@@ -1547,7 +1659,7 @@ int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64
     }
     if (rc == MVP_OK) {
       hipLaunchKernelGGL(k, dim3((unsigned)(B * W)), dim3(1024), lds, s, pts, (int)N, (int)M, out, reinterpret_cast<fps_u64*>(scratch), err,
-                         status, g_fps_spin_limit);
+                         status, g_fps_spin_limit, walk);
       rc = mvp_launch_status();
     }
     if (rc == MVP_OK)  // the repair launch (a no-op unless the flag is set)
