@@ -19,3 +19,5 @@ cp $g/end_$run/graph_node_cost.txt profiles/${r}_graph_node_cost.txt
 cp $g/end_$run/graphgap.txt profiles/${r}_graphgap.txt
 [ -f $g/operating_point_B32.json ] && cp $g/operating_point_B32.json profiles/${r}_operating_point_B32.json
 ls -la profiles | grep ${r}_
+# round 5 (second half): the sampler level by level, its phases, the B = 4 step kernel by kernel
+for f in fps_levels fps_phases b4_timeline_graph b4_timeline_eager; do [ -f $g/end_$run/$f.txt ] && cp $g/end_$run/$f.txt profiles/${r}_$f.txt; done

@@ -17,7 +17,7 @@ for shape, B in ((1, 32), (0, 1)):
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3
     r = idx[0, :4].tolist()
-    print('   picks applied per worker wave (of 2047):', idx[0, 4:4 + 14].tolist())
+    print('   picks applied per worker wave (of 2047):', idx[0, 4:4 + 8].tolist())
     ghz = 2.35
     print('STREAM={} shape={} B={}: {:.0f} us, {} rounds; resolver: scan {:.0f} us ({:.2f} per round), picks {:.0f} us ({:.3f} per pick), waiting for the workers {:.0f} us ({:.2f} per round)'.format(
         os.environ.get('MVP_FPS_STREAM', 'default (512:1:s)'), shape, B, us, r[0], r[1] / ghz / 1e3, r[1] / ghz / 1e3 / r[0], r[2] / ghz / 1e3, r[2] / ghz / 1e3 / 2047, r[3] / ghz / 1e3, r[3] / ghz / 1e3 / r[0]))
