@@ -387,8 +387,8 @@ int mvp_bn_rows_backward_f32(const float* dsrc, const float* out, const uint8_t*
  * reference runs nn.Dropout as its own pass and keeps the mask): out = act(bn(y)) * keep / (1 - drop_p) with keep a counter-based hash of
  * (seed, row * C + column) that forward and backward regenerate -- no mask tensor.  0 <= drop_p < 1, R * C < 2^32.  Independent
  * Bernoulli(1 - drop_p) per element like torch's, not the same random stream.
- * mvp_bn_rows_backward[_dropout]_f32 with K = 1 and dy == NULL: only `stat` (the two BatchNorm-backward column sums) is produced -- the
- * caller forms dy itself (mvp_mlp_layer_backward_wide_p_f32, mode 2). */
+ * mvp_bn_rows_backward[_dropout]_f32 with dy == NULL (K = 1, or K > 1 with arg == NULL: the backward of the SUM over K): only `stat` (the two
+ * BatchNorm-backward column sums) is produced -- the caller forms dy itself (mvp_mlp_layer_backward_wide[_pooled]_p_f32, mode 2). */
 int mvp_bn_rows_forward_dropout_f32(const float* y, const float* gamma, const float* beta, int64_t R, int64_t C, int training, float eps,
                                     float momentum, int relu, float* running_mean, float* running_var, double* stat, float* mean,
                                     float* invstd, float* out, double* partial, float drop_p, uint64_t seed, mvp_stream_t stream);
@@ -579,6 +579,16 @@ int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, const flo
                                       const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
                                       int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
                                       float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
+/* The same with a SUM over pool_k consecutive rows behind the layer (FeatureAggregation's last layer: mvpnet/models/mvpnet_3d.py:40-41,59 sums the
+ * k neighbours): mode 2, G (R / pool_k, C) = the gradient w.r.t. the POOLED output, row r of the layer takes row r / pool_k of it while the rows
+ * are loaded -- no (R, C) gradient tensor and no pass that writes one.  stat_i = the sums mvp_bn_rows_backward_f32(K = pool_k, arg = NULL,
+ * dy = NULL) leaves.  pool_k == 1: exactly mvp_mlp_layer_backward_wide_p_f32 (any mode); pool_k > 1 needs mode 2, drop_p == 0, R % pool_k == 0. */
+int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                             const float* beta_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, int mode,
+                                             int64_t pool_k, float drop_p, uint64_t drop_seed, const float* X, int64_t ldx, const float* act_mean,
+                                             const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
+                                             int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
+                                             float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
 /* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
  * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,

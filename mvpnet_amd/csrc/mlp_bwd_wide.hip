@@ -48,6 +48,7 @@ struct WideArgs {
   float* dbeta_i;
   float inv_rows;        // 1 / R with batch statistics, 0 with running statistics
   int mode;
+  int gk;                // mode 2: row r of the layer takes row r / gk of G (a SUM over gk consecutive rows sits behind the layer; 1 = none)
   Dropout drop;          // mode 2: keep mask of the dropout behind layer i (thresh 0 = none)
   const float* X;        // (R, ldx): y_{i-1}
   int ldx;
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     const float* Yt = (mode != 0 ? p.Yi : p.G) + (size_t)tile * kTR * C;
     const bool clamp = tile == ntiles - 1 && tail_rows < kTR;
     const int o = clamp ? min(rbase + RPP * j, tail_rows - 1) * C + (cok ? cc : 0) : offg[j];
-    t.g[j] = *reinterpret_cast<const f32x4*>(Gt + o);
+    if (mode == 2 && p.gk > 1) {  // the gradient of the pooled output: one row of G per gk rows of the layer
+      const unsigned gr = ((unsigned)tile * kTR + (unsigned)(clamp ? min(rbase + RPP * j, tail_rows - 1) : rbase + RPP * j)) / (unsigned)p.gk;
+      t.g[j] = *reinterpret_cast<const f32x4*>(p.G + (size_t)gr * C + (cok ? cc : 0));
+    } else {
+      t.g[j] = *reinterpret_cast<const f32x4*>(Gt + o);
+    }
     if (mode != 0) t.y[j] = *reinterpret_cast<const f32x4*>(Yt + o);
   };
   auto load_gy = [&](TileRegs<NJ>& t, int tile) {
@@ -476,13 +482,14 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
 }  // namespace
 
 // One-pass backward of shared-MLP layer i with up to 128 channels on either side (see the top of the file and include/mvp_hip.h).
-MVP_API int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
-                                              const float* beta_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, int mode,
-                                              float drop_p, uint64_t drop_seed, const float* X, int64_t ldx, const float* act_mean,
-                                              const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
-                                              int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
-                                              float* workspace, int64_t workspace_floats, int precision, int precision_backward,
-                                              mvp_stream_t stream) {
+MVP_API int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                                     const float* beta_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, int mode,
+                                                     int64_t pool_k, float drop_p, uint64_t drop_seed, const float* X, int64_t ldx, const float* act_mean,
+                                                     const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
+                                                     int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
+                                                     float* workspace, int64_t workspace_floats, int precision, int precision_backward,
+                                                     mvp_stream_t stream) {
+  MVP_REQUIRE(pool_k >= 1 && pool_k <= 255 && (pool_k == 1 || (mode == 2 && drop_p == 0.f)) && R % pool_k == 0);
   MVP_NONNULL(G);
   MVP_NONNULL(X);
   MVP_NONNULL(W);
@@ -521,7 +528,7 @@ MVP_API int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, c
   a.G = G; a.Yi = Yi; a.mean_i = mean_i; a.invstd_i = invstd_i; a.gamma_i = gamma_i; a.beta_i = beta_i; a.stat_i = stat_i;
   a.dgamma_i = dgamma_i; a.dbeta_i = dbeta_i;
   a.inv_rows = training ? 1.0f / (float)R : 0.f;
-  a.mode = mode; a.drop = drop;
+  a.mode = mode; a.gk = (int)pool_k; a.drop = drop;
   a.X = X; a.ldx = (int)ldx;
   a.act = InAct{act_mean, act_invstd, act_gamma, act_beta};
   a.W = W; a.ldw = (int)ldw; a.dW = dW; a.lddw = (int)lddw; a.dZ = dZ;
@@ -586,3 +593,15 @@ MVP_API int mvp_wide_prof_read(unsigned long long* out, int reset) {  // out[102
   return (int)e;
 }
 #endif
+
+MVP_API int mvp_mlp_layer_backward_wide_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                              const float* beta_i, const double* stat_i, float* dgamma_i, float* dbeta_i, int training, int mode,
+                                              float drop_p, uint64_t drop_seed, const float* X, int64_t ldx, const float* act_mean,
+                                              const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
+                                              int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
+                                              float* workspace, int64_t workspace_floats, int precision, int precision_backward,
+                                              mvp_stream_t stream) {
+  return mvp_mlp_layer_backward_wide_pooled_p_f32(G, Yi, mean_i, invstd_i, gamma_i, beta_i, stat_i, dgamma_i, dbeta_i, training, mode, 1, drop_p, drop_seed,
+                                                  X, ldx, act_mean, act_invstd, act_gamma, act_beta, W, ldw, R, C, Cp, dW, lddw, dZ, stat_prev, ticket,
+                                                  workspace, workspace_floats, precision, precision_backward, stream);
+}

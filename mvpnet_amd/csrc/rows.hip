@@ -1328,7 +1328,7 @@ int bn_rows_backward_impl(const float* dsrc, const float* out, const uint8_t* ar
   MVP_NONNULL(gamma);
   MVP_NONNULL(beta);
   MVP_NONNULL(stat);
-  if (K != 1) MVP_NONNULL(dy);  // K == 1, dy == NULL: the two column sums only (the one-pass layer backward forms dy itself: mlp_bwd_wide.hip)
+  if (K != 1 && arg) MVP_NONNULL(dy);  // dy == NULL (K == 1, or the SUM over K): the two column sums only (the one-pass layer backward forms dy itself: mlp_bwd_wide.hip)
   if (dgamma) MVP_NONNULL(dbeta);
   MVP_REQUIRE(G >= 0 && K >= 1 && K <= 255);
   if (K > 1 && arg) MVP_NONNULL(out);  // K > 1 with arg == NULL: backward of the SUM over K

@@ -35,6 +35,9 @@ WIDE_BWD_MIN_ROWS = int(os.environ.get('MVP_BWD_WIDE_MIN_ROWS', '16384'))  # (fe
 # ... and, in its 64-channel instance, the 64 -> 64 layers over very many rows (the aggregation MLP's inner layers: 786 432 rows), where the
 # register-resident one-kernel backward runs at one wave per SIMD.  MVP_BWD_WIDE64=0: those layers stay on mvp_mlp_layer_backward_f32.
 WIDE_BWD_64 = os.environ.get('MVP_BWD_WIDE64', '1') != '0'
+# ... and as the backward of the layer in front of a SUM over the neighbours (mode 2 with one gradient row per K rows).  MVP_BWD_WIDE_POOLED=0: the
+# BatchNorm-backward pass writes dy_L first (A/B switch).
+WIDE_BWD_POOLED = os.environ.get('MVP_BWD_WIDE_POOLED', '1') != '0'
 WIDE_BWD_64_MIN_ROWS = int(os.environ.get('MVP_BWD_WIDE64_MIN_ROWS', '262144'))
 
 
@@ -990,6 +993,10 @@ class MLPChainRows(torch.autograd.Function):
         wl = params[3 * (nl - 1)]
         last_wide = bool(not ctx.pooled and K == 1 and nl >= 2 and wl is not None and g.is_cuda and
                          wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32)
+        # ... and the last layer in front of a SUM over K (FeatureAggregation, arg is None): the same one-pass backward takes the gradient of the
+        # POOLED output and reads row r / K of it (mvp_mlp_layer_backward_wide_pooled_p_f32): no (R, C) gradient tensor, no pass that writes it
+        last_wide_sum = bool(WIDE_BWD_POOLED and not ctx.pooled and K > 1 and arg is None and ctx.dropout[0] == 0 and nl >= 2 and wl is not None and
+                             g.is_cuda and wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32)
         if ctx.pooled:
             # the last layer's (R, cl) output does not exist: its BatchNorm-backward column sums come from the (G, cl) tensors, dy_L is
             # formed inside the one-kernel layer backward from the re-computed y_L
@@ -998,6 +1005,11 @@ class MLPChainRows(torch.autograd.Function):
             L.call('mvp_pool_backward_stats_f32', g, L.ptr(g), L.ptr(out), L.ptr(ysel), L.ptr(means[-1]), L.ptr(invstds[-1]), G, cl, 1,
                    L.ptr(stat_l), L.ptr(_cs_partial(G, cl, g.device)))
             pool = (g, out, arg)
+            dy, dgam, dbet = None, None, None
+        elif last_wide_sum:
+            stat_d = torch.empty(2 * cl, dtype=torch.float64, device=g.device)
+            L.call('mvp_bn_rows_backward_f32', g, L.ptr(g), None, None, L.ptr(ys[-1]), L.ptr(means[-1]), L.ptr(invstds[-1]), L.ptr(params[-2]),
+                   L.ptr(params[-1]), G, K, cl, 1, int(training), L.ptr(stat_d), None, None, None, L.ptr(_cs_partial(R, cl, g.device)))
             dy, dgam, dbet = None, None, None
         elif last_wide:
             # the last layer goes through the one-pass wide backward (mode 2): only the two column sums of dz_L = g * keep * relu'(bn(y_L)) are
@@ -1032,7 +1044,7 @@ class MLPChainRows(torch.autograd.Function):
         gcur, pending = dy, None
         if pool is not None:
             gcur, pending = None, stat_l
-        elif last_wide:
+        elif last_wide or last_wide_sum:
             gcur, pending = g, stat_d
         dw_aside = bool(DW_SIDE_STREAM and ctx.dw_use is not None and ctx.dw_use.aside_ok())
         for i in range(nl - 1, -1, -1):
@@ -1046,7 +1058,7 @@ class MLPChainRows(torch.autograd.Function):
             wide = bool(i > 0 and w is not None and not pool_here and rel is None and need_dz and wide_backward_ok(ctx.prec, R, cout, cin, src.size(1)))
             fuse = wide or pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and rel is None and
                                          (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
-            assert wide or not (last_wide and i == nl - 1)
+            assert wide or not ((last_wide or last_wide_sum) and i == nl - 1)
             if pending is not None and w is None and ctx.defer is not None and ctx.defer.accepts and ctx.defer.info is None:
                 # i == 0, x0 was this layer's pre-BN output and its ONLY consumer gathers it (DeferredFinish): dz_0 goes back unfinished, the
                 # gather forms dy_0 on load.  The BatchNorm parameter gradients are the two column sums themselves.
@@ -1094,14 +1106,15 @@ class MLPChainRows(torch.autograd.Function):
                 break
             if wide:
                 # mode 0: gcur is dy_i; 1: dz_i (finish inside); 2: the gradient of the layer's (dropped-out) activation (last layer)
-                mode = 0 if pending is None else (2 if (last_wide and i == nl - 1) else 1)
+                mode = 0 if pending is None else (2 if ((last_wide or last_wide_sum) and i == nl - 1) else 1)
+                pool_k = K if (last_wide_sum and i == nl - 1) else 1
                 dgb = torch.empty((2, cout), dtype=torch.float32, device=dev) if pending is not None else None
                 ticket = zero_pool.zeros(2, torch.int32, dev)
                 ws_ptr, ws_floats = L.current_dw_workspace(dev)
                 fin = pending is not None
-                L.call('mvp_mlp_layer_backward_wide_f32', src, L.ptr(gcur), L.ptr(ys[i]) if fin else None, L.ptr(means[i]) if fin else None,
+                L.call('mvp_mlp_layer_backward_wide_pooled_f32', src, L.ptr(gcur), L.ptr(ys[i]) if fin else None, L.ptr(means[i]) if fin else None,
                        L.ptr(invstds[i]) if fin else None, L.ptr(params[3 * i + 1]) if fin else None, L.ptr(params[3 * i + 2]) if mode == 2 else None,
-                       L.ptr(pending), L.ptr(None if dgb is None else dgb[0]), L.ptr(None if dgb is None else dgb[1]), int(training), mode,
+                       L.ptr(pending), L.ptr(None if dgb is None else dgb[0]), L.ptr(None if dgb is None else dgb[1]), int(training), mode, pool_k,
                        float(ctx.dropout[0]) if mode == 2 else 0.0, int(ctx.dropout[1]) if mode == 2 else 0, L.ptr(src), src.size(1), L.ptr(act[0]),
                        L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]), L.ptr(w), cin, R, cout, cin, L.ptr(dw), cin, L.ptr(dz), L.ptr(stat), L.ptr(ticket),
                        ws_ptr, ws_floats, prec=ctx.prec)

@@ -1718,6 +1718,78 @@ def test_fps_rounds_kernel_odd_sizes(dev, N, M):
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
 
+@pytest.mark.parametrize('G,K,C,Cp', [(4000, 3, 64, 64), (1367, 5, 128, 128), (100, 32, 32, 64)])
+def test_mlp_layer_backward_wide_behind_a_sum_over_the_neighbours(dev, G, K, C, Cp):
+    """mvp_mlp_layer_backward_wide_pooled_p_f32: mode 2 with ONE gradient row per K rows of the layer (FeatureAggregation sums the k
+    neighbours behind its last layer, mvpnet_3d.py:40-41,59).  Against (a) the two-launch form -- mvp_bn_rows_backward_f32 (K, arg = NULL)
+    writing dy, then the same kernel in mode 0 --,
+    and (b) a float64 evaluation; the column sums come from mvp_bn_rows_backward_f32 with dy == NULL (sums only)."""
+    from mvpnet_amd import _lib as L
+    prec = (L.MLP_PRECISIONS['bf16x6'], L.MLP_PRECISIONS['bf16x3'])
+    hi = torch.float64
+    R = G * K
+    torch.manual_seed(G + K + C)
+    w = torch.randn(C, Cp, device=dev) * 0.2
+    x = torch.randn(R, Cp, device=dev)
+    g = torch.randn(G, C, device=dev)
+    yi = torch.randn(R, C, device=dev) * 1.5 + 0.2
+    mean_i, invstd_i, gamma_i = torch.randn(C, device=dev) * 0.3, torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5
+    beta_i = torch.randn(C, device=dev) * 0.2
+    pm, pi = torch.randn(Cp, device=dev) * 0.3, torch.rand(Cp, device=dev) + 0.5
+    pg, pb = torch.rand(Cp, device=dev) + 0.5, torch.randn(Cp, device=dev) * 0.2
+    partial = lambda: torch.empty(L.lib().mvp_colstats_partial_count(R, C), dtype=hi, device=dev)
+    # (a) two launches: column sums + dy, then mode 0
+    stat2 = torch.empty(2 * C, dtype=hi, device=dev)
+    dy2 = torch.empty(R, C, device=dev)
+    dgb2 = torch.empty(2, C, device=dev)
+    L.call('mvp_bn_rows_backward_f32', g, L.ptr(g), None, None, L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(beta_i), G, K, C, 1, 1,
+           L.ptr(stat2), L.ptr(dy2), L.ptr(dgb2[0]), L.ptr(dgb2[1]), L.ptr(partial()))
+    # sums only
+    stat1 = torch.empty(2 * C, dtype=hi, device=dev)
+    L.call('mvp_bn_rows_backward_f32', g, L.ptr(g), None, None, L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(beta_i), G, K, C, 1, 1,
+           L.ptr(stat1), None, None, None, L.ptr(partial()))
+    np.testing.assert_allclose(stat1.cpu().numpy(), stat2.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    res = []
+    for pooled in (False, True):
+        dw = torch.zeros(C, Cp, device=dev)
+        dz = torch.full((R, Cp), float('nan'), device=dev)
+        stat = torch.zeros(2 * Cp, dtype=hi, device=dev)
+        dgb = torch.full((2, C), float('nan'), device=dev)
+        tk = torch.zeros(1, dtype=torch.int32, device=dev)
+        if pooled:
+            L.call('mvp_mlp_layer_backward_wide_pooled_f32', g, L.ptr(g), L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(beta_i), L.ptr(stat1),
+                   L.ptr(dgb[0]), L.ptr(dgb[1]), 1, 2, K, 0.0, 0, L.ptr(x), Cp, L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(w), Cp, R, C, Cp, L.ptr(dw), Cp,
+                   L.ptr(dz), L.ptr(stat), L.ptr(tk), None, 0, prec=prec)
+            np.testing.assert_array_equal(dgb[0].cpu().numpy(), stat1[C:].float().cpu().numpy())
+            np.testing.assert_array_equal(dgb[1].cpu().numpy(), stat1[:C].float().cpu().numpy())
+        else:
+            L.call('mvp_mlp_layer_backward_wide_pooled_f32', dy2, L.ptr(dy2), None, None, None, None, None, None, None, None, 1, 0, 1, 0.0, 0, L.ptr(x), Cp,
+                   L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(w), Cp, R, C, Cp, L.ptr(dw), Cp, L.ptr(dz), L.ptr(stat), L.ptr(tk), None, 0, prec=prec)
+        res.append((dw, dz, stat))
+    (dw0, dz0, st0), (dw1, dz1, st1) = res
+    # dy formed on load against dy written by the pass in front (fp32 either way; the two may order the finish's operations differently)
+    np.testing.assert_allclose(dz1.cpu().numpy(), dz0.cpu().numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(dz0.abs().max())))
+    np.testing.assert_allclose(dw1.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(dw0.abs().max())))
+    np.testing.assert_allclose(st1.cpu().numpy(), st0.cpu().numpy(), rtol=1e-9, atol=1e-6 * R / 1000)
+    # (b) float64 (the ReLU decisions taken in float32 as the kernels take them)
+    f32 = lambda t: t.detach().cpu().numpy().astype(np.float32)
+    mask_i = torch.from_numpy((((f32(yi) - f32(mean_i)) * f32(invstd_i)) * f32(gamma_i) + f32(beta_i)) > 0).to(dev)
+    mask_prev = torch.from_numpy((((f32(x) - f32(pm)) * f32(pi)) * f32(pg) + f32(pb)) > 0).to(dev)
+    xh_i = (yi.to(hi) - mean_i.to(hi)) * invstd_i.to(hi)
+    dzi = torch.where(mask_i, g.to(hi).repeat_interleave(K, 0), torch.zeros(R, C, dtype=hi, device=dev))
+    dy = (gamma_i.to(hi) * invstd_i.to(hi)) * ((dzi - stat1[:C] / R) - xh_i * (stat1[C:] / R))
+    a = torch.relu(((x.to(hi) - pm.to(hi)) * pi.to(hi)) * pg.to(hi) + pb.to(hi))
+    ref_dw = dy.t() @ a
+    ref_dz = torch.where(mask_prev, dy @ w.to(hi), torch.zeros(R, Cp, dtype=hi, device=dev))
+    np.testing.assert_allclose(dw1.cpu().numpy(), ref_dw.cpu().numpy(), rtol=2e-3, atol=5e-4 * max(1.0, float(ref_dw.abs().max())))
+    np.testing.assert_allclose(dz1.cpu().numpy(), ref_dz.cpu().numpy(), rtol=2e-4, atol=4e-4 * max(1.0, float(ref_dz.abs().max())))
+    # refused: a pool in front of anything but mode 2, dropout behind a pool, rows that are not whole groups
+    bad = L.lib().mvp_mlp_layer_backward_wide_pooled_p_f32
+    base = lambda mode, k, p, rows: (L.ptr(g), L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(beta_i), L.ptr(stat1), None, None, 1, mode, k, p, 0,
+                                     L.ptr(x), Cp, None, None, None, None, L.ptr(w), Cp, rows, C, Cp, L.ptr(dw0), Cp, L.ptr(dz0), None, None, None, 0, 6, 3, None)
+    assert bad(*base(1, K, 0.0, R)) != 0 and bad(*base(2, K, 0.3, R)) != 0 and bad(*base(2, K, 0.0, R - 1)) != 0
+
+
 @pytest.mark.parametrize('R,C,Cout', [(3000, 64, 64), (70001, 64, 64), (66000, 16, 32), (4100, 128, 256)])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16x6'])
 def test_mlp_forward_with_relation_columns_in_the_epilogue(dev, R, C, Cout, prec):
