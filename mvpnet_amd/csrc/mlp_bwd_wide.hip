@@ -118,7 +118,8 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   const bool has_act = FULL || p.act.mean != nullptr;
   const bool cok = FULL || cc < C, xok = FULL || cc < Cp;
   const int ntiles = p.ntiles, step = (int)gridDim.x;
-  const int mode = MODE >= 0 ? MODE : p.mode;
+  const int mode = MODE >= 0 ? (MODE == 3 ? 2 : MODE) : p.mode;  // MODE 3: mode 2 behind a sum over p.gk rows (its own instance: the row
+                                                                  // index division in the loads costs the plain mode 2 40 % when it is a run-time test)
 
   // ---- global addressing: a scalar tile base + per-thread element offsets that do not depend on the tile (4 per tensor); only the LAST
   // tile of a row count that is not a multiple of 64 clamps its rows (its values are masked in P1 / P4)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     const float* Yt = (mode != 0 ? p.Yi : p.G) + (size_t)tile * kTR * C;
     const bool clamp = tile == ntiles - 1 && tail_rows < kTR;
     const int o = clamp ? min(rbase + RPP * j, tail_rows - 1) * C + (cok ? cc : 0) : offg[j];
-    if (mode == 2 && p.gk > 1) {  // the gradient of the pooled output: one row of G per gk rows of the layer
+    if (MODE == 3 || (MODE < 0 && mode == 2 && p.gk > 1)) {  // the gradient of the pooled output: one row of G per gk rows of the layer
       const unsigned gr = ((unsigned)tile * kTR + (unsigned)(clamp ? min(rbase + RPP * j, tail_rows - 1) : rbase + RPP * j)) / (unsigned)p.gk;
       t.g[j] = *reinterpret_cast<const f32x4*>(p.G + (size_t)gr * C + (cok ? cc : 0));
     } else {
@@ -565,6 +566,7 @@ MVP_API int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float
     if (!fast) MVP_WIDE_LAUNCH(NS_, -1, CH_);             \
     else if (mode == 0) MVP_WIDE_LAUNCH(NS_, 0, CH_);     \
     else if (mode == 1) MVP_WIDE_LAUNCH(NS_, 1, CH_);     \
+    else if (pool_k > 1) MVP_WIDE_LAUNCH(NS_, 3, CH_);    \
     else MVP_WIDE_LAUNCH(NS_, 2, CH_);                    \
   } while (0)
   if (ns == 1 && ch == 64) MVP_WIDE_MODES(1, 64);
