@@ -28,7 +28,7 @@ grep lift_ $out/dense_lift/p_kernel_stats.csv | cut -c1-200
 # round 5: the one-pass wide layer backward alone (time, fraction of the HBM peak, the three kernels it replaces), what a graph node costs per kernel kind
 python tools/exp/wide_time.py 2>&1 | grep -v amdgpu.ids > $out/wide_time.txt; cat $out/wide_time.txt
 python tools/exp/graphgap/node_cost.py 2>&1 | grep -v amdgpu.ids > $out/graph_node_cost.txt
-(cd tools/exp/graphgap && { [ -x graphgap ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o graphgap graphgap.hip; } && ./graphgap 150 4000 8 0 && ./graphgap 150 4000 8 64) > $out/graphgap.txt 2>&1
+(cd tools/exp/graphgap && { [ -x graphgap ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -w -o graphgap graphgap.hip 2>/dev/null; } && ./graphgap 150 4000 8 0 && ./graphgap 150 4000 8 64) > $out/graphgap.txt 2>&1
 # round 5 (second half): the sampler alone, level by level, bit-compared with the one-sample kernels -- the kernels of rounds 3-4 (MVP_FPS_STREAM=0)
 # and the resolver-wave kernel; the resolver's phases (a -DMVP_FPS_PHASES build of the library); the B = 4 step kernel by kernel
 (MVP_FPS_ROUNDS=0 python tools/exp/run_fps_rounds.py > /dev/null 2>&1; echo "== MVP_FPS_STREAM=0 (fps_rounds_kernel)"; MVP_FPS_STREAM=0 python tools/exp/run_fps_rounds.py 2>&1 | grep "us$\|equal"; \
