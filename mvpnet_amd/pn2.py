@@ -267,7 +267,7 @@ class FeaturePropagation(nn.Module):
         else:
             raise ValueError('Expected value 3, but {} given.'.format(num_neighbors))
 
-    def forward_rows(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=None, tail=None):
+    def forward_rows(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=None, tail=None, sparse_act=None, act_out=None):
         """rows in / rows out: (B,N,3), (B,M,3), (B,N,C1) or None, (B,M,C2) -> (B,N,C_out).
         tail = (single-layer SharedMLPDO, training): the module that is this level's ONLY consumer, run as the last layer of the same chain
         (PN2SSG: mlp_seg behind the last propagation level) -> (B,N,C_tail): the level's output activation is never materialised, its
@@ -302,7 +302,9 @@ class FeaturePropagation(nn.Module):
                 sink = None
                 if dense_feature is not None and torch.is_grad_enabled() and w0.requires_grad:
                     sink = R.WeightGradSink(w0, 2)  # one gradient buffer for the weight's two column groups
-                z = R.linear_rows(sparse_feature.reshape(B * M, c2), w0, cols=(0, c2), sink=sink).view(B, M, c1)
+                # sparse_act / act_out (rows.ActivationHandOver): sparse_feature is the output of the level before and read by nobody else; this
+                # level's own output goes to the level behind in the same way
+                z = R.linear_rows(sparse_feature.reshape(B * M, c2), w0, cols=(0, c2), sink=sink, act_src=sparse_act).view(B, M, c1)
                 zs = None
                 if dense_feature is not None:
                     zs = R.linear_rows(dense_feature.reshape(B * N, -1), w0, cols=(c2, ctot), sink=sink).view(B, N, c1)
@@ -317,7 +319,7 @@ class FeaturePropagation(nn.Module):
                 if tail is not None:
                     return R.shared_mlp_rows(y1.view(B * N, c1), chain, first_done=True, first_stat=stat1, dropout_p=tail[0].p, training=tail[1],
                                              dropout_last_only=True, defer=defer).view(B, N, -1)
-                return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1, defer=defer).view(B, N, -1)
+                return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1, defer=defer, act_out=act_out).view(B, N, -1)
             if tail is not None:
                 return None
             new_feature = self.interpolator.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry)
@@ -325,9 +327,10 @@ class FeaturePropagation(nn.Module):
             return None
         return R.shared_mlp_rows(new_feature.reshape(B * N, -1), self.mlp).view(B, N, -1)
 
-    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, rows=False, geometry=None, tail=None):
+    def forward(self, dense_xyz, sparse_xyz, dense_feature, sparse_feature, rows=False, geometry=None, tail=None, sparse_act=None, act_out=None):
         if rows:
-            return self.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry, tail=tail)
+            return self.forward_rows(dense_xyz, sparse_xyz, dense_feature, sparse_feature, geometry=geometry, tail=tail, sparse_act=sparse_act,
+                                     act_out=act_out)
         t = lambda x: None if x is None else x.transpose(1, 2).contiguous()
         return self.forward_rows(t(dense_xyz), t(sparse_xyz), t(dense_feature), t(sparse_feature)).transpose(1, 2).contiguous()
 
@@ -616,16 +619,24 @@ class PN2SSG(nn.Module):
             feats.append(feature)
         up = feats[-1]
         x = None
+        hand = None  # rows.ActivationHandOver of the level before: its output `up` is read by this level's first linear layer and nobody else
+        watched = [_has_hooks(fp) for fp in self.fp_modules]
         for level, fp in enumerate(self.fp_modules):
             geo = None if plan is None else plan['fp'][level]
             if MERGE_HEAD and level + 1 == len(self.fp_modules) and up.is_cuda and not _has_hooks(fp) and not _has_hooks(self.mlp_seg):
                 # the segmentation head's MLP is the last propagation level's only consumer: one chain (no activation tensor in between, no
                 # column-statistics pass of its own in backward)
-                x = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True, geometry=geo, tail=(self.mlp_seg, self.training))
+                x = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True, geometry=geo, tail=(self.mlp_seg, self.training),
+                       sparse_act=hand)
                 if x is not None:
                     x = x.reshape(B * N, -1)
                     break
-            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True, geometry=geo)
+            nxt = None
+            if (level + 1 < len(self.fp_modules) and up.is_cuda and torch.is_grad_enabled() and not watched[level] and not watched[level + 1]
+                    and self.fp_modules[level + 1].interpolator is not None):
+                nxt = R.ActivationHandOver()
+            up = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True, geometry=geo, sparse_act=hand, act_out=nxt)
+            hand = nxt
         if x is None:
             x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
         logit = R.linear_rows(x, self.seg_logit.weight, self.seg_logit.bias)  # (B*N, classes)

@@ -635,6 +635,24 @@ class DeferredFinish:
         self.accepts = False  # set by the interpolation node's forward when its backward can take the hand-over (gather path, no skip term)
 
 
+class ActivationHandOver:
+    """Hand-over between two autograd nodes, the other way round from DeferredFinish: a shared-MLP chain (K = 1, no dropout) whose OUTPUT
+    a = relu(bn(y_L)) has exactly one consumer, a LinearRows node (the next propagation level's linear-first factorisation applies its first
+    layer to this level's output: pn2.FeaturePropagation).  The chain's backward starts with the gradient of that activation and needs,
+    before anything else, dz_L = g * [a > 0] and its two BatchNorm-backward column sums -- a pass over (g, y_L) and a reduction launch.
+    The input-gradient kernel of the consumer can do both in its epilogue (mvp_mlp_input_grad_f32 with y_prev: the form the chain uses
+    BETWEEN its own layers): the chain leaves (y_L, mean, invstd, gamma, beta) here in forward, the consumer's backward takes them, returns
+    dz_L instead of g and leaves the sums here; the chain's backward finds them and skips its own pass.  Only for outputs nobody else
+    reads (the caller guarantees it: PN2SSG wires the propagation levels, and not when anybody hooks the modules).
+    MVP_ACT_HANDOVER=0: the chain's own pass (A/B switch)."""
+    ENABLED = os.environ.get('MVP_ACT_HANDOVER', '1') != '0'
+    __slots__ = ('info', 'stat')
+
+    def __init__(self):
+        self.info = None   # set by the chain's forward: (y_L, mean, invstd, gamma, beta)
+        self.stat = None   # set by the consumer's backward: the two column sums of the dz_L it returned
+
+
 class InterpAddRows(torch.autograd.Function):
     """out = interp(feature; index, weight) (+ add); want_stat: also the float64 column sums [sum out | sum out^2]."""
 
@@ -966,6 +984,11 @@ class MLPChainRows(torch.autograd.Function):
                    None, L.ptr(means[-1]), L.ptr(invstds[-1]), L.ptr(out), None, float(drop_p), int(drop_seed))
         elif not pooled:
             out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, pool_sum)
+        ao = opts.get('act_out')
+        ctx.act_out = None
+        if ao is not None and ActivationHandOver.ENABLED and not pooled and K == 1 and drop_p == 0 and training is not None:
+            ao.info, ao.stat = (ys[-1], means[-1], invstds[-1], params[-2], params[-1]), None
+            ctx.act_out = ao
         ctx.first_linear = params[0] is not None
         ctx.pooled = pooled
         ctx.save_for_backward(x0, out, arg, *ys, *means, *invstds, *[p for p in params if p is not None])
@@ -991,13 +1014,19 @@ class MLPChainRows(torch.autograd.Function):
         cl = ys[-1].size(1)
         pool = None
         wl = params[3 * (nl - 1)]
-        last_wide = bool(not ctx.pooled and K == 1 and nl >= 2 and wl is not None and g.is_cuda and
+        # the consumer of this chain's output already applied the ReLU mask and summed the columns (ActivationHandOver): g IS dz_L
+        handed = None
+        if ctx.act_out is not None and ctx.act_out.stat is not None:
+            handed, ctx.act_out.stat = ctx.act_out.stat, None
+        last_wide = bool(handed is None and not ctx.pooled and K == 1 and nl >= 2 and wl is not None and g.is_cuda and
                          wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32)
         # ... and the last layer in front of a SUM over K (FeatureAggregation, arg is None): the same one-pass backward takes the gradient of the
         # POOLED output and reads row r / K of it (mvp_mlp_layer_backward_wide_pooled_p_f32): no (R, C) gradient tensor, no pass that writes it
         last_wide_sum = bool(WIDE_BWD_POOLED and not ctx.pooled and K > 1 and arg is None and ctx.dropout[0] == 0 and nl >= 2 and wl is not None and
                              g.is_cuda and wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32)
-        if ctx.pooled:
+        if handed is not None:
+            dy, dgam, dbet = None, None, None
+        elif ctx.pooled:
             # the last layer's (R, cl) output does not exist: its BatchNorm-backward column sums come from the (G, cl) tensors, dy_L is
             # formed inside the one-kernel layer backward from the re-computed y_L
             ysel = ys[-1]
@@ -1042,7 +1071,9 @@ class MLPChainRows(torch.autograd.Function):
         # layer i's ACTIVATION already masked by its ReLU, with `pending` = its two BatchNorm-backward column sums: the "finish"
         # step (dz_i -> dy_i) then happens INSIDE the fused layer kernel, or as its own pass when the layer cannot be fused.
         gcur, pending = dy, None
-        if pool is not None:
+        if handed is not None:
+            gcur, pending = g, handed
+        elif pool is not None:
             gcur, pending = None, stat_l
         elif last_wide or last_wide_sum:
             gcur, pending = g, stat_d
@@ -1183,8 +1214,12 @@ class LinearRows(torch.autograd.Function):
     """y = x . W^T (+ bias) on rows with the fp32-MFMA kernels (forward, input gradient, weight gradient)."""
 
     @staticmethod
-    def forward(ctx, x, w_full, bias, c0=0, c1=None, sink=None):
+    def forward(ctx, x, w_full, bias, c0=0, c1=None, sink=None, act_src=None):
         ctx.sink = sink
+        # x is the output of a chain that left its last layer here (ActivationHandOver): the input gradient applies that layer's ReLU mask
+        # and sums the columns in its epilogue
+        info = None if act_src is None else act_src.info
+        ctx.act_src = act_src if (info is not None and ActivationHandOver.ENABLED and x.is_cuda and tuple(info[0].shape) == tuple(x.shape)) else None
         prec = ctx.prec = L.current_precision()
         # w_full (C_out, C_tot[,1[,1]]); columns [c0, c1) multiply x (R, >= c1 - c0 columns; extra columns are zero padding).
         # The slice is copied here (one small kernel) and its gradient is written straight into a full-size zeroed gradient
@@ -1224,7 +1259,15 @@ class LinearRows(torch.autograd.Function):
         aside = False
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None, prec=ctx.prec)
+            src = ctx.act_src
+            if src is not None and src.info is not None:
+                yp, pm, pi, pg, pb = src.info
+                stat = zero_pool.zeros(2 * cin, torch.float64, gy.device)
+                L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, L.ptr(yp), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(gx),
+                       L.ptr(stat), L.ptr(_partial(R, cin, gy.device)), prec=ctx.prec)
+                src.stat = stat
+            else:
+                L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None, prec=ctx.prec)
         if ctx.needs_input_grad[1]:
             c0, ncol, shape = ctx.slice
             sink = ctx.sink
@@ -1259,14 +1302,15 @@ class LinearRows(torch.autograd.Function):
                     torch.sum(gy, 0, out=gb)
             else:
                 gb = gy.sum(0)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def linear_rows(x, weight, bias=None, cols=None, sink=None):
+def linear_rows(x, weight, bias=None, cols=None, sink=None, act_src=None):
     """x (R, C_in) float32, weight (C_out, C_in[,1[,1]]), bias (C_out) or None -> (R, C_out).
-    cols=(c0, c1): use only those columns of `weight` (x then has c1 - c0 columns, plus optional zero padding)."""
+    cols=(c0, c1): use only those columns of `weight` (x then has c1 - c0 columns, plus optional zero padding).
+    act_src: an ActivationHandOver filled by the chain whose output x is (and whose ONLY consumer this call is)."""
     c0, c1 = (0, None) if cols is None else cols
-    return LinearRows.apply(x.contiguous(), weight, bias, c0, c1, sink)
+    return LinearRows.apply(x.contiguous(), weight, bias, c0, c1, sink, act_src)
 
 
 def linear_rows_bf16(x, weight, bias=None, scale=None, shift=None, relu=False):
@@ -1495,7 +1539,7 @@ def relation4_rows(src_xyz, tgt_xyz):
 
 
 def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False, first_stat=None, reduce='max', rel=None, dropout_last_only=False,
-                    defer=None):
+                    defer=None, act_out=None):
     """Apply a SharedMLP (stack of pointwise conv + BN + ReLU, common/nn/modules/mlp.py:38-75) to a row
     matrix x (R, ld >= C_in; extra columns are zero padding).  The last layer also takes the max over each
     K consecutive rows when K > 1 (SetAbstraction, pn2/modules.py:107-108), or their sum with reduce='sum'
@@ -1525,6 +1569,8 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             opts['rel'] = (rel.contiguous(), ps[0].w)
         if defer is not None and first_done and bn_training:
             opts['defer'] = defer   # (rows.DeferredFinish: the finish of the first layer's gradient may be left to the node in front)
+        if act_out is not None and K == 1 and dropout_p == 0 and torch.is_grad_enabled():
+            opts['act_out'] = act_out   # (rows.ActivationHandOver: the output's only consumer masks and sums its gradient)
         if DW_SIDE_STREAM and torch.is_grad_enabled():  # (a first layer that ran before the grouping has its own use: WeightGradSink)
             opts['use'] = WeightUse([q.w for li, q in enumerate(ps) if not (first_done and li == 0)])
         # dropout behind the (single) layer: folded into the BatchNorm + ReLU passes (mvp_bn_rows_forward_dropout_f32) unless a graph is

@@ -318,6 +318,55 @@ def test_graphed_train_step_matches_eager(dev, geometry):
     np.testing.assert_allclose(graphed[2], eager[2], rtol=2e-2)
 
 
+def test_activation_hand_over_between_the_propagation_levels(dev):
+    """rows.ActivationHandOver: the next propagation level's first linear layer is the ONLY consumer of a level's output, so its input-gradient
+    kernel applies that output's ReLU mask and sums the two BatchNorm-backward columns in its epilogue, and the level's backward skips its own
+    pass (mvp_bn_rows_backward_f32: column statistics + reduction).  Same loss, same gradients as with the hand-over switched off (up to the order the sums
+    are added in), three hand-overs in the reference network (levels 1 -> 2 -> 3 -> 4), and the statistics passes of those three
+    levels really are gone."""
+    from mvpnet_amd import rows as R
+    from mvpnet_amd import _lib as L
+    from mvpnet_amd.pn2 import PN2SSG
+    torch.manual_seed(21)
+    net = PN2SSG(16, 20, dropout_prob=0.0, **CFG).to(dev).train()
+    pts = torch.rand(3, 3, 1024, device=dev)
+    feat = torch.randn(3, 16, 1024, device=dev)
+    label = torch.randint(0, 20, (3, 1024), device=dev)
+
+    def run(flag):
+        R.ActivationHandOver.ENABLED = flag
+        net.zero_grad(set_to_none=True)
+        calls = collections.Counter()
+        orig = L.call
+
+        def spy(name, t, *a, **kw):
+            if name == 'mvp_mlp_input_grad_f32' and a[5] is not None:   # y_prev given: mask + sums in the epilogue
+                calls['epilogue'] += 1
+            calls[name] += 1
+            return orig(name, t, *a, **kw)
+        L.call = spy
+        try:
+            logit = net({'points': pts, 'feature': feat})['seg_logit']
+            loss = torch.nn.functional.cross_entropy(logit, label)
+            loss.backward()
+        finally:
+            L.call = orig
+            R.ActivationHandOver.ENABLED = True
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in net.named_parameters()}, calls
+
+    l0, g0, c0 = run(False)
+    l1, g1, c1 = run(True)
+    assert l0 == l1
+    assert c0['mvp_bn_rows_backward_f32'] - c1['mvp_bn_rows_backward_f32'] == 3, (c0['mvp_bn_rows_backward_f32'], c1['mvp_bn_rows_backward_f32'])
+    assert c1['epilogue'] - c0['epilogue'] == 3
+    # (the column sums are added in another order: 1e-7 differences that batch-statistics BatchNorm and the max-pool's arg-max amplify at B = 3,
+    # eager against eager as well -- a wrong mask or wrong sums would be errors of order 1)
+    for k in g0:
+        a, b = g1[k].double().cpu().numpy(), g0[k].double().cpu().numpy()
+        assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(b), 1e-12), (k, np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
+
+
 def test_weight_gradients_on_the_side_stream(dev):
     """rows.SideStream: the wide layers' weight gradients run on a second stream and are joined when backward() ends.  Same
     gradients as on one stream (up to the fp32-atomics noise), also when .grad already exists (accumulation: autograd then ADDS on the
