@@ -1264,7 +1264,7 @@ class LinearRows(torch.autograd.Function):
                 yp, pm, pi, pg, pb = src.info
                 stat = zero_pool.zeros(2 * cin, torch.float64, gy.device)
                 L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, L.ptr(yp), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(gx),
-                       L.ptr(stat), L.ptr(_partial(R, cin, gy.device)), prec=ctx.prec)
+                       L.ptr(stat), L.ptr(_partial(R, cin, gy.device) if R > 65536 else None), prec=ctx.prec)  # (<= 512 tiles: fp64 atomics, no reduction launch)
                 src.stat = stat
             else:
                 L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None, prec=ctx.prec)
