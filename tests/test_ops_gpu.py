@@ -1537,6 +1537,40 @@ def test_fps_exact_on_structured_clouds(dev, kind, N, M):
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
 
+@pytest.mark.parametrize('kind', ['far_clusters', 'offset', 'line', 'two_scales', 'sorted_by_x', 'shell', 'flat_axis'])
+@pytest.mark.parametrize('N,M', [(8192, 2048), (4100, 1500)])
+def test_fps_on_clouds_that_stress_the_cells(dev, kind, N, M):
+    """fps_stream_kernel (4097 - 8192 points) splits the cloud into eight k-d cells and lets a wave skip every pick its bounding box proves
+    harmless; the skip must never change a sample.  Clouds chosen against that machinery: clusters 100 units apart (almost every pick is
+    skipped by seven waves), a cloud 10^4 away from the origin (the bound is formed with few significant bits left), a line (two of the
+    three sorts see one key), two scales in one cloud (a 10^-3 cube inside a unit cube: the quantised keys of the small one collapse),
+    input already sorted by x, a spherical shell (boxes overlap heavily), one flat axis.  Indices against the oracle."""
+    from mvpnet_amd.ops import farthest_point_sample
+    rs = np.random.RandomState(N + 3 * M + len(kind))
+    if kind == 'far_clusters':
+        c = (rs.randint(0, 2, (2, 8, 3)) * 100.0) + rs.rand(2, 8, 3)
+        pts = np.stack([c[b][rs.randint(0, 8, N)] for b in range(2)]) + 0.05 * rs.rand(2, N, 3)
+    elif kind == 'offset':
+        pts = rs.rand(2, N, 3) + 1.0e4
+    elif kind == 'line':
+        t = rs.rand(2, N, 1)
+        pts = t * np.array([1.0, 0.5, -0.25]) + 1e-4 * rs.randn(2, N, 3)
+    elif kind == 'two_scales':
+        pts = rs.rand(2, N, 3)
+        pts[:, :N // 2] = 0.3 + 1e-3 * rs.rand(2, N // 2, 3)
+    elif kind == 'sorted_by_x':
+        pts = rs.rand(2, N, 3)
+        pts = np.take_along_axis(pts, np.argsort(pts[..., :1], axis=1).repeat(3, 2), 1)
+    elif kind == 'shell':
+        v = rs.randn(2, N, 3)
+        pts = v / np.linalg.norm(v, axis=2, keepdims=True) * (1.0 + 1e-3 * rs.rand(2, N, 1))
+    else:
+        pts = rs.rand(2, N, 3) * np.array([1.0, 2.0, 0.0]) + np.array([0.0, 0.0, 0.25])
+    pts = pts.astype(np.float32)
+    idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
+    np.testing.assert_array_equal(idx, O().fps(pts, M))
+
+
 @pytest.mark.parametrize('bn_train', [True, False])
 def test_dropout_inside_the_batchnorm_passes(dev, bn_train):
     """SharedMLPDO head (Conv + BN + ReLU + Dropout, mlp.py:86-92) with the dropout folded into the BatchNorm kernels
