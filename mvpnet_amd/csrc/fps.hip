@@ -1847,6 +1847,15 @@ int dispatch(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, int sh
     if (rounds && multi && M > 1 && N <= 65536) {
       int rc = MVP_EUNSUPPORTED;
       static const int force16 = []() { const char* e = getenv("MVP_FPS_MULTI_PPT16"); return e ? atoi(e) : 0; }();  // (tools/exp)
+      // Workgroups per cloud.  With the greedy resolver a round is worth ~15 picks, so the exchange (W x 64 row results read by every
+      // workgroup) weighs less than it did and the update -- 0.25 us per pick and workgroup at 8192 points each -- more: EIGHT workgroups for
+      // clouds beyond 16 384 points (32 768 -> 8192: 5.54 -> 4.58 ms, 65 536 -> 2048: 2.46 -> 1.89; sixteen: 8.7 ms; below 16 384 points
+      // four and eight are equal), while all of a launch's workgroups stay resident (B x W <= 64).  MVP_FPS_MULTI_W=4: four everywhere.
+      static const int multi_w = []() { const char* e = getenv("MVP_FPS_MULTI_W"); return e ? atoi(e) : 8; }();
+      if (multi_w == 8 && B * 8 <= 64 && N > 16384) {
+        if (N <= 32768) rc = launch_rounds_multi<D, 4, 8>(pts, B, N, M, out, status, s);
+        else rc = launch_rounds_multi<D, 8, 8>(pts, B, N, M, out, status, s);
+      } else
       if (N <= 16384 && !force16) rc = launch_rounds_multi<D, 4, 4>(pts, B, N, M, out, status, s);
       else if (N <= 32768 && !force16) rc = launch_rounds_multi<D, 8, 4>(pts, B, N, M, out, status, s);
       else rc = launch_rounds_multi<D, 16, 4>(pts, B, N, M, out, status, s);
