@@ -648,6 +648,12 @@ int mvp_sa_geom_sums_f32(const int32_t* offsets, const int32_t* slots, const flo
 int mvp_sa_train_stats1_f32(const float* zf, const float* dsum, const float* wxyz, const double* gsum, int64_t B, int64_t N, int64_t M, int64_t K,
                             int64_t C1, double* stat, double* zsum, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                             float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream);
+/* The same with a scratch of `scratch_doubles` float64, ZERO on entry: up to 16 replicas of the 5 C1 sums that the workgroups add into (an fp64
+ * atomic on one address costs ~0.16 us and every workgroup ends with one per address: 58 -> ~25 us at 262 144 points); the last workgroup adds the
+ * replicas up into stat / zsum.  scratch == NULL or fewer than 10 C1 doubles: exactly mvp_sa_train_stats1_f32. */
+int mvp_sa_train_stats1_ws_f32(const float* zf, const float* dsum, const float* wxyz, const double* gsum, int64_t B, int64_t N, int64_t M, int64_t K,
+                               int64_t C1, double* stat, double* zsum, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, double* scratch, int64_t scratch_doubles, mvp_stream_t stream);
 
 /* ---- the shared-MLP entry points with the contraction precision as ARGUMENTS (csrc/mlp_prec.hip) -----------------------------------
  * mvp_<name>_p_f32 = mvp_<name>_f32 with two more parameters in front of the stream:

@@ -119,6 +119,7 @@ _SIGNATURES = {
     'mvp_pn2_plan_f32': [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, ctypes.c_int, _f32, _ptr, _i64, _ptr, _ptr, _ptr],
     'mvp_sa_geom_sums_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     'mvp_sa_train_stats1_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_sa_train_stats1_ws_f32': [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
     'mvp_mlp_forward_bn_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr,
                                _ptr, _ptr, _ptr],
     'mvp_mlp_forward_rel_bn_f32': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],

@@ -831,6 +831,9 @@ struct SaStats1Args {
   const double* gsum;     // S1[3], S2[6]
   double* stat;           // 2 C1 + 1, zero on entry: sums of y_1, of y_1^2, ticket
   double* zsum;           // (C1, 3), zero on entry: Z
+  double* rep;            // (nrep, 5 C1) zero on entry, or nullptr: replicas of (stat[0 : 2 C1], zsum) that the workgroups add into -- an fp64 atomic
+  int nrep;               //   on ONE address costs ~0.16 us and every workgroup ends with one per address (measured: 256 workgroups 58 us, 128: 41,
+                          //   512: 100); the last workgroup sums the replicas
   BnFinalize fin;
   int64_t total;          // B * N
   int C1;
@@ -896,12 +899,14 @@ __global__ __launch_bounds__(256) void sa_train_stats1_kernel(SaStats1Args p) {
         tot[4 + i] += a * a * S[3] + b * b * S[6] + cc * cc * S[8] + 2.0 * (a * b * S[4] + a * cc * S[5] + b * cc * S[7]);
       }
     }
+    double* s1 = p.rep ? p.rep + (size_t)(blockIdx.x % p.nrep) * 5 * C1 : p.stat;
+    double* zz = p.rep ? s1 + 2 * C1 : p.zsum;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      atomicAdd(p.stat + c + i, tot[i]);
-      atomicAdd(p.stat + C1 + c + i, tot[4 + i]);
+      atomicAdd(s1 + c + i, tot[i]);
+      atomicAdd(s1 + C1 + c + i, tot[4 + i]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) atomicAdd(p.zsum + (c + i) * 3 + k, tot[8 + 3 * i + k]);
+      for (int k = 0; k < 3; ++k) atomicAdd(zz + (c + i) * 3 + k, tot[8 + 3 * i + k]);
     }
   }
   // the last workgroup finalizes the BatchNorm (as stats_tail)
@@ -913,6 +918,15 @@ __global__ __launch_bounds__(256) void sa_train_stats1_kernel(SaStats1Args p) {
   __syncthreads();
   if (!last) return;
   const BnFinalize& fin = p.fin;
+  if (p.rep) {  // the replicas' sums become stat / zsum (plain stores: the kernels behind this one read them)
+    for (int e = threadIdx.x; e < 5 * C1; e += 256) {
+      double t = 0.0;
+      for (int r = 0; r < p.nrep; ++r) t += __hip_atomic_load(p.rep + (size_t)r * 5 * C1 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e < 2 * C1) __hip_atomic_store(p.stat + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else p.zsum[e - 2 * C1] = t;
+    }
+    __syncthreads();
+  }
   for (int col = threadIdx.x; col < C1; col += 256) {
     const double s1 = __hip_atomic_load(p.stat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double s2 = __hip_atomic_load(p.stat + C1 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1263,9 +1277,10 @@ MVP_API int mvp_sa_geom_sums_f32(const int32_t* offsets, const int32_t* slots, c
 // Forward pass 1 of the level per POINT: batch statistics of y_1 over the B*M*K rows from zf (B,N,C1), dsum / gsum of mvp_sa_geom_sums_f32 and
 // the coordinate columns, + the BatchNorm-1 finalize (as mvp_group_lin_rows_bn_f32 with out == NULL, from 1/8 of the bytes), + zsum (C1,3)
 // float64 (ZERO on entry) = sum_j zf_j (x) D_j for the backward.  stat: 2*C1 + 1 float64, ZERO on entry.
-MVP_API int mvp_sa_train_stats1_f32(const float* zf, const float* dsum, const float* wxyz, const double* gsum, int64_t B, int64_t N, int64_t M,
-                                    int64_t K, int64_t C1, double* stat, double* zsum, float eps, float momentum, float* mean, float* invstd,
-                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream) {
+MVP_API int mvp_sa_train_stats1_ws_f32(const float* zf, const float* dsum, const float* wxyz, const double* gsum, int64_t B, int64_t N, int64_t M,
+                                       int64_t K, int64_t C1, double* stat, double* zsum, float eps, float momentum, float* mean, float* invstd,
+                                       float* running_mean, float* running_var, int64_t* num_batches_tracked, double* scratch,
+                                       int64_t scratch_doubles, mvp_stream_t stream) {
   MVP_NONNULL(zf);
   MVP_NONNULL(dsum);
   MVP_NONNULL(wxyz);
@@ -1277,13 +1292,23 @@ MVP_API int mvp_sa_train_stats1_f32(const float* zf, const float* dsum, const fl
   MVP_REQUIRE(B >= 0 && N > 0 && M >= 0 && K > 0 && C1 > 0);
   if (C1 % 4 != 0 || C1 > 1024 || 256 % (C1 / 4) != 0 || ((uintptr_t)zf % 16) != 0 || ((uintptr_t)dsum % 16) != 0) return MVP_EUNSUPPORTED;
   if (B == 0 || M == 0) return MVP_OK;
-  SaStats1Args a{zf, reinterpret_cast<const float4*>(dsum), wxyz, gsum, stat, zsum,
+  MVP_REQUIRE(scratch_doubles >= 0 && (scratch != nullptr || scratch_doubles == 0));
+  const int nrep = scratch ? (int)std::min<int64_t>(16, scratch_doubles / (5 * C1)) : 0;
+  SaStats1Args a{zf, reinterpret_cast<const float4*>(dsum), wxyz, gsum, stat, zsum, nrep >= 2 ? scratch : nullptr, nrep,
                  BnFinalize{B * M * K, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked}, B * N, (int)C1};
   const int64_t ppw = 256 / (C1 / 4);
   // few workgroups: every one ends with 5 C1 / 4 float64 atomics per lane quad on the same 5 C1 addresses (1024 of them queued for ~100 us)
-  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, cdiv(B * N, ppw * 8)));
+  static const int wgs = []() { const char* e = getenv("MVP_SA_STATS1_WGS"); return e ? atoi(e) : 256; }();  // (A/B: workgroups = atomics per address)
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(wgs, cdiv(B * N, ppw * 8)));
   hipLaunchKernelGGL(sa_train_stats1_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return mvp_launch_status();
+}
+
+MVP_API int mvp_sa_train_stats1_f32(const float* zf, const float* dsum, const float* wxyz, const double* gsum, int64_t B, int64_t N, int64_t M,
+                                    int64_t K, int64_t C1, double* stat, double* zsum, float eps, float momentum, float* mean, float* invstd,
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, mvp_stream_t stream) {
+  return mvp_sa_train_stats1_ws_f32(zf, dsum, wxyz, gsum, B, N, M, K, C1, stat, zsum, eps, momentum, mean, invstd, running_mean, running_var,
+                                    num_batches_tracked, nullptr, 0, stream);
 }
 
 // Backward pass 1 of the level per POINT (see sa_geom_sums_kernel): gz (B,N,C1) = gradient of zf from a plain gather of dz_1 (B,M*32,C1)

@@ -1340,6 +1340,10 @@ def linear_rows_bf16(x, weight, bias=None, scale=None, shift=None, relu=False):
 SA_TRAIN_FUSED = os.environ.get('MVP_SA_TRAIN', '1') != '0'
 
 
+# replicas of the per-point statistics pass' fp64 sums (the workgroups' closing atomics queue per address); MVP_SA_STATS1_REPLICAS=0: none (A/B)
+STATS1_REPLICAS = int(os.environ.get('MVP_SA_STATS1_REPLICAS', '16'))
+
+
 def sa_level_train_widths_ok(c1, c2, c3):
     """Widths csrc/sa_train.hip instantiates: C1, C2 <= 64 with C3 <= 64, or the (33..64, 33..64, 65..128) shape of the reference network's level 2."""
     return c1 >= 4 and max(c1, c2) <= 64 and (c3 <= 64 or (c3 <= 128 and min(c1, c2) > 32))
@@ -1377,9 +1381,11 @@ class SALevelTrain(torch.autograd.Function):
         ctot = w1_full.numel() // w1_full.size(0)
         ctx.w_shape = tuple(w1_full.shape)
         wxyz = weight_slices.get(w1_full, ctot - 3, ctot, 3)
-        arena = zero_pool.zeros(2 * (C1 + C2 + C3) + 3 + 3 * C1, torch.float64, dev)
+        nrep = STATS1_REPLICAS
+        arena = zero_pool.zeros(2 * (C1 + C2 + C3) + 3 + 3 * C1 + nrep * 5 * C1, torch.float64, dev)
         stat1, stat2, stat3 = arena[:2 * C1 + 1], arena[2 * C1 + 1:2 * (C1 + C2) + 2], arena[2 * (C1 + C2) + 2:2 * (C1 + C2 + C3) + 3]
-        zsum = arena[2 * (C1 + C2 + C3) + 3:]
+        zsum = arena[2 * (C1 + C2 + C3) + 3:2 * (C1 + C2 + C3) + 3 + 3 * C1]
+        rep1 = arena[2 * (C1 + C2 + C3) + 3 + 3 * C1:]   # replicas of the first pass' sums (mvp_sa_train_stats1_ws_f32)
         mi = torch.empty(2 * (C1 + C2 + C3), dtype=torch.float32, device=dev)
         m1, i1 = mi[:C1], mi[C1:2 * C1]
         m2, i2 = mi[2 * C1:2 * C1 + C2], mi[2 * C1 + C2:2 * (C1 + C2)]
@@ -1390,8 +1396,8 @@ class SALevelTrain(torch.autograd.Function):
         if dsum is None:  # (not supplied by the geometry plan)
             dsum, gsum = geom_sums(offsets, slots, xyz, centre, K)
         # pass 1: statistics of y_1 (+ BatchNorm-1 finalize) per POINT: y_1 is affine in per-point data (csrc/sa_train.hip)
-        L.call('mvp_sa_train_stats1_f32', zf, L.ptr(zf), L.ptr(dsum), L.ptr(wxyz), L.ptr(gsum), B, N, M, K, C1, L.ptr(stat1), L.ptr(zsum), float(e1),
-               float(mo1), L.ptr(m1), L.ptr(i1), L.ptr(rm1), L.ptr(rv1), L.ptr(nb1))
+        L.call('mvp_sa_train_stats1_ws_f32', zf, L.ptr(zf), L.ptr(dsum), L.ptr(wxyz), L.ptr(gsum), B, N, M, K, C1, L.ptr(stat1), L.ptr(zsum), float(e1),
+               float(mo1), L.ptr(m1), L.ptr(i1), L.ptr(rm1), L.ptr(rv1), L.ptr(nb1), L.ptr(rep1) if nrep else None, rep1.numel())
         level = (L.ptr(zf), L.ptr(xyz), L.ptr(centre), L.ptr(index), L.ptr(wxyz), B, N, M, K, C1, L.ptr(m1), L.ptr(i1), L.ptr(g1), L.ptr(b1), L.ptr(W2), C2)
         # pass 2: statistics of y_2
         L.call('mvp_sa_train_forward_f32', xyz, 2, *level, None, None, None, None, None, 0, L.ptr(stat2), float(e2), float(mo2), L.ptr(m2), L.ptr(i2),

@@ -1967,7 +1967,7 @@ def test_set_abstraction_against_float64_reference(dev, cin, widths, N, M, train
     # (csrc/sa_train.hip) resp. the fused inference level (csrc/sa_fused.hip); the featureless and the 128-wide level the per-layer kernels
     fusable = cin == 64
     assert ep.ran('mvp_sa_train_forward_f32') == (training and fusable) and ep.ran('mvp_sa_train_backward_f32') == (training and fusable), ep.names
-    assert ep.ran('mvp_sa_train_backward1_f32') == (training and fusable) and ep.ran('mvp_sa_train_stats1_f32') == (training and fusable), ep.names
+    assert ep.ran('mvp_sa_train_backward1_f32') == (training and fusable) and ep.ran('mvp_sa_train_stats1_ws_f32') == (training and fusable), ep.names
     assert ep.ran('mvp_sa_fused_forward_f32') == ((not training) and widths[2] <= 128), ep.names
     ref, f64, ws = _sa_reference_f64(sa, xyz, feat, new_xyz, ball, training)
     scale = float(ref.abs().max())
