@@ -454,7 +454,11 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < RPP; ++k) s += sred[(which * RPP + k) * CH + col];
+#if defined(MVP_WIDE_EXP) && (MVP_WIDE_EXP == 5 || MVP_WIDE_EXP == 7)   /* (timing experiment, wrong results: plain stores instead of the closing atomics) */
+      if (col < Cp) p.stat_prev[which * Cp + col] = s;
+#else
       if (col < Cp) atomicAdd(p.stat_prev + which * Cp + col, s);
+#endif
     }
   }
   // ---- dW: one flush per workgroup
@@ -473,7 +477,11 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int co = 32 * a + 8 * (i >> 2) + 4 * h + (i & 3);
+#if defined(MVP_WIDE_EXP) && (MVP_WIDE_EXP == 6 || MVP_WIDE_EXP == 7)
+          if (co < C && ci < Cp) p.dW[(size_t)co * p.lddw + ci] = accw[bb][i];
+#else
           if (co < C && ci < Cp) atomicAdd(p.dW + (size_t)co * p.lddw + ci, accw[bb][i]);
+#endif
         }
       }
     }
