@@ -277,7 +277,8 @@ weight_slices = WeightSlices()
 # engine, so .grad is complete on the caller's stream when backward() returns.  Fork and join are plain stream waits: they are captured
 # with the step under a hipGraph.  Measured: DESIGN.md section 5.
 DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
-LINEAR_ASIDE = os.environ.get('MVP_LINEAR_ASIDE', '1') != '0'  # (A/B switch: whole-weight linear layers' weight / bias gradients beside the chain)
+LINEAR_ASIDE = os.environ.get('MVP_LINEAR_ASIDE', '1') != '0'
+REL_DW_SPLIT = os.environ.get('MVP_REL_DW_SPLIT', '1') != '0'  # (the relation columns' weight gradient on the calling stream at the end of the backward pass)  # (A/B switch: whole-weight linear layers' weight / bias gradients beside the chain)
 _EXP_SKIP_DW = os.environ.get('MVP_EXP_SKIP_DW', '0') == '1'
 
 
@@ -1126,7 +1127,10 @@ class MLPChainRows(torch.autograd.Function):
                 cin_f = src.size(1)
                 for xs, ncol, c0 in ((src, cin_f, 0), (rel, 4, cin_f)):
                     wg_args = (L.ptr(gcur), L.ptr(xs), R, cout, ncol, ncol, None, None, None, None, L.ptr_at(dw, c0), cin)
-                    if dw_aside:
+                    # this is the END of the backward pass when x0 needs no gradient (FeatureAggregation on a frozen 2D branch): nothing is left
+                    # for the calling stream to do, so only the feature columns go beside it and the four relation columns run ON it -- the
+                    # two launches (each streams dy_1 once) overlap instead of queueing on the one side stream (REL_DW_SPLIT: A/B switch)
+                    if dw_aside and not (REL_DW_SPLIT and xs is rel and not need_dz):
                         side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, xs, dw), prec=ctx.prec)
                     else:
                         L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args, prec=ctx.prec)
