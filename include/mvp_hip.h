@@ -589,6 +589,18 @@ int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float* Yi, co
                                              const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W, int64_t ldw,
                                              int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, float* dZ, double* stat_prev, int* ticket,
                                              float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
+/* dW (Cout,Cin) += dy^T . X with the BatchNorm-backward FINISH of the dY operand applied while it is loaded (round 5): dZ (R,Cout) = the gradient
+ * w.r.t. the layer's activation with its ReLU mask applied, Y (R,Cout) its pre-BN output, stat (2 Cout) = [sum dZ | sum dZ * xhat]:
+ * dy = gamma * invstd * ((dZ - stat[c] / R) - xhat * stat[Cout + c] / R) (training = 0: no batch terms), formed in registers with the operations
+ * of mvp_bn_rows_backward_finish_f32 -- the result of that pass followed by mvp_mlp_weight_grad[_ws]_f32 without the pass and without the (R,Cout)
+ * tensor it writes.  For a first layer whose input needs no gradient (FeatureAggregation on a frozen 2D branch, mvpnet/models/mvpnet_3d.py:37-61)
+ * nothing else needs dy.  X (R,ldx) plain (no activation prologue).  workspace / workspace_floats as mvp_mlp_weight_grad_ws_f32 (NULL / 0: fp32
+ * atomics); precision arguments as every `_p_f32` entry point.  Supported: Cout % 4 == 0, 33 <= Cout, 16-byte aligned dZ / Y, and either Cin >= 33
+ * on the split-bf16 kernel (1 or 2 backward pieces) or Cin <= 32 with 16-byte aligned rows on the fp32 kernel; MVP_EUNSUPPORTED otherwise (the
+ * caller then runs the finish pass). */
+int mvp_mlp_weight_grad_finish_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma, const double* stat,
+                                     int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, float* dW, int64_t lddw,
+                                     float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
 /* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
  * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,

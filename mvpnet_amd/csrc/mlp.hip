@@ -555,10 +555,11 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
 // Slabs are double buffered in LDS and the loads of slab s + 1 are issued (unconditionally, clamped) before the MFMAs of slab s:
 // one barrier per slab.  The RS partial tiles are summed through LDS and flushed with ONE fp32 atomic per element and
 // workgroup; the host bounds the number of row splits because those atomics queue per address (~90 ns each).
-template <int TM, int TN, bool VEC>
+template <int TM, int TN, bool VEC, bool FIN = false>
 __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
                                                      int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
-                                                     float* __restrict__ dW, int lddw, float* __restrict__ ws) {
+                                                     float* __restrict__ dW, int lddw, float* __restrict__ ws, DyFinish fin = DyFinish{}) {
+  static_assert(!FIN || VEC, "the finish on load takes whole quadruples");
   constexpr int NBLK = (TM / 32) * (TN / 32);  // output blocks of 32 x 32
   constexpr int RS = 4 / NBLK;                 // waves per output block = row split of the slab
   constexpr int BR = 32 * RS;                  // slab rows
@@ -592,11 +593,25 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
     }
   }
   float4 dn[PD], an[PA];
+  float4 yn[FIN ? PD : 1];
+  float fmu[4], fis[4], fsc[4], fdb[4], fdg[4];  // (FIN) constants of this thread's four dY columns: the arithmetic of bn_rows_bwd_kernel (rows.hip)
+  if constexpr (FIN) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = min(co0 + dq, Cout - 4) + i;
+      fmu[i] = fin.mean[k];
+      fis[i] = fin.invstd[k];
+      fsc[i] = fin.gamma[k] * fis[i];
+      fdb[i] = (float)fin.stat[k] * fin.inv_rows;
+      fdg[i] = (float)fin.stat[Cout + k] * fin.inv_rows;
+    }
+  }
   auto load = [&](int64_t r0) {  // unconditional, addresses clamped into the tensors
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
       const float* src = dY + (size_t)min(r0 + dr + p * RD, R - 1) * Cout;
       const int c = co0 + dq;
+      if constexpr (FIN) yn[p] = *reinterpret_cast<const float4*>(fin.Y + (size_t)min(r0 + dr + p * RD, R - 1) * Cout + min(c, Cout - 4));
       if constexpr (VEC) {
         dn[p] = *reinterpret_cast<const float4*>(src + min(c, Cout - 4));
       } else {
@@ -627,6 +642,16 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
       const bool rok = r0 + m < r_end;
       const int c = co0 + dq;
       float4 v = dn[p];
+      if constexpr (FIN) {  // dz -> dy (same operations, same order as the finish pass)
+        const float yv[4] = {yn[p].x, yn[p].y, yn[p].z, yn[p].w};
+        float dv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xh = (yv[i] - fmu[i]) * fis[i];
+          dv[i] = fsc[i] * ((dv[i] - fdb[i]) - xh * fdg[i]);
+        }
+        v = make_float4(dv[0], dv[1], dv[2], dv[3]);
+      }
       v.x = (rok && c + 0 < Cout) ? v.x : 0.f;
       v.y = (rok && c + 1 < Cout) ? v.y : 0.f;
       v.z = (rok && c + 2 < Cout) ? v.z : 0.f;
@@ -718,10 +743,10 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
 // its next step are in flight under the MFMAs of the current one.  The four partial tiles meet in LDS (two rounds), one fp32
 // atomic per element and workgroup.
 // ---------------------------------------------------------------------------------------------------
-template <int TMB, int TNB, int NS>
+template <int TMB, int TNB, int NS, bool FIN = false>
 __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
                                                         int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
-                                                        float* __restrict__ dW, int lddw, float* __restrict__ ws) {
+                                                        float* __restrict__ dW, int lddw, float* __restrict__ ws, DyFinish fin = DyFinish{}) {
   using SP = SplitPairs<NS>;
   __shared__ float red[2][TMB * TNB * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -759,10 +784,26 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
     }
   }
   float dn[TMB][8], xn[TNB][8];  // raw values of the NEXT step
+  float yn[FIN ? TMB : 1][8];
+  float fmu[TMB], fis[TMB], fsc[TMB], fdb[TMB], fdg[TMB];  // (FIN) per lane: its dY columns never change (arithmetic of bn_rows_bwd_kernel, rows.hip)
+  if constexpr (FIN) {
+#pragma unroll
+    for (int a = 0; a < TMB; ++a) {
+      fmu[a] = fin.mean[dcol[a]];
+      fis[a] = fin.invstd[dcol[a]];
+      fsc[a] = fin.gamma[dcol[a]] * fis[a];
+      fdb[a] = (float)fin.stat[dcol[a]] * fin.inv_rows;
+      fdg[a] = (float)fin.stat[Cout + dcol[a]] * fin.inv_rows;
+    }
+  }
   auto load = [&](int64_t r0) {  // unconditional, rows clamped into the tensor (masked when consumed)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int64_t r = min(r0 + 8 * g + p, R - 1);
+      if constexpr (FIN) {
+#pragma unroll
+        for (int a = 0; a < TMB; ++a) yn[a][p] = fin.Y[(size_t)r * Cout + dcol[a]];
+      }
 #pragma unroll
       for (int a = 0; a < TMB; ++a) dn[a][p] = dY[(size_t)r * Cout + dcol[a]];
 #pragma unroll
@@ -778,7 +819,14 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
     for (int a = 0; a < TMB; ++a) {
       float v[8];
 #pragma unroll
-      for (int p = 0; p < 8; ++p) v[p] = (rok[p] && dok[a]) ? dn[a][p] : 0.f;
+      for (int p = 0; p < 8; ++p) {
+        float d = dn[a][p];
+        if constexpr (FIN) {  // dz -> dy (same operations, same order as the finish pass)
+          const float xh = (yn[a][p] - fmu[a]) * fis[a];
+          d = fsc[a] * ((d - fdb[a]) - xh * fdg[a]);
+        }
+        v[p] = (rok[p] && dok[a]) ? d : 0.f;
+      }
       unsigned q[4][NS];
 #pragma unroll
       for (int h2 = 0; h2 < 4; ++h2) split_pair<NS>(v[2 * h2], v[2 * h2 + 1], q[h2]);
@@ -1055,7 +1103,7 @@ MVP_API int mvp_mlp_forward_pool_f32(const float* X, int64_t R, int64_t Cin, int
 namespace {
 int weight_grad_impl(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, const float* act_mean,
                      const float* act_invstd, const float* act_gamma, const float* act_beta, float* dW, int64_t lddw, float* ws, int64_t ws_floats,
-                     mvp_stream_t stream) {
+                     mvp_stream_t stream, const DyFinish* fin = nullptr) {
   MVP_NONNULL(dY);
   MVP_NONNULL(X);
   MVP_NONNULL(dW);
@@ -1083,6 +1131,19 @@ int weight_grad_impl(const float* dY, const float* X, int64_t R, int64_t Cout, i
       dim3 grid((unsigned)cdiv(Cout, TM), (unsigned)cdiv(Cin, TN), (unsigned)splits);
       // partial tiles through the caller's workspace + an ordered reduction when it is large enough, fp32 atomics otherwise
       float* w = (ws && splits * tiles * (int64_t)(TM * TN) <= ws_floats && splits > 1) ? ws : nullptr;
+      if (fin) {  // the finish of dY on load: the shapes that use it (64-wide dY tiles, one- or two-piece split)
+        if (!(TM == 64 && TN == 64 && (ns == 1 || ns == 2))) return MVP_EUNSUPPORTED;
+        if (ns == 1)
+          hipLaunchKernelGGL((mlp_dw_bf_kernel<2, 2, 1, true>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW,
+                             (int)lddw, w, *fin);
+        else
+          hipLaunchKernelGGL((mlp_dw_bf_kernel<2, 2, 2, true>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW,
+                             (int)lddw, w, *fin);
+        if (w)
+          hipLaunchKernelGGL((dw_reduce_kernel<2, 2>), dim3((unsigned)(tiles * 2 * 2 * 16)), dim3(256), 0, s, w, (int)splits, (int)grid.x, (int)grid.y,
+                             (int)Cout, (int)Cin, dW, (int)lddw);
+        return mvp_launch_status();
+      }
 #define MVP_DWBF(A_, B_)                                                                                                           \
   do {                                                                                                                             \
     if (ns == 1)                                                                                                                   \
@@ -1116,6 +1177,15 @@ int weight_grad_impl(const float* dY, const float* X, int64_t R, int64_t Cout, i
   dim3 grid((unsigned)cdiv(Cout, TM), (unsigned)cdiv(Cin, TN), (unsigned)splits);
   const bool vec = Cout % 4 == 0 && Cin % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dY) % 16 == 0 && ((uintptr_t)X) % 16 == 0;
   float* w = (ws && splits * tiles * (int64_t)(TM * TN) <= ws_floats && splits > 1) ? ws : nullptr;  // as on the split-bf16 path
+  if (fin) {  // (the four relation columns of FeatureAggregation's first layer: 64 x 32 tiles)
+    if (!(TM == 64 && TN == 32 && vec)) return MVP_EUNSUPPORTED;
+    hipLaunchKernelGGL((mlp_dw_kernel<64, 32, true, true>), grid, dim3(kMT), 0, s, dY, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW,
+                       (int)lddw, w, *fin);
+    if (w)
+      hipLaunchKernelGGL((dw_reduce_kernel<2, 1>), dim3((unsigned)(tiles * 2 * 1 * 16)), dim3(256), 0, s, w, (int)splits, (int)grid.x, (int)grid.y,
+                         (int)Cout, (int)Cin, dW, (int)lddw);
+    return mvp_launch_status();
+  }
 #define MVP_DW_LAUNCH(M_, N_)                                                                                                      \
   do {                                                                                                                             \
     if (vec)                                                                                                                       \
@@ -1152,6 +1222,35 @@ MVP_API int mvp_mlp_weight_grad_ws_f32(const float* dY, const float* X, int64_t 
                                        const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                                        float* dW, int64_t lddw, float* workspace, int64_t workspace_floats, mvp_stream_t stream) {
   return weight_grad_impl(dY, X, R, Cout, Cin, ldx, act_mean, act_invstd, act_gamma, act_beta, dW, lddw, workspace, workspace_floats, stream);
+}
+
+// The same with the BatchNorm-backward FINISH of the dY operand applied while it is loaded: dZ (R, Cout) is the gradient w.r.t. the layer's
+// activation with its ReLU mask applied, Y its pre-BN output, stat (2 Cout) the two column sums -- dy = gamma invstd ((dz - stat[c] / R) -
+// xhat stat[Cout + c] / R) is formed in registers with the operations of mvp_bn_rows_backward_finish_f32, so the result is the one of that
+// pass followed by mvp_mlp_weight_grad[_ws]_f32, without the pass and without the (R, Cout) tensor it writes.  For a FIRST layer whose input
+// needs no gradient (FeatureAggregation on a frozen 2D branch: mvpnet_3d.py:37-61) nothing else needs dy.  X without activation.
+// Cout a multiple of 4 with 33 <= Cout, 64-wide dY tiles; Cin >= 33 columns on the split-bf16 kernel (1 or 2 pieces), or Cin <= 32 on the
+// fp32 kernel (16-byte aligned rows); everything else: MVP_EUNSUPPORTED (callers run the finish pass).  workspace as mvp_mlp_weight_grad_ws_f32.
+MVP_API int mvp_mlp_weight_grad_finish_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                                             const double* stat, int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                                             float* dW, int64_t lddw, float* workspace, int64_t workspace_floats, int precision,
+                                             int precision_backward, mvp_stream_t stream) {
+  MVP_NONNULL(Y);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(stat);
+  MVP_REQUIRE((precision == -1 || precision == 0 || precision == 1 || precision == 3 || precision == 6) &&
+              (precision_backward == -1 || precision_backward == 1 || precision_backward == 3 || precision_backward == 6));
+  if (Cout % 4 != 0 || Cout <= 32 || ((uintptr_t)dZ | (uintptr_t)Y) % 16 != 0) return MVP_EUNSUPPORTED;
+  const int old_terms = tl_mlp_terms, old_bwd = tl_mlp_terms_bwd;
+  if (precision >= 0) tl_mlp_terms = precision;
+  if (precision_backward >= 0) tl_mlp_terms_bwd = precision_backward;
+  const DyFinish fin{Y, mean, invstd, gamma, stat, (training && R > 0) ? 1.0f / (float)R : 0.f};
+  const int rc = weight_grad_impl(dZ, X, R, Cout, Cin, ldx, nullptr, nullptr, nullptr, nullptr, dW, lddw, workspace, workspace_floats, stream, &fin);
+  tl_mlp_terms = old_terms;
+  tl_mlp_terms_bwd = old_bwd;
+  return rc;
 }
 
 // d(input) of a layer, fused with the first half of the previous layer's BatchNorm+ReLU backward:

@@ -26,6 +26,15 @@ struct InAct {  // previous layer's BatchNorm + ReLU, per input column (may be n
   const float* beta;
 };
 
+struct DyFinish {  // BatchNorm-backward "finish" of the dY operand on load: dy = gamma invstd ((dz - db) - xhat dg), xhat = (y - mean) invstd
+  const float* Y;        // (R, Cout) pre-BN output of the layer; nullptr = dY is used as it is
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const double* stat;    // (2 Cout): column sums of dz and of dz * xhat
+  float inv_rows;        // 1 / R in training mode, 0 with running statistics (no batch terms)
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -278,6 +278,7 @@ weight_slices = WeightSlices()
 # with the step under a hipGraph.  Measured: DESIGN.md section 5.
 DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
 LINEAR_ASIDE = os.environ.get('MVP_LINEAR_ASIDE', '1') != '0'
+DW_FINISH_ON_LOAD = os.environ.get('MVP_DW_FINISH_ON_LOAD', '1') != '0'  # (A/B: the first layer's finish pass inside its weight-gradient launches)
 REL_DW_SPLIT = os.environ.get('MVP_REL_DW_SPLIT', '1') != '0'  # (the relation columns' weight gradient on the calling stream at the end of the backward pass)  # (A/B switch: whole-weight linear layers' weight / bias gradients beside the chain)
 _EXP_SKIP_DW = os.environ.get('MVP_EXP_SKIP_DW', '0') == '1'
 
@@ -1098,6 +1099,27 @@ class MLPChainRows(torch.autograd.Function):
                 dgb = pending.view(2, cout).to(torch.float32)
                 grads[1], grads[2] = dgb[1], dgb[0]
                 dx0 = gcur
+                break
+            if (pending is not None and not fuse and DW_FINISH_ON_LOAD and i == 0 and rel is not None and not need_dz and ctx.prec[0] != 0 and
+                    ctx.prec[1] in (1, 3) and cout % 4 == 0 and cout > 32 and src.size(1) > 32 and src.size(1) == w.size(1) - 4):
+                # FIRST layer over [x0 | rel] whose input needs no gradient (FeatureAggregation on a frozen 2D branch): dy_0 is needed by the two
+                # weight-gradient launches only, and they form it from (dz_0, y_0) while they load it (mvp_mlp_weight_grad_finish_p_f32): no finish
+                # pass (95 us at the very end of the training stream, where nothing overlaps it), no (R, C) dy tensor.  The BatchNorm parameter
+                # gradients are the two column sums.
+                cin_f = src.size(1)
+                dw = dw_arena[dw_off:dw_off + cout * cin].view(cout, cin)
+                dw_off += cout * cin
+                grads[0] = dw
+                dgb0 = pending.view(2, cout).to(torch.float32)
+                grads[1], grads[2] = dgb0[1], dgb0[0]
+                ws_ptr, ws_floats = L.current_dw_workspace(dev)
+                for xs, ncol, c0 in ((src, cin_f, 0), (rel, 4, cin_f)):
+                    fargs = (L.ptr(gcur), L.ptr(ys[0]), L.ptr(means[0]), L.ptr(invstds[0]), L.ptr(params[1]), L.ptr(pending), int(training), L.ptr(xs), R,
+                             cout, ncol, ncol, L.ptr_at(dw, c0), cin)
+                    if dw_aside and xs is not rel and ws_ptr is None:
+                        side_stream.run(dev, 'mvp_mlp_weight_grad_finish_p_f32', fargs + (None, 0) + tuple(ctx.prec), (gcur, ys[0], xs, dw, pending))
+                    else:
+                        L.call('mvp_mlp_weight_grad_finish_p_f32', gcur, *(fargs + (ws_ptr, ws_floats) + tuple(ctx.prec)))
                 break
             if pending is not None and not fuse:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)

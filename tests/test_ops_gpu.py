@@ -1752,6 +1752,61 @@ def test_fps_rounds_kernel_odd_sizes(dev, N, M):
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
 
+@pytest.mark.parametrize('R,Cout,Cin', [(70001, 64, 64), (5000, 64, 4), (33000, 128, 96), (900, 64, 64)])
+@pytest.mark.parametrize('training', [1, 0])
+@pytest.mark.parametrize('bwd', ['bf16x3', 'bf16'])
+def test_weight_gradient_with_the_finish_on_load(dev, R, Cout, Cin, training, bwd):
+    """mvp_mlp_weight_grad_finish_p_f32: dW += dy^T . X with dy = gamma invstd ((dz - db) - xhat dg) formed while dz and y are loaded --
+    against the two launches it replaces (mvp_bn_rows_backward_finish_f32 writing dy, mvp_mlp_weight_grad_f32 on it: the same fp32 operations,
+    so only the order of the fp32 atomics differs) and against float64; the split-bf16 kernel (64 and 96 input columns) and the fp32
+    kernel (the four relation columns of FeatureAggregation's first layer), a column slice of a wider gradient, both BatchNorm modes."""
+    from mvpnet_amd import _lib as L
+    prec = (L.MLP_PRECISIONS['bf16x6'], L.MLP_PRECISIONS[bwd])
+    hi = torch.float64
+    torch.manual_seed(R + Cout + Cin + training)
+    dz = torch.randn(R, Cout, device=dev)
+    y = torch.randn(R, Cout, device=dev) * 1.3 + 0.1
+    x = torch.randn(R, Cin, device=dev)
+    mean, invstd, gamma = torch.randn(Cout, device=dev) * 0.3, torch.rand(Cout, device=dev) + 0.5, torch.rand(Cout, device=dev) + 0.5
+    beta = torch.zeros(Cout, device=dev)
+    xh = (y.to(hi) - mean.to(hi)) * invstd.to(hi)
+    stat = torch.cat([dz.to(hi).sum(0), (dz.to(hi) * xh).sum(0)])
+    ld = Cin + 8
+    # the two launches
+    dy = torch.empty(R, Cout, device=dev)
+    dgb = torch.empty(2, Cout, device=dev)
+    L.call('mvp_bn_rows_backward_finish_f32', dz, L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), R, Cout, training,
+           L.ptr(stat), L.ptr(dy), L.ptr(dgb[0]), L.ptr(dgb[1]))
+    dw0 = torch.zeros(Cout, ld, device=dev)
+    L.call('mvp_mlp_weight_grad_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, None, None, None, None, L.ptr_at(dw0, 4), ld, prec=prec)
+    # one launch
+    dw1 = torch.zeros(Cout, ld, device=dev)
+    L.call('mvp_mlp_weight_grad_finish_p_f32', dz, L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat), training, L.ptr(x), R, Cout,
+           Cin, Cin, L.ptr_at(dw1, 4), ld, None, 0, prec[0], prec[1])
+    assert float(dw1[:, :4].abs().max()) == 0.0 and float(dw1[:, 4 + Cin:].abs().max()) == 0.0
+    scale = max(1.0, float(dw0.abs().max()))
+    np.testing.assert_allclose(dw1.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    # ... and with the reproducible mode's workspace: bit for bit the two-launch form's workspace result
+    ws = torch.empty(L.lib().mvp_mlp_weight_grad_workspace_floats(), device=dev)
+    dw2, dw3 = torch.zeros(Cout, ld, device=dev), torch.zeros(Cout, ld, device=dev)
+    L.call('mvp_mlp_weight_grad_ws_f32', dy, L.ptr(dy), L.ptr(x), R, Cout, Cin, Cin, None, None, None, None, L.ptr_at(dw2, 4), ld, L.ptr(ws), ws.numel(), prec=prec)
+    L.call('mvp_mlp_weight_grad_finish_p_f32', dz, L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat), training, L.ptr(x), R, Cout,
+           Cin, Cin, L.ptr_at(dw3, 4), ld, L.ptr(ws), ws.numel(), prec[0], prec[1])
+    np.testing.assert_array_equal(dw3.cpu().numpy(), dw2.cpu().numpy())
+    # float64
+    inv = 1.0 / R if training else 0.0
+    dyr = (gamma.to(hi) * invstd.to(hi)) * ((dz.to(hi) - stat[:Cout] * inv) - xh * (stat[Cout:] * inv))
+    ref = dyr.t() @ x.to(hi)
+    loose = 16.0 if bwd == 'bf16x3' else 4096.0
+    np.testing.assert_allclose(dw1[:, 4:4 + Cin].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4 * loose, atol=3e-5 * max(1.0, float(ref.abs().max())) * loose)
+    # refused (the caller then runs the finish pass): narrow dY, fp32 contraction of a wide operand, unaligned operands
+    f = L.lib().mvp_mlp_weight_grad_finish_p_f32
+    base = lambda dzp, co, p0: (dzp, L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat), training, L.ptr(x), R, co, Cin, Cin, L.ptr(dw1), ld, None, 0, p0, 3, None)
+    assert f(*base(L.ptr(dz), 32, 6)) != 0 and f(*base(L.ptr(dz) + 4, Cout, 6)) != 0
+    if Cin > 32:
+        assert f(*base(L.ptr(dz), Cout, 0)) != 0
+
+
 @pytest.mark.parametrize('G,K,C,Cp', [(4000, 3, 64, 64), (1367, 5, 128, 128), (100, 32, 32, 64)])
 def test_mlp_layer_backward_wide_behind_a_sum_over_the_neighbours(dev, G, K, C, Cp):
     """mvp_mlp_layer_backward_wide_pooled_p_f32: mode 2 with ONE gradient row per K rows of the layer (FeatureAggregation sums the k
