@@ -718,6 +718,7 @@ def main():
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
@@ -726,6 +727,7 @@ def main():
         prof.disable()
         pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(45)
     host_elapsed = time.perf_counter() - t0      # python/launch time only (the queue is drained below)
+    host_cpu = time.process_time() - c0          # CPU seconds of ALL threads of the process over the same loop (autograd's thread, the runtime's helpers)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -1010,6 +1012,7 @@ def main():
             'bf16_contraction': bf16_contraction,
             'dense': dense,
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
+            'host_cpu_ms_per_step': round(host_cpu / args.steps * 1e3, 3),
             'ms_per_step_repeats': repeats,
             'with_2d_network': e2e,
             'scene_inference': scene,
