@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 LIFT_BYTES_PER_CHUNK = 13403136 - 2 * 57600  # 2P (uint16 depth, as fed here; 4P for float) + 12N + 2*(4*C*N*k) + 8Nk + 12Nk, P=57600 N=8192 C=64 k=3
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEG_LOSS_BWD_US = 25.0           # seg_loss_bwd_kernel at B = 32 (profiles/r05_step_kernel_stats.csv): the one kernel between the marks bwd_begin and bwd_first
 
 
 class SuppliedFeature2D(torch.nn.Module):
@@ -640,11 +641,56 @@ def main():
         grad_sync(**kw)
         sync_host[0] += time.perf_counter() - ts
 
-    def eager_step(sync=None):
+    def eager_step(sync=None, marks=None):
         cur, nxt = state['cur'], fresh(batch)
-        out = train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=sync if sync is not None else grad_sync, next_batch=nxt)
+        out = train_step(model, loss_fn, optimizer, cur, scheduler=scheduler, grad_sync=sync if sync is not None else grad_sync, next_batch=nxt,
+                         marks=marks)
         state['cur'] = nxt
         return out
+
+    def phase_events(n=50):
+        """Where the training stream spends a step, WITHOUT a profiler: HIP events recorded on it at the marks of train_step over n eager
+        steps (after the timed region).  An event is stamped when the STREAM reaches it, so the time between two marks that
+        have no kernel between them (fwd_end -> bwd_begin: the host issues the next batch's geometry there; bwd_begin -> bwd_first: autograd
+        starts, one 25 us loss-gradient kernel) is time the stream waited for the host."""
+        names = ('begin', 'fwd_end', 'bwd_begin', 'bwd_first', 'bwd_end', 'end')
+        evs, host = [], []
+        torch.cuda.synchronize()
+        origin = torch.cuda.Event(enable_timing=True)
+        origin.record()
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for _ in range(n):
+            rec, hrec = {}, {}
+
+            def mark(name, rec=rec, hrec=hrec):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                rec[name] = e
+                hrec[name] = (time.perf_counter() - h0) * 1e3
+            eager_step(marks=mark)
+            evs.append(rec)
+            host.append(hrec)
+        torch.cuda.synchronize()
+        med = lambda xs: sorted(xs)[len(xs) // 2]
+        # how far the host runs AHEAD of the training stream at each mark: (stamp of the event on the stream) - (host clock when it was recorded),
+        # both from one synchronised origin.  ~0 = the stream reached the mark the moment the host issued it: the host is the bound there.
+        lead = {k: round(med([origin.elapsed_time(r[k]) - h[k] for r, h in zip(evs[n // 2:], host[n // 2:]) if k in r]) * 1e3, 1) for k in names}
+        hspan = lambda a, b: round(med([h[b] - h[a] for h in host if a in h and b in h]) * 1e3, 1)
+        host_us = {'forward': hspan('begin', 'fwd_end'), 'geometry_prefetch': hspan('fwd_end', 'bwd_begin'), 'backward': hspan('bwd_begin', 'bwd_end'),
+                   'optimizer': hspan('bwd_end', 'end'), 'between_steps': round(med([host[i + 1]['begin'] - host[i]['end'] for i in range(n - 1)]) * 1e3, 1)}
+        span = lambda a, b: round(med([r[a].elapsed_time(r[b]) for r in evs if a in r and b in r]) * 1e3, 1)
+        res = {'forward_us': span('begin', 'fwd_end'), 'fwd_end_to_bwd_begin_us': span('fwd_end', 'bwd_begin'),
+               'bwd_begin_to_first_grad_us': span('bwd_begin', 'bwd_first'), 'backward_us': span('bwd_first', 'bwd_end'),
+               'optimizer_us': span('bwd_end', 'end'),
+               'step_to_step_us': round(med([evs[i]['begin'].elapsed_time(evs[i + 1]['begin']) for i in range(n - 1)]) * 1e3, 1)}
+        # the loss-gradient kernel itself sits between bwd_begin and bwd_first (~25 us at B = 32): what is left of the two gaps is the wait
+        res['fwd_bwd_idle_us'] = round(max(0.0, res['fwd_end_to_bwd_begin_us'] + res['bwd_begin_to_first_grad_us'] - SEG_LOSS_BWD_US * args.batch / 32.0), 1)
+        res['host_lead_us'] = lead
+        res['host_us'] = host_us
+        res['note'] = ('medians over {} eager steps of HIP events on the training stream at the marks of mvpnet3d.train_step (no profiler); fwd_bwd_idle_us = '
+                       'the two boundary spans minus the loss-gradient kernel ({} us at B = 32, profiles/r05_step_kernel_stats.csv)'.format(n, SEG_LOSS_BWD_US))
+        return res
 
     if args.launch_only_peer > 0:
         # (no collectives, no timing contract: the host side of the step as fast as this process gets to run it)
@@ -749,6 +795,7 @@ def main():
             torch.cuda.synchronize()
             repeats.append(round((time.perf_counter() - tr) / args.steps * 1e3, 3))
     timer.enabled = False   # (the repeats run exactly what the timed region ran, event pairs around the lifting call included)
+    phases = phase_events() if (world == 1 and not args.graph and not args.host_profile) else None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -985,6 +1032,26 @@ def main():
         finally:
             _lib.set_mlp_precision(before)
             _lib.set_mlp_precision_backward(before_bwd)
+    # ... and with the GRADIENT contractions at the forward's fp32-equivalent precision (bf16x6 instead of the default bf16x3): what gradients
+    # as exact as the reference's fp32 ones cost
+    bf16x6_backward = None
+    if side or os.environ.get('MVP_BENCH_BF16X6_BWD') == '1':
+        before_bwd = {1: 'bf16', 3: 'bf16x3', 6: 'bf16x6'}[_lib.lib().mvp_get_mlp_precision_backward()]
+        _lib.set_mlp_precision_backward('bf16x6')
+        try:
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            t6 = time.perf_counter()
+            for _ in range(8):
+                eager_step()
+            torch.cuda.synchronize()
+            ms6 = (time.perf_counter() - t6) / 8 * 1e3
+            bf16x6_backward = {'chunks_per_s_per_gpu': round(args.batch / (ms6 * 1e-3), 1), 'ms_per_step': round(ms6, 3),
+                               'note': 'MVP_MLP_PRECISION_BWD=bf16x6: gradient contractions with all six bf16 partial products (fp32-equivalent, '
+                                       'like the forward) instead of the default three'}
+        finally:
+            _lib.set_mlp_precision_backward(before_bwd)
     dense = dense_extra(dev) if side else None
 
     if rank == 0:
@@ -1010,9 +1077,12 @@ def main():
             'parity': parity_info(),
             'fp32_mfma': fp32_mfma,
             'bf16_contraction': bf16_contraction,
+            'bf16x6_backward': bf16x6_backward,
             'dense': dense,
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
             'host_cpu_ms_per_step': round(host_cpu / args.steps * 1e3, 3),
+            'phases': phases,
+            'fwd_bwd_idle_us': None if phases is None else phases['fwd_bwd_idle_us'],
             'ms_per_step_repeats': repeats,
             'with_2d_network': e2e,
             'scene_inference': scene,

@@ -71,6 +71,11 @@ int mvp_fps_shape_f64(const double* points, int64_t B, int64_t N, int64_t D, int
 int mvp_fps_checked_f32(const float* points, int64_t B, int64_t N, int64_t D, int64_t M, int64_t* index, int shape, int* status,
                         mvp_stream_t stream);
 int mvp_fps_debug_spin_limit(int polls);
+/* Which kernel family the LAST mvp_fps_* call of the calling thread launched -- the choice is made inside the library from the cloud's shape
+ * (and the MVP_FPS_* lab switches), so tests assert it next to the oracle comparison: 0 none yet, 1 one sample per barrier
+ * (fps_kernel / fps_fast_kernel), 2 fps_rounds_kernel, 3 fps_stream_kernel (4097..8192 float32 points: the training step's sampler),
+ * 4 fps_rounds_multi_kernel (several workgroups per cloud), 5 fps_global_kernel.  A test aid: thread-local, no device work. */
+int mvp_fps_last_kernel(void);
 /* Centroids of a CHAIN of sampling levels from the first level's indices (mvpnet/models/pn2/modules.py:74-87 applied level after level,
  * pn2ssg.py:92-99): outs[l][b, m, :] = points[b, index[b, m], :] for m < counts[l], counts[0] = M >= counts[1] >= ... (host arrays of
  * `levels` <= 8 entries; outs[l] = device pointer to (B, counts[l], D)).  Farthest point sampling of a cloud that is itself the output of

@@ -144,7 +144,7 @@ _SIGNATURES['mvp_mlp_layer_backward_wide_pooled_p_f32'] = [_ptr] * 9 + [ctypes.c
                                                            _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
 _SIGNATURES['mvp_mlp_weight_grad_finish_p_f32'] = [_ptr] * 6 + [ctypes.c_int, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
 EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_ball_query_grid_workspace', 'mvp_knn3_grid_workspace', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
-           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode', 'mvp_fps_debug_spin_limit'] + sorted(_SIGNATURES)
+           'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode', 'mvp_fps_debug_spin_limit', 'mvp_fps_last_kernel'] + sorted(_SIGNATURES)
 
 
 def lib():
@@ -187,6 +187,8 @@ def lib():
         handle.mvp_set_fps_mode.argtypes = [ctypes.c_int]
         handle.mvp_fps_debug_spin_limit.restype = ctypes.c_int
         handle.mvp_fps_debug_spin_limit.argtypes = [ctypes.c_int]
+        handle.mvp_fps_last_kernel.restype = ctypes.c_int
+        handle.mvp_fps_last_kernel.argtypes = []
         if os.environ.get('MVP_MLP_STREAM') is not None:
             handle.mvp_set_mlp_stream(int(os.environ['MVP_MLP_STREAM']))
         handle.mvp_set_mlp_precision_backward.restype = ctypes.c_int
@@ -213,6 +215,17 @@ def set_mlp_precision(name, min_width=0):
     if name not in MLP_PRECISIONS:
         raise ValueError('mlp precision must be one of {}'.format(sorted(MLP_PRECISIONS)))
     check(lib().mvp_set_mlp_precision(MLP_PRECISIONS[name], int(min_width)), 'mvp_set_mlp_precision')
+    global _mlp_min_width
+    _mlp_min_width = int(min_width)
+
+
+_mlp_min_width = 0
+
+
+def mlp_min_width():
+    """The `min_width` of the last set_mlp_precision (layers narrower than it stay on the fp32 MFMA): the hosts of the split-bf16-only entry
+    points (rows.wide_backward_ok, the finish-on-load weight gradient) leave such layers to the per-layer kernels."""
+    return _mlp_min_width
 
 
 def set_mlp_precision_backward(name):

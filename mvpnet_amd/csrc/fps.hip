@@ -20,6 +20,11 @@
 #include <string.h>
 
 namespace {
+// Which kernel family the LAST sampling call of this thread launched (mvp_fps_last_kernel: a test aid -- the choice is made in here from
+// the cloud's shape, invisible to callers; tests assert it so that an edit of the dispatch cannot silently un-test a kernel).
+// 1 fps_kernel / fps_fast_kernel (one sample per barrier), 2 fps_rounds_kernel, 3 fps_stream_kernel, 4 fps_rounds_multi_kernel, 5 fps_global_kernel
+thread_local int t_fps_last_kernel = 0;
+
 
 // ---- packed arg-max key -----------------------------------------------------------------------
 // np.argmax's "first maximum" = max over (value, then LOWER index).  Running distances are >= +0,
@@ -760,10 +765,12 @@ int launch_rounds(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* ou
   if (pad) bytes = 160 * 1024;  // (tools/exp) the workgroup takes the whole LDS of its CU: nothing else is co-resident
   auto k = fps_rounds_kernel<D, PPT, NT, RL>;
   if (bytes > 48 * 1024) {
+    // (a device that cannot grant this much LDS: not an error of the call -- dispatch() falls through to the kernels that stream from global memory)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return MVP_EUNSUPPORTED; }
   }
   static const int dbg = []() { const char* e = getenv("MVP_FPS_DEBUG"); return e ? atoi(e) : 0; }();
+  t_fps_last_kernel = 2;
   hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NT), bytes, s, pts, (int)N, (int)M, out, dbg);
   return mvp_launch_status();
 }
@@ -1244,9 +1251,10 @@ int launch_stream(const float* pts, int64_t B, int64_t N, int64_t M, int64_t* ou
   auto k = fps_stream_kernel<D, PPT, NTW, RL, SORT>;
   if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return MVP_EUNSUPPORTED; }  // (as launch_rounds: the caller falls back)
   }
   static const int dbg = []() { const char* e = getenv("MVP_FPS_DEBUG"); return e ? atoi(e) : 0; }();
+  t_fps_last_kernel = 3;
   hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(NTW + kWave), bytes, s, pts, (int)N, (int)M, out, dbg, (int)head);
   return mvp_launch_status();
 }
@@ -1658,6 +1666,7 @@ int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64
       if (e != hipSuccess) rc = (int)e;
     }
     if (rc == MVP_OK) {
+      t_fps_last_kernel = 4;
       hipLaunchKernelGGL(k, dim3((unsigned)(B * W)), dim3(1024), lds, s, pts, (int)N, (int)M, out, reinterpret_cast<fps_u64*>(scratch), err,
                          status, g_fps_spin_limit, walk);
       rc = mvp_launch_status();
@@ -1665,6 +1674,7 @@ int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64
     if (rc == MVP_OK)  // the repair launch (a no-op unless the flag is set)
       rc = N <= 16384 ? launch_cfg<float, D, 16, 1024>(pts, B, N, M, out, s, err) : N <= 32768 ? launch_cfg<float, D, 32, 1024>(pts, B, N, M, out, s, err)
                                                                                                  : launch_global<float, D>(pts, B, N, M, out, s, err);
+    if (rc == MVP_OK) t_fps_last_kernel = 4;  // (the repair launch recorded itself)
   }
   (void)hipFreeAsync(scratch, s);  // (on every path: the early returns used to leak it)
   return rc;
@@ -1672,6 +1682,7 @@ int launch_rounds_multi(const float* pts, int64_t B, int64_t N, int64_t M, int64
 
 template <typename T, int D, int PPT, int NT>
 int launch_cfg(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, hipStream_t s, const int* guard) {
+  t_fps_last_kernel = 1;
   const size_t part_bytes = 2 * 16 * 16 + (((size_t)M * 4 + 15) & ~(size_t)15);  // keys + output buffer
   const size_t pts_bytes = (size_t)N * 3 * sizeof(T);
   const bool lds = pts_bytes + part_bytes <= 150 * 1024;
@@ -1769,6 +1780,7 @@ int launch_global(const T* pts, int64_t B, int64_t N, int64_t M, int64_t* out, h
     (void)hipGetLastError();
     return MVP_EINVAL;
   }
+  t_fps_last_kernel = 5;
   hipLaunchKernelGGL((fps_global_kernel<T, D, 1024>), dim3((unsigned)B), dim3(1024), 0, s, pts, (int)N, (int)M, mind, out, guard);
   const int rc = mvp_launch_status();
   (void)hipFreeAsync(mind, s);
@@ -1908,6 +1920,7 @@ MVP_API int mvp_fps_checked_f32(const float* points, int64_t B, int64_t N, int64
                                 mvp_stream_t stream) {
   return fps_entry<float>(points, B, N, D, M, index, shape, status, stream);
 }
+MVP_API int mvp_fps_last_kernel(void) { return t_fps_last_kernel; }
 MVP_API int mvp_fps_debug_spin_limit(int polls) {
   const int old = g_fps_spin_limit;
   g_fps_spin_limit = polls > 0 ? polls : (1 << 22);

@@ -261,6 +261,58 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
     // partial tile: `tailc`)
     auto p1 = [&](auto tailc) {
       constexpr bool TAIL = decltype(tailc)::value;
+      if constexpr (FULL && (MODE == 2 || MODE == 3)) {
+        // The mode-2 instances (the gradient arrives at the layer's ACTIVATION: ReLU mask and dropout here) hold seven column constants for dy
+        // and four for a_{i-1}: with both sets alive over the four rows they spilled (8 / 29 registers).  Two loops, one set each.
+        {
+          const f32x4 mu = cst[0 * Q], is = cst[1 * Q], sc = cst[2 * Q], db = cst[3 * Q], dg = cst[4 * Q], ga = cst[5 * Q], be = cst[6 * Q];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int r = rbase + RPP * j;
+            const bool rok = !TAIL || r < rows_here;
+            f32x4 d = tc.g[j];
+            const f32x4 xh = (tc.y[j] - mu) * is;
+            const f32x4 zz = xh * ga + be;
+            const unsigned ebase = ((unsigned)cur * kTR + (unsigned)r) * (unsigned)C + (unsigned)cc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = d[e];
+              if (MODE != 3 && p.drop.thresh) v *= p.drop.factor(ebase + (unsigned)e);
+              d[e] = (zz[e] > 0.f) ? v : 0.f;
+            }
+            d = sc * ((d - db) - xh * dg);
+            if (TAIL) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[e] = rok ? d[e] : 0.f;
+            }
+            load_gy_row(tc, nload, j);  // this row's registers are free: the next tile's row is requested at once
+            unsigned d0[NS], d1[NS];
+            split_pair<NS>(d[0], d[1], d0);
+            split_pair<NS>(d[2], d[3], d1);
+            const int off = r * kRowB + c4 * 8;
+#pragma unroll
+            for (int pc = 0; pc < NS; ++pc) *reinterpret_cast<uint2*>(L + oDy + pc * kTimg + off) = make_uint2(d0[pc], d1[pc]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        const f32x4 pm = cst[7 * Q], pi = cst[8 * Q], pg = cst[9 * Q], pb = cst[10 * Q];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int r = rbase + RPP * j;
+          const bool rok = !TAIL || r < rows_here;
+          f32x4 a = ((xk[j] - pm) * pi) * pg + pb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = (a[e] > 0.f && rok) ? a[e] : 0.f;
+          unsigned a0[NS], a1[NS];
+          split_pair<NS>(a[0], a[1], a0);
+          split_pair<NS>(a[2], a[3], a1);
+          const int off = r * kRowB + c4 * 8;
+#pragma unroll
+          for (int pc = 0; pc < NS; ++pc) *reinterpret_cast<uint2*>(L + oA + pc * kTimg + off) = make_uint2(a0[pc], a1[pc]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
       const f32x4 mu = cst[0 * Q], is = cst[1 * Q], sc = cst[2 * Q], db = cst[3 * Q], dg = cst[4 * Q], ga = cst[5 * Q], be = cst[6 * Q];
       const f32x4 pm = cst[7 * Q], pi = cst[8 * Q], pg = cst[9 * Q], pb = cst[10 * Q];
 #pragma unroll
@@ -274,10 +326,12 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
           const f32x4 xh = (tc.y[j] - mu) * is;
           if (mode == 2) {
             const f32x4 zz = xh * ga + be;
+            const unsigned ebase = ((unsigned)cur * kTR + (unsigned)r) * (unsigned)C + (unsigned)cc;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float v = d[e];
-              if (p.drop.thresh) v *= p.drop.factor((unsigned)(((int64_t)cur * kTR + r) * C + cc + e));
+              // (32-bit counter: the host checks R * C < 2^32; MODE 3 -- behind a sum over the neighbours -- never has a dropout)
+              if (MODE != 3 && p.drop.thresh) v *= p.drop.factor(ebase + (unsigned)e);
               d[e] = (zz[e] > 0.f) ? v : 0.f;
             }
           }

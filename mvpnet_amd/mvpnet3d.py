@@ -318,15 +318,24 @@ def prefetch_geometry_many(model, batches):
 PREFETCH_AT = os.environ.get('MVP_PREFETCH_AT', 'backward')  # where train_step starts the next batch's geometry: 'backward' | 'forward'
 
 
-def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, next_batch=None):
+def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_norm=0.0, grad_sync=None, next_batch=None, marks=None):
     """One iteration of the reference loop (mvpnet/train_mvpnet_3d.py:158-180,287-288):
     zero_grad -> forward -> SegLoss -> backward -> [grad all-reduce] -> [clip] -> step -> scheduler.
-    next_batch: the batch of the NEXT iteration (already on the device); its geometry is prefetched."""
+    next_batch: the batch of the NEXT iteration (already on the device); its geometry is prefetched.
+    marks: a callable(name) invoked at 'begin', 'fwd_end' (loss enqueued), 'bwd_begin' (just before loss.backward()), 'bwd_first' (from a
+    hook on the logits' gradient: the first backward kernel is enqueued), 'bwd_end', 'end' -- a measurement aid (bench.py records HIP
+    events on the training stream there: where the stream waits for the host shows up as time between two marks)."""
+    if marks is not None:
+        marks('begin')
     optimizer.zero_grad()
     if next_batch is not None and PREFETCH_AT == 'forward':
         data_batch = dict(data_batch, prefetch_next=next_batch)  # launched right after this batch's lifting
     preds = model(data_batch)
     loss = loss_fn(preds, data_batch)['seg_loss']
+    if marks is not None:
+        marks('fwd_end')
+        if preds['seg_logit'].requires_grad:
+            preds['seg_logit'].register_hook(lambda g: marks('bwd_first'))
     if next_batch is not None and PREFETCH_AT == 'backward':
         # The next batch's coordinate-only work (FPS chain, ball queries, 3-NN, transposed indices: ~3 ms of side-stream kernels) starts
         # HERE, beside the backward pass, not beside the forward: the forward's deep levels are chains of 10-40 us kernels that the
@@ -334,7 +343,11 @@ def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_n
         # 7.6 -> 8.9 ms), the backward is dominated by 100-350 us kernels that share the chip gracefully.
         prefetch_geometry(model, next_batch)
         prefetch_features_2d(model, next_batch)  # (a frozen 2D branch only: its forward of the NEXT batch runs beside this backward pass)
+    if marks is not None:
+        marks('bwd_begin')
     loss.backward()
+    if marks is not None:
+        marks('bwd_end')
     if grad_sync is not None:
         grad_sync(weight_sum=getattr(loss_fn, 'last_weight_sum', None))  # == the gradient of ONE loss over the gathered batch
     if max_grad_norm > 0:
@@ -342,6 +355,8 @@ def train_step(model, loss_fn, optimizer, data_batch, scheduler=None, max_grad_n
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
+    if marks is not None:
+        marks('end')
     return loss.detach(), preds
 
 

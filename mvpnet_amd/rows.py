@@ -41,10 +41,19 @@ WIDE_BWD_POOLED = os.environ.get('MVP_BWD_WIDE_POOLED', '1') != '0'
 WIDE_BWD_64_MIN_ROWS = int(os.environ.get('MVP_BWD_WIDE64_MIN_ROWS', '262144'))
 
 
+def aligned16(*tensors):
+    """True when every tensor (None allowed) starts on a 16-byte boundary: the one-pass backward and the finish-on-load weight gradient read
+    whole 16-byte row pieces and answer MVP_EUNSUPPORTED otherwise (a contiguous() view keeps its storage offset) -- their callers then keep
+    the per-layer kernels instead of raising in the middle of a backward pass."""
+    return all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
+
+
 def wide_backward_ok(prec, R, cout, cin, ldx):
     """True when a layer (R rows, cin -> cout, input row stride ldx) takes the one-pass wide backward: a one- or two-piece backward split,
     whole 16-byte quadruples per row, and either more than 64 and at most 128 channels or the 64 -> 64 shape over very many rows."""
     if not (WIDE_BWD and prec[0] != 0 and prec[1] in (1, 3) and cout % 4 == 0 and cin % 4 == 0 and ldx % 4 == 0):
+        return False
+    if max(cout, cin) < L.mlp_min_width():  # (mvp_set_mlp_precision's min_width: such layers run on the fp32 MFMA, which the one-pass kernel has not)
         return False
     if 64 < max(cout, cin) <= 128:
         return R >= WIDE_BWD_MIN_ROWS
@@ -1021,11 +1030,13 @@ class MLPChainRows(torch.autograd.Function):
         if ctx.act_out is not None and ctx.act_out.stat is not None:
             handed, ctx.act_out.stat = ctx.act_out.stat, None
         last_wide = bool(handed is None and not ctx.pooled and K == 1 and nl >= 2 and wl is not None and g.is_cuda and
-                         wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32)
+                         wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32 and
+                         aligned16(g, ys[-1], ys[nl - 2]))
         # ... and the last layer in front of a SUM over K (FeatureAggregation, arg is None): the same one-pass backward takes the gradient of the
         # POOLED output and reads row r / K of it (mvp_mlp_layer_backward_wide_pooled_p_f32): no (R, C) gradient tensor, no pass that writes it
         last_wide_sum = bool(WIDE_BWD_POOLED and not ctx.pooled and K > 1 and arg is None and ctx.dropout[0] == 0 and nl >= 2 and wl is not None and
-                             g.is_cuda and wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32)
+                             g.is_cuda and wide_backward_ok(ctx.prec, R, wl.size(0), wl.size(1), ys[nl - 2].size(1)) and R * cl < 2 ** 32 and
+                             aligned16(g, ys[-1], ys[nl - 2]))
         if handed is not None:
             dy, dgam, dbet = None, None, None
         elif ctx.pooled:
@@ -1088,7 +1099,8 @@ class MLPChainRows(torch.autograd.Function):
             src = None if w is None else (x0 if i == 0 else ys[i - 1])
             pool_here = pool is not None and i == nl - 1
             rel, w0_param = ctx.rel if i == 0 else (None, None)
-            wide = bool(i > 0 and w is not None and not pool_here and rel is None and need_dz and wide_backward_ok(ctx.prec, R, cout, cin, src.size(1)))
+            wide = bool(i > 0 and w is not None and not pool_here and rel is None and need_dz and wide_backward_ok(ctx.prec, R, cout, cin, src.size(1)) and
+                        aligned16(gcur, ys[i], src))
             fuse = wide or pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and rel is None and
                                          (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
             assert wide or not ((last_wide or last_wide_sum) and i == nl - 1)
@@ -1101,7 +1113,8 @@ class MLPChainRows(torch.autograd.Function):
                 dx0 = gcur
                 break
             if (pending is not None and not fuse and DW_FINISH_ON_LOAD and i == 0 and rel is not None and not need_dz and ctx.prec[0] != 0 and
-                    ctx.prec[1] in (1, 3) and cout % 4 == 0 and cout > 32 and src.size(1) > 32 and src.size(1) == w.size(1) - 4):
+                    ctx.prec[1] in (1, 3) and cout % 4 == 0 and cout > 32 and src.size(1) > 32 and src.size(1) == w.size(1) - 4 and
+                    aligned16(gcur, ys[0]) and max(cout, src.size(1)) >= L.mlp_min_width()):
                 # FIRST layer over [x0 | rel] whose input needs no gradient (FeatureAggregation on a frozen 2D branch): dy_0 is needed by the two
                 # weight-gradient launches only, and they form it from (dz_0, y_0) while they load it (mvp_mlp_weight_grad_finish_p_f32): no finish
                 # pass (95 us at the very end of the training stream, where nothing overlaps it), no (R, C) dy tensor.  The BatchNorm parameter
@@ -1117,7 +1130,10 @@ class MLPChainRows(torch.autograd.Function):
                     fargs = (L.ptr(gcur), L.ptr(ys[0]), L.ptr(means[0]), L.ptr(invstds[0]), L.ptr(params[1]), L.ptr(pending), int(training), L.ptr(xs), R,
                              cout, ncol, ncol, L.ptr_at(dw, c0), cin)
                     if dw_aside and xs is not rel and ws_ptr is None:
-                        side_stream.run(dev, 'mvp_mlp_weight_grad_finish_p_f32', fargs + (None, 0) + tuple(ctx.prec), (gcur, ys[0], xs, dw, pending))
+                        # (everything the side-stream kernel reads stays alive until the join -- also the statistics and gamma, which this node's saved
+                        # tensors would otherwise release to the calling stream's allocator when the node is freed: ADVICE r5)
+                        side_stream.run(dev, 'mvp_mlp_weight_grad_finish_p_f32', fargs + (None, 0) + tuple(ctx.prec),
+                                        (gcur, ys[0], xs, dw, pending, means[0], invstds[0], params[1]))
                     else:
                         L.call('mvp_mlp_weight_grad_finish_p_f32', gcur, *(fargs + (ws_ptr, ws_floats) + tuple(ctx.prec)))
                 break

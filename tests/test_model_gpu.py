@@ -257,9 +257,13 @@ def test_mvpnet3d_full_chunk(dev):
         np.testing.assert_allclose(logit.cpu().numpy(), g[mode + '_seg_logit'], rtol=0, atol=ATOL[mode])
 
 
+@pytest.mark.parametrize('reproducible', [False, True])
 @pytest.mark.parametrize('geometry', ['eager', 'captured', 'pipelined'])
-def test_graphed_train_step_matches_eager(dev, geometry):
-    """mvpnet3d.GraphedTrainStep (forward + backward replayed from one HIP graph, geometry of the next batch forked inside it)
+def test_graphed_train_step_matches_eager(dev, geometry, reproducible):
+    """reproducible: the same comparison in the reproducible mode (_lib.set_deterministic: no fp32 atomics anywhere in the step), where eager
+    and replay have no run-to-run noise to amplify and the TIGHT bars hold -- a missing stream dependency or a stale gradient in a captured copy
+    shows there even if the atomic mode's loose bars would hide it.
+    mvpnet3d.GraphedTrainStep (forward + backward replayed from one HIP graph, geometry of the next batch forked inside it)
     follows the eager train_step: three iterations on two alternating batches (input copies, the geometry hand-over between
     replays and the static gradients are all exercised; longer trajectories diverge chaotically at B = 2 from the 1e-7 noise of
     the fp32 atomics alone, eager against eager as well)."""
@@ -282,6 +286,17 @@ def test_graphed_train_step_matches_eager(dev, geometry):
              'pose': t(st('pose')), 'pixel_box': t(st('pixel_box')), 'k': 3}
         return b, t(st('feature_2d')).view(len(ids) * 2, 30, 40, 16).permute(0, 3, 1, 2)
 
+    from mvpnet_amd import _lib as L
+    old_mode = L.set_deterministic(reproducible)
+    try:
+        _graphed_against_eager(dev, geometry, reproducible, build, batch_of)
+    finally:
+        L.set_deterministic(old_mode)
+
+
+def _graphed_against_eager(dev, geometry, reproducible, build, batch_of):
+    import copy
+    from mvpnet_amd.mvpnet3d import SegLoss, train_step, GraphedTrainStep, PipelinedTrainStep, prefetch_geometry
     # eager reference
     m1 = build()
     o1 = torch.optim.SGD(m1.parameters(), lr=0.05)  # (Adam turns 1e-7 gradient noise from the fp32 atomics into 1e-3 parameter changes)
@@ -313,6 +328,11 @@ def test_graphed_train_step_matches_eager(dev, geometry):
         graphed.append(float(g.step(seq[i], seq[i + 1])[0]))
     # (the 1e-7 run-to-run noise of the fp32 atomics is amplified by every SGD step at B = 2 -- eager against eager as well; one full GPU run in
     # round 5 missed the former 1e-5 / 5e-3 bars on a box where the other four runs of the same code passed)
+    if reproducible:
+        np.testing.assert_allclose(graphed[0], eager[0], rtol=1e-6)
+        np.testing.assert_allclose(graphed[1], eager[1], rtol=1e-5)
+        np.testing.assert_allclose(graphed[2], eager[2], rtol=5e-3)
+        return
     np.testing.assert_allclose(graphed[0], eager[0], rtol=1e-5)
     np.testing.assert_allclose(graphed[1], eager[1], rtol=2e-4)
     np.testing.assert_allclose(graphed[2], eager[2], rtol=2e-2)

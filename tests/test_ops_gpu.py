@@ -2,6 +2,7 @@
 (1) the golden vectors generated from the reference and (2) the CPU oracle on seeded inputs,
 plus size-independent properties at full BASELINE sizes.  Index results are bit-exact."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -93,6 +94,13 @@ def test_fps_vs_oracle(dev, B, N, M, D):
     pts = rs.rand(B, N, D).astype(np.float32)
     idx = farthest_point_sample(g(pts, dev), M, transpose=False).cpu().numpy()
     np.testing.assert_array_equal(idx, O().fps(pts, M))
+    # ... and it was the kernel this shape is meant to exercise (the library picks it from the shape: mvp_fps_last_kernel, include/mvp_hip.h).
+    # Under one of the MVP_FPS_* lab switches the choice is the switch's, not the default's: nothing to assert then.
+    from mvpnet_amd import _lib as L
+    if not any(k.startswith('MVP_FPS_') for k in os.environ):
+        ran = L.lib().mvp_fps_last_kernel()
+        want = 3 if 4096 < N <= 8192 else 2 if 512 < N <= 4096 else 4 if 8192 < N <= 65536 else 1
+        assert ran == want, 'N = {}: kernel family {} ran, {} expected (1 one-sample, 2 rounds, 3 stream, 4 rounds across workgroups)'.format(N, ran, want)
 
 
 @pytest.mark.parametrize('B,N,M,D,kind', [(2, 40000, 300, 3, 'uniform'), (1, 33000, 128, 2, 'uniform'), (1, 50000, 200, 3, 'lattice'),
@@ -2302,6 +2310,8 @@ def test_fps_rounds_across_workgroups(dev, B, N, M, D):
     exp = O().fps(pts_h[:2], M)
     idx = ops.farthest_point_sample(pts, M, transpose=False)
     np.testing.assert_array_equal(idx[:2].cpu().numpy(), exp)
+    if not any(k.startswith('MVP_FPS_') for k in os.environ):
+        assert L.lib().mvp_fps_last_kernel() == 4, 'fps_rounds_multi_kernel is the kernel this test is about'
     x = torch.randn(786432, 64, device=dev)
     w = torch.randn(64, 64, device=dev) * 0.1
     y = torch.empty(786432, 64, device=dev)
