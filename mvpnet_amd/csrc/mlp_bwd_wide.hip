@@ -581,7 +581,10 @@ MVP_API int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float
   const int bwd = precision_backward >= 0 ? precision_backward : mlp_terms_bwd();
   const int ns = terms == 0 ? 0 : (bwd == 6 ? 3 : bwd == 1 ? 1 : 2);
   // 16-byte row pieces: every row of G / Yi / X / dZ must start on a 16-byte boundary and hold whole quadruples
-  if (ns == 0 || ns == 3 || C > kWCh || Cp > kWCh || C % 4 || Cp % 4 || ldx % 4 || ((uintptr_t)G | (uintptr_t)X | (uintptr_t)dZ | (uintptr_t)Yi) % 16)
+  // Three pieces per operand (bf16x6: gradients as exact as fp32 ones) exist for the CH = 64 instances only: their images are 3 x 27 KB = 83 KB of
+  // LDS; at CH = 128 they would be 3 x (34 + 2 x 17) KB = 204 KB of the 160 a CU has, so those layers keep the per-layer kernels at bf16x6.
+  if (ns == 0 || (ns == 3 && (C > 64 || Cp > 64)) || C > kWCh || Cp > kWCh || C % 4 || Cp % 4 || ldx % 4 ||
+      ((uintptr_t)G | (uintptr_t)X | (uintptr_t)dZ | (uintptr_t)Yi) % 16)
     return MVP_EUNSUPPORTED;
   Dropout drop;
   if (make_dropout(mode == 2 ? drop_p : 0.f, drop_seed, R, C, 1, &drop) != MVP_OK) return MVP_EINVAL;
@@ -631,7 +634,8 @@ MVP_API int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float
     else if (pool_k > 1) MVP_WIDE_LAUNCH(NS_, 3, CH_);    \
     else MVP_WIDE_LAUNCH(NS_, 2, CH_);                    \
   } while (0)
-  if (ns == 1 && ch == 64) MVP_WIDE_MODES(1, 64);
+  if (ns == 3) MVP_WIDE_MODES(3, 64);
+  else if (ns == 1 && ch == 64) MVP_WIDE_MODES(1, 64);
   else if (ns == 1) MVP_WIDE_MODES(1, 128);
   else if (ch == 64) MVP_WIDE_MODES(2, 64);
   else MVP_WIDE_MODES(2, 128);

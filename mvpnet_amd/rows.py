@@ -49,9 +49,12 @@ def aligned16(*tensors):
 
 
 def wide_backward_ok(prec, R, cout, cin, ldx):
-    """True when a layer (R rows, cin -> cout, input row stride ldx) takes the one-pass wide backward: a one- or two-piece backward split,
-    whole 16-byte quadruples per row, and either more than 64 and at most 128 channels or the 64 -> 64 shape over very many rows."""
-    if not (WIDE_BWD and prec[0] != 0 and prec[1] in (1, 3) and cout % 4 == 0 and cin % 4 == 0 and ldx % 4 == 0):
+    """True when a layer (R rows, cin -> cout, input row stride ldx) takes the one-pass wide backward: whole 16-byte quadruples per row, and
+    either more than 64 and at most 128 channels (a one- or two-piece backward split) or the 64 -> 64 shape over very many rows (any split:
+    bf16, bf16x3, bf16x6)."""
+    if not (WIDE_BWD and prec[0] != 0 and prec[1] in (1, 3, 6) and cout % 4 == 0 and cin % 4 == 0 and ldx % 4 == 0):
+        return False
+    if prec[1] == 6 and max(cout, cin) > 64:  # three pieces per operand fit the LDS for the 64-channel instance only (csrc/mlp_bwd_wide.hip)
         return False
     if max(cout, cin) < L.mlp_min_width():  # (mvp_set_mlp_precision's min_width: such layers run on the fp32 MFMA, which the one-pass kernel has not)
         return False
