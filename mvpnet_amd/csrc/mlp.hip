@@ -1122,6 +1122,16 @@ int weight_grad_impl(const float* dY, const float* X, int64_t R, int64_t Cout, i
     // g_mlp_min_width wide; Cin >= 8 (the 4-column coordinate operand of the first set-abstraction layer stays on fp32)
     const int ns = (std::max(Cin, Cout) >= g_mlp_min_width && Cin >= 8) ? mlp_bwd_pieces() : 0;
     if (ns != 0) {
+      if (!ws) {
+        // layers with multiples of 128 channels on both sides over many rows: 16-byte row pieces -> LDS images -> transpose reads
+        // (mlp_bwd_wide.hip, the DWO instances) instead of this file's 4-byte operand loads; not in the reproducible mode (its partial
+        // tiles go through the workspace in mlp_dw_bf_kernel's layout)
+        const int rcw = fin ? mlp_dw_wide_launch(dY, fin->Y, fin->mean, fin->invstd, fin->gamma, fin->stat, fin->inv_rows, X, ldx, act_mean, act_invstd,
+                                                 act_gamma, act_beta, R, Cout, Cin, dW, lddw, ns, s)
+                            : mlp_dw_wide_launch(dY, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, X, ldx, act_mean, act_invstd, act_gamma, act_beta,
+                                                 R, Cout, Cin, dW, lddw, ns, s);
+        if (rcw != MVP_EUNSUPPORTED) return rcw;
+      }
       static const int64_t wg_target = []() { const char* e = getenv("MVP_DW_WORKGROUPS"); return e ? (int64_t)atoi(e) : (int64_t)1024; }();
       int64_t splits = std::min<int64_t>(cdiv(wg_target, tiles), 512);
       int64_t rows_per_block = cdiv(cdiv(R, splits), 64) * 64;

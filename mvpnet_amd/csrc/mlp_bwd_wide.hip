@@ -63,6 +63,9 @@ struct WideArgs {
   int* ticket;           // zero on entry: tiles beyond the first of each workgroup are taken by ticket; nullptr: static round-robin
   int64_t R;
   int C, Cp, ntiles;
+  // DWO instances (weight gradient only, a (c_out block, c_in block) pair of 128 x 128 per blockIdx.y): C / Cp are the WHOLE layer's widths
+  // on entry, ldg the row stride of G / Yi (= the whole C), nbb the number of c_in blocks
+  int ldg, nbb;
 };
 
 __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {  // ds_read_b64_tr_b16: lane p of a 16-lane group supplies 8 bytes, gets column p of the 4 x 16 block
@@ -89,8 +92,27 @@ struct TileRegs {  // one thread's 16-byte pieces of a tile: rows rbase + RPP j 
 // CH = 128 or 64: the channel capacity of the instance (row pieces, images and the MFMA tiling follow it).  CH = 64 is the shape of the
 // aggregation MLP's inner layers (786 432 rows x 64 -> 64): 16 pieces per row, 32 rows per pass of the 512 threads, waves 0 - 3 take the four
 // dX tiles and waves 4 - 7 the four dW tiles; 58 KB of LDS.
-template <int NS, int MODE, int CH>
-__global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
+// DWO: the weight gradient ALONE, dW (C, Cp) += dy^T . a for layers of any width, in (128 c_out) x (128 c_in) blocks: blockIdx.y names the
+// block, the workgroups of a block share its row tiles round-robin, P1 + P2b of the tile loop run as they are (16-byte row pieces -> bf16 images ->
+// transpose reads -> MFMA) and everything that belongs to dX is compiled out (no W image, no P2a / P3 / P4, no column sums).  Replaces
+// mlp_dw_bf_kernel (4-byte operand loads, 64 x 64 blocks: every operand re-read twice as often) for the 256- / 512-wide layers behind
+// mvp_mlp_weight_grad_f32 and its finish-on-load form (MODE 0: G is dy; 1: G is dz, the finish happens in P1).
+template <int NS, int MODE, int CH, bool DWO = false>
+__global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs pin) {
+  WideArgs p = pin;
+  if constexpr (DWO) {
+    const int ab = (int)blockIdx.y / p.nbb, bb = (int)blockIdx.y - ab * p.nbb;
+    const int co0 = ab * CH, ci0 = bb * CH;
+    p.G += co0;
+    if (p.Yi) { p.Yi += co0; p.mean_i += co0; p.invstd_i += co0; p.gamma_i += co0; p.stat_i += co0; }
+    p.X += ci0;
+    if (p.act.mean) { p.act.mean += ci0; p.act.invstd += ci0; p.act.gamma += ci0; p.act.beta += ci0; }
+    p.dW += (size_t)co0 * p.lddw + ci0;
+    p.Cp = min(CH, pin.Cp - ci0);
+    p.C = min(CH, pin.C - co0);
+  }
+  const int ldg = DWO ? pin.ldg : (MODE >= 0 ? CH : p.C);   // row stride of G / Yi
+  const int cstat = DWO ? pin.C : (MODE >= 0 ? CH : p.C);   // stat_i = [sum dz (whole C) | sum dz xhat]
   constexpr bool FULL = MODE >= 0;
   using SP = SplitPairs<NS>;
   constexpr int Q = CH / 4;          // 16-byte pieces per row
@@ -102,7 +124,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   constexpr int kRowB = CH * 2 + 16; // bytes per LDS image row: CH bf16 + 16 bytes of padding (see the bank notes at the W image)
   constexpr int kWimg = CH * kRowB;     // 34 KB per piece (CH 128)
   constexpr int kTimg = kTR * kRowB;    // 17 KB per piece
-  constexpr int oW = 0, oDy = NS * kWimg, oA = oDy + NS * kTimg, oMisc = oA + NS * kTimg, oCst = oMisc + 64;  // + 11 x CH column constants
+  constexpr int oW = 0, oDy = DWO ? 0 : NS * kWimg, oA = oDy + NS * kTimg, oMisc = oA + NS * kTimg, oCst = oMisc + 64;  // + 11 x CH column constants
   static_assert(2 * NS * kTimg >= kTR * CH * 4, "the dX staging tile aliases the dy / a images");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int* misc = reinterpret_cast<int*>(lds + oMisc);
@@ -115,9 +137,10 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   const int n = lane & 31, h = lane >> 5;
   const int c4 = tid % Q, cc = 4 * c4, rbase = tid / Q;  // this thread's 4 columns and its rows rbase + RPP j of every tile
   const int C = FULL ? CH : p.C, Cp = FULL ? CH : p.Cp;
-  const bool has_act = FULL || p.act.mean != nullptr;
+  const bool has_act = (FULL && !DWO) || p.act.mean != nullptr;
   const bool cok = FULL || cc < C, xok = FULL || cc < Cp;
   const int ntiles = p.ntiles, step = (int)gridDim.x;
+  static_assert(!DWO || (MODE == 0 || MODE == 1 || MODE == -1), "weight-gradient instances: dy given or formed from dz");
   const int mode = MODE >= 0 ? (MODE == 3 ? 2 : MODE) : p.mode;  // MODE 3: mode 2 behind a sum over p.gk rows (its own instance: the row
                                                                   // index division in the loads costs the plain mode 2 40 % when it is a run-time test)
 
@@ -126,15 +149,15 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   int offg[NJ], offx[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    offg[j] = (rbase + RPP * j) * C + (cok ? cc : 0);
+    offg[j] = (rbase + RPP * j) * ldg + (cok ? cc : 0);
     offx[j] = (rbase + RPP * j) * p.ldx + (xok ? cc : 0);
   }
   const int tail_rows = (int)(p.R - (int64_t)(ntiles - 1) * kTR);  // rows of the last tile: 1 .. 64
   auto load_gy_row = [&](TileRegs<NJ>& t, int tile, int j) {
-    const float* Gt = p.G + (size_t)tile * kTR * C;
-    const float* Yt = (mode != 0 ? p.Yi : p.G) + (size_t)tile * kTR * C;
+    const float* Gt = p.G + (size_t)tile * kTR * ldg;
+    const float* Yt = (mode != 0 ? p.Yi : p.G) + (size_t)tile * kTR * ldg;
     const bool clamp = tile == ntiles - 1 && tail_rows < kTR;
-    const int o = clamp ? min(rbase + RPP * j, tail_rows - 1) * C + (cok ? cc : 0) : offg[j];
+    const int o = clamp ? min(rbase + RPP * j, tail_rows - 1) * ldg + (cok ? cc : 0) : offg[j];
     if (MODE == 3 || (MODE < 0 && mode == 2 && p.gk > 1)) {  // the gradient of the pooled output: one row of G per gk rows of the layer
       const unsigned gr = ((unsigned)tile * kTR + (unsigned)(clamp ? min(rbase + RPP * j, tail_rows - 1) : rbase + RPP * j)) / (unsigned)p.gk;
       t.g[j] = *reinterpret_cast<const f32x4*>(p.G + (size_t)gr * C + (cok ? cc : 0));
@@ -168,7 +191,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   // instead of an XOR permutation keeps every LDS address of the tile loop "per-lane base + immediate".
   // A thread takes a 4 (c_out) x 4 (c_in) block: four 16-byte loads along c_in (coalesced), transposed in registers into 8-byte pieces
   // along c_out; all loads of both rounds are requested before the first is used.
-  {
+  if constexpr (!DWO) {
     constexpr int NRD = (Q * Q + kWT - 1) / kWT;  // rounds over the Q x Q blocks: 2 (CH 128) / 1 (CH 64: half of the threads)
     f32x4 wv[NRD][4];
 #pragma unroll
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
       }
     }
   }
-  if (mode != 0 && p.dgamma_i && blockIdx.x == 0)
+  if (!DWO && mode != 0 && p.dgamma_i && blockIdx.x == 0)
     for (int col = tid; col < C; col += kWT) {
       p.dbeta_i[col] = (float)p.stat_i[col];
       p.dgamma_i[col] = (float)p.stat_i[C + col];
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
         if (mode != 0 && col < C) {
           const float isd = p.invstd_i[col], gam = p.gamma_i[col];
           v = k == 0 ? p.mean_i[col] : k == 1 ? isd : k == 2 ? gam * isd : k == 3 ? (float)p.stat_i[col] * p.inv_rows
-              : k == 4 ? (float)p.stat_i[C + col] * p.inv_rows : k == 5 ? gam : (mode == 2 ? p.beta_i[col] : 0.f);
+              : k == 4 ? (float)p.stat_i[cstat + col] * p.inv_rows : k == 5 ? gam : (mode == 2 ? p.beta_i[col] : 0.f);
         }
       } else if (has_act && col < Cp) {
         v = k == 7 ? p.act.mean[col] : k == 8 ? p.act.invstd[col] : k == 9 ? p.act.gamma[col] : p.act.beta[col];
@@ -419,6 +442,13 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (DWO) {  // nothing else to do with this tile: the images are free again once every wave has read them
+      __syncthreads();
+      cur = nxt;
+      nxt = after;
+      ++it;
+      continue;
+    }
     // ---- P2a: dX[32 rb .. +31][32 cb .. +31] = sum over c_out of dy . W   (CH / 16 steps of 16 c_out)
     f32x16 accz;
 #pragma unroll
@@ -495,7 +525,7 @@ __global__ __launch_bounds__(kWT, 2) void mlp_bwd_wide_kernel(WideArgs p) {
   }
 
   // ---- column sums of dz_{i-1}: RPP threads per column quadruple -> LDS -> one fp64 atomic per column and workgroup
-  if (p.stat_prev) {
+  if (!DWO && p.stat_prev) {
     double* sred = reinterpret_cast<double*>(lds);  // [2][RPP][CH] = 32 KB from the start of the allocation (every image is dead: the loop ended on a barrier)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -649,6 +679,49 @@ MVP_API int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float
     rc = mvp_launch_status();
   }
   return rc;
+}
+
+// Weight gradient of a wide layer through the DWO instances (see the kernel): dW (C, lddw)[:, :Cp] += dy^T . act(X), dy = G (Yi == nullptr) or
+// formed from dz = G while it is loaded (Yi, mean, invstd, gamma, stat, inv_rows: the finish of mvp_bn_rows_backward_finish_f32).  Called by
+// weight_grad_impl (mlp.hip) for the shapes it is built for; MVP_EUNSUPPORTED = the caller keeps mlp_dw_bf_kernel.
+int mlp_dw_wide_launch(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i, const double* stat_i,
+                       float inv_rows, const float* X, int64_t ldx, const float* act_mean, const float* act_invstd, const float* act_gamma,
+                       const float* act_beta, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, int ns, hipStream_t s) {
+  static const int64_t min_rows = []() { const char* e = getenv("MVP_DW_WIDE_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();  // (<0: never)
+  if (min_rows < 0 || R < min_rows || (ns != 1 && ns != 2) || C % kWCh || Cp % kWCh || ldx % 4 || R >= (1ll << 31) * kTR ||
+      ((uintptr_t)G | (uintptr_t)X | (uintptr_t)Yi) % 16)
+    return MVP_EUNSUPPORTED;
+  WideArgs a{};
+  a.G = G; a.Yi = Yi; a.mean_i = mean_i; a.invstd_i = invstd_i; a.gamma_i = gamma_i; a.beta_i = nullptr; a.stat_i = stat_i;
+  a.dgamma_i = nullptr; a.dbeta_i = nullptr;
+  a.inv_rows = inv_rows;
+  a.mode = Yi ? 1 : 0; a.gk = 1; a.drop = Dropout{0u, 0u, 1.0f};
+  a.X = X; a.ldx = (int)ldx; a.act = InAct{act_mean, act_invstd, act_gamma, act_beta};
+  a.W = nullptr; a.ldw = 0; a.dW = dW; a.lddw = (int)lddw; a.ws = nullptr; a.dZ = nullptr; a.stat_prev = nullptr; a.ticket = nullptr;
+  a.R = R; a.C = (int)C; a.Cp = (int)Cp; a.ntiles = (int)cdiv(R, kTR);
+  a.ldg = (int)C; a.nbb = (int)(Cp / kWCh);
+  static const int cus = []() {
+    int n = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n > 0 ? n : 256;
+  }();
+  const int nblk = (int)((C / kWCh) * (Cp / kWCh));
+  // one workgroup per CU in all (two images of 34 KB per operand + the column constants: 74 KB of LDS, 256 registers at two waves per SIMD);
+  // every workgroup closes with one atomic per element of its block, so a block's workgroups are also bounded by what those cost
+  const int gx = std::max(1, std::min(a.ntiles, std::max(cus / nblk, 8)));
+  const size_t row_b = (size_t)kWCh * 2 + 16;
+  const size_t ldsz = (size_t)ns * 2 * kTR * row_b + 64 + 11 * (size_t)kWCh * 4;
+#define MVP_DWO_LAUNCH(NS_, MODE_)                                                                                              \
+  do {                                                                                                                          \
+    auto k = mlp_bwd_wide_kernel<NS_, MODE_, kWCh, true>;                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz); \
+    if (e != hipSuccess) { (void)hipGetLastError(); return MVP_EUNSUPPORTED; }                                                    \
+    hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)nblk), dim3(kWT), ldsz, s, a);                                            \
+  } while (0)
+  if (ns == 1) { if (a.mode) MVP_DWO_LAUNCH(1, 1); else MVP_DWO_LAUNCH(1, 0); }
+  else { if (a.mode) MVP_DWO_LAUNCH(2, 1); else MVP_DWO_LAUNCH(2, 0); }
+#undef MVP_DWO_LAUNCH
+  return mvp_launch_status();
 }
 
 #ifdef MVP_WIDE_PROF

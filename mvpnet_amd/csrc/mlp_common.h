@@ -17,6 +17,11 @@ static inline int mlp_fwd_pieces() { return mlp_terms() == 1 ? 1 : mlp_terms() =
 // pieces per operand of the backward contractions: 0 (fp32 MFMA) when the forward runs fp32, else from the backward setting
 static inline int mlp_bwd_pieces() { return mlp_terms() == 0 ? 0 : (mlp_terms_bwd() == 6 ? 3 : mlp_terms_bwd() == 1 ? 1 : 2); }
 
+// mlp_bwd_wide.hip: the weight gradient of a wide layer with the row tile staged in LDS (see there); MVP_EUNSUPPORTED = not a shape it is built for
+int mlp_dw_wide_launch(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i, const double* stat_i,
+                       float inv_rows, const float* X, int64_t ldx, const float* act_mean, const float* act_invstd, const float* act_gamma,
+                       const float* act_beta, int64_t R, int64_t C, int64_t Cp, float* dW, int64_t lddw, int ns, hipStream_t s);
+
 namespace {
 
 struct InAct {  // previous layer's BatchNorm + ReLU, per input column (may be null = identity)

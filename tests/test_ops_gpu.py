@@ -888,7 +888,9 @@ def mlp_precision(request):
 
 @pytest.mark.parametrize('R,Cin,ldx,Cout', [(1000, 68, 68, 32), (4096, 64, 64, 64), (777, 131, 132, 128), (300, 259, 260, 256),
                                             (129, 768, 768, 256), (5000, 32, 32, 20), (64, 3, 4, 32), (1, 128, 128, 512),
-                                            (70001, 64, 64, 128), (140000, 32, 32, 64), (33000, 128, 128, 256), (40000, 320, 320, 256)])
+                                            (70001, 64, 64, 128), (140000, 32, 32, 64), (33000, 128, 128, 256), (40000, 320, 320, 256),
+                                            # (weight gradient through the LDS-tile kernel: multiples of 128 on both sides, >= 16384 rows)
+                                            (16500, 256, 256, 512), (70001, 256, 260, 256), (131072, 128, 128, 256)])
 def test_mlp_kernels_vs_torch(dev, R, Cin, ldx, Cout, mlp_precision):
     """mvp_mlp_forward / weight_grad / input_grad vs a float64 torch matmul on awkward shapes -- rows not a multiple of 128, K not a
     multiple of 32, padded leading dimension, Cout not a multiple of 32 -- and on shapes large enough for the 128-column tiles,
@@ -1762,7 +1764,9 @@ def test_fps_rounds_kernel_odd_sizes(dev, N, M):
     np.testing.assert_array_equal(idx, O().fps(pts, M))
 
 
-@pytest.mark.parametrize('R,Cout,Cin', [(70001, 64, 64), (5000, 64, 4), (33000, 128, 96), (900, 64, 64)])
+@pytest.mark.parametrize('R,Cout,Cin', [(70001, 64, 64), (5000, 64, 4), (33000, 128, 96), (900, 64, 64),
+                                        # multiples of 128 on both sides over >= 16384 rows: the LDS-tile weight gradient (mlp_bwd_wide.hip, DWO instances)
+                                        (33000, 256, 128), (20001, 128, 256), (16384, 512, 256)])
 @pytest.mark.parametrize('training', [1, 0])
 @pytest.mark.parametrize('bwd', ['bf16x3', 'bf16'])
 def test_weight_gradient_with_the_finish_on_load(dev, R, Cout, Cin, training, bwd):
