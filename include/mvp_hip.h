@@ -606,6 +606,29 @@ int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float* Yi, co
 int mvp_mlp_weight_grad_finish_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma, const double* stat,
                                      int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, float* dW, int64_t lddw,
                                      float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
+/* The same with X = the previous layer's PRE-BN output and its BatchNorm + ReLU applied while it is loaded (act_*: as mvp_mlp_weight_grad_f32, all
+ * NULL = X plain): the weight gradient of an INNER layer whose finish pass is skipped (round 6: the 256- / 512-wide layers, whose input gradient
+ * forms dy on load as well -- mvp_mlp_input_grad_wide_p_f32).  Same support matrix as above; an activation needs the split-bf16 kernel (Cin >= 33). */
+int mvp_mlp_weight_grad_finish_act_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma, const double* stat,
+                                         int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, const float* act_mean,
+                                         const float* act_invstd, const float* act_gamma, const float* act_beta, float* dW, int64_t lddw,
+                                         float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
+/* Input gradient of a WIDE shared-MLP layer i (C = 64 .. 512 output channels in multiples of 64, Cp input channels in multiples of 128) in one
+ * pass (round 6, csrc/mlp_dx_wide.hip; replaces, for the 256- / 512-wide layers of mvpnet/models/pn2/pn2ssg.py:26,30,69-82, the BatchNorm-backward
+ * finish pass + mvp_mlp_input_grad_f32 + its reduction launch; autograd through common/nn/modules/conv.py:41-51):
+ *   dZ (R,Cp) = (dy_i . W) * [ bn(y_{i-1}) > 0 ],  stat_prev (2 Cp, accumulated into) += [sum dZ | sum dZ * xhat_{i-1}],
+ * with dy_i = G (Yi == NULL) or formed from dz_i = G while it is loaded (Yi, mean_i, invstd_i, gamma_i, stat_i, training: as
+ * mvp_mlp_weight_grad_finish_p_f32; dgamma_i / dbeta_i (may be NULL) <- the two halves of stat_i).  X (R,ldx) = y_{i-1} with the BatchNorm of
+ * layer i-1 in act_* (required).  W (C,ldw) is read through a pre-split bf16 image that the call writes into `workspace` first
+ * (mvp_mlp_input_grad_wide_workspace_bytes(C, Cp) bytes, 16-byte aligned, contents irrelevant, not kept).  One- or two-piece backward split,
+ * 16-byte aligned G / Yi / X / dZ, ldx % 4 == 0; MVP_EUNSUPPORTED otherwise (the caller keeps the per-layer kernels).  No dW: the weight
+ * gradient of such a layer is its own launch (mvp_mlp_weight_grad_f32 / mvp_mlp_weight_grad_finish_act_p_f32). */
+int64_t mvp_mlp_input_grad_wide_workspace_bytes(int64_t C, int64_t Cp);
+int mvp_mlp_input_grad_wide_p_f32(const float* G, const float* Yi, const float* mean_i, const float* invstd_i, const float* gamma_i,
+                                  const double* stat_i, float* dgamma_i, float* dbeta_i, int training, const float* X, int64_t ldx,
+                                  const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, const float* W,
+                                  int64_t ldw, int64_t R, int64_t C, int64_t Cp, float* dZ, double* stat_prev, void* workspace,
+                                  int64_t workspace_bytes, int precision, int precision_backward, mvp_stream_t stream);
 /* dW (Cout,Cin) += dY (R,Cout)^T . act(X (R,ldx)[:, :Cin]) with the same act() prologue.  lddw >= Cin = row stride of dW:
  * Cin for a dense gradient, the full weight's column count when dW points at a column slice of it. */
 int mvp_mlp_weight_grad_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,

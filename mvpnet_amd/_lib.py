@@ -143,7 +143,11 @@ _SIGNATURES['mvp_mlp_layer_backward_wide_p_f32'] = [_ptr] * 9 + [ctypes.c_int, c
 _SIGNATURES['mvp_mlp_layer_backward_wide_pooled_p_f32'] = [_ptr] * 9 + [ctypes.c_int, ctypes.c_int, _i64, _f32, ctypes.c_uint64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
                                                            _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
 _SIGNATURES['mvp_mlp_weight_grad_finish_p_f32'] = [_ptr] * 6 + [ctypes.c_int, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
-EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_ball_query_grid_workspace', 'mvp_knn3_grid_workspace', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
+_SIGNATURES['mvp_mlp_weight_grad_finish_act_p_f32'] = [_ptr] * 6 + [ctypes.c_int, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, ctypes.c_int,
+                                                        ctypes.c_int, _ptr]
+_SIGNATURES['mvp_mlp_input_grad_wide_p_f32'] = [_ptr] * 8 + [ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64,
+                                                 ctypes.c_int, ctypes.c_int, _ptr]
+EXPORTS = ['mvp_version', 'mvp_strerror', 'mvp_lift_workspace_bytes', 'mvp_ball_query_grid_workspace', 'mvp_knn3_grid_workspace', 'mvp_mlp_weight_grad_workspace_floats', 'mvp_mlp_input_grad_wide_workspace_bytes', 'mvp_group_lin_partial_count', 'mvp_colstats_partial_count',
            'mvp_set_mlp_precision', 'mvp_get_mlp_precision', 'mvp_mlp_layer_backward_partial_count', 'mvp_set_mlp_stream', 'mvp_set_mlp_precision_backward', 'mvp_get_mlp_precision_backward', 'mvp_mlp_precision_scope', 'mvp_set_fps_mode', 'mvp_fps_debug_spin_limit', 'mvp_fps_last_kernel'] + sorted(_SIGNATURES)
 
 
@@ -168,6 +172,8 @@ def lib():
         handle.mvp_group_lin_partial_count.argtypes = [_i64, _i64, _i64, _i64]
         handle.mvp_mlp_weight_grad_workspace_floats.restype = ctypes.c_int64
         handle.mvp_mlp_weight_grad_workspace_floats.argtypes = []
+        handle.mvp_mlp_input_grad_wide_workspace_bytes.restype = ctypes.c_int64
+        handle.mvp_mlp_input_grad_wide_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
         handle.mvp_colstats_partial_count.restype = ctypes.c_int64
         handle.mvp_colstats_partial_count.argtypes = [_i64, _i64]
         handle.mvp_set_mlp_precision.restype = ctypes.c_int

@@ -1263,6 +1263,29 @@ MVP_API int mvp_mlp_weight_grad_finish_p_f32(const float* dZ, const float* Y, co
   return rc;
 }
 
+MVP_API int mvp_mlp_weight_grad_finish_act_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                                                 const double* stat, int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                                                 const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
+                                                 float* dW, int64_t lddw, float* workspace, int64_t workspace_floats, int precision,
+                                                 int precision_backward, mvp_stream_t stream) {
+  MVP_NONNULL(Y);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(stat);
+  MVP_REQUIRE((precision == -1 || precision == 0 || precision == 1 || precision == 3 || precision == 6) &&
+              (precision_backward == -1 || precision_backward == 1 || precision_backward == 3 || precision_backward == 6));
+  if (Cout % 4 != 0 || Cout <= 32 || ((uintptr_t)dZ | (uintptr_t)Y) % 16 != 0 || (act_mean && Cin <= 32)) return MVP_EUNSUPPORTED;
+  const int old_terms = tl_mlp_terms, old_bwd = tl_mlp_terms_bwd;
+  if (precision >= 0) tl_mlp_terms = precision;
+  if (precision_backward >= 0) tl_mlp_terms_bwd = precision_backward;
+  const DyFinish fin{Y, mean, invstd, gamma, stat, (training && R > 0) ? 1.0f / (float)R : 0.f};
+  const int rc = weight_grad_impl(dZ, X, R, Cout, Cin, ldx, act_mean, act_invstd, act_gamma, act_beta, dW, lddw, workspace, workspace_floats, stream, &fin);
+  tl_mlp_terms = old_terms;
+  tl_mlp_terms_bwd = old_bwd;
+  return rc;
+}
+
 // d(input) of a layer, fused with the first half of the previous layer's BatchNorm+ReLU backward:
 //   dZ (R,Cin) = (dY (R,Cout) . W) * [ bn(y_prev) > 0 ],   W (Cout,Cin) = the layer's weight exactly as the forward uses it
 //   stat[0:Cin] = column sums of dZ (= d beta), stat[Cin:2Cin] = column sums of dZ * xhat (= d gamma)

@@ -41,6 +41,26 @@ WIDE_BWD_POOLED = os.environ.get('MVP_BWD_WIDE_POOLED', '1') != '0'
 WIDE_BWD_64_MIN_ROWS = int(os.environ.get('MVP_BWD_WIDE64_MIN_ROWS', '262144'))
 
 
+# Layers wider than the one-pass backward takes (256 / 512 channels: set-abstraction levels 3 - 4, propagation levels 1 - 3): the input gradient in
+# one pass with the BatchNorm-backward finish on load (mvp_mlp_input_grad_wide_p_f32, csrc/mlp_dx_wide.hip) instead of finish pass + input-gradient
+# GEMM + reduction launch, the weight gradient beside it with the same finish on load.  OFF by default: alone on the chip the one-pass form is
+# 15 - 40 % faster than the launches it replaces (profiles/r06_dx_wide_alone.txt), inside the training step it is 0.6 % SLOWER (6.295 -> 6.33 ms,
+# profiles/r06_dx_wide_step_ab.txt): a persistent workgroup per CU with 123 KB of LDS leaves no room for the kernels of the other two streams
+# (weight gradients, the next batch's geometry) that the many small workgroups of the per-layer kernels share the CUs with, and the weight image
+# costs a launch per layer.  MVP_DX_WIDE=1 switches it on (tests/test_model_gpu.py runs the network both ways).
+DX_WIDE = os.environ.get('MVP_DX_WIDE', '0') == '1'
+DX_WIDE_MIN_ROWS = int(os.environ.get('MVP_DX_WIDE_MIN_ROWS', '16384'))
+DX_WIDE_MAX_COUT = int(os.environ.get('MVP_DX_WIDE_MAXC', '512'))
+
+
+def dx_wide_ok(prec, R, cout, cin, ldx, finish):
+    """True when a layer's input gradient (R rows, cin -> cout, input row stride ldx, `finish`: its own gradient still needs the
+    BatchNorm-backward finish) takes mvp_mlp_input_grad_wide_p_f32: whole 64 x 128 weight blocks, a one- or two-piece backward split, at most
+    256 channels with a pending finish (512 without)."""
+    return bool(DX_WIDE and prec[0] != 0 and prec[1] in (1, 3) and R >= DX_WIDE_MIN_ROWS and cout % 64 == 0 and cin % 128 == 0 and ldx % 4 == 0 and
+                cout <= min(DX_WIDE_MAX_COUT, 256 if finish else 512) and max(cout, cin) >= L.mlp_min_width())
+
+
 def aligned16(*tensors):
     """True when every tensor (None allowed) starts on a 16-byte boundary: the one-pass backward and the finish-on-load weight gradient read
     whole 16-byte row pieces and answer MVP_EUNSUPPORTED otherwise (a contiguous() view keeps its storage offset) -- their callers then keep
@@ -1106,6 +1126,8 @@ class MLPChainRows(torch.autograd.Function):
                         aligned16(gcur, ys[i], src))
             fuse = wide or pool_here or (split and w is not None and cout <= FUSE_BWD_MAX_COUT and cin <= FUSE_BWD_MAX_CIN and rel is None and
                                          (not need_dz or cin % 4 == 0) and (i > 0 or src.size(1) == cin or not need_dz))
+            dxw = bool(not fuse and i > 0 and w is not None and rel is None and need_dz and not L.DW_WORKSPACE and
+                       dx_wide_ok(ctx.prec, R, cout, cin, src.size(1), pending is not None) and aligned16(gcur, ys[i], src) and w.is_contiguous())
             assert wide or not ((last_wide or last_wide_sum) and i == nl - 1)
             if pending is not None and w is None and ctx.defer is not None and ctx.defer.accepts and ctx.defer.info is None:
                 # i == 0, x0 was this layer's pre-BN output and its ONLY consumer gathers it (DeferredFinish): dz_0 goes back unfinished, the
@@ -1140,7 +1162,7 @@ class MLPChainRows(torch.autograd.Function):
                     else:
                         L.call('mvp_mlp_weight_grad_finish_p_f32', gcur, *(fargs + (ws_ptr, ws_floats) + tuple(ctx.prec)))
                 break
-            if pending is not None and not fuse:
+            if pending is not None and not fuse and not dxw:
                 # dz_i -> dy_i as its own pass (also hands back the BatchNorm parameter gradients)
                 dyi = torch.empty((R, cout), dtype=torch.float32, device=dev)
                 dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
@@ -1150,6 +1172,43 @@ class MLPChainRows(torch.autograd.Function):
                 dgam, dbet = dgb[0], dgb[1]
             if pending is None:
                 grads[3 * i + 1], grads[3 * i + 2] = dgam, dbet
+            if dxw:
+                # a 256- / 512-wide inner layer: input gradient in one pass (finish of dz_i on load when it is pending, ReLU mask + column sums of
+                # layer i - 1 in the epilogue), the weight gradient beside the chain with the same finish on load -- no finish pass, no dy_i tensor
+                act = (means[i - 1], invstds[i - 1], params[3 * i - 2], params[3 * i - 1])
+                dw = dw_arena[dw_off:dw_off + cout * cin].view(cout, cin)
+                dw_off += cout * cin
+                grads[3 * i] = dw
+                stat = st_arena[st_off:st_off + 2 * cin]
+                st_off += 2 * cin
+                dz = torch.empty((R, cin), dtype=torch.float32, device=dev)
+                fin = pending is not None
+                dgb = torch.empty((2, cout), dtype=torch.float32, device=dev) if fin else None
+                if fin:
+                    wg_name = 'mvp_mlp_weight_grad_finish_act_p_f32'
+                    wg_args = (L.ptr(gcur), L.ptr(ys[i]), L.ptr(means[i]), L.ptr(invstds[i]), L.ptr(params[3 * i + 1]), L.ptr(pending), int(training), L.ptr(src),
+                               R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin, None, 0) + tuple(ctx.prec)
+                    wg_keep = (gcur, ys[i], means[i], invstds[i], params[3 * i + 1], pending, src, dw) + act
+                    if dw_aside:
+                        side_stream.run(dev, wg_name, wg_args, wg_keep)
+                    else:
+                        L.call(wg_name, gcur, *wg_args)
+                else:
+                    wg_args = (L.ptr(gcur), L.ptr(src), R, cout, cin, src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]), L.ptr(dw), cin)
+                    if dw_aside:
+                        side_stream.run(dev, 'mvp_mlp_weight_grad_f32', wg_args, (gcur, src, dw) + act, prec=ctx.prec)
+                    else:
+                        L.call('mvp_mlp_weight_grad_f32', gcur, *wg_args, prec=ctx.prec)
+                nbytes = int(L.lib().mvp_mlp_input_grad_wide_workspace_bytes(cout, cin))
+                wimg = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                L.call('mvp_mlp_input_grad_wide_f32', gcur, L.ptr(gcur), L.ptr(ys[i]) if fin else None, L.ptr(means[i]) if fin else None,
+                       L.ptr(invstds[i]) if fin else None, L.ptr(params[3 * i + 1]) if fin else None, L.ptr(pending), L.ptr(None if dgb is None else dgb[0]),
+                       L.ptr(None if dgb is None else dgb[1]), int(training), L.ptr(src), src.size(1), L.ptr(act[0]), L.ptr(act[1]), L.ptr(act[2]), L.ptr(act[3]),
+                       L.ptr(w), cin, R, cout, cin, L.ptr(dz), L.ptr(stat), L.ptr(wimg), nbytes, prec=ctx.prec)
+                if fin:
+                    grads[3 * i + 1], grads[3 * i + 2] = dgb[0], dgb[1]
+                gcur, pending = dz, stat
+                continue
             if w is None:  # i == 0: x0 was this layer's pre-BN output, its gradient is dy itself
                 dx0 = gcur
                 break

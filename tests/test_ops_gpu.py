@@ -2582,3 +2582,77 @@ def test_training_level_with_empty_ball_slots_and_a_missing_transposed_index(dev
         assert rel(gp1[k], gp0[k]) <= 2e-5, (k, rel(gp1[k], gp0[k]))
     for k in b0:
         np.testing.assert_allclose(b1[k].float().cpu().numpy(), b0[k].float().cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('R,C,Cp,ldx', [(33000, 256, 128, 128), (20001, 128, 256, 256), (16384, 512, 256, 256), (65, 256, 256, 260), (64, 64, 128, 128),
+                                        (4100, 192, 128, 128), (131072, 256, 128, 128), (1, 256, 256, 256)])
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_mlp_input_grad_wide(dev, R, C, Cp, ldx, precision):
+    """mvp_mlp_input_grad_wide_p_f32 (csrc/mlp_dx_wide.hip: the input gradient of a 256- / 512-wide layer with persistent workgroups, 64-row tiles,
+    the weight read per tile from a pre-split image in 64 x 128 blocks) against a float64 evaluation of what it fuses (autograd through
+    common/nn/modules/conv.py:41-51): the BatchNorm-backward finish of layer i on load (mode 1) or a given dy_i (mode 0), dz_{i-1} with the ReLU
+    mask of layer i-1 and its two column sums; row counts that are not multiples of the 64-row tile, two / three / four / eight weight blocks
+    (resident and streamed), one and two c_in blocks, a row stride wider than the layer; and the weight gradient that goes with it
+    (mvp_mlp_weight_grad_finish_act_p_f32: finish AND the previous layer's activation on load) against float64 as well."""
+    from mvpnet_amd import _lib as L
+    prec = (L.MLP_PRECISIONS['bf16' if precision == 'bf16' else 'bf16x6'], L.MLP_PRECISIONS[precision])
+    loose = {'bf16x3': 16.0, 'bf16': 4096.0}[precision]
+    hi = torch.float64
+    torch.manual_seed(R + C + Cp)
+    w = torch.randn(C, Cp, device=dev) * 0.2
+    x = torch.randn(R, ldx, device=dev)
+    gsrc = torch.randn(R, C, device=dev)
+    yi = torch.randn(R, C, device=dev) * 1.5 + 0.2
+    mean_i, invstd_i, gamma_i = torch.randn(C, device=dev) * 0.3, torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5
+    stat_i = torch.randn(2 * C, device=dev, dtype=hi) * R * 0.01
+    pm, pi = torch.randn(Cp, device=dev) * 0.3, torch.rand(Cp, device=dev) + 0.5
+    pg, pb = torch.rand(Cp, device=dev) + 0.5, torch.randn(Cp, device=dev) * 0.2
+    nbytes = int(L.lib().mvp_mlp_input_grad_wide_workspace_bytes(C, Cp))
+    assert nbytes >= C * Cp * 4
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    xh_i = (yi.to(hi) - mean_i.to(hi)) * invstd_i.to(hi)
+    f32 = lambda t: t.detach().cpu().numpy().astype(np.float32)
+    # the ReLU mask is a DECISION: taken as the kernel takes it, in float32 with its operation order
+    mask_prev = torch.from_numpy((((f32(x[:, :Cp]) - f32(pm)) * f32(pi)) * f32(pg) + f32(pb)) > 0).to(dev)
+    xh = (x[:, :Cp].to(hi) - pm.to(hi)) * pi.to(hi)
+    a_prev = torch.relu(xh * pg.to(hi) + pb.to(hi))
+    for mode in (0, 1):
+        if mode == 1 and C > 256:   # (the finish on load keeps y_i beside dz_i in registers: up to 256 channels; refused, see the end of the test)
+            continue
+        for training in ((1, 0) if mode else (1,)):
+            inv = 1.0 / R if training else 0.0
+            dy = gsrc.to(hi) if mode == 0 else (gamma_i.to(hi) * invstd_i.to(hi)) * ((gsrc.to(hi) - stat_i[:C] * inv) - xh_i * (stat_i[C:] * inv))
+            ref_dz = torch.where(mask_prev, dy @ w.to(hi), torch.zeros(R, Cp, dtype=hi, device=dev))
+            dz = torch.full((R, Cp), float('nan'), device=dev)
+            stat = torch.zeros(2 * Cp, dtype=hi, device=dev)
+            dgb = torch.full((2, C), float('nan'), device=dev)
+            L.call('mvp_mlp_input_grad_wide_f32', gsrc, L.ptr(gsrc), L.ptr(yi) if mode else None, L.ptr(mean_i) if mode else None, L.ptr(invstd_i) if mode else None,
+                   L.ptr(gamma_i) if mode else None, L.ptr(stat_i) if mode else None, L.ptr(dgb[0]) if mode else None, L.ptr(dgb[1]) if mode else None, training,
+                   L.ptr(x), ldx, L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(w), Cp, R, C, Cp, L.ptr(dz), L.ptr(stat), L.ptr(ws), nbytes, prec=prec)
+            tag = 'mode={} training={}'.format(mode, training)
+            if mode:
+                np.testing.assert_array_equal(dgb[0].cpu().numpy(), stat_i[C:].float().cpu().numpy())
+                np.testing.assert_array_equal(dgb[1].cpu().numpy(), stat_i[:C].float().cpu().numpy())
+            sz = max(1.0, float(ref_dz.abs().max()))
+            np.testing.assert_allclose(dz.cpu().numpy(), ref_dz.cpu().numpy(), rtol=1e-5 * loose, atol=2e-5 * sz * loose, err_msg=tag)
+            big = max(1.0, R / 5000.0)
+            np.testing.assert_allclose(stat[:Cp].cpu().numpy(), ref_dz.sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
+            np.testing.assert_allclose(stat[Cp:].cpu().numpy(), (ref_dz * xh).sum(0).cpu().numpy(), rtol=1e-5 * loose, atol=2e-3 * loose * big * sz, err_msg=tag)
+            if mode:   # the weight gradient beside it: finish and activation on load
+                dw = torch.zeros(C, Cp + 4, device=dev)
+                L.call('mvp_mlp_weight_grad_finish_act_f32', gsrc, L.ptr(gsrc), L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(stat_i), training,
+                       L.ptr(x), R, C, Cp, ldx, L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(dw), Cp + 4, None, 0, prec=prec)
+                ref_dw = dy.t() @ a_prev
+                sw = max(1.0, float(ref_dw.abs().max()))
+                np.testing.assert_allclose(dw[:, :Cp].cpu().numpy(), ref_dw.cpu().numpy(), rtol=1e-4 * loose, atol=3e-5 * sw * loose, err_msg=tag)
+                assert float(dw[:, Cp:].abs().max()) == 0.0, tag
+    # what the entry point refuses (callers then keep the finish pass + mvp_mlp_input_grad_f32)
+    bad = L.lib().mvp_mlp_input_grad_wide_p_f32
+    args = lambda Cx, Cpx, p1, xp: (L.ptr(gsrc), None, None, None, None, None, None, None, 1, xp, ldx, L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(w), Cpx,
+                                     R, Cx, Cpx, L.ptr(dz), L.ptr(stat), L.ptr(ws), nbytes, 6, p1, None)
+    assert bad(*args(C, Cp, 6, L.ptr(x))) != 0                       # three-piece backward split
+    assert bad(*args(C - 32, Cp, 3, L.ptr(x))) != 0 and bad(*args(C, Cp - 64, 3, L.ptr(x))) != 0   # not whole weight blocks
+    assert bad(*args(C, Cp, 3, L.ptr(x) + 4)) != 0                   # unaligned rows
+    if C > 256:   # a pending finish at more than 256 channels
+        assert bad(L.ptr(gsrc), L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(stat_i), None, None, 1, L.ptr(x), ldx, L.ptr(pm), L.ptr(pi),
+                   L.ptr(pg), L.ptr(pb), L.ptr(w), Cp, R, C, Cp, L.ptr(dz), L.ptr(stat), L.ptr(ws), nbytes, 6, 3, None) != 0
