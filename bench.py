@@ -107,7 +107,7 @@ class TimedLifting:
         return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else float('nan')
 
 
-TRAFFIC_FILES = ('r05_step_traffic.json', 'r04_step_traffic.json', 'r03_step_traffic.json')  # the newest committed PMC table of the step
+TRAFFIC_FILES = ('r06_step_traffic.json', 'r05_step_traffic.json', 'r04_step_traffic.json', 'r03_step_traffic.json')  # the newest committed PMC table of the step
 
 
 def lift_traffic(batch):
@@ -283,7 +283,7 @@ def parity_info():
            'train_mode_logit_bar': '3e-4 vs the reference fp32 fixture AND max |gpu - f64| <= 1.5 x max |reference fp32 - f64| (25 batch-statistics BatchNorms: the '
                                    'reference fp32 path itself is ~2.7e-4 from the float64 value of its graph, so 1e-4 against it is not attainable by any fp32 implementation)',
            'index_ops': 'bit-exact (FPS, ball query, 3-NN, pixel k-NN)'}
-    for name in ('r05_operating_point_B32.json', 'r04_operating_point_B32.json', 'r03_operating_point_B32.json', 'r02_operating_point_B8_bf16x6_bwd_bf16x3.json'):
+    for name in ('r06_operating_point_B32.json', 'r05_operating_point_B32.json', 'r04_operating_point_B32.json', 'r03_operating_point_B32.json', 'r02_operating_point_B8_bf16x6_bwd_bf16x3.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             with open(path) as f:

@@ -16,7 +16,7 @@ def timed(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for R, C, Cp, tag in [(131072, 256, 128, 'SA3 L3'), (32768, 512, 256, 'SA4 L3'), (32768, 256, 256, 'SA4 L2'), (65536, 128, 256, 'FP3 L2'), (16384, 256, 256, 'FP2 L2')]:
+for R, C, Cp, tag in [(131072, 256, 128, 'SA3 L3'), (32768, 256, 256, 'SA4 L2'), (65536, 128, 256, 'FP3 L2'), (16384, 256, 256, 'FP2 L2')]:
     g = torch.randn(R, C, device=dev); y = torch.randn(R, C, device=dev); x = torch.randn(R, Cp, device=dev); w = torch.randn(C, Cp, device=dev) * 0.1
     m, i = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     pm, pi = torch.zeros(Cp, device=dev), torch.ones(Cp, device=dev)
