@@ -606,6 +606,13 @@ int mvp_mlp_layer_backward_wide_pooled_p_f32(const float* G, const float* Yi, co
 int mvp_mlp_weight_grad_finish_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma, const double* stat,
                                      int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, float* dW, int64_t lddw,
                                      float* workspace, int64_t workspace_floats, int precision, int precision_backward, mvp_stream_t stream);
+/* The same for a FIRST layer over [X (R,Cin) | REL (R,4)] in ONE launch (round 6): dW (Cout,lddw)[:, :Cin] += dy^T . X and dWrel (Cout,lddw)[:, :4] += dy^T . REL
+ * -- FeatureAggregation's first conv over cat[feature, src - tgt, |src - tgt|^2] (mvpnet/models/mvpnet_3d.py:55-58), whose weight gradient was two
+ * launches that each streamed dZ and Y (the last, exposed kernels of the backward pass).  33 <= Cin <= 64, 33 <= Cout, one- or two-piece backward
+ * split, fp32 atomics only (the reproducible mode keeps the two launches); MVP_EUNSUPPORTED otherwise. */
+int mvp_mlp_weight_grad_finish_rel_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma, const double* stat,
+                                         int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, const float* REL, float* dW,
+                                         float* dWrel, int64_t lddw, int precision, int precision_backward, mvp_stream_t stream);
 /* The same with X = the previous layer's PRE-BN output and its BatchNorm + ReLU applied while it is loaded (act_*: as mvp_mlp_weight_grad_f32, all
  * NULL = X plain): the weight gradient of an INNER layer whose finish pass is skipped (round 6: the 256- / 512-wide layers, whose input gradient
  * forms dy on load as well -- mvp_mlp_input_grad_wide_p_f32).  Same support matrix as above; an activation needs the split-bf16 kernel (Cin >= 33). */

@@ -143,6 +143,7 @@ _SIGNATURES['mvp_mlp_layer_backward_wide_p_f32'] = [_ptr] * 9 + [ctypes.c_int, c
 _SIGNATURES['mvp_mlp_layer_backward_wide_pooled_p_f32'] = [_ptr] * 9 + [ctypes.c_int, ctypes.c_int, _i64, _f32, ctypes.c_uint64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
                                                            _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
 _SIGNATURES['mvp_mlp_weight_grad_finish_p_f32'] = [_ptr] * 6 + [ctypes.c_int, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
+_SIGNATURES['mvp_mlp_weight_grad_finish_rel_p_f32'] = [_ptr] * 6 + [ctypes.c_int, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, ctypes.c_int, ctypes.c_int, _ptr]
 _SIGNATURES['mvp_mlp_weight_grad_finish_act_p_f32'] = [_ptr] * 6 + [ctypes.c_int, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, ctypes.c_int,
                                                         ctypes.c_int, _ptr]
 _SIGNATURES['mvp_mlp_input_grad_wide_p_f32'] = [_ptr] * 8 + [ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64,

@@ -743,12 +743,17 @@ __global__ __launch_bounds__(kMT) void mlp_dw_kernel(const float* __restrict__ d
 // its next step are in flight under the MFMAs of the current one.  The four partial tiles meet in LDS (two rounds), one fp32
 // atomic per element and workgroup.
 // ---------------------------------------------------------------------------------------------------
-template <int TMB, int TNB, int NS, bool FIN = false>
+// REL: four EXTRA operand columns X2 (R, 4) whose gradient goes to dW2 (Cout, lddw)[:, :4] -- FeatureAggregation's relation columns beside its
+// 64 feature columns (mvpnet_3d.py:55-58): one more 32-column B block (28 of them zero) per step instead of a second launch that streams dY
+// (and, with FIN, Y) again; one c_in tile only (gridDim.y == 1).
+template <int TMB, int TNB, int NS, bool FIN = false, bool REL = false>
 __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t R,
                                                         int Cout, int Cin, int ldx, InAct act, int64_t rows_per_block,
-                                                        float* __restrict__ dW, int lddw, float* __restrict__ ws, DyFinish fin = DyFinish{}) {
+                                                        float* __restrict__ dW, int lddw, float* __restrict__ ws, DyFinish fin = DyFinish{},
+                                                        const float* __restrict__ X2 = nullptr, float* __restrict__ dW2 = nullptr) {
   using SP = SplitPairs<NS>;
-  __shared__ float red[2][TMB * TNB * 16 * 64];
+  constexpr int NRB = REL ? TMB : 0;   // extra accumulator blocks
+  __shared__ float red[2][(TMB * TNB + NRB) * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, g = lane >> 5;
   const int co0 = blockIdx.x * (32 * TMB), ci0 = blockIdx.y * (32 * TNB);
@@ -761,6 +766,11 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
     for (int b = 0; b < TNB; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  f32x16 accr[REL ? TMB : 1];
+#pragma unroll
+  for (int a = 0; a < (REL ? TMB : 1); ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accr[a][i] = 0.f;
   // this lane's columns: fixed for the whole kernel, so the activation parameters live in registers
   int dcol[TMB], xcol[TNB];
   bool dok[TMB], xok[TNB];
@@ -784,6 +794,7 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
     }
   }
   float dn[TMB][8], xn[TNB][8];  // raw values of the NEXT step
+  float rn[REL ? 8 : 1];          // (REL) column c < 4 of X2
   float yn[FIN ? TMB : 1][8];
   float fmu[TMB], fis[TMB], fsc[TMB], fdb[TMB], fdg[TMB];  // (FIN) per lane: its dY columns never change (arithmetic of bn_rows_bwd_kernel, rows.hip)
   if constexpr (FIN) {
@@ -808,9 +819,10 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
       for (int a = 0; a < TMB; ++a) dn[a][p] = dY[(size_t)r * Cout + dcol[a]];
 #pragma unroll
       for (int b = 0; b < TNB; ++b) xn[b][p] = X[(size_t)r * ldx + xcol[b]];
+      if constexpr (REL) rn[p] = X2[(size_t)r * 4 + (c & 3)];
     }
   };
-  u32x4 fa[TMB][NS], fb[TNB][NS];
+  u32x4 fa[TMB][NS], fb[TNB][NS], fbr[REL ? NS : 1];
   auto prepare = [&](int64_t r0) {  // mask, activate, split -> fragments of the CURRENT step
     bool rok[8];
 #pragma unroll
@@ -851,6 +863,16 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
 #pragma unroll
       for (int pc = 0; pc < NS; ++pc) fb[b][pc] = u32x4{q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
     }
+    if constexpr (REL) {
+      float v[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) v[p] = (rok[p] && c < 4) ? rn[p] : 0.f;
+      unsigned q[4][NS];
+#pragma unroll
+      for (int h2 = 0; h2 < 4; ++h2) split_pair<NS>(v[2 * h2], v[2 * h2 + 1], q[h2]);
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) fbr[pc] = u32x4{q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
+    }
   };
   // steps of 16 rows; wave w takes steps w, w + 4, ...
   int64_t r0 = r_begin + (int64_t)wave * 16;
@@ -868,6 +890,14 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
         for (int b = 0; b < TNB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a][SP::A[q]]),
                                                              __builtin_bit_cast(bf16x8, fb[b][SP::B[q]]), acc[a][b], 0, 0, 0);
+    if constexpr (REL) {
+#pragma unroll
+      for (int q = 0; q < SP::N; ++q)
+#pragma unroll
+        for (int a = 0; a < TMB; ++a)
+          accr[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a][SP::A[q]]), __builtin_bit_cast(bf16x8, fbr[SP::B[q]]),
+                                                           accr[a], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -880,6 +910,12 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
       for (int b = 0; b < TNB; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) red[slot][((a * TNB + b) * 16 + i) * 64 + lane] = acc[a][b][i];
+    if constexpr (REL) {
+#pragma unroll
+      for (int a = 0; a < TMB; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[slot][((TMB * TNB + a) * 16 + i) * 64 + lane] = accr[a][i];
+    }
   };
   auto absorb = [&](int slot) {
 #pragma unroll
@@ -888,8 +924,15 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
       for (int b = 0; b < TNB; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][b][i] += red[slot][((a * TNB + b) * 16 + i) * 64 + lane];
+    if constexpr (REL) {
+#pragma unroll
+      for (int a = 0; a < TMB; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accr[a][i] += red[slot][((TMB * TNB + a) * 16 + i) * 64 + lane];
+    }
   };
   static_assert(NBLK <= 4, "tile");
+  static_assert(!REL || sizeof(red) <= 64 * 1024, "LDS");
   if (wave >= 2) publish(wave - 2);
   __syncthreads();
   if (wave < 2) absorb(wave);
@@ -923,6 +966,15 @@ __global__ __launch_bounds__(kMT) void mlp_dw_bf_kernel(const float* __restrict_
 #endif
         }
       }
+    if constexpr (REL) {
+#pragma unroll
+      for (int a = 0; a < TMB; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = co0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * g;
+          if (co < Cout && c < 4) atomicAdd(dW2 + (size_t)co * lddw + c, accr[a][i]);
+        }
+    }
   }
 }
 
@@ -1261,6 +1313,50 @@ MVP_API int mvp_mlp_weight_grad_finish_p_f32(const float* dZ, const float* Y, co
   tl_mlp_terms = old_terms;
   tl_mlp_terms_bwd = old_bwd;
   return rc;
+}
+
+// The finish-on-load weight gradient of a FIRST layer over [X (R, Cin <= 64) | REL (R, 4)] in ONE launch: dW (Cout, lddw)[:, :Cin] += dy^T . X and
+// dWrel (Cout, lddw)[:, :4] += dy^T . REL (FeatureAggregation's first layer, mvpnet_3d.py:55-58: the two launches it replaces each stream dZ and Y).
+// Split-bf16 contraction with one or two backward pieces, fp32 atomics (no workspace form: the reproducible mode keeps the two launches).
+MVP_API int mvp_mlp_weight_grad_finish_rel_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                                                 const double* stat, int training, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
+                                                 const float* REL, float* dW, float* dWrel, int64_t lddw, int precision, int precision_backward,
+                                                 mvp_stream_t stream) {
+  MVP_NONNULL(dZ);
+  MVP_NONNULL(Y);
+  MVP_NONNULL(mean);
+  MVP_NONNULL(invstd);
+  MVP_NONNULL(gamma);
+  MVP_NONNULL(stat);
+  MVP_NONNULL(X);
+  MVP_NONNULL(REL);
+  MVP_NONNULL(dW);
+  MVP_NONNULL(dWrel);
+  MVP_REQUIRE(R >= 0 && Cin > 0 && Cout > 0 && ldx >= Cin && lddw >= Cin && lddw >= 4 && lddw < (1 << 24) && Cout < (1 << 20));
+  MVP_REQUIRE((precision == -1 || precision == 0 || precision == 1 || precision == 3 || precision == 6) &&
+              (precision_backward == -1 || precision_backward == 1 || precision_backward == 3 || precision_backward == 6));
+  const int terms = precision >= 0 ? precision : mlp_terms();
+  const int bwd = precision_backward >= 0 ? precision_backward : mlp_terms_bwd();
+  const int ns = terms == 0 ? 0 : (bwd == 6 ? 3 : bwd == 1 ? 1 : 2);
+  if ((ns != 1 && ns != 2) || Cout <= 32 || Cin <= 32 || Cin > 64 || std::max(Cin, Cout) < g_mlp_min_width) return MVP_EUNSUPPORTED;
+  if (R == 0) return MVP_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static const int64_t wg_target = []() { const char* e = getenv("MVP_DW_WORKGROUPS"); return e ? (int64_t)atoi(e) : (int64_t)1024; }();
+  const int64_t tiles = cdiv(Cout, 64);
+  int64_t splits = std::min<int64_t>(cdiv(wg_target, tiles), 512);
+  int64_t rows_per_block = cdiv(cdiv(R, splits), 64) * 64;
+  if (rows_per_block < 256) rows_per_block = 256;
+  splits = cdiv(R, rows_per_block);
+  const DyFinish fin{Y, mean, invstd, gamma, stat, training ? 1.0f / (float)R : 0.f};
+  const InAct act{nullptr, nullptr, nullptr, nullptr};
+  dim3 grid((unsigned)tiles, 1, (unsigned)splits);
+  if (ns == 1)
+    hipLaunchKernelGGL((mlp_dw_bf_kernel<2, 2, 1, true, true>), grid, dim3(kMT), 0, s, dZ, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW,
+                       (int)lddw, nullptr, fin, REL, dWrel);
+  else
+    hipLaunchKernelGGL((mlp_dw_bf_kernel<2, 2, 2, true, true>), grid, dim3(kMT), 0, s, dZ, X, R, (int)Cout, (int)Cin, (int)ldx, act, rows_per_block, dW,
+                       (int)lddw, nullptr, fin, REL, dWrel);
+  return mvp_launch_status();
 }
 
 MVP_API int mvp_mlp_weight_grad_finish_act_p_f32(const float* dZ, const float* Y, const float* mean, const float* invstd, const float* gamma,

@@ -311,6 +311,7 @@ weight_slices = WeightSlices()
 DW_SIDE_STREAM = os.environ.get('MVP_DW_SIDE_STREAM', '1') != '0'
 LINEAR_ASIDE = os.environ.get('MVP_LINEAR_ASIDE', '1') != '0'
 DW_FINISH_ON_LOAD = os.environ.get('MVP_DW_FINISH_ON_LOAD', '1') != '0'  # (A/B: the first layer's finish pass inside its weight-gradient launches)
+REL_DW_FUSED = os.environ.get('MVP_REL_DW_FUSED', '1') != '0'  # (A/B: FeatureAggregation's first-layer weight gradient, feature + relation columns, in ONE launch)
 REL_DW_SPLIT = os.environ.get('MVP_REL_DW_SPLIT', '1') != '0'  # (the relation columns' weight gradient on the calling stream at the end of the backward pass)  # (A/B switch: whole-weight linear layers' weight / bias gradients beside the chain)
 _EXP_SKIP_DW = os.environ.get('MVP_EXP_SKIP_DW', '0') == '1'
 
@@ -1151,6 +1152,13 @@ class MLPChainRows(torch.autograd.Function):
                 dgb0 = pending.view(2, cout).to(torch.float32)
                 grads[1], grads[2] = dgb0[1], dgb0[0]
                 ws_ptr, ws_floats = L.current_dw_workspace(dev)
+                if REL_DW_FUSED and ws_ptr is None and 32 < cin_f <= 64 and aligned16(src, rel):
+                    # ... and both column groups from ONE launch (mvp_mlp_weight_grad_finish_rel_p_f32: the relation columns as a third operand block):
+                    # the two launches below each stream dz_0 and y_0 -- 1.0 GB for what is 0.6 GB, HBM-bound, with nothing left to overlap them.
+                    # On the calling stream: nothing else is queued behind it.
+                    L.call('mvp_mlp_weight_grad_finish_rel_p_f32', gcur, L.ptr(gcur), L.ptr(ys[0]), L.ptr(means[0]), L.ptr(invstds[0]), L.ptr(params[1]),
+                           L.ptr(pending), int(training), L.ptr(src), R, cout, cin_f, cin_f, L.ptr(rel), L.ptr(dw), L.ptr_at(dw, cin_f), cin, *ctx.prec)
+                    break
                 for xs, ncol, c0 in ((src, cin_f, 0), (rel, 4, cin_f)):
                     fargs = (L.ptr(gcur), L.ptr(ys[0]), L.ptr(means[0]), L.ptr(invstds[0]), L.ptr(params[1]), L.ptr(pending), int(training), L.ptr(xs), R,
                              cout, ncol, ncol, L.ptr_at(dw, c0), cin)

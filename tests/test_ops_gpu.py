@@ -2656,3 +2656,43 @@ def test_mlp_input_grad_wide(dev, R, C, Cp, ldx, precision):
     if C > 256:   # a pending finish at more than 256 channels
         assert bad(L.ptr(gsrc), L.ptr(yi), L.ptr(mean_i), L.ptr(invstd_i), L.ptr(gamma_i), L.ptr(stat_i), None, None, 1, L.ptr(x), ldx, L.ptr(pm), L.ptr(pi),
                    L.ptr(pg), L.ptr(pb), L.ptr(w), Cp, R, C, Cp, L.ptr(dz), L.ptr(stat), L.ptr(ws), nbytes, 6, 3, None) != 0
+
+
+@pytest.mark.parametrize('R,Cout,Cin', [(70001, 64, 64), (786432, 64, 64), (900, 64, 48), (5000, 128, 64), (1, 64, 64)])
+@pytest.mark.parametrize('training', [1, 0])
+@pytest.mark.parametrize('bwd', ['bf16x3', 'bf16'])
+def test_weight_gradient_of_the_first_aggregation_layer_in_one_launch(dev, R, Cout, Cin, training, bwd):
+    """mvp_mlp_weight_grad_finish_rel_p_f32: the weight gradient of a first layer over [X | REL (R,4)] -- FeatureAggregation's conv over
+    cat[feature, src - tgt, |src - tgt|^2] (mvpnet_3d.py:55-58) -- with the BatchNorm-backward finish of dz on load, feature and relation columns from ONE
+    launch, against float64 and against the two launches it replaces (mvp_mlp_weight_grad_finish_p_f32 per column group)."""
+    from mvpnet_amd import _lib as L
+    prec = (L.MLP_PRECISIONS['bf16x6'], L.MLP_PRECISIONS[bwd])
+    hi = torch.float64
+    torch.manual_seed(R + Cout + Cin + training)
+    dz = torch.randn(R, Cout, device=dev)
+    y = torch.randn(R, Cout, device=dev) * 1.3 + 0.1
+    x = torch.randn(R, Cin, device=dev)
+    rel = torch.randn(R, 4, device=dev) * 0.3
+    mean, invstd, gamma = torch.randn(Cout, device=dev) * 0.3, torch.rand(Cout, device=dev) + 0.5, torch.rand(Cout, device=dev) + 0.5
+    xh = (y.to(hi) - mean.to(hi)) * invstd.to(hi)
+    stat = torch.cat([dz.to(hi).sum(0), (dz.to(hi) * xh).sum(0)])
+    ld = Cin + 4
+    dw = torch.zeros(Cout, ld, device=dev)
+    L.call('mvp_mlp_weight_grad_finish_rel_p_f32', dz, L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat), training, L.ptr(x), R, Cout,
+           Cin, Cin, L.ptr(rel), L.ptr(dw), L.ptr_at(dw, Cin), ld, prec[0], prec[1])
+    inv = 1.0 / R if training else 0.0
+    dyr = (gamma.to(hi) * invstd.to(hi)) * ((dz.to(hi) - stat[:Cout] * inv) - xh * (stat[Cout:] * inv))
+    ref = torch.cat([dyr.t() @ x.to(hi), dyr.t() @ rel.to(hi)], 1)
+    loose = 16.0 if bwd == 'bf16x3' else 4096.0
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4 * loose, atol=3e-5 * max(1.0, float(ref.abs().max())) * loose)
+    # the two launches (feature columns on the split-bf16 kernel, relation columns on the fp32 kernel)
+    dw2 = torch.zeros(Cout, ld, device=dev)
+    for xs, ncol, c0 in ((x, Cin, 0), (rel, 4, Cin)):
+        L.call('mvp_mlp_weight_grad_finish_p_f32', dz, L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat), training, L.ptr(xs), R, Cout,
+               ncol, ncol, L.ptr_at(dw2, c0), ld, None, 0, prec[0], prec[1])
+    np.testing.assert_allclose(dw.cpu().numpy(), dw2.cpu().numpy(), rtol=1e-4 * loose, atol=3e-5 * max(1.0, float(ref.abs().max())) * loose)
+    # refused: a three-piece split, more than 64 feature columns
+    f = L.lib().mvp_mlp_weight_grad_finish_rel_p_f32
+    args = lambda cin, p1: (L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat), training, L.ptr(x), R, Cout, cin, Cin, L.ptr(rel), L.ptr(dw),
+                            L.ptr_at(dw, Cin), ld, 6, p1, None)
+    assert f(*args(Cin, 6)) != 0 and f(*args(32, 3)) != 0
