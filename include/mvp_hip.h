@@ -524,6 +524,13 @@ int mvp_pool_backward_stats_f32(const float* dout, const float* out, const float
 int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ,
                            double* stat, double* partial, mvp_stream_t stream);
+/* The same with the DROPOUT that sits behind the previous layer's activation (round 6; common/nn/modules/mlp.py:86-92: the segmentation head in front
+ * of the logit layer, mvpnet/models/pn2/pn2ssg.py:111-118): dZ = (dY . W) * keep * 1/(1-p) * [bn(y_prev) > 0] with the keep mask regenerated from
+ * (drop_p, drop_seed, element index) exactly as mvp_bn_rows_forward_dropout_f32 made it.  dZ and stat are then what the head's backward starts
+ * from: its own pass over (gradient, y) for the two column sums (123 us + a reduction per step) is not run.  y_prev required; R * Cin < 2^32. */
+int mvp_mlp_input_grad_dropout_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev,
+                                   const float* mean, const float* invstd, const float* gamma, const float* beta, float drop_p,
+                                   uint64_t drop_seed, float* dZ, double* stat, double* partial, mvp_stream_t stream);
 
 /* The WHOLE backward of shared-MLP layer i in one kernel (csrc/mlp_bwd.hip): BatchNorm-backward "finish" + weight gradient + input
  * gradient with the previous layer's ReLU mask and BatchNorm-backward column sums, from ONE read of dz_i, y_i and y_{i-1}
@@ -727,6 +734,9 @@ int mvp_mlp_forward_pool_p_f32(const float* X, int64_t R, int64_t Cin, int64_t l
 int mvp_mlp_input_grad_p_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev, const
     float* mean, const float* invstd, const float* gamma, const float* beta, float* dZ, double* stat, double* partial, int
     precision, int precision_backward, mvp_stream_t stream);
+int mvp_mlp_input_grad_dropout_p_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev, const
+    float* mean, const float* invstd, const float* gamma, const float* beta, float drop_p, uint64_t drop_seed, float* dZ, double* stat,
+    double* partial, int precision, int precision_backward, mvp_stream_t stream);
 int mvp_mlp_weight_grad_p_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx, const float*
     act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta, float* dW, int64_t lddw, int precision,
     int precision_backward, mvp_stream_t stream);

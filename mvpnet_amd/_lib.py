@@ -99,6 +99,7 @@ _SIGNATURES = {
     'mvp_mlp_weight_grad_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr],
     'mvp_mlp_weight_grad_ws_f32': [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr],
     'mvp_mlp_input_grad_f32': [_ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    'mvp_mlp_input_grad_dropout_f32': [_ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, ctypes.c_uint64, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_layer_backward_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
                                    _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     'mvp_mlp_layer_backward_ws_f32': [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
@@ -133,7 +134,7 @@ _SIGNATURES = {
     'mvp_seg_confusion_f32': [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr],
 }
 # the shared-MLP entry points with the precision as arguments (csrc/mlp_prec.hip): base parameters + (precision, precision_backward)
-for _n in ['mvp_mlp_forward_f32', 'mvp_mlp_forward_bn_f32', 'mvp_mlp_forward_rel_bn_f32', 'mvp_mlp_forward_pool_f32', 'mvp_mlp_input_grad_f32',
+for _n in ['mvp_mlp_forward_f32', 'mvp_mlp_forward_bn_f32', 'mvp_mlp_forward_rel_bn_f32', 'mvp_mlp_forward_pool_f32', 'mvp_mlp_input_grad_f32', 'mvp_mlp_input_grad_dropout_f32',
            'mvp_mlp_weight_grad_f32', 'mvp_mlp_weight_grad_ws_f32', 'mvp_mlp_layer_backward_f32', 'mvp_mlp_layer_backward_ws_f32',
            'mvp_sa_fused_forward_f32', 'mvp_sa_train_forward_f32', 'mvp_sa_train_backward_f32']:
     _SIGNATURES[_n[:-4] + '_p_f32'] = _SIGNATURES[_n][:-1] + [ctypes.c_int, ctypes.c_int, _ptr]

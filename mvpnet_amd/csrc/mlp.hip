@@ -20,6 +20,7 @@
 #include "common.h"
 #include "stats_reduce.h"
 #include "mlp_common.h"
+#include "dropout.h"
 #include <algorithm>
 
 // mlp_stream.hip: persistent streaming forward for long narrow layers (MVP_EUNSUPPORTED when the layer does not qualify)
@@ -58,6 +59,10 @@ struct EpiBwd {
   // a 68-wide operand they cost a 214 MB concatenated tensor and 2.3x the layer's time).  rel (R,4), wrel (Cout,4); null = none.
   const float* rel;
   const float* wrel;
+  // Backward only: the dropout that sits behind the previous layer's activation (SharedMLPDO, mlp.py:86-92: the segmentation head in front of the
+  // logit layer): dz = da * keep * scale * relu'(bn(y)), the keep mask regenerated from (seed, element index) as the forward made it (dropout.h);
+  // thresh 0 = none.
+  Dropout drop;
 };
 
 // WT = false: W is (Cout, ldw) row-major, element (output column co, k) at W[co * ldw + k]   (forward: the conv weight)
@@ -482,7 +487,8 @@ __global__ __launch_bounds__(kMT, (BN == 128 && VEC && WT && NS == 0) ? MVP_MLP_
         if (epi.y) {
           const float yp = VEC ? Ss[wave][((i & 3) + 8 * (i >> 2) + rh) * kLdS + cl] : epi.y[(size_t)r * Cout + co];
           const float xh = (yp - em) * ei;
-          y = (xh * eg + eb > 0.f) ? y : 0.f;  // dz = da * relu'(bn(y_prev))
+          if (epi.drop.thresh) y *= epi.drop.factor((unsigned)((size_t)r * Cout + co));
+          y = (xh * eg + eb > 0.f) ? y : 0.f;  // dz = da * [keep * scale] * relu'(bn(y_prev))
           s += y;
           q += y * xh;
         } else {
@@ -1386,9 +1392,9 @@ MVP_API int mvp_mlp_weight_grad_finish_act_p_f32(const float* dZ, const float* Y
 //   dZ (R,Cin) = (dY (R,Cout) . W) * [ bn(y_prev) > 0 ],   W (Cout,Cin) = the layer's weight exactly as the forward uses it
 //   stat[0:Cin] = column sums of dZ (= d beta), stat[Cin:2Cin] = column sums of dZ * xhat (= d gamma)
 // y_prev == NULL: plain dX = dY . W (no masking, no statistics).
-MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin,
-                                   const float* y_prev, const float* mean, const float* invstd, const float* gamma,
-                                   const float* beta, float* dZ, double* stat, double* partial, mvp_stream_t stream) {
+namespace {
+int input_grad_impl(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, float drop_p, uint64_t drop_seed, float* dZ, double* stat, double* partial, mvp_stream_t stream) {
   MVP_NONNULL(dY);
   MVP_NONNULL(W);
   MVP_NONNULL(dZ);
@@ -1404,6 +1410,7 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
   if (R == 0) return MVP_OK;
   InAct act{nullptr, nullptr, nullptr, nullptr};
   EpiBwd epi{y_prev, mean, invstd, gamma, beta};
+  if (make_dropout(y_prev ? drop_p : 0.f, drop_seed, R, Cin, 1, &epi.drop) != MVP_OK) return MVP_EINVAL;
   double* st = y_prev ? stat : nullptr;
   const unsigned gx = (unsigned)cdiv(R, kBM);
   // roles: X = dY (R, Cout as the K dimension), W read across (WT), output columns = Cin
@@ -1411,6 +1418,24 @@ MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, con
   if (st && partial)
     launch_stats_reduce(partial, (int64_t)gx, (int)(2 * Cin), stat, s);
   return mvp_launch_status();
+}
+}  // namespace
+
+MVP_API int mvp_mlp_input_grad_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin,
+                                   const float* y_prev, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* dZ, double* stat, double* partial, mvp_stream_t stream) {
+  return input_grad_impl(dY, R, Cout, W, Cin, y_prev, mean, invstd, gamma, beta, 0.f, 0, dZ, stat, partial, stream);
+}
+
+// The same with the DROPOUT that sits behind the previous layer's activation (drop_p, drop_seed as mvp_bn_rows_forward_dropout_f32 took them): the
+// epilogue regenerates the keep mask, so dZ is the gradient w.r.t. that layer's pre-BN output up to its BatchNorm-backward finish and `stat` its two
+// column sums -- the consumer of a SharedMLPDO layer's output (the logit layer behind the segmentation head) hands both to that layer's backward,
+// which then needs no statistics pass over (gradient, y) of its own.  R * Cin < 2^32.
+MVP_API int mvp_mlp_input_grad_dropout_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, float drop_p, uint64_t drop_seed, float* dZ,
+                                           double* stat, double* partial, mvp_stream_t stream) {
+  MVP_NONNULL(y_prev);
+  return input_grad_impl(dY, R, Cout, W, Cin, y_prev, mean, invstd, gamma, beta, drop_p, drop_seed, dZ, stat, partial, stream);
 }
 
 // Contraction precision of the shared-MLP kernels (forward, input gradient, weight gradient):

@@ -64,6 +64,12 @@ MVP_API int mvp_mlp_input_grad_p_f32(const float* dY, int64_t R, int64_t Cout, c
                                      double* partial, int precision, int precision_backward, mvp_stream_t stream) {
   MVP_WITH_PRECISION(mvp_mlp_input_grad_f32(dY, R, Cout, W, Cin, y_prev, mean, invstd, gamma, beta, dZ, stat, partial, stream));
 }
+MVP_API int mvp_mlp_input_grad_dropout_p_f32(const float* dY, int64_t R, int64_t Cout, const float* W, int64_t Cin, const float* y_prev,
+                                             const float* mean, const float* invstd, const float* gamma, const float* beta, float drop_p,
+                                             uint64_t drop_seed, float* dZ, double* stat, double* partial, int precision, int precision_backward,
+                                             mvp_stream_t stream) {
+  MVP_WITH_PRECISION(mvp_mlp_input_grad_dropout_f32(dY, R, Cout, W, Cin, y_prev, mean, invstd, gamma, beta, drop_p, drop_seed, dZ, stat, partial, stream));
+}
 MVP_API int mvp_mlp_weight_grad_p_f32(const float* dY, const float* X, int64_t R, int64_t Cout, int64_t Cin, int64_t ldx,
                                       const float* act_mean, const float* act_invstd, const float* act_gamma, const float* act_beta,
                                       float* dW, int64_t lddw, int precision, int precision_backward, mvp_stream_t stream) {

@@ -30,6 +30,7 @@ NATIVE_PLAN = os.environ.get('MVP_NATIVE_PLAN', '1') != '0'
 # The segmentation head's SharedMLPDO as the last layer of the last feature-propagation level's chain (it is that level's only consumer);
 # 0 = two chains with the level's output activation in between (A/B switch)
 MERGE_HEAD = os.environ.get('MVP_MERGE_HEAD', '1') != '0'
+HEAD_HANDOVER = os.environ.get('MVP_HEAD_HANDOVER', '1') != '0'  # (A/B: the head's ReLU / dropout mask + column sums in the logit layer's input gradient)
 
 
 def centroid_levels(xyz, index, counts):
@@ -318,7 +319,7 @@ class FeaturePropagation(nn.Module):
                     y1, stat1 = y1[0], (y1[1], y1[2])
                 if tail is not None:
                     return R.shared_mlp_rows(y1.view(B * N, c1), chain, first_done=True, first_stat=stat1, dropout_p=tail[0].p, training=tail[1],
-                                             dropout_last_only=True, defer=defer).view(B, N, -1)
+                                             dropout_last_only=True, defer=defer, act_out=act_out).view(B, N, -1)
                 return R.shared_mlp_rows(y1.view(B * N, c1), self.mlp, first_done=True, first_stat=stat1, defer=defer, act_out=act_out).view(B, N, -1)
             if tail is not None:
                 return None
@@ -620,17 +621,22 @@ class PN2SSG(nn.Module):
         up = feats[-1]
         x = None
         hand = None  # rows.ActivationHandOver of the level before: its output `up` is read by this level's first linear layer and nobody else
+        head_hand = None
         watched = [_has_hooks(fp) for fp in self.fp_modules]
         for level, fp in enumerate(self.fp_modules):
             geo = None if plan is None else plan['fp'][level]
             if MERGE_HEAD and level + 1 == len(self.fp_modules) and up.is_cuda and not _has_hooks(fp) and not _has_hooks(self.mlp_seg):
                 # the segmentation head's MLP is the last propagation level's only consumer: one chain (no activation tensor in between, no
                 # column-statistics pass of its own in backward)
+                # ... and the logit layer is the head's only consumer (rows.ActivationHandOver, HEAD_HANDOVER): its input gradient applies the head's
+                # dropout + ReLU mask and sums the two BatchNorm-backward columns in its epilogue
+                head_hand = R.ActivationHandOver() if (HEAD_HANDOVER and torch.is_grad_enabled() and not _has_hooks(self.seg_logit)) else None
                 x = fp(xyzs[-2 - level], xyzs[-1 - level], feats[-2 - level], up, rows=True, geometry=geo, tail=(self.mlp_seg, self.training),
-                       sparse_act=hand)
+                       sparse_act=hand, act_out=head_hand)
                 if x is not None:
                     x = x.reshape(B * N, -1)
                     break
+                head_hand = None
             nxt = None
             if (level + 1 < len(self.fp_modules) and up.is_cuda and torch.is_grad_enabled() and not watched[level] and not watched[level + 1]
                     and self.fp_modules[level + 1].interpolator is not None):
@@ -639,7 +645,7 @@ class PN2SSG(nn.Module):
             hand = nxt
         if x is None:
             x = R.shared_mlp_rows(up.reshape(B * N, -1), self.mlp_seg, dropout_p=self.mlp_seg.p, training=self.training)
-        logit = R.linear_rows(x, self.seg_logit.weight, self.seg_logit.bias)  # (B*N, classes)
+        logit = R.linear_rows(x, self.seg_logit.weight, self.seg_logit.bias, act_src=head_hand)  # (B*N, classes)
         # (B,classes,N) as the reference returns it -- as a transposed VIEW of the rows: the loss and the vote kernels take strided logits,
         # the gradient comes back in the same layout (mvpnet3d._SegLossFn), so neither direction pays a transposing copy
         return {'seg_logit': logit.view(B, N, self.num_classes).transpose(1, 2)}

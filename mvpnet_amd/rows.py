@@ -1021,8 +1021,9 @@ class MLPChainRows(torch.autograd.Function):
             out, arg = _bn_apply(ys[-1], means[-1], invstds[-1], params[-2], params[-1], G, K, cl, True, pool_sum)
         ao = opts.get('act_out')
         ctx.act_out = None
-        if ao is not None and ActivationHandOver.ENABLED and not pooled and K == 1 and drop_p == 0 and training is not None:
-            ao.info, ao.stat = (ys[-1], means[-1], invstds[-1], params[-2], params[-1]), None
+        if ao is not None and ActivationHandOver.ENABLED and not pooled and K == 1 and training is not None:
+            # (drop_p > 0: the dropout folded into this chain's BatchNorm + ReLU pass -- the consumer regenerates the keep mask from (p, seed))
+            ao.info, ao.stat = (ys[-1], means[-1], invstds[-1], params[-2], params[-1], float(drop_p), int(drop_seed)), None
             ctx.act_out = ao
         ctx.first_linear = params[0] is not None
         ctx.pooled = pooled
@@ -1373,10 +1374,15 @@ class LinearRows(torch.autograd.Function):
             gx = torch.empty_like(x)
             src = ctx.act_src
             if src is not None and src.info is not None:
-                yp, pm, pi, pg, pb = src.info
+                yp, pm, pi, pg, pb, drop_p, drop_seed = src.info
                 stat = zero_pool.zeros(2 * cin, torch.float64, gy.device)
-                L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, L.ptr(yp), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(gx),
-                       L.ptr(stat), L.ptr(_partial(R, cin, gy.device) if R > 65536 else None), prec=ctx.prec)  # (<= 512 tiles: fp64 atomics, no reduction launch)
+                part = L.ptr(_partial(R, cin, gy.device) if R > 65536 else None)  # (<= 512 tiles: fp64 atomics, no reduction launch)
+                if drop_p > 0:  # x is the DROPPED-OUT activation (the segmentation head in front of the logit layer): keep mask regenerated in the epilogue
+                    L.call('mvp_mlp_input_grad_dropout_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, L.ptr(yp), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb),
+                           drop_p, drop_seed, L.ptr(gx), L.ptr(stat), part, prec=ctx.prec)
+                else:
+                    L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, L.ptr(yp), L.ptr(pm), L.ptr(pi), L.ptr(pg), L.ptr(pb), L.ptr(gx),
+                           L.ptr(stat), part, prec=ctx.prec)
                 src.stat = stat
             else:
                 L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, cout, L.ptr(w), cin, None, None, None, None, None, L.ptr(gx), None, None, prec=ctx.prec)
@@ -1687,8 +1693,7 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
             opts['rel'] = (rel.contiguous(), ps[0].w)
         if defer is not None and first_done and bn_training:
             opts['defer'] = defer   # (rows.DeferredFinish: the finish of the first layer's gradient may be left to the node in front)
-        if act_out is not None and K == 1 and dropout_p == 0 and torch.is_grad_enabled():
-            opts['act_out'] = act_out   # (rows.ActivationHandOver: the output's only consumer masks and sums its gradient)
+
         if DW_SIDE_STREAM and torch.is_grad_enabled():  # (a first layer that ran before the grouping has its own use: WeightGradSink)
             opts['use'] = WeightUse([q.w for li, q in enumerate(ps) if not (first_done and li == 0)])
         # dropout behind the (single) layer: folded into the BatchNorm + ReLU passes (mvp_bn_rows_forward_dropout_f32) unless a graph is
@@ -1698,6 +1703,10 @@ def shared_mlp_rows(x, mlp, K=1, dropout_p=0.0, training=False, first_done=False
         if fold:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())  # torch's CPU generator: follows torch.manual_seed
             opts['drop_p'], opts['drop_seed'] = float(dropout_p), seed & 0x7fffffffffffffff
+        # (rows.ActivationHandOver: the output's only consumer masks and sums its gradient -- with a dropout behind the last layer only when it is
+        # folded into this chain's kernels, i.e. when the consumer's input IS this node's output; F.dropout below would sit between the two)
+        if act_out is not None and K == 1 and torch.is_grad_enabled() and (dropout_p == 0 or not training or fold):
+            opts['act_out'] = act_out
         out = MLPChainRows.apply(x.contiguous(), bn_training, K, eps_mom, buffers, first_stat if bn_training else None, opts, *params)
         return F.dropout(out, p=dropout_p, training=training, inplace=False) if (dropout_p > 0 and not fold) else out
     assert not first_done and rel is None, 'first_done / rel need the fused path (BN + ReLU, no bias, no dropout)'

@@ -2696,3 +2696,45 @@ def test_weight_gradient_of_the_first_aggregation_layer_in_one_launch(dev, R, Co
     args = lambda cin, p1: (L.ptr(dz), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(stat), training, L.ptr(x), R, Cout, cin, Cin, L.ptr(rel), L.ptr(dw),
                             L.ptr_at(dw, Cin), ld, 6, p1, None)
     assert f(*args(Cin, 6)) != 0 and f(*args(32, 3)) != 0
+
+
+@pytest.mark.parametrize('R,Cout,Cin', [(20000, 20, 128), (262144, 20, 128), (777, 13, 64), (4097, 128, 128)])
+@pytest.mark.parametrize('drop_p', [0.5, 0.25])
+def test_input_gradient_with_the_dropout_of_the_layer_in_front(dev, R, Cout, Cin, drop_p):
+    """mvp_mlp_input_grad_dropout_f32: the input gradient of the layer BEHIND a SharedMLPDO layer (the logit layer behind the segmentation head,
+    pn2ssg.py:111-118; mlp.py:86-92) applies that layer's dropout keep mask (regenerated from the seed), its ReLU mask and sums its two
+    BatchNorm-backward columns in the epilogue.  Against the library's own two-pass form with the same keep mask: plain input gradient, then
+    mvp_bn_rows_backward_dropout_f32 (eval-mode finish with unit scale = dz itself + the two sums), and the sums against float64 of that dz."""
+    from mvpnet_amd import _lib as L
+    torch.manual_seed(R + Cout)
+    seed = 987654321012345
+    gy = torch.randn(R, Cout, device=dev)
+    w = torch.randn(Cout, Cin, device=dev) * 0.3
+    y = torch.randn(R, Cin, device=dev) * 1.2 + 0.1
+    mean, invstd = torch.randn(Cin, device=dev) * 0.3, torch.rand(Cin, device=dev) + 0.5
+    gamma, beta = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.2
+    part = lambda: torch.empty(((R + 127) // 128) * 2 * Cin, dtype=torch.float64, device=dev) if R > 65536 else None
+    # one pass
+    dz1 = torch.full((R, Cin), float('nan'), device=dev)
+    st1 = torch.zeros(2 * Cin, dtype=torch.float64, device=dev)
+    L.call('mvp_mlp_input_grad_dropout_f32', gy, L.ptr(gy), R, Cout, L.ptr(w), Cin, L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), drop_p, seed,
+           L.ptr(dz1), L.ptr(st1), L.ptr(part()))
+    # two passes: plain gradient, then the dropped-out layer's own backward pass in eval mode with unit scale (dy = gamma * invstd * dz -> divide)
+    gx = torch.empty(R, Cin, device=dev)
+    L.call('mvp_mlp_input_grad_f32', gy, L.ptr(gy), R, Cout, L.ptr(w), Cin, None, None, None, None, None, L.ptr(gx), None, None)
+    dy = torch.empty(R, Cin, device=dev)
+    st0 = torch.zeros(2 * Cin, dtype=torch.float64, device=dev)
+    dgb = torch.empty(2, Cin, device=dev)
+    L.call('mvp_bn_rows_backward_dropout_f32', gx, L.ptr(gx), L.ptr(y), L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), R, Cin, 1, 0, L.ptr(st0), L.ptr(dy),
+           L.ptr(dgb[0]), L.ptr(dgb[1]), L.ptr(torch.empty(L.lib().mvp_colstats_partial_count(R, Cin), dtype=torch.float64, device=dev)), drop_p, seed)
+    dz0 = dy.double() / (gamma.double() * invstd.double())
+    keep = (dz0 != 0).float().mean().item()
+    assert abs(keep - 0.5 * (1 - drop_p)) < 0.08, keep   # roughly half of the kept elements pass the ReLU (a mask really was applied)
+    sz = max(1.0, float(dz0.abs().max()))
+    np.testing.assert_allclose(dz1.cpu().numpy(), dz0.cpu().numpy(), rtol=2e-5, atol=2e-5 * sz)
+    xh = (y.double() - mean.double()) * invstd.double()
+    big = max(1.0, R / 5000.0)
+    # (the kernel carries a lane's run of 16 rows in fp32 before it goes to fp64: ~1e-7 of the sum of magnitudes)
+    np.testing.assert_allclose(st1[:Cin].cpu().numpy(), dz1.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3 * big * sz)
+    np.testing.assert_allclose(st1[Cin:].cpu().numpy(), (dz1.double() * xh).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3 * big * sz)
+    np.testing.assert_allclose(st1.cpu().numpy(), st0.cpu().numpy(), rtol=1e-4, atol=2e-3 * big * sz)
