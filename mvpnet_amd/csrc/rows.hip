@@ -391,15 +391,38 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __re
   int* sl = slots + (size_t)b * E;
   for (int i = tid; i < N; i += 1024) cnt[i] = 0;
   __syncthreads();
-  // (four index loads in flight per lane: a pass is a chain of load -> LDS atomic per entry, 64 entries per lane at the 8192-point level)
-  for (int64_t e0 = tid; e0 < E; e0 += 4 * 1024) {
-    int64_t j[4];
+  // A pass is a chain of load -> LDS atomic per entry (64 entries per lane at the 8192-point level): eight 16-byte loads = sixteen entries in
+  // flight per lane (round 6; four 8-byte loads before): 60 -> 53 us for 32 clouds of 65 536 entries, 250 -> 219 us for two of 262 144 alone
+  // (tools/exp/csr_time.py) -- what is left is the fill pass' scattered 4-byte stores from one workgroup per cloud
+  constexpr int kCU = 8;
+  const bool pairs = (E & 1) == 0 && (reinterpret_cast<uintptr_t>(ix) & 15) == 0;
+  auto for_entries = [&](auto&& fn) {
+    if (pairs) {
+      const longlong2* ix2 = reinterpret_cast<const longlong2*>(ix);
+      const int64_t E2 = E >> 1;
+      for (int64_t e0 = tid; e0 < E2; e0 += kCU * 1024) {
+        longlong2 j[kCU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) j[u] = e0 + u * 1024 < E ? ix[e0 + u * 1024] : -1;
+        for (int u = 0; u < kCU; ++u) j[u] = e0 + u * 1024 < E2 ? ix2[e0 + u * 1024] : longlong2{-1, -1};
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (j[u] >= 0 && j[u] < N) atomicAdd(&cnt[j[u]], 1);
-  }
+        for (int u = 0; u < kCU; ++u) {
+          fn((int64_t)j[u].x, 2 * (e0 + u * 1024));
+          fn((int64_t)j[u].y, 2 * (e0 + u * 1024) + 1);
+        }
+      }
+    } else {
+      for (int64_t e0 = tid; e0 < E; e0 += 4 * 1024) {
+        int64_t j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = e0 + u * 1024 < E ? ix[e0 + u * 1024] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fn(j[u], e0 + u * 1024);
+      }
+    }
+  };
+  for_entries([&](int64_t j, int64_t) {
+    if (j >= 0 && j < N) atomicAdd(&cnt[j], 1);
+  });
   __syncthreads();
   // exclusive scan of cnt over contiguous runs of `per` points per thread
   const int per = (N + 1023) / 1024;
@@ -425,14 +448,9 @@ __global__ __launch_bounds__(1024) void csr_build_lds_kernel(const int64_t* __re
       o[j0 + i + 1] = run;
     }
   __syncthreads();
-  for (int64_t e0 = tid; e0 < E; e0 += 4 * 1024) {
-    int64_t j[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) j[u] = e0 + u * 1024 < E ? ix[e0 + u * 1024] : -1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (j[u] >= 0 && j[u] < N) sl[atomicAdd(&cnt[j[u]], 1)] = (int)(e0 + u * 1024);
-  }
+  for_entries([&](int64_t j, int64_t e) {
+    if (j >= 0 && j < N) sl[atomicAdd(&cnt[j], 1)] = (int)e;
+  });
   if (!sorted) return;
   __syncthreads();  // (workgroup-scope: the slots written above are read back below by other lanes of THIS workgroup)
   // ascending positions inside every list (insertion sort: 8 entries on average in the grouping, 3 in the interpolation)
