@@ -63,8 +63,9 @@ def test_dense_lift(dev):
     # independent algorithm (masked brute force over all 384000 pixels) on the full chunk
     brute = pixel_knn(xyz, mask, pts, k)
     assert torch.equal(brute, knn)
-    # C oracle on a seeded subset of the queries
-    sel = np.random.RandomState(5).choice(DENSE['nb_pts'], 1024, replace=False)
+    # C oracle on a seeded subset of the queries (an eighth of every chunk: ~3 x 10^9 pinned distance evaluations on one host core; the full chunk is
+    # covered by the independent brute-force kernel above, which is itself held to the oracle in tests/test_ops_gpu.py)
+    sel = np.random.RandomState(5).choice(DENSE['nb_pts'], 4096, replace=False)
     eknn = c_oracle.pixel_knn(exyz, emask, np.ascontiguousarray(bt['points'][:, sel]), k)
     np.testing.assert_array_equal(knn.cpu().numpy()[:, sel], eknn)
 
