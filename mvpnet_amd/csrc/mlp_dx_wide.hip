@@ -8,7 +8,7 @@
 //     (+ a reduction launch for the sums)
 // with one workgroup per 128-row tile whose A operand goes global -> registers slab by slab: 0.29 of the HBM peak, half of its cycles waiting.
 // Here the finish happens while dz_i is loaded (no dy_i tensor, no finish pass), persistent workgroups stream 64-row tiles with the next
-// block's rows in flight, and the weight -- too large for the LDS as a whole: 256 x 256 in two bf16 pieces is 256 KB -- is read per tile from
+// tile's rows in flight, and the weight -- too large for the LDS as a whole: 256 x 256 in two bf16 pieces is 256 KB -- is read per tile from
 // a PRE-SPLIT IMAGE in global memory (L2 resident: 0.3 - 1.2 MB per layer, written by one small launch) in (64 c_out) x (128 c_in) blocks,
 // double buffered under the MFMAs.  A whole one-pass backward (dW in accumulator registers beside it) does not extend to these widths: the
 // dW of a 256 x 256 layer is 64 K floats = every register of a CU, so the weight gradient stays its own launch beside the chain
@@ -17,13 +17,18 @@
 // Decomposition.  blockIdx.y = the c_in block (128 columns of dz_{i-1}); the workgroups of a block share its row tiles round-robin.  Per tile
 //   for every c_out block kb of 64:
 //     P1   each thread turns its two 16-byte pieces of dz_i / y_i into dy_i, splits them into bf16 pieces, row-major LDS image (Dy[kb & 1]);
-//          the next block's pieces and the next weight block are requested at once
+//          the same block of the NEXT tile and the weight block after next are requested at once
 //     P2   wave (rb, cbk) adds  dX[32 rows, 32 c_in] += Dy . Wimg  (4 steps of 16 c_out, one or three products per step)
 //   P3   the dX tile goes through LDS (aliases the Dy images) to become full rows
 //   P4   every thread meets its y_{i-1} values (in registers since the tile began): ReLU mask, xhat, the two BatchNorm-backward column sums
 //        of layer i-1, 16-byte streaming stores of dz_{i-1}
 // Traffic: C_i (2 C_i with the finish) + 2 C_{i-1} floats per row and c_in block from HBM; C_i x 128 x 4 bytes of weight image per tile from L2.
 // LDS: 2 weight blocks (37 KB each at two pieces) + 2 Dy blocks (18 KB) + constants = 123 KB: one workgroup per CU, two waves per SIMD.
+//
+// Status (round 6): 15 - 40 % faster than the launches it replaces alone on the chip, 0.6 % slower inside the training step (a
+// workgroup that takes a whole CU leaves no room for the kernels of the weight-gradient and geometry streams) -- rows.DX_WIDE is off by default.
+// What bounds it alone: a weight block's transfer cannot start before the block before it has been consumed (two LDS buffers, staged through
+// registers), so every block step waits out a round trip to L2; a third buffer filled by LDS-DMA loads would give it two steps of lead.
 #include "mlp_common.h"
 #include <algorithm>
 #include <stdlib.h>
