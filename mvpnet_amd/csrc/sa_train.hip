@@ -68,17 +68,20 @@ struct BallRows {
   float p[3], q[3];
   bool ok;
 };
+// (g: the wave's ball, a SCALAR -- callers pass it through readfirstlane --, so the chunk index, its division and the row bases are scalar
+// arithmetic and the per-lane part of every address is a 32-bit offset: the 64-bit per-lane address arithmetic of the first version was 8 - 10 %
+// of these VALU-bound kernels' vector instructions)
 template <int C1B>
-__device__ __forceinline__ void gather_issue(const SaSrc& p, int64_t g, int64_t j, int lh, BallRows<C1B>& r) {
-  const int64_t b = g / p.M;
+__device__ __forceinline__ void gather_issue(const SaSrc& p, int g, int64_t j, int lh, BallRows<C1B>& r) {
+  const int b = g / p.M;
   r.ok = j >= 0 && j < p.N;
-  const size_t pj = (size_t)b * p.N + (r.ok ? j : 0);
-  const float* zr = p.zf + pj * p.C1;
+  const unsigned jj = r.ok ? (unsigned)j : 0u;
+  const float* zr = p.zf + (size_t)b * p.N * p.C1 + jj * (unsigned)p.C1;
 #pragma unroll
   for (int sl = 0; sl < C1B; ++sl)
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) r.z[sl][tt] = *reinterpret_cast<const float4*>(zr + min(32 * sl + 8 * tt + 4 * lh, p.C1 - 4));
-  const float* pp = p.xyz + pj * 3;
+  const float* pp = p.xyz + (size_t)b * p.N * 3 + jj * 3u;
   const float* qc = p.centre + (size_t)g * 3;
   r.p[0] = pp[0]; r.p[1] = pp[1]; r.p[2] = pp[2];
   r.q[0] = qc[0]; r.q[1] = qc[1]; r.q[2] = qc[2];
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kFT) void sa_train_fwd_kernel(SaFwdArgs p) {
   float* st = tiles[wave];
   const int64_t t_begin = (int64_t)blockIdx.x * p.tiles_per_wg;
   const int64_t t_end = min(p.s.G, t_begin + p.tiles_per_wg);
-  int64_t g = t_begin + wave;
+  int g = __builtin_amdgcn_readfirstlane((int)(t_begin + wave));   // (the wave's ball: scalar -- see gather_issue)
   // pipeline: the index of ball g + 8 and the rows of ball g + 4 are in flight while ball g is worked on
   BallRows<C1B> rn;
   int64_t jn = -1;
@@ -308,11 +311,12 @@ __global__ __launch_bounds__(kFT) void sa_train_fwd_kernel(SaFwdArgs p) {
         if (omax > vmax || (omax == vmax && ormax < rmax)) { vmax = omax; rmax = ormax; }
         if (omin < vmin || (omin == vmin && ormin < rmin)) { vmin = omin; rmin = ormin; }
         if (lh == 0 && cok) {
-          const size_t o = (size_t)g * C3 + 32 * jb + li;
-          p.ymax[o] = vmax;
-          p.ymin[o] = vmin;
-          p.amax[o] = (uint8_t)rmax;
-          p.amin[o] = (uint8_t)rmin;
+          const size_t ob = (size_t)g * C3;
+          const unsigned o = (unsigned)(32 * jb + li);
+          (p.ymax + ob)[o] = vmax;
+          (p.ymin + ob)[o] = vmin;
+          (p.amax + ob)[o] = (uint8_t)rmax;
+          (p.amin + ob)[o] = (uint8_t)rmin;
         }
         if (!cok) s = q = 0.f;
         ssum[jb] += s;
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(kFT, ((LAYER == 3 ? C1B * C2B * C3B <= 2 : C1B * C2
 
   const int64_t t_begin = (int64_t)blockIdx.x * p.tiles_per_wg;
   const int64_t t_end = min(p.s.G, t_begin + p.tiles_per_wg);
-  int64_t g = t_begin + wave;
+  int g = __builtin_amdgcn_readfirstlane((int)(t_begin + wave));   // (the wave's ball: scalar -- see gather_issue)
   // pipeline: the index of ball g + 8 and the rows of ball g + 4 are in flight while ball g is worked on
   BallRows<C1B> rn;
   int64_t jn = -1;
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(kFT, ((LAYER == 3 ? C1B * C2B * C3B <= 2 : C1B * C2
       const float* Gt = p.G + (size_t)g * 32 * C;
       const int col = min(32 * a + c, C - 1);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) gn[q] = Gt[(8 * (q >> 2) + 4 * h + (q & 3)) * C + col];
+      for (int q = 0; q < 16; ++q) gn[q] = Gt[(unsigned)((8 * (q >> 2) + 4 * h + (q & 3)) * C + col)];
     };
     if constexpr (LAYER == 2) load_g(0);
     // ---- the ball's y_1 (row layout), then x = y_{i-1} in accumulator layout and, for LAYER 2, y_2 in accumulator layout
@@ -589,9 +593,10 @@ __global__ __launch_bounds__(kFT, ((LAYER == 3 ? C1B * C2B * C3B <= 2 : C1B * C2
               yl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, far[b][s][SP::A[qd]]),
                                                           __builtin_bit_cast(bf16x8, wf[SP::B[qd]]), yl, 0, 0, 0);
           }
-        const size_t go = (size_t)g * C + min(co, C - 1);
-        const float dd = (p.pool_out[go] > 0.f) ? p.pool_dout[go] : 0.f;
-        const int ar = (int)p.pool_arg[go];
+        const size_t gb = (size_t)g * C;
+        const unsigned go = (unsigned)min(co, C - 1);
+        const float dd = ((p.pool_out + gb)[go] > 0.f) ? (p.pool_dout + gb)[go] : 0.f;
+        const int ar = (int)(p.pool_arg + gb)[go];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int row = 8 * (q >> 2) + 4 * h + (q & 3);
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(kFT, ((LAYER == 3 ? C1B * C2B * C3B <= 2 : C1B * C2
       __builtin_amdgcn_wave_barrier();
     }
     // ---- epilogue: ReLU mask + column sums against the x values in registers, 16-byte stores through the tile
-    const int64_t r0 = g * 32;
+    float* const Zb = p.dZ + (size_t)g * 32 * Cp;
 #pragma unroll
     for (int b = 0; b < CPB; ++b) {
       float s = 0.f, tq = 0.f;
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(kFT, ((LAYER == 3 ? C1B * C2B * C3B <= 2 : C1B * C2
         const int row = pp * 8 + (lane >> 3), c4 = (lane & 7) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * kFLd + c4);
         const int cc = 32 * b + c4;
-        if (cc < Cp) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.dZ + (size_t)(r0 + row) * Cp + cc));  // Cp % 4 == 0
+        if (cc < Cp) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Zb + (unsigned)(row * Cp + cc)));  // Cp % 4 == 0
       }
       __builtin_amdgcn_wave_barrier();
     }
