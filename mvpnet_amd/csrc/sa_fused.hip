@@ -75,18 +75,19 @@ __global__ __launch_bounds__(kFT) void sa_fused_fwd_kernel(SaArgs p) {
   float* st = tiles[wave];
   const int64_t t_begin = (int64_t)blockIdx.x * p.tiles_per_wg;
   const int64_t t_end = min(p.G, t_begin + p.tiles_per_wg);
-  int64_t g = t_begin + wave;
+  int g = __builtin_amdgcn_readfirstlane((int)(t_begin + wave));   // the wave's ball, a SCALAR: chunk index, division and row bases in scalar
+                                                                  // arithmetic, 32-bit per-lane offsets (as csrc/sa_train.hip, round 6)
   int64_t jn = g < t_end ? p.index[(size_t)g * 32 + li] : -1;  // neighbour of the NEXT ball (its index load is in flight early)
   for (; g < t_end; g += 4) {
     const int64_t j = jn;
     if (g + 4 < t_end) jn = p.index[(size_t)(g + 4) * 32 + li];
-    const int64_t b = g / p.M;
+    const int b = g / (int)p.M;
     const bool ok = j >= 0 && j < p.N;
-    const size_t pj = (size_t)b * p.N + (ok ? j : 0);
+    const unsigned jj = ok ? (unsigned)j : 0u;
     // ---- gather: this neighbour's share of the zf row + its coordinates relative to the centroid
     float v1[C1B][4][4];
     if (p.zf) {
-      const float* zr = p.zf + pj * C1;
+      const float* zr = p.zf + (size_t)b * p.N * C1 + jj * (unsigned)C1;
 #pragma unroll
       for (int sl = 0; sl < C1B; ++sl)
 #pragma unroll
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kFT) void sa_fused_fwd_kernel(SaArgs p) {
           v1[sl][tt][0] = a.x; v1[sl][tt][1] = a.y; v1[sl][tt][2] = a.z; v1[sl][tt][3] = a.w;
         }
     }
-    const float* pp = p.xyz + pj * 3;
+    const float* pp = p.xyz + (size_t)b * p.N * 3 + jj * 3u;
     const float* qc = p.centre + (size_t)g * 3;
     const float dx = pp[0] - qc[0], dy = pp[1] - qc[1], dz = pp[2] - qc[2];
     // ---- layer 1 (its feature part is zf) + BatchNorm 1 + ReLU, in the operation order of group_lin_rows_kernel / bn_act
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(kFT) void sa_fused_fwd_kernel(SaArgs p) {
       if (ob > best || (ob == best && ok2 < bk)) { best = ob; bk = ok2; }
       const int col = 32 * jb + li;
       if (lh == 0 && col < C3) {
-        p.out[(size_t)g * C3 + col] = best;
-        if (p.arg) p.arg[(size_t)g * C3 + col] = (uint8_t)bk;
+        (p.out + (size_t)g * C3)[(unsigned)col] = best;
+        if (p.arg) (p.arg + (size_t)g * C3)[(unsigned)col] = (uint8_t)bk;
       }
     }
   }
